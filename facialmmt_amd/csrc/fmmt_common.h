@@ -1,0 +1,110 @@
+// Device-side helpers shared by every kernel of libfmmt_hip (gfx950 / CDNA4 only).
+//
+// Conventions used throughout csrc/:
+//   * a wavefront is 64 lanes; kernels hard-code 64.
+//   * activations are token-major row-major matrices [rows][channels]; element type T is
+//     float (parity mode) or __bf16 (throughput mode); every reduction / accumulator is fp32.
+//   * MFMA operand maps (cdna_hip_programming.md section 3):
+//       16x16x32 bf16 : A[i = lane&15][k = (lane>>4)*8 + e], B[k = (lane>>4)*8 + e][j = lane&15], e = 0..7
+//       16x16x4  f32  : A[i = lane&15][k = lane>>4],         B[k = lane>>4][j = lane&15]
+//       C/D (both)    : D[i = (lane>>4)*4 + r][j = lane&15], r = 0..3
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+#define FMMT_DT_F32 0
+#define FMMT_DT_BF16 1
+
+#define FMMT_CHECK_LAUNCH()                                   \
+    do {                                                      \
+        hipError_t e__ = hipGetLastError();                   \
+        if (e__ != hipSuccess) return (int)e__;               \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// 16-byte vector access.  Vec<T>::N elements per 16 B.
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct Vec;
+template <> struct Vec<float> {
+    static constexpr int N = 4;
+    f32x4 v;
+    __device__ __forceinline__ float get(int i) const { return v[i]; }
+    __device__ __forceinline__ void set(int i, float x) { v[i] = x; }
+};
+template <> struct Vec<bf16> {
+    static constexpr int N = 8;
+    bf16x8 v;
+    __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+    __device__ __forceinline__ void set(int i, float x) { v[i] = (bf16)x; }
+};
+
+template <typename T> __device__ __forceinline__ Vec<T> ldvec(const T* p) {
+    Vec<T> r;
+    r.v = *reinterpret_cast<const decltype(r.v)*>(p);
+    return r;
+}
+template <typename T> __device__ __forceinline__ void stvec(T* p, const Vec<T>& r) {
+    *reinterpret_cast<decltype(r.v)*>(p) = r.v;
+}
+template <typename T> __device__ __forceinline__ Vec<T> zerovec() {
+    Vec<T> r;
+#pragma unroll
+    for (int i = 0; i < Vec<T>::N; ++i) r.set(i, 0.f);
+    return r;
+}
+
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(bf16 x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float x) { return (bf16)x; }
+
+// ---------------------------------------------------------------------------------------------
+// exact (erf) GELU and its derivative -- nn.GELU() / F.gelu default
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// ---------------------------------------------------------------------------------------------
+// reductions inside a 16-lane group (DPP row) and a full 64-lane wave
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float group16_sum(float v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = group16_sum(v);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// counter-based RNG for attention-probability dropout (replayed bit-identically in backward):
+// splitmix64 of (seed, element index) -> 24-bit uniform
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float hash_uniform(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+// per-sample (DropPath) multiplier lookup: rowscale == nullptr -> 1
+__device__ __forceinline__ float row_scale(const float* rowscale, int row, int rows_per_scale) {
+    return rowscale ? rowscale[row / rows_per_scale] : 1.0f;
+}

@@ -1,0 +1,489 @@
+// Linear layers of the hot path as hand-written MFMA kernels for gfx950.
+//
+//   linear_nt_kernel : y = epi(x . w^T + b) [+ residual]        (forward and input-gradient GEMMs)
+//   linear_tn_kernel : dw = dy^T . x, db = colsum(dy)           (weight-gradient GEMM, split over M)
+//
+// Both keep the *weight* on the MFMA "A" side and the *activation* on the "B" side, so the
+// accumulator fragment of a lane is a run of consecutive output channels of ONE token: the
+// epilogue (bias, GELU, residual, DropPath scale) works on contiguous vectors and stores rows.
+#include "fmmt_common.h"
+#include "../../include/fmmt.h"
+
+namespace {
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16> {
+    static constexpr int KM = 32;  // K per MFMA
+    static constexpr int KP = 8;   // K elements per lane
+    using frag = bf16x8;
+    static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ frag load(const bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
+};
+template <> struct Mma<float> {
+    static constexpr int KM = 4;
+    static constexpr int KP = 1;
+    using frag = float;
+    static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ frag load(const float* p) { return *p; }
+};
+
+// XCD-aware, bijective block remap: consecutive logical tiles share an XCD's L2
+// (cdna_hip_programming.md T1; the dispatcher places block b on XCD b % 8).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+struct LinArgs {
+    int M, N, K;
+    const void* x; int ldx;
+    const void* w; int ldw;
+    const float* bias;
+    void* y; int ldy;
+    void* y_pre;
+    int epi;
+    const void* aux; int ldaux;
+    const void* res; int ldres;
+    const float* rowscale; int rows_per_scale;
+    int tiles_n;
+};
+
+// ---------------------------------------------------------------------------------------------
+// NT kernel: 256 threads = 4 waves (2 along M x 2 along N); block tile BM x BN, K step BK.
+// LDS: double-buffered weight tile [BN][BK+pad] and activation tile [BM][BK+pad]; one barrier per
+// K step; the next tile's global loads are in flight while the MFMAs of the current one run.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int BM, int BN, int BK>
+__global__ __launch_bounds__(256) void linear_nt_kernel(LinArgs p) {
+    constexpr int VEC = Vec<T>::N;
+    constexpr int PITCH = BK + VEC;
+    constexpr int KM = Mma<T>::KM, KP = Mma<T>::KP;
+    constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 16, NT = WN / 16;
+    constexpr int KV = BK / VEC;                        // 16-byte vectors per tile row
+    constexpr int W_VECS = BN * KV, X_VECS = BM * KV;
+    constexpr int WV = (W_VECS + 255) / 256, XV = (X_VECS + 255) / 256;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* Ws = reinterpret_cast<T*>(smem);                 // [2][BN][PITCH]
+    T* Xs = Ws + 2 * BN * PITCH;                        // [2][BM][PITCH]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 15, lg = lane >> 4;
+
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_m = logical / p.tiles_n, tile_n = logical % p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
+    const T* __restrict__ wg = reinterpret_cast<const T*>(p.w);
+
+    Vec<T> wreg[WV], xreg[XV];
+
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            const int v = tid + i * 256;
+            if (v < W_VECS) {
+                const int row = v / KV, kc = (v % KV) * VEC;
+                const int n = min(n0 + row, p.N - 1);
+                wreg[i] = (k0 + kc < p.K) ? ldvec<T>(wg + (size_t)n * p.ldw + k0 + kc) : zerovec<T>();
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            const int v = tid + i * 256;
+            if (v < X_VECS) {
+                const int row = v / KV, kc = (v % KV) * VEC;
+                const int m = min(m0 + row, p.M - 1);
+                xreg[i] = (k0 + kc < p.K) ? ldvec<T>(xg + (size_t)m * p.ldx + k0 + kc) : zerovec<T>();
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+        T* wsb = Ws + buf * BN * PITCH;
+        T* xsb = Xs + buf * BM * PITCH;
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            const int v = tid + i * 256;
+            if (v < W_VECS) stvec<T>(wsb + (v / KV) * PITCH + (v % KV) * VEC, wreg[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            const int v = tid + i * 256;
+            if (v < X_VECS) stvec<T>(xsb + (v / KV) * PITCH + (v % KV) * VEC, xreg[i]);
+        }
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // weight-row permutation inside a wave tile: MFMA row i of n-tile nt is output channel
+    // (i>>2)*(4*NT) + nt*4 + (i&3), so that a lane's accumulators cover 4*NT consecutive channels.
+    const int wrow_base = wn * WN + (li >> 2) * (4 * NT) + (li & 3);
+    const int xrow_base = wm * WM + li;
+    const int koff = lg * KP;
+
+    const int nk = (p.K + BK - 1) / BK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * BK);
+        const T* wsb = Ws + cur * BN * PITCH;
+        const T* xsb = Xs + cur * BM * PITCH;
+#pragma unroll
+        for (int kk = 0; kk < BK / KM; ++kk) {
+            typename Mma<T>::frag wf[NT], xf[MT];
+#pragma unroll
+            for (int b = 0; b < NT; ++b) wf[b] = Mma<T>::load(wsb + (wrow_base + b * 4) * PITCH + kk * KM + koff);
+#pragma unroll
+            for (int a = 0; a < MT; ++a) xf[a] = Mma<T>::load(xsb + (xrow_base + a * 16) * PITCH + kk * KM + koff);
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b) acc[a][b] = Mma<T>::mma(wf[b], xf[a], acc[a][b]);
+        }
+        if (kt + 1 < nk) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    T* __restrict__ yg = reinterpret_cast<T*>(p.y);
+    T* __restrict__ ypre = reinterpret_cast<T*>(p.y_pre);
+    const T* __restrict__ auxg = reinterpret_cast<const T*>(p.aux);
+    const T* __restrict__ resg = reinterpret_cast<const T*>(p.res);
+    const int ncol0 = n0 + wn * WN + lg * (4 * NT);
+#pragma unroll
+    for (int a = 0; a < MT; ++a) {
+        const int m = m0 + wm * WM + a * 16 + li;
+        if (m >= p.M) continue;
+        const float rs = row_scale(p.rowscale, m, p.rows_per_scale);
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            const int n = ncol0 + b * 4;
+            if (n + 4 > p.N) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r];
+            if (p.bias) {
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += bb[r];
+            }
+            if (p.epi == FMMT_EPI_GELU) {
+                if (ypre) {
+                    T o[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(v[r]);
+                    if constexpr (sizeof(T) == 2) {
+                        *reinterpret_cast<uint2*>(ypre + (size_t)m * p.ldy + n) = *reinterpret_cast<const uint2*>(o);
+                    } else {
+                        *reinterpret_cast<uint4*>(ypre + (size_t)m * p.ldy + n) = *reinterpret_cast<const uint4*>(o);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+            } else if (p.epi == FMMT_EPI_GELU_BWD) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_f(to_f32(auxg[(size_t)m * p.ldaux + n + r]));
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= rs;
+            if (resg) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += to_f32(resg[(size_t)m * p.ldres + n + r]);
+            }
+            T o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(v[r]);
+            if constexpr (sizeof(T) == 2) {
+                *reinterpret_cast<uint2*>(yg + (size_t)m * p.ldy + n) = *reinterpret_cast<const uint2*>(o);
+            } else {
+                *reinterpret_cast<uint4*>(yg + (size_t)m * p.ldy + n) = *reinterpret_cast<const uint4*>(o);
+            }
+        }
+    }
+}
+
+template <typename T, int BM, int BN, int BK>
+int launch_nt(const LinArgs& a, hipStream_t st) {
+    constexpr int VEC = Vec<T>::N;
+    constexpr size_t lds = (size_t)2 * (BM + BN) * (BK + VEC) * sizeof(T);
+    LinArgs p = a;
+    p.tiles_n = (a.N + BN - 1) / BN;
+    const int tiles_m = (a.M + BM - 1) / BM;
+    hipLaunchKernelGGL((linear_nt_kernel<T, BM, BN, BK>), dim3(tiles_m * p.tiles_n), dim3(256), lds, st, p);
+    FMMT_CHECK_LAUNCH();
+    return 0;
+}
+
+template <typename T>
+int dispatch_nt(const LinArgs& a, hipStream_t st) {
+    constexpr int BK = sizeof(T) == 2 ? 32 : 16;
+    // BN = 96 when it tiles N exactly and 128 would not (C = 96, 288, 192, 576 ...)
+    const bool n96 = (a.N % 96 == 0) && (a.N % 128 != 0);
+    if (n96) return launch_nt<T, 128, 96, BK>(a, st);
+    return launch_nt<T, 128, 128, BK>(a, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// TN kernel (weight gradient).  Output tile 128 (n) x 128 (k); the contraction runs over tokens m,
+// which is the *row* index of both operands, so MFMA fragments need 8 consecutive m for one channel:
+// bf16 uses the gfx950 LDS transpose read (ds_read_b64_tr_b16) on tiles kept in natural
+// [m][channel] layout; f32 reads single dwords.  A and B use the same read pattern, so the order of
+// m inside a fragment cancels in the contraction.
+// ---------------------------------------------------------------------------------------------
+struct TnArgs {
+    int M, N, K;
+    const void* dy; int lddy;
+    const void* x; int ldx;
+    float* part_w;      // [splits][N][K]
+    float* part_b;      // [splits][N] or nullptr
+    const float* rowscale; int rows_per_scale;
+    int tiles_k;
+    int chunk;          // rows of m per split (multiple of the m step)
+};
+
+__device__ __forceinline__ bf16x8 lds_tr_frag(const bf16* s, int pitch, int c0, int li, int lg) {
+    // 16-lane group lg covers token rows lg*8 .. lg*8+7; lane li supplies row (li>>2) (+4), column
+    // chunk (li&3)*4 and receives column li of the 4x16 block (4 tokens).
+    const bf16* a0 = s + (lg * 8 + (li >> 2)) * pitch + c0 + (li & 3) * 4;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * pitch));
+    union { struct { s16x4 lo, hi; } s; bf16x8 v; } u;
+    u.s.lo = lo;
+    u.s.hi = hi;
+    return u.v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void linear_tn_kernel(TnArgs p) {
+    constexpr int VEC = Vec<T>::N;
+    constexpr int BMS = sizeof(T) == 2 ? 32 : 16;       // token rows per step
+    constexpr int PITCH = 128 + VEC;
+    constexpr int CV = 128 / VEC;                       // vectors per tile row
+    constexpr int NV = BMS * CV / 256;                  // vectors per thread per operand (= 2)
+
+    __shared__ __attribute__((aligned(16))) T As[2][BMS * PITCH];
+    __shared__ __attribute__((aligned(16))) T Bs[2][BMS * PITCH];
+    __shared__ float bsum[16][128];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wk = wave & 1;
+    const int li = lane & 15, lg = lane >> 4;
+    const int tile_n = blockIdx.x / p.tiles_k, tile_k = blockIdx.x % p.tiles_k;
+    const int n0 = tile_n * 128, k0 = tile_k * 128;
+    const int split = blockIdx.y;
+    const int mbeg = split * p.chunk, mend = min(p.M, mbeg + p.chunk);
+
+    const T* __restrict__ dyg = reinterpret_cast<const T*>(p.dy);
+    const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
+    const bool do_bias = (p.part_b != nullptr) && (tile_k == 0);
+
+    Vec<T> areg[NV], breg[NV];
+    float colsum[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) colsum[e] = 0.f;
+
+    auto gload = [&](int mb) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = tid + i * 256;
+            const int row = v / CV, c = (v % CV) * VEC;
+            const int m = mb + row;
+            const bool mv = m < mend;
+            if (mv && n0 + c < p.N) {
+                areg[i] = ldvec<T>(dyg + (size_t)m * p.lddy + n0 + c);
+                if (p.rowscale) {
+                    const float s = p.rowscale[m / p.rows_per_scale];
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) areg[i].set(e, areg[i].get(e) * s);
+                }
+            } else {
+                areg[i] = zerovec<T>();
+            }
+            breg[i] = (mv && k0 + c < p.K) ? ldvec<T>(xg + (size_t)m * p.ldx + k0 + c) : zerovec<T>();
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = tid + i * 256;
+            const int row = v / CV, c = (v % CV) * VEC;
+            stvec<T>(&As[buf][row * PITCH + c], areg[i]);
+            stvec<T>(&Bs[buf][row * PITCH + c], breg[i]);
+            if (do_bias) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) colsum[e] += areg[i].get(e);
+            }
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nsteps = (mend - mbeg + BMS - 1) / BMS;
+    if (nsteps > 0) {
+        gload(mbeg);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const int cur = s & 1;
+        if (s + 1 < nsteps) gload(mbeg + (s + 1) * BMS);
+        if constexpr (sizeof(T) == 2) {
+            bf16x8 af[4], bf_[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) af[a] = lds_tr_frag(reinterpret_cast<const bf16*>(As[cur]), PITCH, wn * 64 + a * 16, li, lg);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bf_[b] = lds_tr_frag(reinterpret_cast<const bf16*>(Bs[cur]), PITCH, wk * 64 + b * 16, li, lg);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf_[b], acc[a][b], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < BMS / 4; ++kk) {
+                float af[4], bf_[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) af[a] = As[cur][(kk * 4 + lg) * PITCH + wn * 64 + a * 16 + li];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) bf_[b] = Bs[cur][(kk * 4 + lg) * PITCH + wk * 64 + b * 16 + li];
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], bf_[b], acc[a][b], 0, 0, 0);
+            }
+        }
+        if (s + 1 < nsteps) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    float* pw = p.part_w + (size_t)split * p.N * p.K;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int k = k0 + wk * 64 + b * 16 + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 64 + a * 16 + lg * 4 + r;
+                if (n < p.N && k < p.K) pw[(size_t)n * p.K + k] = acc[a][b][r];
+            }
+        }
+
+    if (do_bias) {
+        // thread's column chunk is (tid % CV) for every vector it staged; 256/CV threads share it
+        const int cchunk = tid % CV, rowgrp = tid / CV;   // rowgrp < 256/CV (16 for bf16, 8 for f32)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) bsum[rowgrp][cchunk * VEC + e] = colsum[e];
+        __syncthreads();
+        if (tid < 128) {
+            float t = 0.f;
+            for (int g = 0; g < 256 / CV; ++g) t += bsum[g][tid];
+            if (n0 + tid < p.N) p.part_b[(size_t)split * p.N + n0 + tid] = t;
+        }
+    }
+}
+
+__global__ void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n, int splits) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float t = 0.f;
+    for (int s = 0; s < splits; ++s) t += part[(size_t)s * n + i];
+    out[i] = t;
+}
+
+struct TnPlan { int tiles_n, tiles_k, splits, chunk; size_t bytes; };
+
+TnPlan tn_plan(int M, int N, int K) {
+    TnPlan pl;
+    pl.tiles_n = (N + 127) / 128;
+    pl.tiles_k = (K + 127) / 128;
+    const int tiles = pl.tiles_n * pl.tiles_k;
+    int splits = (1024 + tiles - 1) / tiles;
+    const int max_by_rows = (M + 255) / 256;
+    if (splits > max_by_rows) splits = max_by_rows;
+    if (splits < 1) splits = 1;
+    // keep the partial buffer under 512 MiB
+    while (splits > 1 && (size_t)splits * N * K * 4 > ((size_t)512 << 20)) --splits;
+    int chunk = (M + splits - 1) / splits;
+    chunk = (chunk + 31) / 32 * 32;
+    pl.splits = (M + chunk - 1) / chunk;
+    pl.chunk = chunk;
+    pl.bytes = (size_t)pl.splits * ((size_t)N * K + N) * sizeof(float);
+    return pl;
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int fmmt_linear_fwd(int dtype, int M, int N, int K,
+                               const void* x, int ldx, const void* w, int ldw, const float* bias,
+                               void* y, int ldy, void* y_pre,
+                               int epi, const void* aux, int ldaux,
+                               const void* res, int ldres, const float* rowscale, int rows_per_scale,
+                               void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0) return FMMT_EINVAL;
+    const int vec = dtype == FMMT_BF16 ? 8 : 4;
+    if (dtype != FMMT_BF16 && dtype != FMMT_F32) return FMMT_EINVAL;
+    if (K % vec || N % 4 || ldx % vec || ldw % vec || ldy % 4) return FMMT_EINVAL;
+    if (epi == FMMT_EPI_GELU_BWD && (!aux || ldaux % 4)) return FMMT_EINVAL;
+    if (res && ldres % 4) return FMMT_EINVAL;
+    if (rowscale && rows_per_scale <= 0) return FMMT_EINVAL;
+    if (!aligned16(x) || !aligned16(w) || !aligned16(y) || (bias && !aligned16(bias)) ||
+        (res && !aligned16(res)) || (aux && !aligned16(aux)) || (y_pre && !aligned16(y_pre)))
+        return FMMT_EALIGN;
+    LinArgs a{M, N, K, x, ldx, w, ldw, bias, y, ldy, y_pre, epi, aux, ldaux, res, ldres, rowscale, rows_per_scale, 0};
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    return dtype == FMMT_BF16 ? dispatch_nt<bf16>(a, st) : dispatch_nt<float>(a, st);
+}
+
+extern "C" size_t fmmt_linear_wgrad_workspace(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    return tn_plan(M, N, K).bytes;
+}
+
+extern "C" int fmmt_linear_wgrad(int dtype, int M, int N, int K,
+                                 const void* dy, int lddy, const void* x, int ldx,
+                                 float* dw, float* db, const float* rowscale, int rows_per_scale,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0) return FMMT_EINVAL;
+    if (dtype != FMMT_BF16 && dtype != FMMT_F32) return FMMT_EINVAL;
+    const int vec = dtype == FMMT_BF16 ? 8 : 4;
+    if (N % vec || K % vec || lddy % vec || ldx % vec) return FMMT_EINVAL;
+    if (rowscale && rows_per_scale <= 0) return FMMT_EINVAL;
+    if (!aligned16(dy) || !aligned16(x) || !aligned16(dw) || !aligned16(workspace)) return FMMT_EALIGN;
+    const TnPlan pl = tn_plan(M, N, K);
+    if (workspace_bytes < pl.bytes) return FMMT_EWORKSPACE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    float* part_w = reinterpret_cast<float*>(workspace);
+    float* part_b = db ? part_w + (size_t)pl.splits * N * K : nullptr;
+    TnArgs a{M, N, K, dy, lddy, x, ldx, part_w, part_b, rowscale, rows_per_scale, pl.tiles_k, pl.chunk};
+    dim3 grid(pl.tiles_n * pl.tiles_k, pl.splits);
+    if (dtype == FMMT_BF16) hipLaunchKernelGGL(linear_tn_kernel<bf16>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(linear_tn_kernel<float>, grid, dim3(256), 0, st, a);
+    FMMT_CHECK_LAUNCH();
+    const size_t nw = (size_t)N * K;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, part_w, dw, nw, pl.splits);
+    FMMT_CHECK_LAUNCH();
+    if (db) {
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 255) / 256), dim3(256), 0, st, part_b, db, (size_t)N, pl.splits);
+        FMMT_CHECK_LAUNCH();
+    }
+    return 0;
+}

@@ -1,0 +1,206 @@
+// Small streaming kernels of the hot path: patch im2col / col2im (PatchEmbed's 4x4 stride-4 conv is
+// run as a GEMM on the gathered patches), BatchNorm1d of the embedding head, the cross-modal input
+// embedding (scale + sinusoidal position with the zero-is-padding rule) and an elementwise scale.
+#include "fmmt_common.h"
+#include "../../include/fmmt.h"
+
+namespace {
+
+constexpr int IMG = 224, PS = 4, GRID = 56, KPATCH = 48;
+
+// thread <-> (n, c, y, px): reads 4 contiguous pixels of one image row, moves them to/from
+// cols[(n*3136 + (y/4)*56 + px)][c*16 + (y%4)*4 .. +4]
+template <typename T, bool TO_COLS>
+__global__ void patch_cols_kernel(const T* __restrict__ src, T* __restrict__ dst, size_t total) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int px = (int)(t % GRID);
+    size_t r = t / GRID;
+    const int y = (int)(r % IMG);
+    r /= IMG;
+    const int c = (int)(r % 3);
+    const size_t n = r / 3;
+    const size_t img_off = ((n * 3 + c) * IMG + y) * IMG + (size_t)px * PS;
+    const size_t col_off = ((n * GRID + (y >> 2)) * GRID + px) * KPATCH + c * 16 + (y & 3) * PS;
+    const T* s = TO_COLS ? src + img_off : src + col_off;
+    T* d = TO_COLS ? dst + col_off : dst + img_off;
+    if constexpr (sizeof(T) == 2) *reinterpret_cast<uint2*>(d) = *reinterpret_cast<const uint2*>(s);
+    else *reinterpret_cast<uint4*>(d) = *reinterpret_cast<const uint4*>(s);
+}
+
+template <typename T>
+__global__ void bn1d_fwd_kernel(int n, int C, const T* __restrict__ x, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, float* running_mean, float* running_var,
+                                float momentum, float eps, int training, T* __restrict__ y,
+                                float* save_mean, float* save_invstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float mean, invstd;
+    if (training) {
+        float s = 0.f;
+        for (int r = 0; r < n; ++r) s += to_f32(x[(size_t)r * C + c]);
+        mean = s / n;
+        float q = 0.f;
+        for (int r = 0; r < n; ++r) {
+            const float d = to_f32(x[(size_t)r * C + c]) - mean;
+            q += d * d;
+        }
+        const float var = q / n;
+        invstd = rsqrtf(var + eps);
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (n > 1 ? q / (n - 1) : var);
+    } else {
+        mean = running_mean[c];
+        invstd = rsqrtf(running_var[c] + eps);
+    }
+    if (save_mean) save_mean[c] = mean;
+    if (save_invstd) save_invstd[c] = invstd;
+    const float g = gamma[c] * invstd, b = beta[c] - mean * g;
+    for (int r = 0; r < n; ++r) y[(size_t)r * C + c] = from_f32<T>(to_f32(x[(size_t)r * C + c]) * g + b);
+}
+
+template <typename T>
+__global__ void bn1d_bwd_kernel(int n, int C, const T* __restrict__ dy, const T* __restrict__ x,
+                                const float* __restrict__ gamma, const float* __restrict__ save_mean,
+                                const float* __restrict__ save_invstd, int training, T* __restrict__ dx,
+                                float* dgamma, float* dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float mean = save_mean[c], invstd = save_invstd[c];
+    float sb = 0.f, sg = 0.f;
+    for (int r = 0; r < n; ++r) {
+        const float g = to_f32(dy[(size_t)r * C + c]);
+        sb += g;
+        sg += g * (to_f32(x[(size_t)r * C + c]) - mean) * invstd;
+    }
+    if (dgamma) dgamma[c] = sg;
+    if (dbeta) dbeta[c] = sb;
+    const float k = gamma[c] * invstd;
+    if (training) {
+        const float inv_n = 1.f / n;
+        for (int r = 0; r < n; ++r) {
+            const float xh = (to_f32(x[(size_t)r * C + c]) - mean) * invstd;
+            dx[(size_t)r * C + c] = from_f32<T>(k * (to_f32(dy[(size_t)r * C + c]) - sb * inv_n - xh * sg * inv_n));
+        }
+    } else {
+        for (int r = 0; r < n; ++r) dx[(size_t)r * C + c] = from_f32<T>(k * to_f32(dy[(size_t)r * C + c]));
+    }
+}
+
+template <typename T>
+__global__ void posemb_scale_kernel(int L, int B, int E, const T* __restrict__ x, const float* __restrict__ table,
+                                    float scale, T* __restrict__ y) {
+    constexpr int VEC = Vec<T>::N;
+    const int chunks = E / VEC;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)L * B * chunks) return;
+    const int c = (int)(t % chunks);
+    const size_t row = t / chunks;                  // = time * B + b
+    const int time = (int)(row / B);
+    const int pos = (to_f32(x[row * E]) != 0.f) ? time + 1 : 0;
+    const Vec<T> v = ldvec<T>(x + row * E + c * VEC);
+    Vec<T> o;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o.set(e, scale * v.get(e) + table[(size_t)pos * E + c * VEC + e]);
+    stvec<T>(y + row * E + c * VEC, o);
+}
+
+template <typename T>
+__global__ void scale_kernel(size_t nvec, const T* __restrict__ x, float alpha, T* __restrict__ y) {
+    constexpr int VEC = Vec<T>::N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+        const Vec<T> v = ldvec<T>(x + i * VEC);
+        Vec<T> o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o.set(e, alpha * v.get(e));
+        stvec<T>(y + i * VEC, o);
+    }
+}
+
+bool dt_ok(int dtype) { return dtype == FMMT_BF16 || dtype == FMMT_F32; }
+
+}  // namespace
+
+extern "C" int fmmt_version(void) { return 1; }
+
+extern "C" int fmmt_patch_im2col(int dtype, int n_img, const void* img, void* cols, void* stream) {
+    if (!dt_ok(dtype) || n_img <= 0) return FMMT_EINVAL;
+    const size_t total = (size_t)n_img * 3 * IMG * GRID;
+    dim3 grid((unsigned)((total + 255) / 256));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == FMMT_BF16) hipLaunchKernelGGL((patch_cols_kernel<bf16, true>), grid, dim3(256), 0, st, (const bf16*)img, (bf16*)cols, total);
+    else hipLaunchKernelGGL((patch_cols_kernel<float, true>), grid, dim3(256), 0, st, (const float*)img, (float*)cols, total);
+    FMMT_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int fmmt_patch_col2im(int dtype, int n_img, const void* cols, void* dimg, void* stream) {
+    if (!dt_ok(dtype) || n_img <= 0) return FMMT_EINVAL;
+    const size_t total = (size_t)n_img * 3 * IMG * GRID;
+    dim3 grid((unsigned)((total + 255) / 256));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == FMMT_BF16) hipLaunchKernelGGL((patch_cols_kernel<bf16, false>), grid, dim3(256), 0, st, (const bf16*)cols, (bf16*)dimg, total);
+    else hipLaunchKernelGGL((patch_cols_kernel<float, false>), grid, dim3(256), 0, st, (const float*)cols, (float*)dimg, total);
+    FMMT_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int fmmt_batchnorm1d_fwd(int dtype, int n, int C, const void* x, const float* gamma, const float* beta,
+                                    float* running_mean, float* running_var, float momentum, float eps,
+                                    int training, void* y, float* save_mean, float* save_invstd, void* stream) {
+    if (!dt_ok(dtype) || n <= 0 || C <= 0) return FMMT_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid((C + 63) / 64);
+    if (dtype == FMMT_BF16)
+        hipLaunchKernelGGL(bn1d_fwd_kernel<bf16>, grid, dim3(64), 0, st, n, C, (const bf16*)x, gamma, beta, running_mean,
+                           running_var, momentum, eps, training, (bf16*)y, save_mean, save_invstd);
+    else
+        hipLaunchKernelGGL(bn1d_fwd_kernel<float>, grid, dim3(64), 0, st, n, C, (const float*)x, gamma, beta, running_mean,
+                           running_var, momentum, eps, training, (float*)y, save_mean, save_invstd);
+    FMMT_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int fmmt_batchnorm1d_bwd(int dtype, int n, int C, const void* dy, const void* x, const float* gamma,
+                                    const float* save_mean, const float* save_invstd, int training,
+                                    void* dx, float* dgamma, float* dbeta, void* stream) {
+    if (!dt_ok(dtype) || n <= 0 || C <= 0) return FMMT_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid((C + 63) / 64);
+    if (dtype == FMMT_BF16)
+        hipLaunchKernelGGL(bn1d_bwd_kernel<bf16>, grid, dim3(64), 0, st, n, C, (const bf16*)dy, (const bf16*)x, gamma,
+                           save_mean, save_invstd, training, (bf16*)dx, dgamma, dbeta);
+    else
+        hipLaunchKernelGGL(bn1d_bwd_kernel<float>, grid, dim3(64), 0, st, n, C, (const float*)dy, (const float*)x, gamma,
+                           save_mean, save_invstd, training, (float*)dx, dgamma, dbeta);
+    FMMT_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int fmmt_posemb_scale_fwd(int dtype, int L, int B, int E, const void* x, const float* table,
+                                     float scale, void* y, void* stream) {
+    if (!dt_ok(dtype) || L <= 0 || B <= 0 || E <= 0) return FMMT_EINVAL;
+    const int vec = dtype == FMMT_BF16 ? 8 : 4;
+    if (E % vec) return FMMT_EINVAL;
+    const size_t total = (size_t)L * B * (E / vec);
+    dim3 grid((unsigned)((total + 255) / 256));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == FMMT_BF16) hipLaunchKernelGGL(posemb_scale_kernel<bf16>, grid, dim3(256), 0, st, L, B, E, (const bf16*)x, table, scale, (bf16*)y);
+    else hipLaunchKernelGGL(posemb_scale_kernel<float>, grid, dim3(256), 0, st, L, B, E, (const float*)x, table, scale, (float*)y);
+    FMMT_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int fmmt_scale(int dtype, size_t n, const void* x, float alpha, void* y, void* stream) {
+    if (!dt_ok(dtype) || n == 0) return FMMT_EINVAL;
+    const int vec = dtype == FMMT_BF16 ? 8 : 4;
+    if (n % vec) return FMMT_EINVAL;
+    const size_t nvec = n / vec;
+    size_t blocks = (nvec + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == FMMT_BF16) hipLaunchKernelGGL(scale_kernel<bf16>, dim3((unsigned)blocks), dim3(256), 0, st, nvec, (const bf16*)x, alpha, (bf16*)y);
+    else hipLaunchKernelGGL(scale_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, nvec, (const float*)x, alpha, (float*)y);
+    FMMT_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,383 @@
+"""Host side of the C ABI: torch.autograd.Functions whose forward/backward are calls into
+libfmmt_hip.so through ctypes (facialmmt_amd/_lib.py).  PyTorch is used for what it is good at here
+-- device memory (caching allocator), streams, autograd bookkeeping -- never for the arithmetic of
+the hot path.  Every op raises if the library is missing or a launch fails (no fallback)."""
+from __future__ import annotations
+
+import math
+
+import torch
+from torch.autograd import Function
+
+from . import _lib
+from ._lib import EPI_GELU, EPI_GELU_BWD, EPI_NONE, check, dtype_code
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _need_cuda(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise _lib.FmmtError(f"{what}: the hot path runs on the GPU only (got a {t.device} tensor); "
+                             f"the CPU restatement lives in oracle/ and is test infrastructure")
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+# ------------------------------------------------------------------------------------------------
+# raw launch helpers (no autograd)
+# ------------------------------------------------------------------------------------------------
+def linear_raw(x2, w, bias, *, epi=EPI_NONE, y_pre=None, aux=None, res=None, rowscale=None, rows_per_scale=1):
+    """y[M,N] = epi(x2[M,K] @ w[N,K]^T + bias) ; y = res + rowscale*y.  x2, w same dtype, contiguous."""
+    M, K = x2.shape
+    N = w.shape[0]
+    y = torch.empty((M, N), dtype=x2.dtype, device=x2.device)
+    lib = _lib.load()
+    rc = lib.fmmt_linear_fwd(dtype_code(x2.dtype), M, N, K, _p(x2), K, _p(w), K, _p(bias), _p(y), N, _p(y_pre),
+                             epi, _p(aux), N, _p(res), N, _p(rowscale), rows_per_scale, _st())
+    check(rc, f"fmmt_linear_fwd(M={M},N={N},K={K})")
+    return y
+
+
+def wgrad_raw(dy2, x2, want_bias, rowscale=None, rows_per_scale=1):
+    """dw[N,K] fp32 = (s*dy2)^T @ x2 ; db[N] fp32 = colsum(s*dy2)."""
+    M, N = dy2.shape
+    K = x2.shape[1]
+    lib = _lib.load()
+    dw = torch.empty((N, K), dtype=torch.float32, device=dy2.device)
+    db = torch.empty((N,), dtype=torch.float32, device=dy2.device) if want_bias else None
+    nbytes = lib.fmmt_linear_wgrad_workspace(M, N, K)
+    ws = _ws(nbytes, dy2.device)
+    rc = lib.fmmt_linear_wgrad(dtype_code(dy2.dtype), M, N, K, _p(dy2), N, _p(x2), K, _p(dw), _p(db),
+                               _p(rowscale), rows_per_scale, _p(ws), nbytes, _st())
+    check(rc, f"fmmt_linear_wgrad(M={M},N={N},K={K})")
+    return dw, db
+
+
+def _lp(w: torch.Tensor, dtype) -> torch.Tensor:
+    """parameter in the activation dtype (fp32 master -> bf16 shadow in throughput mode)"""
+    w = w.detach()
+    return w if w.dtype == dtype else w.to(dtype)
+
+
+# ------------------------------------------------------------------------------------------------
+# Linear:  y = res + rowscale * (x W^T + b)
+# ------------------------------------------------------------------------------------------------
+class LinearFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, res, rowscale, rows_per_scale):
+        _need_cuda(x, "linear")
+        K = x.shape[-1]
+        x2 = x.reshape(-1, K).contiguous()
+        w = _lp(weight, x.dtype).contiguous()
+        res2 = res.reshape(-1, weight.shape[0]).contiguous() if res is not None else None
+        y = linear_raw(x2, w, bias.detach() if bias is not None else None, res=res2, rowscale=rowscale,
+                       rows_per_scale=rows_per_scale)
+        ctx.save_for_backward(x2, w, rowscale)
+        ctx.has_bias = bias is not None
+        ctx.has_res = res is not None
+        ctx.rps = rows_per_scale
+        ctx.xshape = x.shape
+        return y.reshape(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, rowscale = ctx.saved_tensors
+        N = w.shape[0]
+        dy2 = dy.reshape(-1, N).contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = linear_raw(dy2, w.t().contiguous(), None, rowscale=rowscale, rows_per_scale=ctx.rps).reshape(ctx.xshape)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw, db = wgrad_raw(dy2, x2, ctx.has_bias, rowscale, ctx.rps)
+        dres = dy if ctx.has_res else None
+        return dx, dw, db, dres, None, None
+
+
+def linear(x, weight, bias=None, res=None, rowscale=None, rows_per_scale=1):
+    return LinearFn.apply(x, weight, bias, res, rowscale, rows_per_scale)
+
+
+# ------------------------------------------------------------------------------------------------
+# MLP:  y = res + rowscale * (gelu(x W1^T + b1) W2^T + b2)      (Mlp of Swin; fc1/gelu/fc2 of the
+# cross-modal layer).  GELU lives in fc1's epilogue, GELU' in the epilogue of fc2's input-gradient GEMM.
+# ------------------------------------------------------------------------------------------------
+class MlpFn(Function):
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, res, rowscale, rows_per_scale):
+        _need_cuda(x, "mlp")
+        K = x.shape[-1]
+        x2 = x.reshape(-1, K).contiguous()
+        w1l, w2l = _lp(w1, x.dtype).contiguous(), _lp(w2, x.dtype).contiguous()
+        train = any(ctx.needs_input_grad)      # grad mode is off inside Function.forward; this is the reliable signal
+        h_pre = torch.empty((x2.shape[0], w1.shape[0]), dtype=x.dtype, device=x.device) if train else None
+        h = linear_raw(x2, w1l, b1.detach(), epi=EPI_GELU, y_pre=h_pre)
+        res2 = res.reshape(-1, w2.shape[0]).contiguous() if res is not None else None
+        y = linear_raw(h, w2l, b2.detach(), res=res2, rowscale=rowscale, rows_per_scale=rows_per_scale)
+        ctx.save_for_backward(x2, w1l, w2l, h_pre, h, rowscale)
+        ctx.rps = rows_per_scale
+        ctx.has_res = res is not None
+        ctx.xshape = x.shape
+        return y.reshape(*x.shape[:-1], w2.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w1l, w2l, h_pre, h, rowscale = ctx.saved_tensors
+        dy2 = dy.reshape(-1, w2l.shape[0]).contiguous()
+        # d(h_pre) = (s * dy @ W2) * gelu'(h_pre)   [fused epilogue]
+        dh = linear_raw(dy2, w2l.t().contiguous(), None, epi=EPI_GELU_BWD, aux=h_pre, rowscale=rowscale,
+                        rows_per_scale=ctx.rps)
+        dw2, db2 = wgrad_raw(dy2, h, True, rowscale, ctx.rps)
+        dx = linear_raw(dh, w1l.t().contiguous(), None).reshape(ctx.xshape) if ctx.needs_input_grad[0] else None
+        dw1, db1 = wgrad_raw(dh, x2, True)
+        return dx, dw1, db1, dw2, db2, (dy if ctx.has_res else None), None, None
+
+
+def mlp(x, w1, b1, w2, b2, res=None, rowscale=None, rows_per_scale=1):
+    return MlpFn.apply(x, w1, b1, w2, b2, res, rowscale, rows_per_scale)
+
+
+# ------------------------------------------------------------------------------------------------
+# LayerNorm (optionally with the PatchMerging 2x2 gather folded in)
+# ------------------------------------------------------------------------------------------------
+class LayerNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, merge_hw):
+        _need_cuda(x, "layer_norm")
+        lib = _lib.load()
+        x = x.contiguous()
+        if merge_hw:
+            n, L, Cq = x.shape
+            assert L == merge_hw * merge_hw
+            M, C = n * (merge_hw // 2) ** 2, 4 * Cq
+            out_shape = (n, (merge_hw // 2) ** 2, C)
+        else:
+            C = x.shape[-1]
+            M = x.numel() // C
+            out_shape = x.shape
+        y = torch.empty(out_shape, dtype=x.dtype, device=x.device)
+        mean = torch.empty(M, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+        g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        rc = lib.fmmt_layernorm_fwd(dtype_code(x.dtype), M, C, _p(x), _p(g), _p(b), eps, _p(y), _p(mean), _p(rstd),
+                                    merge_hw, _st())
+        check(rc, f"fmmt_layernorm_fwd(M={M},C={C},merge={merge_hw})")
+        ctx.save_for_backward(x, mean, rstd, g)
+        ctx.dims = (M, C, merge_hw)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, g = ctx.saved_tensors
+        M, C, merge_hw = ctx.dims
+        lib = _lib.load()
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dg = torch.empty(C, dtype=torch.float32, device=x.device)
+        db = torch.empty(C, dtype=torch.float32, device=x.device)
+        nbytes = lib.fmmt_layernorm_bwd_workspace(C)
+        ws = _ws(nbytes, x.device)
+        rc = lib.fmmt_layernorm_bwd(dtype_code(x.dtype), M, C, _p(dy), _p(x), _p(mean), _p(rstd), _p(g), None, _p(dx),
+                                    _p(dg), _p(db), merge_hw, _p(ws), nbytes, _st())
+        check(rc, f"fmmt_layernorm_bwd(M={M},C={C},merge={merge_hw})")
+        return dx, dg, db, None, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-5, merge_hw=0):
+    return LayerNormFn.apply(x, gamma, beta, eps, merge_hw)
+
+
+# ------------------------------------------------------------------------------------------------
+# (shifted-)window attention core on token-order qkv
+# ------------------------------------------------------------------------------------------------
+class WindowAttnCoreFn(Function):
+    @staticmethod
+    def forward(ctx, qkv, table, index_i32, mask, n_img, H, W, num_heads, shift, scale):
+        _need_cuda(qkv, "window_attention")
+        lib = _lib.load()
+        qkv = qkv.contiguous()
+        C = qkv.shape[-1] // 3
+        nW = (H // 7) * (W // 7)
+        out = torch.empty((n_img * H * W, C), dtype=qkv.dtype, device=qkv.device)
+        lse = torch.empty((n_img * nW * num_heads * 49,), dtype=torch.float32, device=qkv.device)
+        tab = table.detach().float().contiguous()
+        m = mask.detach().float().contiguous() if mask is not None else None
+        nWm = m.shape[0] if m is not None else 0
+        rc = lib.fmmt_window_attn_fwd(dtype_code(qkv.dtype), n_img, H, W, C, num_heads, shift, _p(qkv), _p(tab),
+                                      _p(index_i32), _p(m), nWm, scale, _p(out), _p(lse), _st())
+        check(rc, f"fmmt_window_attn_fwd(n={n_img},H={H},W={W},C={C},heads={num_heads},shift={shift})")
+        ctx.save_for_backward(qkv, out, lse, tab, index_i32, m)
+        ctx.cfg = (n_img, H, W, C, num_heads, shift, scale, nWm)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse, tab, index_i32, m = ctx.saved_tensors
+        n_img, H, W, C, num_heads, shift, scale, nWm = ctx.cfg
+        lib = _lib.load()
+        dout = dout.contiguous()
+        dqkv = torch.empty_like(qkv)
+        dtable = torch.empty_like(tab)
+        nbytes = lib.fmmt_window_attn_bwd_workspace(num_heads)
+        ws = _ws(nbytes, qkv.device)
+        rc = lib.fmmt_window_attn_bwd(dtype_code(qkv.dtype), n_img, H, W, C, num_heads, shift, _p(qkv), _p(out), _p(dout),
+                                      _p(lse), _p(tab), _p(index_i32), _p(m), nWm, scale, _p(dqkv), _p(dtable),
+                                      _p(ws), nbytes, _st())
+        check(rc, "fmmt_window_attn_bwd")
+        return dqkv, dtable, None, None, None, None, None, None, None, None
+
+
+def window_attn_core(qkv, table, index_i32, mask, n_img, H, W, num_heads, shift, scale):
+    return WindowAttnCoreFn.apply(qkv, table, index_i32, mask, n_img, H, W, num_heads, shift, scale)
+
+
+# ------------------------------------------------------------------------------------------------
+# cross-modal multi-head attention core (time-major)
+# ------------------------------------------------------------------------------------------------
+class MhaCoreFn(Function):
+    """q: (Lq,B,E); kv: either a packed (Lk,B,2E) tensor [k | v] (v is None) or separate k, v (Lk,B,E)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, num_heads, scale, dropout_p, seed):
+        _need_cuda(q, "multihead_attention")
+        lib = _lib.load()
+        q = q.contiguous()
+        Lq, B, E = q.shape
+        packed = v is None
+        k = k.contiguous()
+        if packed:
+            Lk, ldkv = k.shape[0], 2 * E
+            kp, vp = k.data_ptr(), k.data_ptr() + E * k.element_size()
+        else:
+            v = v.contiguous()
+            Lk, ldkv = k.shape[0], E
+            kp, vp = k.data_ptr(), v.data_ptr()
+        out = torch.empty_like(q)
+        lse = torch.empty((B * num_heads * Lq,), dtype=torch.float32, device=q.device)
+        rc = lib.fmmt_mha_fwd(dtype_code(q.dtype), Lq, Lk, B, E, num_heads, _p(q), E, kp, vp, ldkv, scale,
+                              dropout_p, seed, _p(out), E, _p(lse), _st())
+        check(rc, f"fmmt_mha_fwd(Lq={Lq},Lk={Lk},B={B},E={E},heads={num_heads})")
+        ctx.save_for_backward(q, k, v, out, lse)
+        ctx.cfg = (Lq, Lk, B, E, num_heads, scale, dropout_p, seed, packed, ldkv)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, lse = ctx.saved_tensors
+        Lq, Lk, B, E, num_heads, scale, dropout_p, seed, packed, ldkv = ctx.cfg
+        lib = _lib.load()
+        dout = dout.contiguous()
+        dq = torch.empty_like(q)
+        dk = torch.empty_like(k)
+        if packed:
+            kp, vp = k.data_ptr(), k.data_ptr() + E * k.element_size()
+            dkp, dvp, dv = dk.data_ptr(), dk.data_ptr() + E * k.element_size(), None
+        else:
+            dv = torch.empty_like(v)
+            kp, vp, dkp, dvp = k.data_ptr(), v.data_ptr(), dk.data_ptr(), dv.data_ptr()
+        rc = lib.fmmt_mha_bwd(dtype_code(q.dtype), Lq, Lk, B, E, num_heads, _p(q), E, kp, vp, ldkv, scale, dropout_p,
+                              seed, _p(out), _p(dout), E, _p(lse), _p(dq), E, dkp, dvp, ldkv, _st())
+        check(rc, "fmmt_mha_bwd")
+        return dq, dk, dv, None, None, None, None
+
+
+def mha_core(q, k, v, num_heads, scale, dropout_p=0.0, seed=0):
+    return MhaCoreFn.apply(q, k, v, num_heads, scale, float(dropout_p), int(seed))
+
+
+# ------------------------------------------------------------------------------------------------
+# PatchEmbed gather, BatchNorm1d, cross-modal input embedding
+# ------------------------------------------------------------------------------------------------
+class PatchIm2colFn(Function):
+    @staticmethod
+    def forward(ctx, img):
+        _need_cuda(img, "patch_embed")
+        lib = _lib.load()
+        img = img.contiguous()
+        n = img.shape[0]
+        cols = torch.empty((n * 3136, 48), dtype=img.dtype, device=img.device)
+        check(lib.fmmt_patch_im2col(dtype_code(img.dtype), n, _p(img), _p(cols), _st()), "fmmt_patch_im2col")
+        ctx.n = n
+        return cols
+
+    @staticmethod
+    def backward(ctx, dcols):
+        lib = _lib.load()
+        dcols = dcols.contiguous()
+        dimg = torch.empty((ctx.n, 3, 224, 224), dtype=dcols.dtype, device=dcols.device)
+        check(lib.fmmt_patch_col2im(dtype_code(dcols.dtype), ctx.n, _p(dcols), _p(dimg), _st()), "fmmt_patch_col2im")
+        return dimg
+
+
+def patch_im2col(img):
+    return PatchIm2colFn.apply(img)
+
+
+class BatchNorm1dFn(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, training):
+        _need_cuda(x, "batch_norm")
+        lib = _lib.load()
+        x = x.contiguous()
+        n, C = x.shape
+        y = torch.empty_like(x)
+        sm = torch.empty(C, dtype=torch.float32, device=x.device)
+        si = torch.empty(C, dtype=torch.float32, device=x.device)
+        g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        rc = lib.fmmt_batchnorm1d_fwd(dtype_code(x.dtype), n, C, _p(x), _p(g), _p(b), _p(running_mean), _p(running_var),
+                                      momentum, eps, int(training), _p(y), _p(sm), _p(si), _st())
+        check(rc, "fmmt_batchnorm1d_fwd")
+        ctx.save_for_backward(x, g, sm, si)
+        ctx.training = bool(training)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g, sm, si = ctx.saved_tensors
+        lib = _lib.load()
+        dy = dy.contiguous()
+        n, C = x.shape
+        dx = torch.empty_like(x)
+        dg = torch.empty(C, dtype=torch.float32, device=x.device)
+        db = torch.empty(C, dtype=torch.float32, device=x.device)
+        rc = lib.fmmt_batchnorm1d_bwd(dtype_code(x.dtype), n, C, _p(dy), _p(x), _p(g), _p(sm), _p(si), int(ctx.training),
+                                      _p(dx), _p(dg), _p(db), _st())
+        check(rc, "fmmt_batchnorm1d_bwd")
+        return dx, dg, db, None, None, None, None, None
+
+
+def batch_norm_1d(x, gamma, beta, running_mean, running_var, momentum, eps, training):
+    return BatchNorm1dFn.apply(x, gamma, beta, running_mean, running_var, momentum, eps, training)
+
+
+class PosEmbScaleFn(Function):
+    @staticmethod
+    def forward(ctx, x, table, scale):
+        _need_cuda(x, "positional_embedding")
+        lib = _lib.load()
+        x = x.contiguous()
+        L, B, E = x.shape
+        y = torch.empty_like(x)
+        check(lib.fmmt_posemb_scale_fwd(dtype_code(x.dtype), L, B, E, _p(x), _p(table), scale, _p(y), _st()),
+              f"fmmt_posemb_scale_fwd(L={L},B={B},E={E})")
+        ctx.scale = scale
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        check(lib.fmmt_scale(dtype_code(dy.dtype), dy.numel(), _p(dy), ctx.scale, _p(dx), _st()), "fmmt_scale")
+        return dx, None, None
+
+
+def posemb_scale(x, table, scale):
+    return PosEmbScaleFn.apply(x, table, float(scale))

@@ -1,0 +1,179 @@
+/* libfmmt_hip -- C ABI of the MI355X (gfx950) hot path of FacialMMT.
+ *
+ * Drop-in boundary.  The reference has no native code: the interface each entry
+ * point replaces is a piece of `torch.nn` module maths, cited per function as file:line relative to
+ * the reference tree.  Rules of the ABI:
+ *   - plain C: device pointers, sizes, a hipStream_t passed as void*; no torch / C++ types;
+ *   - nothing is allocated or freed inside: outputs, saved-for-backward tensors and workspaces are
+ *     caller-owned device buffers (the Python host allocates them with torch's caching allocator);
+ *   - every launch is asynchronous on `stream`; no global mutable state (re-entrant per stream);
+ *   - return value: 0 on success, a positive hipError_t from the launch, or a negative FMMT_E* for
+ *     argument errors (shape/alignment) -- never a silent fallback;
+ *   - `dtype` selects the activation element type: FMMT_F32 (parity mode, exact-fp32 MFMA/VALU) or
+ *     FMMT_BF16 (throughput mode: bf16 storage, fp32 accumulate / softmax / statistics).
+ *     Parameters that are *reduced into* (weight/bias/affine gradients, statistics) are always fp32.
+ *   - all matrices are row-major; "ld" = leading dimension in elements; pointers 16-byte aligned,
+ *     channel counts multiples of 8 (bf16) / 4 (f32).
+ */
+#ifndef FMMT_H
+#define FMMT_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FMMT_F32 0
+#define FMMT_BF16 1
+
+#define FMMT_EINVAL (-1)   /* bad shape / unsupported size */
+#define FMMT_EALIGN (-2)   /* pointer or leading dimension not 16-byte aligned */
+#define FMMT_EWORKSPACE (-3) /* workspace too small */
+
+/* epilogue flags of fmmt_linear_fwd */
+#define FMMT_EPI_GELU 1       /* y = gelu(acc + bias)          (nn.GELU / F.gelu, exact erf form) */
+#define FMMT_EPI_GELU_BWD 2   /* y = acc * gelu'(aux)          (backward of the line above)        */
+
+int fmmt_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Linear layers.  Replaces nn.Linear / F.linear at every site of the hot path:
+ *   Swin_Transformer.py:19-21,25-28 (Mlp fc1/fc2), :105-107,120,142 (qkv / proj), :304,326
+ *   (PatchMerging.reduction), :493 (head Linear(37632,512)); multihead_attention.py:152-158
+ *   (_in_proj slices), :130 (out_proj); CrossmodalTransformer.py:129-130,156-158 (fc1/fc2).
+ *
+ * y[M,N] = epi( x[M,K] . w[N,K]^T + bias[N] )  then  y = res[M,N] + rowscale[m / rows_per_scale] * y
+ *   - w is the nn.Linear weight layout (out_features, in_features), element type = dtype;
+ *   - bias (fp32) may be NULL; res (dtype) may be NULL; rowscale (fp32, DropPath per-sample multiplier,
+ *     Swin_Transformer.py:267-268) may be NULL;
+ *   - FMMT_EPI_GELU: if y_pre != NULL the pre-activation (acc + bias) is stored there as well;
+ *   - FMMT_EPI_GELU_BWD: aux[M,N] (dtype) holds the saved pre-activation.
+ * The same entry point computes input gradients: dx[M,K] = dy[M,N] . (w^T)[K,N]^T with a transposed
+ * copy of the weight.  K % 8 == 0 (bf16) / K % 4 == 0 (f32), N % 4 == 0.
+ */
+int fmmt_linear_fwd(int dtype, int M, int N, int K,
+                    const void* x, int ldx, const void* w, int ldw, const float* bias,
+                    void* y, int ldy, void* y_pre,
+                    int epi, const void* aux, int ldaux,
+                    const void* res, int ldres, const float* rowscale, int rows_per_scale,
+                    void* stream);
+
+/* Weight/bias gradients of the same layers (autograd of F.linear):
+ *   dw[N,K] (fp32) = sum_m s_m * dy[m,N]^T x[m,K],   db[N] (fp32) = sum_m s_m * dy[m,N]   (db may be NULL)
+ * with s_m = rowscale[m / rows_per_scale] (NULL -> 1).  The contraction over M is split across
+ * workgroups into fp32 partials in `workspace` and combined in a fixed order (deterministic).
+ * Query the workspace size first.  N % 8 == 0 and K % 8 == 0 (bf16) / % 4 (f32). */
+size_t fmmt_linear_wgrad_workspace(int M, int N, int K);
+int fmmt_linear_wgrad(int dtype, int M, int N, int K,
+                      const void* dy, int lddy, const void* x, int ldx,
+                      float* dw, float* db, const float* rowscale, int rows_per_scale,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LayerNorm.  Replaces nn.LayerNorm (eps 1e-5) at Swin_Transformer.py:198,204,239,268 (norm1/2),
+ * :305,325 (PatchMerging.norm over the 2x2 concat), :410,421 (PatchEmbed.norm), :491 (head norm);
+ * CrossmodalTransformer.py:131,144-150,155,87-88.
+ *
+ * y[r,:] = (x_r - mean_r) * rstd_r * gamma + beta; mean/rstd (fp32, [M]) are saved for backward.
+ * merge_hw > 0 selects the PatchMerging gather (Swin_Transformer.py:316-323): x is the
+ * (n, H=W=merge_hw, C/4) token grid, logical row r = (n, h2, w2) and logical channel block q of
+ * width C/4 reads token (2*h2 + (q&1), 2*w2 + (q>>1)); y is the dense [M, C] matrix.
+ */
+int fmmt_layernorm_fwd(int dtype, int M, int C, const void* x, const float* gamma, const float* beta,
+                       float eps, void* y, float* mean, float* rstd, int merge_hw, void* stream);
+
+/* dx = add + LN'(dy) ; dgamma/dbeta (fp32 [C]) are reduced deterministically through `workspace`
+ * (fmmt_layernorm_bwd_workspace(C) bytes).  `add` (dtype, same layout as dx) may be NULL.  With merge_hw > 0, dy is
+ * the dense [M, C] gradient and dx / add use the (n, H, W, C/4) token-grid layout (the scatter is a
+ * permutation, every element is written once). */
+size_t fmmt_layernorm_bwd_workspace(int C);
+int fmmt_layernorm_bwd(int dtype, int M, int C, const void* dy, const void* x, const float* mean,
+                       const float* rstd, const float* gamma, const void* add, void* dx,
+                       float* dgamma, float* dbeta, int merge_hw,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (Shifted-)window attention core.  Replaces, in one kernel and without materialising anything:
+ * torch.roll (Swin_Transformer.py:244,261), window_partition (:33-45,249-250), the per-head
+ * q*scale @ k^T + relative_position_bias_table[relative_position_index] + attn_mask -> softmax ->
+ * @ v of WindowAttention.forward (:120-141) and window_reverse (:48-62,256-257).
+ *
+ * qkv : [n_img * H * W, 3C] token order (output of the qkv Linear applied per token), dtype
+ * out : [n_img * H * W, C]  token order, head h occupies channels [h*hd, (h+1)*hd), hd = C/num_heads (== 32)
+ * lse : fp32 [n_img * nW * num_heads * 49] log-sum-exp per query row (saved for backward)
+ * table: fp32 [(2*7-1)^2, num_heads]; index: int32 [49*49]; mask: fp32 [nW_mask,49,49] or NULL,
+ *        window b_ uses mask[b_ % nW_mask] (WindowAttention.forward's broadcast, :131-134)
+ * window size is 7 (swin_conf.yaml:20); H, W multiples of 7; shift in [0,7).
+ */
+int fmmt_window_attn_fwd(int dtype, int n_img, int H, int W, int C, int num_heads, int shift,
+                         const void* qkv, const float* table, const int32_t* index,
+                         const float* mask, int nW_mask, float scale,
+                         void* out, float* lse, void* stream);
+
+/* dqkv [n_img*H*W, 3C] (dtype, every element written); dtable fp32 [(169), num_heads] (overwritten).
+ * workspace: fmmt_window_attn_bwd_workspace(num_heads) bytes. */
+size_t fmmt_window_attn_bwd_workspace(int num_heads);
+int fmmt_window_attn_bwd(int dtype, int n_img, int H, int W, int C, int num_heads, int shift,
+                         const void* qkv, const void* out, const void* dout, const float* lse,
+                         const float* table, const int32_t* index, const float* mask, int nW_mask,
+                         float scale, void* dqkv, float* dtable,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Multi-head attention core of the cross-modal encoder.  Replaces multihead_attention.py:85
+ * (q *= scaling), :94-98 (head split), :109 (bmm), :121 (fp32 softmax), :124 (dropout), :126 (bmm),
+ * :128 (head merge).  Time-major operands: q [Lq, B, E], k / v [Lk, B, ldkv] (k and v may be column
+ * slices of one packed projection: pass the slice pointers and the shared row pitch ldkv).
+ * head_dim = E / num_heads must be 64 or 32.  Dropout: keep-mask = hash(seed, element) >= p, kept
+ * probabilities scaled by 1/(1-p); p == 0 disables.  The head-averaged weights the reference also
+ * returns (:133-134) are discarded by every caller (CrossmodalTransformer.py:147,151) and are not produced.
+ */
+int fmmt_mha_fwd(int dtype, int Lq, int Lk, int B, int E, int num_heads,
+                 const void* q, int ldq, const void* k, const void* v, int ldkv, float scale,
+                 float dropout_p, uint64_t seed, void* out, int ldo, float* lse, void* stream);
+int fmmt_mha_bwd(int dtype, int Lq, int Lk, int B, int E, int num_heads,
+                 const void* q, int ldq, const void* k, const void* v, int ldkv, float scale,
+                 float dropout_p, uint64_t seed, const void* out, const void* dout, int ldo,
+                 const float* lse, void* dq, int lddq, void* dk, void* dv, int lddkv, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * PatchEmbed.  Conv2d(3,96,k=4,s=4) + flatten + transpose (Swin_Transformer.py:407,419) has
+ * non-overlapping 4x4 patches, so it is exactly a Linear over the gathered patches:
+ *   cols = im2col(img)  [n*3136, 48], column order (c, ky, kx) == proj.weight.view(96, 48);
+ *   fmmt_linear_fwd(cols, proj.weight.view(96,48), proj.bias) ; fmmt_layernorm_fwd (norm, :420-421).
+ * img: [n, 3, 224, 224] NCHW (dtype).  col2im is the exact inverse permutation (every pixel belongs
+ * to one patch) and turns d(cols) into d(img).
+ */
+int fmmt_patch_im2col(int dtype, int n_img, const void* img, void* cols, void* stream);
+int fmmt_patch_col2im(int dtype, int n_img, const void* cols, void* dimg, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * BatchNorm1d(512) of the embedding head (Swin_Transformer.py:494).  x,y: [n, C] (dtype).
+ * training != 0: batch statistics (biased variance for normalisation), running_mean/var updated
+ * in place with `momentum` (unbiased variance), save_mean/save_invstd written for backward.
+ * training == 0: running statistics.
+ */
+int fmmt_batchnorm1d_fwd(int dtype, int n, int C, const void* x, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, float momentum, float eps,
+                         int training, void* y, float* save_mean, float* save_invstd, void* stream);
+int fmmt_batchnorm1d_bwd(int dtype, int n, int C, const void* dy, const void* x, const float* gamma,
+                         const float* save_mean, const float* save_invstd, int training,
+                         void* dx, float* dgamma, float* dbeta, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Cross-modal input embedding.  Replaces `embed_scale * x_in + embed_positions(x_in[..., 0])`
+ * (CrossmodalTransformer.py:63-66,71-74; position_embedding.py:8-27,63-76): position of (t, b) is
+ * t+1 where x[t,b,0] != 0 and 0 (the zeroed padding row of the table) otherwise.
+ * x,y: [L, B, E] time-major (dtype); table: fp32 [>= L+1, E].
+ */
+int fmmt_posemb_scale_fwd(int dtype, int L, int B, int E, const void* x, const float* table,
+                          float scale, void* y, void* stream);
+
+/* y = alpha * x elementwise (backward of the embedding scale); n elements, n % 8 == 0. */
+int fmmt_scale(int dtype, size_t n, const void* x, float alpha, void* y, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

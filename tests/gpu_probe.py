@@ -1,0 +1,274 @@
+"""Development probe (not a pytest file): runs every C-ABI entry point against a plain torch
+reference on the GPU and prints max errors without stopping at the first failure.
+Usage on the GPU box:  python tests/gpu_probe.py > gpurun_out/probe.log 2>&1"""
+import os
+import sys
+import time
+import traceback
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from facialmmt_amd import ops, synth  # noqa: E402
+from facialmmt_amd._lib import EPI_GELU, EPI_GELU_BWD  # noqa: E402
+from oracle import crossmodal as OC  # noqa: E402
+from oracle import swin as OS  # noqa: E402
+
+dev = torch.device("cuda:0")
+RES = []
+
+
+def rnd(name, shape, seed=0, scale=1.0, dtype=torch.float32):
+    return (synth.tensor(name, shape, seed=seed) * scale).to(dev).to(dtype)
+
+
+def report(name, got, ref, tol):
+    got, ref = got.float(), ref.float()
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    ok = err <= tol * max(scale, 1e-6) and torch.isfinite(got).all().item()
+    RES.append((name, ok))
+    print(f"{'OK  ' if ok else 'FAIL'} {name:58s} max|err|={err:.3e} ref_scale={scale:.3e} tol={tol:g}", flush=True)
+
+
+def section(fn):
+    try:
+        fn()
+    except Exception:
+        RES.append((fn.__name__, False))
+        print(f"EXC  {fn.__name__}")
+        traceback.print_exc()
+    torch.cuda.synchronize()
+
+
+def t_linear():
+    for dt, tol in ((torch.float32, 2e-5), (torch.bfloat16, 2e-2)):
+        for (M, N, K) in [(200, 96, 96), (333, 288, 96), (128, 128, 64), (1000, 384, 96), (77, 96, 384), (50, 512, 37632 // 8), (130, 768, 3072)]:
+            x = rnd("x", (M, K), 1, dtype=dt)
+            w = rnd("w", (N, K), 2, K ** -0.5, dtype=dt)
+            b = rnd("b", (N,), 3, 0.1)
+            ref = x.double() @ w.double().t() + b.double()
+            report(f"linear {dt} {M}x{N}x{K}", ops.linear_raw(x, w, b), ref, tol)
+        M, N, K = 300, 384, 96
+        x = rnd("x", (M, K), 1, dtype=dt)
+        w = rnd("w", (N, K), 2, K ** -0.5, dtype=dt)
+        b = rnd("b", (N,), 3, 0.1)
+        pre = x.double() @ w.double().t() + b.double()
+        ypre = torch.empty((M, N), dtype=dt, device=dev)
+        y = ops.linear_raw(x, w, b, epi=EPI_GELU, y_pre=ypre)
+        report(f"linear gelu {dt}", y, OS.gelu_erf(pre), tol)
+        report(f"linear gelu pre {dt}", ypre, pre, tol)
+        res = rnd("res", (M, N), 4, dtype=dt)
+        rs = rnd("rs", (3,), 5).abs() + 0.5
+        y = ops.linear_raw(x, w, b, res=res, rowscale=rs, rows_per_scale=100)
+        report(f"linear res+rowscale {dt}", y, res.double() + rs.double().repeat_interleave(100)[:, None] * pre, tol)
+        aux = rnd("aux", (M, N), 6, dtype=dt)
+        a64 = aux.double().requires_grad_(True)
+        g = torch.autograd.grad(OS.gelu_erf(a64).sum(), a64)[0]
+        y = ops.linear_raw(x, w, None, epi=EPI_GELU_BWD, aux=aux)
+        report(f"linear gelu_bwd {dt}", y, (x.double() @ w.double().t()) * g, tol)
+
+
+def t_wgrad():
+    for dt, tol in ((torch.float32, 2e-5), (torch.bfloat16, 2e-2)):
+        for (M, N, K) in [(500, 96, 96), (3136, 288, 96), (777, 384, 96), (1000, 96, 384), (100, 512, 1024), (6272, 96, 48)]:
+            dy = rnd("dy", (M, N), 1, dtype=dt)
+            x = rnd("x", (M, K), 2, dtype=dt)
+            dw, db = ops.wgrad_raw(dy, x, True)
+            report(f"wgrad dw {dt} {M}x{N}x{K}", dw, dy.double().t() @ x.double(), tol)
+            report(f"wgrad db {dt} {M}x{N}x{K}", db, dy.double().sum(0), tol)
+        M, N, K = 600, 192, 96
+        dy = rnd("dy", (M, N), 1, dtype=dt)
+        x = rnd("x", (M, K), 2, dtype=dt)
+        rs = rnd("rs", (6,), 5).abs() + 0.5
+        dw, db = ops.wgrad_raw(dy, x, True, rs, 100)
+        s = rs.double().repeat_interleave(100)[:, None]
+        report(f"wgrad rowscale dw {dt}", dw, (dy.double() * s).t() @ x.double(), tol)
+        report(f"wgrad rowscale db {dt}", db, (dy.double() * s).sum(0), tol)
+
+
+def t_layernorm():
+    for dt, tol in ((torch.float32, 1e-5), (torch.bfloat16, 1.5e-2)):
+        for (M, C) in [(100, 96), (77, 192), (50, 384), (33, 768), (20, 1536), (10, 500 if dt == torch.float32 else 504)]:
+            x = rnd("x", (M, C), 1, dtype=dt).requires_grad_(True)
+            g = (rnd("g", (C,), 2) * 0.2 + 1).requires_grad_(True)
+            b = (rnd("b", (C,), 3) * 0.1).requires_grad_(True)
+            y = ops.layer_norm(x, g, b)
+            xr = x.detach().double().requires_grad_(True)
+            gr, br = g.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True)
+            yr = OS.layer_norm(xr, gr, br)
+            report(f"ln fwd {dt} {M}x{C}", y, yr, tol)
+            dy = rnd("dy", (M, C), 4, dtype=dt)
+            y.backward(dy)
+            yr.backward(dy.double())
+            report(f"ln bwd dx {dt} {M}x{C}", x.grad, xr.grad, tol * 2)
+            report(f"ln bwd dg {dt} {M}x{C}", g.grad, gr.grad, tol * 2)
+            report(f"ln bwd db {dt} {M}x{C}", b.grad, br.grad, tol * 2)
+        for (n, H, Cq) in [(2, 56, 96), (3, 14, 384)]:
+            x = rnd("x", (n, H * H, Cq), 1, dtype=dt).requires_grad_(True)
+            g = (rnd("g", (4 * Cq,), 2) * 0.2 + 1).requires_grad_(True)
+            b = (rnd("b", (4 * Cq,), 3) * 0.1).requires_grad_(True)
+            y = ops.layer_norm(x, g, b, 1e-5, H)
+            xr = x.detach().double().requires_grad_(True)
+            gq = xr.reshape(n, H // 2, 2, H // 2, 2, Cq)
+            cat = torch.cat([gq[:, :, 0, :, 0], gq[:, :, 1, :, 0], gq[:, :, 0, :, 1], gq[:, :, 1, :, 1]], -1).reshape(n, -1, 4 * Cq)
+            yr = OS.layer_norm(cat, g.detach().double(), b.detach().double())
+            report(f"ln merge fwd {dt} H={H}", y, yr, tol)
+            dy = rnd("dy", tuple(y.shape), 4, dtype=dt)
+            y.backward(dy)
+            yr.backward(dy.double())
+            report(f"ln merge bwd dx {dt} H={H}", x.grad, xr.grad, tol * 2)
+
+
+def _wattn_ref(qkv, table, mask, n_img, H, C, nh, shift):
+    idx = OS.window_token_index(H, H, 7, shift).to(qkv.device)
+    nW = idx.shape[0]
+    hd = C // nh
+    t = qkv.reshape(n_img, H * H, 3, nh, hd)[:, idx.reshape(-1)].reshape(n_img * nW, 49, 3, nh, hd)
+    q = t[:, :, 0].transpose(1, 2) * hd ** -0.5
+    k, v = t[:, :, 1].transpose(1, 2), t[:, :, 2].transpose(1, 2)
+    s = q @ k.transpose(-1, -2) + table[OS.relative_position_index(7).to(qkv.device).reshape(-1)].reshape(49, 49, nh).permute(2, 0, 1)
+    if mask is not None:
+        s = (s.reshape(n_img, nW, nh, 49, 49) + mask[None, :, None]).reshape(n_img * nW, nh, 49, 49)
+    o = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(n_img, nW * 49, C)
+    out = torch.empty(n_img, H * H, C, dtype=o.dtype, device=o.device)
+    out[:, idx.reshape(-1)] = o
+    return out.reshape(-1, C)
+
+
+def t_wattn():
+    index = OS.relative_position_index(7).to(dev).int().contiguous()
+    for dt, tol in ((torch.float32, 2e-5), (torch.bfloat16, 2e-2)):
+        for (n_img, H, C, nh, shift) in [(2, 14, 96, 3, 0), (2, 14, 96, 3, 3), (1, 28, 192, 6, 3), (3, 7, 768, 24, 0), (5, 14, 384, 12, 3)]:
+            qkv = rnd("qkv", (n_img * H * H, 3 * C), 1, dtype=dt).requires_grad_(True)
+            table = (rnd("tab", (169, nh), 2) * 0.5).requires_grad_(True)
+            mask = OS.shift_mask(H, H, 7, shift).to(dev) if shift else None
+            out = ops.window_attn_core(qkv, table, index, mask, n_img, H, H, nh, shift, 32 ** -0.5)
+            q64 = qkv.detach().double().requires_grad_(True)
+            t64 = table.detach().double().requires_grad_(True)
+            ref = _wattn_ref(q64, t64, mask.double() if mask is not None else None, n_img, H, C, nh, shift)
+            tag = f"{dt} n{n_img} H{H} C{C} s{shift}"
+            report(f"wattn fwd {tag}", out, ref, tol)
+            dy = rnd("dy", (n_img * H * H, C), 3, dtype=dt)
+            out.backward(dy)
+            ref.backward(dy.double())
+            report(f"wattn bwd dqkv {tag}", qkv.grad, q64.grad, tol * 2)
+            report(f"wattn bwd dtable {tag}", table.grad, t64.grad, tol * 2)
+
+
+def t_mha():
+    for dt, tol in ((torch.float32, 2e-5), (torch.bfloat16, 2e-2)):
+        for (Lq, Lk, B, E, nh) in [(38, 128, 2, 768, 12), (128, 38, 1, 768, 12), (166, 160, 4, 768, 12), (70, 33, 2, 256, 8)]:
+            hd = E // nh
+            q = rnd("q", (Lq, B, E), 1, dtype=dt).requires_grad_(True)
+            kv = rnd("kv", (Lk, B, 2 * E), 2, dtype=dt).requires_grad_(True)
+            out = ops.mha_core(q, kv, None, nh, hd ** -0.5)
+            q64, kv64 = q.detach().double().requires_grad_(True), kv.detach().double().requires_grad_(True)
+            qq = (q64 * hd ** -0.5).reshape(Lq, B * nh, hd).transpose(0, 1)
+            kk = kv64[:, :, :E].reshape(Lk, B * nh, hd).transpose(0, 1)
+            vv = kv64[:, :, E:].reshape(Lk, B * nh, hd).transpose(0, 1)
+            ref = (torch.softmax(qq @ kk.transpose(1, 2), -1) @ vv).transpose(0, 1).reshape(Lq, B, E)
+            tag = f"{dt} {Lq}x{Lk} B{B} E{E}"
+            report(f"mha fwd {tag}", out, ref, tol)
+            dy = rnd("dy", (Lq, B, E), 3, dtype=dt)
+            out.backward(dy)
+            ref.backward(dy.double())
+            report(f"mha bwd dq {tag}", q.grad, q64.grad, tol * 2)
+            report(f"mha bwd dkv {tag}", kv.grad, kv64.grad, tol * 2)
+        # separate k, v tensors + dropout statistics
+        q = rnd("q", (64, 2, 768), 1, dtype=dt)
+        k = rnd("k", (96, 2, 768), 2, dtype=dt)
+        v = torch.ones((96, 2, 768), dtype=dt, device=dev)
+        o0 = ops.mha_core(q, k, v, 12, 0.125, 0.0, 0)
+        report(f"mha v=1 p=0 {dt}", o0, torch.ones_like(o0), tol)
+        o1 = ops.mha_core(q, k, v, 12, 0.125, 0.25, 1234)
+        print(f"     dropout p=0.25: mean(out)={o1.float().mean().item():.4f} (expect ~1), std={o1.float().std().item():.4f}")
+
+
+def t_misc():
+    for dt, tol in ((torch.float32, 1e-6), (torch.bfloat16, 1e-6)):
+        img = rnd("img", (2, 3, 224, 224), 1, dtype=dt).requires_grad_(True)
+        cols = ops.patch_im2col(img)
+        ref = img.detach().reshape(2, 3, 56, 4, 56, 4).permute(0, 2, 4, 1, 3, 5).reshape(2 * 3136, 48)
+        report(f"im2col {dt}", cols, ref, tol)
+        cols.backward(cols.detach())
+        report(f"col2im {dt}", img.grad, img.detach(), tol)
+    for dt, tol in ((torch.float32, 1e-5), (torch.bfloat16, 1.5e-2)):
+        for training in (True, False):
+            x = rnd("x", (7, 512), 1, dtype=dt).requires_grad_(True)
+            g = (rnd("g", (512,), 2) * 0.2 + 1).requires_grad_(True)
+            b = (rnd("b", (512,), 3) * 0.1).requires_grad_(True)
+            rm, rv = rnd("rm", (512,), 4) * 0.1, rnd("rv", (512,), 5).abs() + 0.5
+            rm2, rv2 = rm.clone(), rv.clone()
+            y = ops.batch_norm_1d(x, g, b, rm, rv, 0.1, 1e-5, training)
+            xr, gr, br = x.detach().float().requires_grad_(True), g.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+            yr = torch.nn.functional.batch_norm(xr, rm2, rv2, gr, br, training, 0.1, 1e-5)
+            report(f"bn fwd {dt} train={training}", y, yr, tol)
+            report(f"bn running_mean {dt} train={training}", rm, rm2, 1e-5)
+            report(f"bn running_var {dt} train={training}", rv, rv2, 1e-5 if dt == torch.float32 else 2e-2)
+            dy = rnd("dy", (7, 512), 6, dtype=dt)
+            y.backward(dy)
+            yr.backward(dy.float())
+            report(f"bn bwd dx {dt} train={training}", x.grad, xr.grad, tol * 4)
+            report(f"bn bwd dg {dt} train={training}", g.grad, gr.grad, tol * 4)
+        x = rnd("x", (38, 2, 768), 1, dtype=dt)
+        x[30:] = 0
+        x[1, 0, 0] = 0
+        tab = OC.sinusoidal_table(39, 768).to(dev)
+        y = ops.posemb_scale(x, tab, 768 ** 0.5)
+        report(f"posemb {dt}", y, OC.embed(x.float(), 768), tol)
+
+
+def t_speed():
+    """first timing impressions of the dominant kernels at bench-like sizes (bf16)"""
+    def timeit(fn, n=10):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+    dt = torch.bfloat16
+    for (M, N, K) in [(2007040, 288, 96), (2007040, 96, 96), (2007040, 384, 96), (2007040, 96, 384),
+                      (501760, 768, 192), (125440, 1536, 384), (125440, 384, 1536), (31360, 3072, 768), (640, 512, 37632)]:
+        x = torch.randn(M, K, device=dev, dtype=dt)
+        w = torch.randn(N, K, device=dev, dtype=dt)
+        b = torch.randn(N, device=dev)
+        t = timeit(lambda: ops.linear_raw(x, w, b))
+        dy = torch.randn(M, N, device=dev, dtype=dt)
+        t2 = timeit(lambda: ops.wgrad_raw(dy, x, True))
+        fl = 2.0 * M * N * K
+        byts = (M * K + M * N + N * K) * 2
+        print(f"     gemm {M}x{N}x{K}: fwd {t*1e3:8.3f} ms {fl/t/1e12:7.1f} TF/s {byts/t/1e9:7.0f} GB/s | wgrad {t2*1e3:8.3f} ms {fl/t2/1e12:7.1f} TF/s", flush=True)
+    index = OS.relative_position_index(7).to(dev).int().contiguous()
+    for (n_img, H, C, nh) in [(640, 56, 96, 3), (640, 28, 192, 6), (640, 14, 384, 12), (640, 7, 768, 24)]:
+        qkv = torch.randn(n_img * H * H, 3 * C, device=dev, dtype=dt).requires_grad_(True)
+        table = torch.randn(169, nh, device=dev).requires_grad_(True)
+        mask = OS.shift_mask(H, H, 7, 3).to(dev) if H > 7 else None
+        t = timeit(lambda: ops.window_attn_core(qkv, table, index, mask, n_img, H, H, nh, 3 if H > 7 else 0, 32 ** -0.5), 5)
+        out = ops.window_attn_core(qkv, table, index, mask, n_img, H, H, nh, 3 if H > 7 else 0, 32 ** -0.5)
+        dy = torch.randn_like(out)
+        t2 = timeit(lambda: torch.autograd.grad(out, (qkv, table), dy, retain_graph=True), 5)
+        print(f"     wattn n{n_img} H{H} C{C}: fwd {t*1e3:8.3f} ms | bwd {t2*1e3:8.3f} ms", flush=True)
+    for (M, C) in [(2007040, 96), (125440, 384)]:
+        x = torch.randn(M, C, device=dev, dtype=dt).requires_grad_(True)
+        g = torch.ones(C, device=dev, requires_grad=True)
+        b = torch.zeros(C, device=dev, requires_grad=True)
+        t = timeit(lambda: ops.layer_norm(x, g, b))
+        y = ops.layer_norm(x, g, b)
+        dy = torch.randn_like(y)
+        t2 = timeit(lambda: torch.autograd.grad(y, (x, g, b), dy, retain_graph=True))
+        print(f"     ln {M}x{C}: fwd {t*1e3:8.3f} ms {M*C*4/t/1e9:7.0f} GB/s | bwd {t2*1e3:8.3f} ms {M*C*6/t2/1e9:7.0f} GB/s", flush=True)
+
+
+if __name__ == "__main__":
+    print(torch.cuda.get_device_name(0), torch.version.hip)
+    for f in (t_linear, t_wgrad, t_layernorm, t_wattn, t_mha, t_misc):
+        section(f)
+    bad = [n for n, ok in RES if not ok]
+    print(f"\nSUMMARY: {len(RES) - len(bad)} ok, {len(bad)} failed")
+    for n in bad:
+        print("  FAILED:", n)
+    if "--speed" in sys.argv:
+        section(t_speed)
