@@ -1,0 +1,189 @@
+"""Task models; host-side mirror of the reference's src/models.py (callers of
+the hot path, API preserved): same class names, constructor arguments (an argparse-style namespace),
+attribute names / state_dict keys and forward signatures.  The Swin backbone and the two cross-modal
+encoders run on libfmmt_hip; the text encoder stays the HuggingFace RoBERTa/BERT on PyTorch-ROCm.
+
+Differences from the reference, on purpose:
+  * no hard-coded .cuda() (ref src/models.py:114-115): buffers are created on the input's device;
+  * the per-utterance token slicing (ref :112-150), a Python double loop with one host sync per token,
+    is restated as cumsum + gather on the device with no host synchronisation (same result; pinned by
+    tests/test_models_cpu.py against a literal loop);
+  * the activations handed to the HIP encoders are cast to the compute dtype of the module
+    (`compute_dtype`, bf16 for throughput / fp32 for parity) and back."""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .modules.CrossmodalTransformer import CrossModalTransformerEncoder
+from .modules.SwinTransformer.backbone_def import BackboneFactory
+from .modules.Transformer import AdditiveAttention, MELDTransEncoder
+
+DEFAULT_SWIN_CONF = os.path.join(os.path.dirname(os.path.abspath(__file__)), "modules", "SwinTransformer", "swin_conf.yaml")
+
+
+class SwinForAffwildClassification(nn.Module):
+    """Swin features -> Linear(512,64) -> ReLU -> Linear(64,num_labels) [-> Gumbel-softmax on the
+    target task] [-> loss]  (ref src/models.py:14-37)."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.num_labels = args.num_labels
+        self.swin = BackboneFactory(args.backbone_type, args.backbone_conf_file).get_backbone()
+        self.linear = nn.Linear(512, 64)
+        self.nonlinear = nn.ReLU()
+        self.classifier = nn.Linear(64, args.num_labels)
+        self.tau = args.tau
+
+    def forward(self, images_feature=None, is_trg_task=None, labels=None, criterion=None):
+        feats = self.swin(images_feature)
+        logits = self.classifier(self.nonlinear(self.linear(feats.to(self.linear.weight.dtype))))
+        if is_trg_task:
+            logits = F.gumbel_softmax(logits, self.tau)
+        if labels is not None:
+            return criterion(logits, labels)
+        return logits
+
+
+def slice_target_utterance(text_feats, sep_mask, utt_idx, max_len: int, roberta: bool):
+    """Word-level features of the target utterance of each dialogue (ref src/models.py:112-150).
+
+    text_feats (B, T, H); sep_mask (B, T) marks each utterance's closing separator; utt_idx (B,) is the
+    position of the target utterance in its dialogue.  Utterance 0 spans tokens [1, first_sep); utterance
+    u > 0 spans [prev_sep + (2 if roberta else 1), cur_sep); at most max_len tokens are kept; rows whose
+    dialogue has fewer than u+1 separators stay zero.  Returns (features (B,max_len,H), mask (B,max_len))."""
+    B, T, H = text_feats.shape
+    dev = text_feats.device
+    sep = sep_mask.to(dev) == 1
+    order = torch.cumsum(sep.long(), dim=1)                                    # 1-based rank of each separator
+    u = torch.as_tensor(utt_idx, device=dev).long().view(B, 1)
+    is_cur = sep & (order == u + 1)
+    is_prev = sep & (order == u)
+    has_cur = is_cur.any(dim=1)
+    cur = torch.argmax(is_cur.long(), dim=1)
+    prev = torch.argmax(is_prev.long(), dim=1)
+    first = u.view(B) == 0
+    gap = 2 if roberta else 1
+    start = torch.where(first, torch.ones_like(cur), prev + gap)
+    length = torch.where(first, cur - 1, cur - prev - gap)
+    length = torch.where(has_cur, length, torch.zeros_like(length)).clamp(min=0, max=max_len)
+    t = torch.arange(max_len, device=dev).view(1, max_len)
+    keep = t < length.view(B, 1)
+    idx = (start.view(B, 1) + t).clamp(max=T - 1)
+    out = torch.gather(text_feats, 1, idx.unsqueeze(-1).expand(B, max_len, H)) * keep.unsqueeze(-1).to(text_feats.dtype)
+    return out, keep.to(torch.float32)
+
+
+class MultiModalTransformerForClassification(nn.Module):
+    """PLM -> target-utterance slicing; audio / vision linear + self-attention encoders; four cross-modal
+    encoder calls; additive-attention pooling; classifier (ref src/models.py:41-188)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.choice_modality = config.choice_modality
+        self.num_labels = config.num_labels
+        self.get_text_utt_max_lens = config.get_text_utt_max_lens
+        self.hidden_size = config.hidden_size
+        self.text_pretrained_model = 'roberta' if config.pretrainedtextmodel_path.split('/')[-1] == 'roberta-large' else 'bert'
+        self.audio_emb_dim = config.audio_featExtr_dim
+        self.audio_utt_Transformernum = config.audio_utt_Transformernum
+        self.get_audio_utt_max_lens = config.get_audio_utt_max_lens
+        self.crossmodal_num_heads_TA = config.crossmodal_num_heads_TA
+        self.crossmodal_layers_TA = config.crossmodal_layers_TA
+        self.crossmodal_attn_dropout_TA = config.crossmodal_attn_dropout_TA
+        self.crossmodal_num_heads_TA_V = config.crossmodal_num_heads_TA_V
+        self.crossmodal_layers_TA_V = config.crossmodal_layers_TA_V
+        self.crossmodal_attn_dropout_TA_V = config.crossmodal_attn_dropout_TA_V
+        self.vision_emb_dim = config.vision_featExtr_dim + config.num_labels
+        self.vision_utt_Transformernum = config.vision_utt_Transformernum
+        self.get_vision_utt_max_lens = config.get_vision_utt_max_lens
+        self.compute_dtype = getattr(config, "compute_dtype", torch.float32)
+
+        plm = self._build_plm(config)
+        if self.text_pretrained_model == 'roberta':
+            self.roberta = plm
+        else:
+            self.bert = plm
+        self.text_linear = nn.Linear(plm.config.hidden_size, self.hidden_size)
+        self.audio_linear = nn.Linear(self.audio_emb_dim, self.hidden_size)
+        self.audio_utt_transformer = MELDTransEncoder(config, self.audio_utt_Transformernum, self.get_audio_utt_max_lens, self.hidden_size)
+        self.vision_linear = nn.Linear(self.vision_emb_dim, self.hidden_size)
+        self.vision_utt_transformer = MELDTransEncoder(config, self.vision_utt_Transformernum, self.get_vision_utt_max_lens, self.hidden_size)
+        self.attention = AdditiveAttention(self.hidden_size, self.hidden_size)
+        self.CrossModalTrans_TA = CrossModalTransformerEncoder(self.hidden_size, self.crossmodal_num_heads_TA,
+                                                               self.crossmodal_layers_TA, self.crossmodal_attn_dropout_TA)
+        self.CrossModalTrans_TA_V = CrossModalTransformerEncoder(self.hidden_size, self.crossmodal_num_heads_TA_V,
+                                                                 self.crossmodal_layers_TA_V, self.crossmodal_attn_dropout_TA_V)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+        self.classifier = nn.Linear(self.hidden_size, self.num_labels)
+
+    def _build_plm(self, config):
+        """HF from_pretrained as in the reference (:72-77); `config.plm_config` (a transformers config
+        object) selects random initialisation instead -- there are no checkpoints on the benchmark box."""
+        injected = getattr(config, "plm_module", None)
+        if injected is not None:                       # test fixtures inject a deterministic stand-in encoder
+            return injected
+        from transformers import BertModel, RobertaModel
+        cls = RobertaModel if self.text_pretrained_model == 'roberta' else BertModel
+        plm_config = getattr(config, "plm_config", None)
+        if plm_config is not None:
+            return cls(plm_config, add_pooling_layer=False) if getattr(config, "plm_no_pooler", False) else cls(plm_config)
+        return cls.from_pretrained(config.pretrainedtextmodel_path)
+
+    def forward(self, batch_text_input_ids=None, batch_text_input_mask=None, batch_text_sep_mask=None,
+                audio_inputs=None, audio_mask=None, vision_inputs=None, new_vision_mask=None, batchUtt_in_dia_idx=None):
+        plm = self.roberta if self.text_pretrained_model == 'roberta' else self.bert
+        text_out = plm(batch_text_input_ids, batch_text_input_mask)[0]                   # (B, T, plm_hidden)
+        text_utt_linear = self.text_linear(text_out.to(self.text_linear.weight.dtype))
+        text_feat, text_mask = slice_target_utterance(text_utt_linear, batch_text_sep_mask, batchUtt_in_dia_idx,
+                                                      self.get_text_utt_max_lens, self.text_pretrained_model == 'roberta')
+        del text_utt_linear
+
+        audio_ext = (1.0 - audio_mask.unsqueeze(1).unsqueeze(2)) * -10000.0
+        audio_utt = self.audio_utt_transformer(self.audio_linear(audio_inputs), audio_ext)
+        vision_ext = (1.0 - new_vision_mask.unsqueeze(1).unsqueeze(2)) * -10000.0
+        vision_utt = self.vision_utt_transformer(self.vision_linear(vision_inputs), vision_ext)
+
+        # cross-modal fusion on the HIP path, time-major, in the module's compute dtype
+        cd = self.compute_dtype
+        out_dtype = text_feat.dtype
+        t_tm = text_feat.transpose(0, 1).contiguous().to(cd)
+        a_tm = audio_utt.transpose(0, 1).contiguous().to(cd)
+        v_tm = vision_utt.transpose(0, 1).contiguous().to(cd)
+        text_x_audio = self.CrossModalTrans_TA(t_tm, a_tm, a_tm)
+        audio_x_text = self.CrossModalTrans_TA(a_tm, t_tm, t_tm)
+        ta = torch.cat((text_x_audio, audio_x_text), dim=0)
+        vision_x_ta = self.CrossModalTrans_TA_V(v_tm, ta, ta)
+        ta_x_vision = self.CrossModalTrans_TA_V(ta, v_tm, v_tm)
+        final = torch.cat((ta_x_vision, vision_x_ta), dim=0).transpose(0, 1).to(out_dtype)
+        final_mask = torch.cat((text_mask.to(audio_mask.dtype), audio_mask, new_vision_mask), dim=1)
+
+        pooled, _ = self.attention(final, final_mask)
+        return self.classifier(self.dropout(pooled))
+
+
+class meld_utt_transformer(nn.Module):
+    """Unimodal (V-only) classifier on pre-extracted features (ref src/models.py:192-223)."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.modality_origin_emb = args.vision_featExtr_dim
+        self.modality_utt_Transformernum = args.vision_utt_Transformernum
+        self.get_utt_max_lens = args.get_vision_utt_max_lens
+        self.hidden_size = args.hidden_size
+        self.hidden_dropout_prob = args.hidden_dropout_prob
+        self.modality_linear = nn.Linear(self.modality_origin_emb, self.hidden_size)
+        self.utt_transformer = MELDTransEncoder(args, self.modality_utt_Transformernum, self.get_utt_max_lens, self.hidden_size)
+        self.attention = AdditiveAttention(self.hidden_size, self.hidden_size)
+        self.mm_dropout = nn.Dropout(self.hidden_dropout_prob)
+        self.classifier = nn.Linear(self.hidden_size, args.num_labels)
+
+    def forward(self, inputs=None, utt_mask=None):
+        ext = utt_mask.unsqueeze(1).unsqueeze(2).to(dtype=next(self.parameters()).dtype)
+        ext = (1.0 - ext) * -10000.0
+        h = self.utt_transformer(self.modality_linear(inputs), ext)
+        pooled, _ = self.attention(h, utt_mask)
+        return self.classifier(self.mm_dropout(pooled))

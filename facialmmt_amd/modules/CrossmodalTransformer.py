@@ -1,0 +1,119 @@
+"""Cross-modal (MulT-style) transformer encoder on the HIP path; host-side mirror of the reference's
+modules/CrossmodalTransformer.py: same classes, constructor signatures and state_dict keys
+(`layers.{i}.self_attn.{in_proj_weight,in_proj_bias,out_proj.*}`, `layers.{i}.{fc1,fc2}.*`,
+`layers.{i}.layer_norms.{0,1}.*`, `layer_norm.*`, `version`, `embed_positions._float_tensor`).
+
+Per call: one fused embed kernel per distinct input (sqrt(E) x + sinusoid[pos]), and per layer
+LN -> q / packed-kv GEMMs -> flash-style attention core -> out_proj GEMM with the residual in its epilogue
+-> LN -> fc1(+GELU) -> fc2(+residual).  When the caller passes the same tensor as x_in_k and x_in_v
+(the model always does, src/models.py:171-177) the key-side embedding and LayerNorm are computed once
+instead of twice (bit-identical: every dropout on that path is 0)."""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import ops
+from .multihead_attention import MultiheadAttention
+from .position_embedding import SinusoidalPositionalEmbedding
+
+
+def Linear(in_features, out_features, bias=True):
+    m = nn.Linear(in_features, out_features, bias)
+    nn.init.xavier_uniform_(m.weight)
+    if bias:
+        nn.init.constant_(m.bias, 0.)
+    return m
+
+
+def LayerNorm(embedding_dim):
+    return nn.LayerNorm(embedding_dim)
+
+
+class TransformerEncoderLayer(nn.Module):
+    """pre-LN block: x + MHA(LN0(x), LN0(x_k), LN0(x_v)) ; x + fc2(gelu(fc1(LN1(x))))  (ref :98-171)."""
+
+    def __init__(self, embed_dim, num_heads=4, attn_dropout=0.1, gelu_dropout=0.1, res_dropout=0.1, attn_mask=False):
+        super().__init__()
+        self.embed_dim = embed_dim
+        self.num_heads = num_heads
+        self.self_attn = MultiheadAttention(embed_dim=self.embed_dim, num_heads=self.num_heads, attn_dropout=attn_dropout)
+        self.attn_mask = attn_mask
+        self.gelu_dropout = gelu_dropout
+        self.res_dropout = res_dropout
+        self.normalize_before = True
+        self.fc1 = Linear(self.embed_dim, 4 * self.embed_dim)
+        self.fc2 = Linear(4 * self.embed_dim, self.embed_dim)
+        self.layer_norms = nn.ModuleList([LayerNorm(self.embed_dim) for _ in range(2)])
+
+    def _ln(self, i, x):
+        ln = self.layer_norms[i]
+        return ops.layer_norm(x, ln.weight, ln.bias, ln.eps)
+
+    def forward(self, x, x_k=None, x_v=None):
+        if self.attn_mask:
+            raise NotImplementedError("facialmmt_amd HIP path: future mask (attn_mask=True is never used by the model)")
+        fused = not self.training or (self.res_dropout == 0.0 and self.gelu_dropout == 0.0)
+        xn = self._ln(0, x)
+        if x_k is None and x_v is None:
+            kn = vn = xn
+        else:
+            kn = self._ln(0, x_k)
+            vn = kn if x_v is x_k else self._ln(0, x_v)
+        if fused:
+            x = self.self_attn.attend(xn, kn, vn, res=x)
+            return ops.mlp(self._ln(1, x), self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, res=x)
+        # non-zero residual / gelu dropouts (not used by the model's configuration): un-fused epilogues
+        a = self.self_attn.attend(xn, kn, vn)
+        x = x + F.dropout(a, p=self.res_dropout, training=True)
+        h = ops.linear(self._ln(1, x), self.fc1.weight, self.fc1.bias)
+        h = F.dropout(F.gelu(h), p=self.gelu_dropout, training=True)
+        h = ops.linear(h, self.fc2.weight, self.fc2.bias)
+        return x + F.dropout(h, p=self.res_dropout, training=True)
+
+
+class CrossModalTransformerEncoder(nn.Module):
+    """(L_q,B,E), (L_k,B,E), (L_k,B,E) -> (L_q,B,E), time-major (ref :9-96)."""
+
+    def __init__(self, embed_dim, num_heads, layers, attn_dropout=0.0, gelu_dropout=0.0, res_dropout=0.0,
+                 embed_dropout=0.0, attn_mask=False):
+        super().__init__()
+        self.dropout = embed_dropout
+        self.attn_dropout = attn_dropout
+        self.embed_dim = embed_dim
+        self.embed_scale = math.sqrt(embed_dim)
+        self.embed_positions = SinusoidalPositionalEmbedding(embed_dim)
+        self.attn_mask = attn_mask
+        self.layers = nn.ModuleList([
+            TransformerEncoderLayer(embed_dim, num_heads=num_heads, attn_dropout=attn_dropout, gelu_dropout=gelu_dropout,
+                                    res_dropout=res_dropout, attn_mask=attn_mask) for _ in range(layers)])
+        self.register_buffer('version', torch.Tensor([2]))
+        self.normalize = True
+        if self.normalize:
+            self.layer_norm = LayerNorm(embed_dim)
+
+    def _embed(self, x_in):
+        if self.embed_positions is not None:
+            x = ops.posemb_scale(x_in, self.embed_positions.table(x_in.shape[0], x_in.device), self.embed_scale)
+        else:
+            x = self.embed_scale * x_in
+        return F.dropout(x, p=self.dropout, training=self.training) if self.dropout > 0 else x
+
+    def forward(self, x_in, x_in_k=None, x_in_v=None):
+        x = self._embed(x_in)
+        x_k = x_v = None
+        if x_in_k is not None and x_in_v is not None:
+            x_k = self._embed(x_in_k)
+            share = (x_in_v is x_in_k) and not (self.training and self.dropout > 0)
+            x_v = x_k if share else self._embed(x_in_v)
+        for layer in self.layers:
+            x = layer(x, x_k, x_v) if x_k is not None else layer(x)
+        if self.normalize:
+            x = ops.layer_norm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
+        return x
+
+    def max_positions(self):
+        return self.embed_positions.max_positions()

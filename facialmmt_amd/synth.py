@@ -132,3 +132,29 @@ def tensor(name: str, shape, seed: int = 0, lo: float = -1.0, hi: float = 1.0, d
     if device is not None or dtype is not None:
         t = t.to(device=device, dtype=dtype)
     return t
+
+
+def make_standin_plm(vocab: int = 1000, hidden: int = 1024, seed: int = 7):
+    """Deterministic stand-in for the HuggingFace text encoder used by the parity fixtures:
+    an embedding table -> (B, T, hidden) zeroed where the attention mask is 0.  It exposes
+    `.config.hidden_size` and returns a tuple like the HF models.  Not a model of RoBERTa: it only makes
+    the *surrounding* arithmetic (slicing, fusion, pooling) comparable between reference and build."""
+    import torch
+    import torch.nn as nn
+    from types import SimpleNamespace
+
+    class StandInPLM(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.config = SimpleNamespace(hidden_size=hidden)
+            self.emb = nn.Embedding(vocab, hidden)
+            with torch.no_grad():
+                self.emb.weight.copy_(torch.from_numpy(uniform("standin_plm.emb", (vocab, hidden), seed, -1.0, 1.0)))
+
+        def forward(self, input_ids, attention_mask=None, **kw):
+            h = self.emb(input_ids)
+            if attention_mask is not None:
+                h = h * attention_mask.unsqueeze(-1).to(h.dtype)
+            return (h,)
+
+    return StandInPLM()

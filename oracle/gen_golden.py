@@ -56,7 +56,7 @@ SAMPLE_MAX = 6144
 
 def pack(t: torch.Tensor) -> dict:
     """full tensor if small; else a strided sample plus fp64 sum / abs-sum over everything."""
-    a = t.detach().to(torch.float32).contiguous().cpu().numpy()
+    a = t.detach().to(torch.float32).contiguous().cpu().numpy().copy()   # copy: never alias live module state
     flat = a.reshape(-1)
     d = {"shape": np.array(a.shape, dtype=np.int64),
          "sum": np.array(flat.astype(np.float64).sum()),
@@ -74,6 +74,27 @@ def pack(t: torch.Tensor) -> dict:
 def flatten(prefix: str, d: dict, out: dict):
     for k, v in d.items():
         out[f"{prefix}/{k}"] = v
+
+
+def synth_multimodal_inputs(synth, B, T, La, Lv):
+    """(ids, attn_mask, sep_mask, audio, audio_mask, vision(+7), vision_mask, utt_idx) for the G6 fixtures.
+    Dialogue i has separators every 9+i tokens; target utterances 0, 2, 1; ragged masks."""
+    ids = torch.from_numpy(synth.randint("mm_ids", (B, T), 3, 1000, seed=13))
+    ids[:, 0] = 0
+    attn = torch.zeros(B, T)
+    sep = torch.zeros(B, T)
+    for i in range(B):
+        step = 9 + i
+        n_valid = T - 6 * i
+        attn[i, :n_valid] = 1
+        for pos in range(step, n_valid, step):
+            sep[i, pos] = 1
+    audio = synth.tensor("mm_audio", (B, La, 300), seed=14)
+    amask = torch.ones(B, La); amask[1, La - 5:] = 0
+    vision = synth.tensor("mm_vision", (B, Lv, 519), seed=15)
+    vmask = torch.ones(B, Lv); vmask[2, Lv - 7:] = 0
+    utt = torch.tensor([0, 2, 1][:B])
+    return ids, attn, sep, audio, amask, vision, vmask, utt
 
 
 def main():
@@ -237,6 +258,31 @@ def main():
         flatten("grad/" + name, pack(dict(enc.named_parameters())[name].grad), g)
     torch.set_grad_enabled(False)
     np.savez_compressed(os.path.join(OUT, "crossmodal.npz"), **g)
+
+    # ------------------------------------------------------------------ callers (G6): multimodal model with a stand-in PLM
+    g = {}
+    from facialmmt_amd.config import default_args
+    for plm_name in ("roberta-large", "bert-large"):
+        cfg = default_args(get_audio_utt_max_lens=24, get_vision_utt_max_lens=20,
+                           pretrainedtextmodel_path="pretrained_model/" + plm_name)
+        standin = synth.make_standin_plm()
+        RM.RobertaModel.from_pretrained = staticmethod(lambda path: standin)
+        RM.BertModel.from_pretrained = staticmethod(lambda path: standin)
+        mm = RM.MultiModalTransformerForClassification(cfg).eval()
+        synth.fill_state_dict(mm, seed=200)
+        standin.emb.weight.copy_(synth.make_standin_plm().emb.weight)       # fill_state_dict re-filled it: restore the stand-in table
+        tag = plm_name.split("-")[0]
+        keys["multimodal_" + tag] = [[k, list(v.shape), str(v.dtype)] for k, v in mm.state_dict().items()]
+        inp = synth_multimodal_inputs(synth, B=3, T=64, La=24, Lv=20)
+        flatten(f"mm/{tag}", pack(mm(*inp)), g)
+    cfg = default_args(get_vision_utt_max_lens=20)
+    vm = RM.meld_utt_transformer(cfg).eval()
+    synth.fill_state_dict(vm, seed=201)
+    keys["meld_utt"] = [[k, list(v.shape), str(v.dtype)] for k, v in vm.state_dict().items()]
+    vin = synth.tensor("vfeat", (2, 20, 512), seed=12)
+    vmask = torch.ones(2, 20); vmask[1, 14:] = 0
+    flatten("meld_utt", pack(vm(vin, vmask)), g)
+    np.savez_compressed(os.path.join(OUT, "multimodal.npz"), **g)
 
     with open(os.path.join(OUT, "state_dict_keys.json"), "w") as f:
         json.dump(keys, f)

@@ -1,0 +1,24 @@
+"""Development timing: Swin fwd / fwd+bwd at the bench size (bf16, N frames)."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from facialmmt_amd import synth
+from facialmmt_amd.modules.SwinTransformer import Swin_Transformer as S
+from facialmmt_amd.modules.SwinTransformer.backbone_def import BackboneFactory
+dev = torch.device("cuda:0")
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 640
+swin = BackboneFactory("SwinTransformer", os.path.join(os.path.dirname(S.__file__), "swin_conf.yaml")).get_backbone()
+synth.fill_state_dict(swin, seed=100)
+swin.to(dev).train()
+x = torch.randn(N, 3, 224, 224, device=dev, dtype=torch.bfloat16)
+def step(bwd=True):
+    out = swin(x)
+    if bwd:
+        out.float().square().mean().backward()
+for bwd in (False, True):
+    for _ in range(2): step(bwd)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(3): step(bwd)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
+    fl = 9.0255e9 * N * (3 if bwd else 1)
+    print(f"N={N} {'fwd+bwd' if bwd else 'fwd    '}: {dt*1e3:8.2f} ms  {N/dt:9.1f} frames/s  {fl/dt/1e12:7.1f} TF/s  mem={torch.cuda.max_memory_allocated()/2**30:.1f} GiB", flush=True)

@@ -1,0 +1,152 @@
+"""CPU tests of the host side: ABI surface, state_dict compatibility with the reference, host logic,
+loud failure when the HIP path cannot run, synthetic-data generator stability."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from facialmmt_amd import _lib, synth
+from facialmmt_amd.config import default_args
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "fmmt.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(fmmt_\w+)\s*\(", src)))
+
+
+def test_header_and_ctypes_signatures_agree():
+    assert _header_functions() == sorted(_lib.SIGNATURES)
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    if not os.path.exists(_lib.LIB_PATH):
+        from facialmmt_amd.build import build
+        build(verbose=False)
+    lib = _lib.load()
+    for name in _header_functions():
+        assert hasattr(lib, name), name
+    assert lib.fmmt_version() >= 1
+    # argument validation happens before any launch, so it is testable without a GPU
+    assert lib.fmmt_linear_fwd(1, 10, 96, 95, None, 95, None, 95, None, None, 96, None, 0, None, 96, None, 96, None, 1, None) == -1
+    assert lib.fmmt_linear_fwd(7, 10, 96, 96, None, 96, None, 96, None, None, 96, None, 0, None, 96, None, 96, None, 1, None) == -1
+    assert lib.fmmt_window_attn_fwd(1, 1, 15, 14, 96, 3, 0, None, None, None, None, 0, 1.0, None, None, None) == -1
+    assert lib.fmmt_window_attn_fwd(1, 1, 14, 14, 96, 4, 0, None, None, None, None, 0, 1.0, None, None, None) == -1
+    assert lib.fmmt_mha_fwd(1, 8, 8, 1, 500, 4, None, 500, None, None, 500, 1.0, 0.0, 0, None, 500, None, None) == -1
+    assert lib.fmmt_layernorm_fwd(1, 8, 100, None, None, None, 1e-5, None, None, None, 0, None) == -1
+    assert lib.fmmt_linear_wgrad_workspace(2007040, 288, 96) > 0
+    assert lib.fmmt_window_attn_bwd_workspace(3) == 3 * 256 * 49 * 49 * 4
+
+
+def test_hot_path_refuses_cpu_tensors():
+    from facialmmt_amd import ops
+    with pytest.raises(_lib.FmmtError, match="GPU only"):
+        ops.linear(torch.zeros(4, 96), torch.zeros(96, 96), torch.zeros(96))
+    with pytest.raises(_lib.FmmtError):
+        ops.layer_norm(torch.zeros(4, 96), torch.ones(96), torch.zeros(96))
+
+
+def test_state_dict_keys_match_reference(golden):
+    from facialmmt_amd import models
+    from facialmmt_amd.modules.CrossmodalTransformer import CrossModalTransformerEncoder
+    from facialmmt_amd.modules.multihead_attention import MultiheadAttention
+    from facialmmt_amd.modules.SwinTransformer import Swin_Transformer as S
+
+    def keys(m):
+        return [[k, list(v.shape), str(v.dtype)] for k, v in m.state_dict().items()]
+    args = default_args()
+    aff = models.SwinForAffwildClassification(args)
+    assert keys(aff) == golden.keys["affwild"]
+    assert keys(aff.swin) == golden.keys["swin"]
+    assert keys(CrossModalTransformerEncoder(768, 12, 2, 0.1)) == golden.keys["crossmodal"]
+    assert keys(CrossModalTransformerEncoder(500, 4, 2, 0, 0, 0, 0)) == golden.keys["enc500"]
+    assert keys(MultiheadAttention(768, 12, attn_dropout=0.1)) == golden.keys["mha"]
+    assert keys(S.SwinTransformerBlock(96, (56, 56), 3, shift_size=3)) == golden.keys["blk0_shift3"]
+    assert keys(S.SwinTransformerBlock(768, (7, 7), 24, shift_size=3)) == golden.keys["blk3_shift3"]   # shift forced to 0: no mask entry
+    assert keys(S.PatchMerging((56, 56), 96)) == golden.keys["pm0"]
+    assert keys(S.PatchEmbed(224, 4, 3, 96, torch.nn.LayerNorm)) == golden.keys["pe"]
+    for plm in ("roberta", "bert"):
+        cfg = default_args(get_audio_utt_max_lens=24, get_vision_utt_max_lens=20,
+                           pretrainedtextmodel_path=f"pretrained_model/{plm}-large", plm_module=synth.make_standin_plm())
+        assert keys(models.MultiModalTransformerForClassification(cfg)) == golden.keys["multimodal_" + plm]
+    assert keys(models.meld_utt_transformer(default_args(get_vision_utt_max_lens=20))) == golden.keys["meld_utt"]
+
+
+def test_structural_buffers_match_oracle():
+    from facialmmt_amd.modules.SwinTransformer import Swin_Transformer as S
+    from oracle import swin as OS
+    for H in (56, 28, 14):
+        assert torch.equal(S.build_shift_mask(H, H, 7, 3), OS.shift_mask(H, H, 7, 3))
+    assert torch.equal(S.WindowAttention(96, (7, 7), 3).relative_position_index, OS.relative_position_index(7))
+    blk = S.SwinTransformerBlock(768, (7, 7), 24, shift_size=3)
+    assert blk.shift_size == 0 and blk.attn_mask is None
+
+
+def test_reference_asserts_are_kept():
+    from facialmmt_amd.modules.SwinTransformer import Swin_Transformer as S
+    with pytest.raises(AssertionError, match="doesn't match model"):
+        S.PatchEmbed(224, 4, 3, 96)(torch.zeros(1, 3, 112, 112))
+    with pytest.raises(AssertionError, match="wrong size"):
+        S.SwinTransformerBlock(96, (56, 56), 3)(torch.zeros(1, 100, 96))
+    with pytest.raises(AssertionError, match="not even"):
+        S.PatchMerging((7, 7), 768)(torch.zeros(1, 49, 768))
+    with pytest.raises(NotImplementedError):
+        S.WindowAttention(96, (8, 8), 3).cuda if False else S.WindowAttention(96, (8, 8), 3)._check()
+
+
+def test_slice_target_utterance_matches_literal_loop():
+    from facialmmt_amd.models import slice_target_utterance
+    from oracle.multimodal import slice_target_utterance_loop
+    g = torch.Generator().manual_seed(0)
+    for trial in range(20):
+        B, T, H = 5, 60, 8
+        feats = torch.randn(B, T, H, generator=g)
+        sep = torch.zeros(B, T)
+        for i in range(B):                      # separators at least 3 tokens apart (closer ones make the reference itself raise)
+            pos = 1
+            while True:
+                pos += int(torch.randint(3, 14, (1,), generator=g))
+                if pos >= T:
+                    break
+                sep[i, pos] = 1
+        utt = torch.randint(0, 5, (B,), generator=g)
+        for roberta in (True, False):
+            a, am = slice_target_utterance(feats, sep, utt, 7, roberta)
+            b, bm = slice_target_utterance_loop(feats, sep, utt, 7, roberta)
+            assert torch.equal(a, b) and torch.equal(am, bm)
+
+
+def test_positional_embedding_module_matches_oracle(golden):
+    from facialmmt_amd.modules.position_embedding import SinusoidalPositionalEmbedding
+    pin = torch.from_numpy(golden.files["crossmodal"]["posemb/in"])
+    golden.check("crossmodal", "posemb/out", SinusoidalPositionalEmbedding(768)(pin), atol=1e-6, rtol=1e-6)
+
+
+def test_droppath_scale_statistics():
+    from facialmmt_amd.modules.SwinTransformer.Swin_Transformer import DropPath
+    torch.manual_seed(0)
+    dp = DropPath(0.3).train()
+    s = dp.sample_scale(20000, "cpu")
+    assert [round(float(v), 4) for v in s.unique()] == [0.0, round(1 / 0.7, 4)]
+    assert abs(s.mean().item() - 1.0) < 0.02
+    assert DropPath(0.3).eval().sample_scale(8, "cpu") is None
+
+
+def test_synth_is_stable():
+    """the generator is the contract between the committed goldens and the GPU box: pin a few values"""
+    u = synth.uniform("frames", (4,), seed=1)
+    assert u.dtype == np.float32
+    assert np.allclose(u, synth.uniform("frames", (2, 2), seed=1).reshape(-1))
+    assert np.array_equal(synth.uniform("frames", (1000,), seed=1)[:4], u)
+    assert synth.uniform("a", (3,), 0).tolist() != synth.uniform("b", (3,), 0).tolist()
+    assert synth.randint("x", (100,), 3, 10).min() >= 3 and synth.randint("x", (100,), 3, 10).max() < 10
+
+
+def test_swin_mac_formula_matches_survey():
+    from oracle.swin import swin_macs_per_frame
+    m = swin_macs_per_frame()
+    assert abs(m["total"] / 1e9 - 4.5128) < 2e-3 and abs(m["stage0"] / 1e6 - 811.9) < 0.2 and abs(m["head"] / 1e6 - 19.27) < 0.01

@@ -153,3 +153,42 @@ def test_crossmodal_grads(golden):
     for n in sorted({k.split("/")[1] for k in z.files if k.startswith("grad/layer")}):
         ref, _ = golden.expected("crossmodal", f"grad/{n}")
         golden.check("crossmodal", f"grad/{n}", sd[n].grad, atol=2e-4 * float(np.abs(ref).max()) + 1e-7, rtol=2e-3, sum_rtol=1e-3)
+
+
+# ---------------------------------------------------------------------------------------------
+# callers around the hot path: multimodal model with the stand-in text encoder
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("plm", ["roberta", "bert"])
+def test_multimodal_logits(golden, plm):
+    from facialmmt_amd.config import default_args
+    from oracle import multimodal as OM
+    from oracle.gen_golden import synth_multimodal_inputs
+    cfg = default_args(get_audio_utt_max_lens=24, get_vision_utt_max_lens=20)
+    sd = synth.state_dict_from_keys(golden.keys["multimodal_" + plm], seed=200)
+    inp = synth_multimodal_inputs(synth, B=3, T=64, La=24, Lv=20)
+    with torch.no_grad():
+        out = OM.multimodal_logits(sd, synth.make_standin_plm(), cfg, *inp, roberta=(plm == "roberta"))
+    golden.check("multimodal", f"mm/{plm}", out, atol=1e-4, rtol=1e-4)
+
+
+def test_meld_utt_logits(golden):
+    from facialmmt_amd.config import default_args
+    from oracle import multimodal as OM
+    cfg = default_args(get_vision_utt_max_lens=20)
+    sd = synth.state_dict_from_keys(golden.keys["meld_utt"], seed=201)
+    vmask = torch.ones(2, 20)
+    vmask[1, 14:] = 0
+    with torch.no_grad():
+        out = OM.meld_utt_logits(sd, cfg, synth.tensor("vfeat", (2, 20, 512), seed=12), vmask)
+    golden.check("multimodal", "meld_utt", out, atol=1e-4, rtol=1e-4)
+
+
+def test_bn_running_stats(golden, swin_sd):
+    """running_mean/var after one training step = 0.9*old + 0.1*batch (unbiased var) -- Swin_Transformer.py:494."""
+    frames = synth.tensor("frames", (8, 3, 224, 224), seed=1)
+    with torch.no_grad():
+        _, stages = OS.swin_forward_features(swin_sd, frames[:4], training=True, return_stages=True)
+        x = OS.layer_norm(stages[-1], swin_sd["output_layer.0.weight"], swin_sd["output_layer.0.bias"])
+        pre = x.reshape(4, -1) @ swin_sd["output_layer.2.weight"].t() + swin_sd["output_layer.2.bias"]
+    golden.check("swin_full", "bn_running_mean_after", 0.9 * swin_sd["output_layer.3.running_mean"] + 0.1 * pre.mean(0), atol=1e-4, rtol=1e-4)
+    golden.check("swin_full", "bn_running_var_after", 0.9 * swin_sd["output_layer.3.running_var"] + 0.1 * pre.var(0, unbiased=True), atol=1e-4, rtol=1e-4)
