@@ -1,0 +1,166 @@
+"""GPU parity of the Swin encoder (HIP path behind the reference's module API) against the golden
+vectors produced by the reference itself: blocks / window attention / patch merging / patch embed per
+stage geometry, whole-model eval (N=8 and the batch-of-1 duplication), train-mode BatchNorm and running
+statistics, pre-Gumbel logits, and gradients (d input + 20 parameter gradients).  Tolerance: 1e-3
+absolute+relative in fp32 (north_star); bf16 is held to 3e-2 of the output scale against fp32."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from facialmmt_amd import synth
+
+pytestmark = pytest.mark.gpu
+GEO = [(56, 96, 3), (28, 192, 6), (14, 384, 12), (7, 768, 24)]
+TOL = dict(atol=1e-3, rtol=1e-3)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def S():
+    from facialmmt_amd.modules.SwinTransformer import Swin_Transformer
+    return Swin_Transformer
+
+
+@pytest.fixture(scope="module")
+def swin(dev, S):
+    from facialmmt_amd.modules.SwinTransformer.backbone_def import BackboneFactory
+    m = BackboneFactory("SwinTransformer", os.path.join(os.path.dirname(S.__file__), "swin_conf.yaml")).get_backbone()
+    synth.fill_state_dict(m, seed=100)
+    return m.to(dev)
+
+
+@pytest.mark.parametrize("s", [0, 1, 2, 3])
+@pytest.mark.parametrize("shift", [0, 3])
+def test_block_and_window_attention(golden, dev, S, s, shift):
+    from oracle.swin import window_token_index
+    H, C, nh = GEO[s]
+    blk = S.SwinTransformerBlock(C, (H, H), nh, window_size=7, shift_size=shift, drop_path=0.0).eval()
+    synth.fill_state_dict(blk, seed=10 + s, prefix=f"blk{s}.")
+    blk.to(dev)
+    x = synth.tensor(f"blk_in{s}", (2, H * H, C), seed=s).to(dev)
+    with torch.no_grad():
+        golden.check("swin_parts", f"block_s{s}_shift{shift}", blk(x), **TOL)
+        idx = window_token_index(H, H, 7, blk.shift_size).to(dev)
+        xw = x[:1, idx.reshape(-1)].reshape(-1, 49, C)
+        golden.check("swin_parts", f"wattn_s{s}_shift{shift}", blk.attn(xw, mask=blk.attn_mask), **TOL)
+
+
+@pytest.mark.parametrize("s", [0, 1, 2])
+def test_patch_merging(golden, dev, S, s):
+    H, C, _ = GEO[s]
+    pm = S.PatchMerging((H, H), C).eval()
+    synth.fill_state_dict(pm, seed=20 + s, prefix=f"pm{s}.")
+    pm.to(dev)
+    with torch.no_grad():
+        golden.check("swin_parts", f"merge_s{s}", pm(synth.tensor(f"blk_in{s}", (2, H * H, C), seed=s).to(dev)), **TOL)
+
+
+def test_patch_embed(golden, dev, S):
+    pe = S.PatchEmbed(224, 4, 3, 96, torch.nn.LayerNorm).eval()
+    synth.fill_state_dict(pe, seed=30, prefix="pe.")
+    pe.to(dev)
+    with torch.no_grad():
+        golden.check("swin_parts", "patch_embed", pe(synth.tensor("frames", (2, 3, 224, 224), seed=1).to(dev)), **TOL)
+
+
+def test_swin_eval_and_stage_taps(golden, dev, swin):
+    frames = synth.tensor("frames", (8, 3, 224, 224), seed=1).to(dev)
+    swin.eval()
+    with torch.no_grad():
+        golden.check("swin_full", "swin_eval_n8", swin(frames), **TOL)
+        golden.check("swin_full", "swin_eval_n1", swin(frames[:1]), **TOL)
+        x = swin.patch_embed(frames[:2])
+        for s, layer in enumerate(swin.layers):
+            x = layer(x)
+            golden.check("swin_full", f"swin_stage{s}_n2", x, **TOL)
+        o32 = swin(frames)
+        o16 = swin(frames.bfloat16()).float()
+    assert (o16 - o32).abs().max().item() <= 3e-2 * o32.abs().max().item()
+
+
+def _no_droppath(swin, S):
+    for m in swin.modules():
+        if isinstance(m, S.DropPath):
+            m.drop_prob = 0.0
+
+
+def test_swin_train_batchnorm_and_running_stats(golden, dev, swin, S):
+    frames = synth.tensor("frames", (8, 3, 224, 224), seed=1).to(dev)
+    _no_droppath(swin, S)       # goldens were produced with DropPath = identity
+    swin.train()
+    bn = swin.output_layer[3]
+    rm0, rv0, nb0 = bn.running_mean.clone(), bn.running_var.clone(), int(bn.num_batches_tracked)
+    with torch.no_grad():
+        golden.check("swin_full", "swin_train_n4", swin(frames[:4]), atol=2e-3, rtol=2e-3)
+    golden.check("swin_full", "bn_running_mean_after", bn.running_mean, **TOL)
+    golden.check("swin_full", "bn_running_var_after", bn.running_var, **TOL)
+    assert int(bn.num_batches_tracked) == nb0 + 1
+    with torch.no_grad():
+        bn.running_mean.copy_(rm0)
+        bn.running_var.copy_(rv0)
+    swin.eval()
+
+
+def test_affwild_logits_and_gradients(golden, dev, S):
+    from facialmmt_amd import models
+    from facialmmt_amd.config import default_args
+    aff = models.SwinForAffwildClassification(default_args())
+    synth.fill_state_dict(aff, seed=100)
+    aff.to(dev)
+    _no_droppath(aff.swin, S)
+    frames = synth.tensor("frames", (8, 3, 224, 224), seed=1).to(dev)
+    aff.eval()
+    with torch.no_grad():
+        golden.check("swin_full", "affwild_logits_n4", aff(frames[:4], is_trg_task=False), **TOL)
+    aff.train()
+    xin = frames[:3].clone().requires_grad_(True)
+    probe = synth.tensor("probe7", (3, 7), seed=3).to(dev)
+    (aff(xin, is_trg_task=False) * probe).sum().backward()
+    golden.check("swin_full", "grad/input", xin.grad, atol=2e-5, rtol=5e-3, sum_rtol=1e-3)
+    params = dict(aff.named_parameters())
+    z = golden.files["swin_full"]
+    names = sorted({k.split("/")[1] for k in z.files if k.startswith("grad/") and k.split("/")[1] not in ("input", "swin.output_layer.2.bias")})
+    assert len(names) >= 20
+    for n in names:
+        ref, _ = golden.expected("swin_full", f"grad/{n}")
+        golden.check("swin_full", f"grad/{n}", params[n].grad, atol=1e-3 * float(np.abs(ref).max()) + 1e-7, rtol=5e-3, sum_rtol=2e-3)
+
+
+def test_droppath_matches_oracle_with_explicit_masks(dev, S):
+    """stochastic depth: feed the same per-sample multipliers to the oracle and to the HIP block"""
+    from oracle import swin as OS
+    H, C, nh = 14, 384, 12
+    blk = S.SwinTransformerBlock(C, (H, H), nh, window_size=7, shift_size=3, drop_path=0.25).train()
+    synth.fill_state_dict(blk, seed=12, prefix="blk2.")
+    blk.to(dev)
+    x = synth.tensor("blk_in2", (6, H * H, C), seed=2).to(dev)
+    torch.manual_seed(5)
+    s1 = blk.drop_path.sample_scale(6, dev)
+    s2 = blk.drop_path.sample_scale(6, dev)
+    torch.manual_seed(5)
+    with torch.no_grad():
+        got = blk(x)
+        sd = {k: v for k, v in blk.state_dict().items()}
+        ref = OS.swin_block(sd, "", x, H, H, nh, 3, (s1, s2))
+    assert (s1 == 0).any() or (s2 == 0).any()
+    assert (got - ref).abs().max().item() < 1e-3
+
+
+def test_full_size_batch_independence_bf16(dev, swin):
+    """BASELINE size (160 frames = one utterance, bf16, eval): frames are independent units, so the
+    features of a sub-batch must be bit-identical to the same rows of the full batch."""
+    swin.eval()
+    g = torch.Generator(device="cpu").manual_seed(1)
+    frames = torch.randn(160, 3, 224, 224, generator=g).to(dev).bfloat16()
+    with torch.no_grad():
+        full = swin(frames)
+        part = swin(frames[40:104])
+    assert torch.isfinite(full).all()
+    assert torch.equal(full[40:104], part)
