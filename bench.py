@@ -1,0 +1,264 @@
+"""Benchmark of the FacialMMT hot path on MI355X (contract: see the task prompt / DESIGN.md section 6).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = one target-task training step (train.py:54-143) on a synthetic MELD-shaped batch of
+`--utts` utterances per GPU (BASELINE.json configs[1]: T+A+V, RoBERTa-large, 160-frame face sequence,
+batch 4, bf16): Swin-tiny forward+backward over utts*160 frames of 3x224x224 on the HIP path, frame
+filter, RoBERTa-large (PyTorch-ROCm, bf16 autocast, random init), audio/vision self-attention encoders,
+the four cross-modal encoder calls on the HIP path, cross-entropy, backward through everything, gradient
+clip + AdamW step on the multimodal model EVERY step (the reference steps every 4th micro-batch; stepping
+every time only adds work).  Inputs are resident in HBM before the timed region.
+
+Rank 0 prints ONE JSON line: metric utterances/s (whole job), plus
+  roofline     -- the dominant kernel (linear_nt_kernel<bf16,128,128,32>, the MFMA GEMM of every
+                  Linear layer) timed live with HIP events on the launch stream during the timed steps:
+                  achieved = sum(2*M*N*K) / sum(duration) against the 2.5 PFLOP/s dense bf16 MFMA peak;
+  cpu_baseline -- the oracle (CPU restatement, fp32) timed on the host cores of this box on a bounded
+                  sample of the same workload (N=1 only)."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0            # MI355X dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+SWIN_FWD_GFLOP_PER_FRAME = 9.0255    # BASELINE.md section 2 (reference's own flops() formulas x 2)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--utts", type=int, default=4, help="utterances per GPU per step (BASELINE configs[1]: 4)")
+    ap.add_argument("--frames", type=int, default=160, help="face frames per utterance (vision_max_utt_len)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=8, help="frames in the CPU-baseline Swin sample")
+    return ap.parse_args()
+
+
+def synth_batch(args, dev, rank, cfg):
+    """seeded synthetic MELD-shaped batch, generated on the device"""
+    g = torch.Generator(device=dev).manual_seed(1111 + rank)
+    B, Lv, La, T = args.utts, args.frames, cfg.get_audio_utt_max_lens, 512
+    act = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    # raw 112x112 uint8 crops -> [0,1] -> Normalize(.5,.5) -> bicubic x2 (utils/dataset.py:18-20,41-57)
+    raw = torch.randint(0, 256, (B * Lv, 3, 112, 112), generator=g, device=dev, dtype=torch.uint8)
+    frames = torch.nn.functional.interpolate((raw.float() / 255.0 - 0.5) / 0.5, size=(224, 224), mode="bicubic", align_corners=False)
+    frames = frames.to(act).contiguous()
+    del raw
+    ids = torch.randint(3, 50265, (B, T), generator=g, device=dev)
+    ids[:, 0] = 0
+    attn = torch.zeros(B, T, device=dev)
+    attn[:, :400] = 1
+    sep = torch.zeros(B, T, device=dev)
+    sep[:, 20:400:20] = 1                                     # an utterance separator every 20 tokens
+    utt_idx = torch.arange(B, device=dev) % 8
+    audio = torch.randn(B, La, cfg.audio_featExtr_dim, generator=g, device=dev)
+    amask = torch.zeros(B, La, device=dev)
+    amask[:, :96] = 1
+    vision = torch.randn(B, Lv, cfg.vision_featExtr_dim, generator=g, device=dev)
+    vmask = torch.ones(B, Lv, device=dev)
+    labels = torch.randint(0, 7, (B,), generator=g, device=dev)
+    num_imgs = torch.full((B,), Lv, device=dev, dtype=torch.long)
+    return (ids, attn, sep, audio, amask, vision, vmask, labels, frames, num_imgs, utt_idx)
+
+
+def build_models(args, dev, cfg):
+    from transformers import RobertaConfig
+    from facialmmt_amd import models
+    act = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    cfg.compute_dtype = act
+    cfg.plm_config = RobertaConfig(vocab_size=50265, hidden_size=1024, num_hidden_layers=24, num_attention_heads=16,
+                                   intermediate_size=4096, max_position_embeddings=514, type_vocab_size=1, pad_token_id=1)
+    cfg.plm_no_pooler = True
+    torch.manual_seed(cfg.seed)
+    swin = models.SwinForAffwildClassification(cfg).to(dev).train()
+    mm = models.MultiModalTransformerForClassification(cfg).to(dev).train()
+    return swin, mm
+
+
+class KernelTimer:
+    """HIP-event timing of one kernel family on the launch stream, live inside the timed region."""
+
+    def __init__(self):
+        self.events = []
+        self.enabled = False
+
+    def install(self):
+        from facialmmt_amd import ops
+        raw = ops.linear_raw
+        timer = self
+
+        def timed_linear_raw(x2, w, bias, **kw):
+            if not timer.enabled or x2.dtype != torch.bfloat16:
+                return raw(x2, w, bias, **kw)
+            M, K = x2.shape
+            N = w.shape[0]
+            bn = 96 if (N % 96 == 0 and N % 128 != 0) else 128
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            y = raw(x2, w, bias, **kw)
+            e.record()
+            timer.events.append((bn, 2.0 * M * N * K, (M * K + N * K + M * N) * 2.0, s, e))
+            return y
+
+        ops.linear_raw = timed_linear_raw
+
+    def summary(self):
+        out = {}
+        for bn, fl, by, s, e in self.events:
+            d = out.setdefault(bn, [0, 0.0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += fl
+            d[2] += by
+            d[3] += s.elapsed_time(e) * 1e-3
+        return out
+
+
+def cpu_baseline(args, cfg):
+    """The oracle (oracle/*.py, fp32 CPU restatement) timed on this box's host cores on a bounded sample:
+    Swin forward+backward on `cpu_frames` frames (scaled to `frames` per utterance) + the fusion stack
+    forward+backward for one utterance (PLM excluded: it is the same third-party library on both sides).
+    Reported as utterances/s of the section-8 hot path."""
+    import numpy as np
+    from facialmmt_amd import synth
+    from oracle import crossmodal as OC
+    from oracle import swin as OS
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    with open(os.path.join(ROOT, "tests", "golden", "state_dict_keys.json")) as f:
+        keys = json.load(f)
+    sd = synth.state_dict_from_keys(keys["affwild"], seed=100)
+    for v in sd.values():
+        v.requires_grad_(True)
+    nF = args.cpu_frames
+    x = synth.tensor("frames", (nF, 3, 224, 224), seed=1)
+
+    def swin_step():
+        for v in sd.values():
+            v.grad = None
+        OS.swin_affwild_logits(sd, x, training=True).square().sum().backward()
+    swin_step()
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        swin_step()
+        ts.append(time.perf_counter() - t0)
+    t_swin = float(np.median(ts)) / nF * args.frames
+    esd = synth.state_dict_from_keys(keys["crossmodal"], seed=50, prefix="enc.")
+    for v in esd.values():
+        v.requires_grad_(True)
+    La, Lv, Lt = cfg.get_audio_utt_max_lens, args.frames, cfg.get_text_utt_max_lens
+    t_, a_, v_ = (synth.tensor(n, (L, 1, 768), seed=60) for n, L in (("t", Lt), ("a", La), ("v", Lv)))
+
+    def fusion_step():
+        ta = torch.cat((OC.crossmodal_encoder(esd, t_, a_, a_), OC.crossmodal_encoder(esd, a_, t_, t_)), 0)
+        out = torch.cat((OC.crossmodal_encoder(esd, ta, v_, v_), OC.crossmodal_encoder(esd, v_, ta, ta)), 0)
+        out.square().mean().backward()
+    fusion_step()
+    t0 = time.perf_counter()
+    fusion_step()
+    t_fus = time.perf_counter() - t0
+    return {"value": round(1.0 / (t_swin + t_fus), 5), "unit": "utterances/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fp32 fwd+bwd: Swin+head on {nF} frames (median of 3, scaled x{args.frames / nF:g} to {args.frames} frames/utt: "
+                      f"{t_swin:.2f} s) + 4 cross-modal encoder calls for 1 utterance ({t_fus:.2f} s); text encoder excluded"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the hot path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+
+    from facialmmt_amd.config import default_args
+    from facialmmt_amd.parallel import wrap_ddp
+    from facialmmt_amd.train_step import TargetStep
+    cfg = default_args(get_vision_utt_max_lens=args.frames, trg_accumulation_steps=1)
+    swin, mm = build_models(args, dev, cfg)
+    ddp = wrap_ddp(mm, dev) if world > 1 else None
+    opt = torch.optim.AdamW(mm.parameters(), lr=cfg.trg_lr, weight_decay=cfg.weight_decay)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: min(1.0, (s + 1) / 100.0))
+    step = TargetStep(swin, mm, opt, sched, cfg, autocast_dtype=torch.bfloat16 if args.dtype == "bf16" else None, ddp_model=ddp)
+    batch = synth_batch(args, dev, rank, cfg)
+    timer = KernelTimer()
+    timer.install()
+
+    kept = None
+    for _ in range(args.warmup):
+        _, m = step(batch)
+        kept = m
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.enabled = rank == 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, kept = step(batch)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = args.utts * world * args.steps / elapsed
+        fams = timer.summary()
+        roof = None
+        if fams:
+            bn, (cnt, fl, by, sec) = max(fams.items(), key=lambda kv: kv[1][3])
+            achieved = fl / sec / 1e12
+            roof = {"bound": "mfma", "kernel": f"linear_nt_kernel<bf16,128,{bn},32>", "achieved": round(achieved, 1),
+                    "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+                    "traffic": None, "launches_per_step": cnt // args.steps,
+                    "avg_launch_us": round(sec / cnt * 1e6, 1), "algorithmic_GB_per_s": round(by / sec / 1e9, 0),
+                    "share_of_step": round(sec / elapsed, 3)}
+        flops_step = args.utts * (args.frames * SWIN_FWD_GFLOP_PER_FRAME * 3 + (335 + 29.7) * 3) * 1e9
+        line = {
+            "metric": "utterances/sec T+A+V forward+bwd, 160-frame face seq, 1/2/4/8 GPU",
+            "value": round(value, 3), "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"configs[1]: T+A+V, RoBERTa-large (random init), {args.frames}-frame face seq 3x224x224, "
+                                   f"batch {args.utts} utterances/GPU, {args.dtype}, fwd+bwd+AdamW every step",
+                       "global_batch": args.utts * world, "frames_per_step_per_gpu": args.utts * args.frames,
+                       "parallelism": f"dp{world}", "kept_frame_fraction": round(float(kept.mean().item()), 3),
+                       "model_tflops_per_s_per_gpu": round(flops_step / (ms * 1e-3) / 1e12, 1)},
+            "roofline": roof,
+            "cpu_baseline": None,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args, cfg)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

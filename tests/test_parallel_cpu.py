@@ -1,0 +1,75 @@
+"""world_size-2 gloo test of the data-parallel path: sharding utterances over 2 ranks and averaging
+gradients equals the single-process gradient over the whole batch; no_sync accumulation included.
+(The modules used are the torch-op callers around the hot path: the HIP kernels need a GPU.)"""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from facialmmt_amd import synth
+from facialmmt_amd.config import default_args
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _model():
+    from facialmmt_amd.models import meld_utt_transformer
+    torch.manual_seed(0)
+    m = meld_utt_transformer(default_args(get_vision_utt_max_lens=12, vision_utt_Transformernum=1, hidden_dropout_prob=0.0,
+                                          attention_probs_dropout_prob=0.0, hidden_size=96, intermediate_size=192,
+                                          num_attention_heads=4, vision_featExtr_dim=32))
+    return synth.fill_state_dict(m, seed=3)
+
+
+def _data():
+    x = synth.tensor("ddp_x", (8, 12, 32), seed=4)
+    mask = torch.ones(8, 12)
+    mask[3, 7:] = 0
+    y = torch.from_numpy(synth.randint("ddp_y", (8,), 0, 7, seed=5))
+    return x, mask, y
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from facialmmt_amd.parallel import accumulate, shard_utterances, wrap_ddp
+    m = _model()
+    ddp = wrap_ddp(m)
+    x, mask, y = _data()
+    idx = list(shard_utterances(8, rank, world))
+    half = len(idx) // 2
+    for micro, sl in enumerate((idx[:half], idx[half:])):          # two micro-steps, exchange only on the last
+        with accumulate(ddp, micro == 1):
+            loss = torch.nn.functional.cross_entropy(ddp(x[sl], mask[sl]), y[sl], reduction="sum") / 4.0
+            loss.backward()
+    ret[rank] = {k: p.grad.clone() for k, p in m.named_parameters()}
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_equals_single_process():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    m = _model()
+    x, mask, y = _data()
+    # DDP averages over ranks: each rank's local loss is sum/4 over its 4 utterances -> mean over ranks = sum/8
+    (torch.nn.functional.cross_entropy(m(x, mask), y, reduction="sum") / 8.0).backward()
+    for k, p in m.named_parameters():
+        for r in range(world):
+            assert torch.allclose(ret[r][k], p.grad, atol=1e-5, rtol=1e-4), k
+
+
+def test_shard_utterances_partitions():
+    from facialmmt_amd.parallel import shard_utterances
+    for n, w in [(32, 8), (16, 4), (8, 8), (7, 4), (1, 2)]:
+        got = [i for r in range(w) for i in shard_utterances(n, r, w)]
+        assert got == list(range(n))
