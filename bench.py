@@ -138,7 +138,9 @@ def cpu_baseline(args, cfg):
     from facialmmt_amd import synth
     from oracle import crossmodal as OC
     from oracle import swin as OS
-    cores = os.cpu_count() or 1
+    # 256 hardware threads on the GPU box make torch's CPU ops slower, not faster (measured: 234 s for the
+    # 8-frame step with 256 threads vs ~2 s with 8-16); use 16 threads and say so.
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     with open(os.path.join(ROOT, "tests", "golden", "state_dict_keys.json")) as f:
         keys = json.load(f)
@@ -152,12 +154,15 @@ def cpu_baseline(args, cfg):
         for v in sd.values():
             v.grad = None
         OS.swin_affwild_logits(sd, x, training=True).square().sum().backward()
+    t0 = time.perf_counter()
     swin_step()
-    ts = []
-    for _ in range(3):
-        t0 = time.perf_counter()
-        swin_step()
-        ts.append(time.perf_counter() - t0)
+    ts = [time.perf_counter() - t0]
+    if ts[0] < 10.0:                                   # bounded: skip the repeats if one step is already slow
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            swin_step()
+            ts.append(time.perf_counter() - t0)
     t_swin = float(np.median(ts)) / nF * args.frames
     esd = synth.state_dict_from_keys(keys["crossmodal"], seed=50, prefix="enc.")
     for v in esd.values():
@@ -169,12 +174,15 @@ def cpu_baseline(args, cfg):
         ta = torch.cat((OC.crossmodal_encoder(esd, t_, a_, a_), OC.crossmodal_encoder(esd, a_, t_, t_)), 0)
         out = torch.cat((OC.crossmodal_encoder(esd, ta, v_, v_), OC.crossmodal_encoder(esd, v_, ta, ta)), 0)
         out.square().mean().backward()
-    fusion_step()
     t0 = time.perf_counter()
     fusion_step()
     t_fus = time.perf_counter() - t0
+    if t_fus < 10.0:
+        t0 = time.perf_counter()
+        fusion_step()
+        t_fus = time.perf_counter() - t0
     return {"value": round(1.0 / (t_swin + t_fus), 5), "unit": "utterances/s", "cores": cores, "kind": "port",
-            "sample": f"oracle fp32 fwd+bwd: Swin+head on {nF} frames (median of 3, scaled x{args.frames / nF:g} to {args.frames} frames/utt: "
+            "sample": f"oracle fp32 fwd+bwd: Swin+head on {nF} frames ({cores} threads, median of {len(ts)}, scaled x{args.frames / nF:g} to {args.frames} frames/utt: "
                       f"{t_swin:.2f} s) + 4 cross-modal encoder calls for 1 utterance ({t_fus:.2f} s); text encoder excluded"}
 
 

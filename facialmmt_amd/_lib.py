@@ -20,14 +20,16 @@ _p, _i, _f, _sz, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_uint64
 SIGNATURES = {
     "fmmt_version": (_i, []),
     "fmmt_linear_fwd": (_i, [_i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p]),
+    "fmmt_linear_splitk_workspace": (_sz, [_i, _i, _i]),
+    "fmmt_linear_fwd_splitk": (_i, [_i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _i, _p, _sz, _p]),
     "fmmt_linear_wgrad_workspace": (_sz, [_i, _i, _i]),
     "fmmt_linear_wgrad": (_i, [_i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p, _i, _p, _sz, _p]),
     "fmmt_layernorm_fwd": (_i, [_i, _i, _i, _p, _p, _p, _f, _p, _p, _p, _i, _p]),
     "fmmt_layernorm_bwd_workspace": (_sz, [_i]),
     "fmmt_layernorm_bwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _sz, _p]),
-    "fmmt_window_attn_fwd": (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _f, _p, _p, _p]),
+    "fmmt_window_attn_fwd": (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _i, _f, _p, _p, _p]),
     "fmmt_window_attn_bwd_workspace": (_sz, [_i]),
-    "fmmt_window_attn_bwd": (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _f, _p, _p, _p, _sz, _p]),
+    "fmmt_window_attn_bwd": (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p, _p, _p, _sz, _p]),
     "fmmt_mha_fwd": (_i, [_i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i, _f, _f, _u64, _p, _i, _p, _p]),
     "fmmt_mha_bwd": (_i, [_i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i, _f, _f, _u64, _p, _p, _i, _p, _p, _i, _p, _p, _i, _p]),
     "fmmt_patch_im2col": (_i, [_i, _i, _p, _p, _p]),

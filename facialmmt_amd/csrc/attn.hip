@@ -13,6 +13,7 @@
 // per-wave partials in a fixed order (deterministic, no atomics).
 #include "fmmt_common.h"
 #include "../../include/fmmt.h"
+#include "wattn_args.h"
 
 namespace {
 
@@ -23,22 +24,6 @@ constexpr int KP = 36;       // LDS row pitch (floats) of a 49 x 32 tile: 16-byt
 constexpr int BP = 50;       // LDS row pitch of the 49 x 49 bias tile
 constexpr int WA_BWD_WAVES_PER_HEAD_MAX = 256;
 
-struct WaArgs {
-    int n_img, H, W, C, nH, shift;
-    const void* qkv;
-    const float* table;
-    const int32_t* index;
-    const float* mask;
-    int nW_mask;
-    float scale;
-    void* out;
-    float* lse;
-    // backward
-    const void* dout;
-    void* dqkv;
-    float* part;       // [nH][waves_per_head][49*49]
-    int groups_per_head;   // workgroups per head
-};
 
 template <typename T> __device__ __forceinline__ void load_row32(const T* p, float* r) {
     constexpr int VEC = Vec<T>::N;
@@ -289,20 +274,29 @@ __global__ __launch_bounds__(256) void wattn_bwd_kernel(WaArgs p) {
     for (int t = lane; t < TOK * TOK; t += 64) part[t] = DB[wave][(t / TOK) * BP + (t % TOK)];
 }
 
-// dtable[r][h] = sum over (i,j) with index[i][j] == r of sum_w part[h][w][i][j]   (fixed order)
-__global__ void wattn_dtable_kernel(const float* __restrict__ part, const int32_t* __restrict__ index,
-                                    int nH, int waves, float* __restrict__ dtable) {
+// d(bias table), deterministic two-stage reduction of the per-wave partials:
+//   dense[h][e] = sum_w part[h][w][e]           (one thread per (h, e): coalesced over e)
+//   dtable[r][h] = sum_{e : index[e] == r} dense[h][e]
+__global__ void wattn_dense_kernel(const float* __restrict__ part, int nH, int waves, float* __restrict__ dense) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int nrel = (2 * WS - 1) * (2 * WS - 1);
-    if (t >= nrel * nH) return;
+    if (t >= nH * TOK * TOK) return;
+    const int h = t / (TOK * TOK), e = t - h * TOK * TOK;
+    const float* pe = part + (size_t)h * waves * TOK * TOK + e;
+    float a = 0.f;
+    for (int w = 0; w < waves; ++w) a += pe[(size_t)w * TOK * TOK];
+    dense[t] = a;
+}
+
+__global__ __launch_bounds__(64) void wattn_dtable_kernel(const float* __restrict__ dense, const int32_t* __restrict__ index,
+                                                          int nH, float* __restrict__ dtable) {
+    // one wave per table entry (r, h): lanes stride over the 2401 (i,j) pairs, fixed-order wave reduction
+    const int t = blockIdx.x;
     const int r = t / nH, h = t - r * nH;
     float a = 0.f;
-    for (int e = 0; e < TOK * TOK; ++e) {
-        if (index[e] != r) continue;
-        const float* pe = part + (size_t)h * waves * TOK * TOK + e;
-        for (int w = 0; w < waves; ++w) a += pe[(size_t)w * TOK * TOK];
-    }
-    dtable[t] = a;
+    for (int e = threadIdx.x; e < TOK * TOK; e += 64)
+        if (index[e] == r) a += dense[h * TOK * TOK + e];
+    a = wave_sum(a);
+    if (threadIdx.x == 0) dtable[t] = a;
 }
 
 int wa_groups_per_head(int B_, int nH, bool bwd) {
@@ -567,49 +561,55 @@ int mha_check(int dtype, int Lq, int Lk, int B, int E, int nH) {
 
 extern "C" int fmmt_window_attn_fwd(int dtype, int n_img, int H, int W, int C, int num_heads, int shift,
                                     const void* qkv, const float* table, const int32_t* index,
-                                    const float* mask, int nW_mask, float scale,
+                                    const float* mask, int nW_mask, int mask_is_shift, float scale,
                                     void* out, float* lse, void* stream) {
     if (int e = wa_check(dtype, n_img, H, W, C, num_heads, shift)) return e;
     if (mask && nW_mask <= 0) return FMMT_EINVAL;
     WaArgs a{};
     a.n_img = n_img; a.H = H; a.W = W; a.C = C; a.nH = num_heads; a.shift = shift; a.qkv = qkv; a.table = table;
-    a.index = index; a.mask = mask; a.nW_mask = nW_mask; a.scale = scale; a.out = out; a.lse = lse;
+    a.index = index; a.mask = mask; a.nW_mask = nW_mask; a.mask_is_shift = mask_is_shift; a.scale = scale; a.out = out; a.lse = lse;
     const int B_ = n_img * (H / WS) * (W / WS);
     a.groups_per_head = wa_groups_per_head(B_, num_heads, false);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid(num_heads * a.groups_per_head);
-    if (dtype == FMMT_BF16) hipLaunchKernelGGL(wattn_fwd_kernel<bf16>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(wattn_fwd_kernel<float>, grid, dim3(256), 0, st, a);
+    if (dtype == FMMT_BF16) return fmmt_wattn_mfma_fwd_launch(a, (int)grid.x, st);     // matrix-core path
+    hipLaunchKernelGGL(wattn_fwd_kernel<float>, grid, dim3(256), 0, st, a);             // exact-fp32 parity path
     FMMT_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" size_t fmmt_window_attn_bwd_workspace(int num_heads) {
-    return (size_t)num_heads * WA_BWD_WAVES_PER_HEAD_MAX * TOK * TOK * sizeof(float);
+    return (size_t)num_heads * (WA_BWD_WAVES_PER_HEAD_MAX + 1) * TOK * TOK * sizeof(float);   // per-wave partials + dense
 }
 
 extern "C" int fmmt_window_attn_bwd(int dtype, int n_img, int H, int W, int C, int num_heads, int shift,
                                     const void* qkv, const void* out, const void* dout, const float* lse,
                                     const float* table, const int32_t* index, const float* mask, int nW_mask,
-                                    float scale, void* dqkv, float* dtable,
+                                    int mask_is_shift, float scale, void* dqkv, float* dtable,
                                     void* workspace, size_t workspace_bytes, void* stream) {
     if (int e = wa_check(dtype, n_img, H, W, C, num_heads, shift)) return e;
     if (mask && nW_mask <= 0) return FMMT_EINVAL;
     if (workspace_bytes < fmmt_window_attn_bwd_workspace(num_heads)) return FMMT_EWORKSPACE;
     WaArgs a{};
     a.n_img = n_img; a.H = H; a.W = W; a.C = C; a.nH = num_heads; a.shift = shift; a.qkv = qkv; a.table = table;
-    a.index = index; a.mask = mask; a.nW_mask = nW_mask; a.scale = scale; a.out = const_cast<void*>(out);
+    a.index = index; a.mask = mask; a.nW_mask = nW_mask; a.mask_is_shift = mask_is_shift; a.scale = scale; a.out = const_cast<void*>(out);
     a.lse = const_cast<float*>(lse); a.dout = dout; a.dqkv = dqkv; a.part = reinterpret_cast<float*>(workspace);
     const int B_ = n_img * (H / WS) * (W / WS);
     a.groups_per_head = wa_groups_per_head(B_, num_heads, true);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid(num_heads * a.groups_per_head);
-    if (dtype == FMMT_BF16) hipLaunchKernelGGL(wattn_bwd_kernel<bf16>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(wattn_bwd_kernel<float>, grid, dim3(256), 0, st, a);
-    FMMT_CHECK_LAUNCH();
+    if (dtype == FMMT_BF16) {
+        if (int rc = fmmt_wattn_mfma_bwd_launch(a, (int)grid.x, st)) return rc;
+    } else {
+        hipLaunchKernelGGL(wattn_bwd_kernel<float>, grid, dim3(256), 0, st, a);
+        FMMT_CHECK_LAUNCH();
+    }
     const int nt = (2 * WS - 1) * (2 * WS - 1) * num_heads;
-    hipLaunchKernelGGL(wattn_dtable_kernel, dim3((nt + 63) / 64), dim3(64), 0, st, a.part, index, num_heads,
-                       a.groups_per_head * 4, dtable);
+    float* dense = a.part + (size_t)num_heads * WA_BWD_WAVES_PER_HEAD_MAX * TOK * TOK;
+    const int nd = num_heads * TOK * TOK;
+    hipLaunchKernelGGL(wattn_dense_kernel, dim3((nd + 255) / 256), dim3(256), 0, st, a.part, num_heads, a.groups_per_head * 4, dense);
+    FMMT_CHECK_LAUNCH();
+    hipLaunchKernelGGL(wattn_dtable_kernel, dim3(nt), dim3(64), 0, st, dense, index, num_heads, dtable);
     FMMT_CHECK_LAUNCH();
     return 0;
 }

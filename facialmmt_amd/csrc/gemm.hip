@@ -50,6 +50,8 @@ struct LinArgs {
     const void* res; int ldres;
     const float* rowscale; int rows_per_scale;
     int tiles_n;
+    int ksplit;        // K range per blockIdx.y (split-K); 0 = no split
+    float* part;       // split-K: fp32 partials [split][M][N] instead of the epilogue
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -83,6 +85,8 @@ __global__ __launch_bounds__(256) void linear_nt_kernel(LinArgs p) {
     const T* __restrict__ wg = reinterpret_cast<const T*>(p.w);
 
     Vec<T> wreg[WV], xreg[XV];
+    const int kbeg = p.ksplit ? blockIdx.y * p.ksplit : 0;
+    const int kend = p.ksplit ? min(p.K, kbeg + p.ksplit) : p.K;
 
     auto gload = [&](int k0) {
 #pragma unroll
@@ -91,7 +95,7 @@ __global__ __launch_bounds__(256) void linear_nt_kernel(LinArgs p) {
             if (v < W_VECS) {
                 const int row = v / KV, kc = (v % KV) * VEC;
                 const int n = min(n0 + row, p.N - 1);
-                wreg[i] = (k0 + kc < p.K) ? ldvec<T>(wg + (size_t)n * p.ldw + k0 + kc) : zerovec<T>();
+                wreg[i] = (k0 + kc < kend) ? ldvec<T>(wg + (size_t)n * p.ldw + k0 + kc) : zerovec<T>();
             }
         }
 #pragma unroll
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(256) void linear_nt_kernel(LinArgs p) {
             if (v < X_VECS) {
                 const int row = v / KV, kc = (v % KV) * VEC;
                 const int m = min(m0 + row, p.M - 1);
-                xreg[i] = (k0 + kc < p.K) ? ldvec<T>(xg + (size_t)m * p.ldx + k0 + kc) : zerovec<T>();
+                xreg[i] = (k0 + kc < kend) ? ldvec<T>(xg + (size_t)m * p.ldx + k0 + kc) : zerovec<T>();
             }
         }
     };
@@ -131,13 +135,13 @@ __global__ __launch_bounds__(256) void linear_nt_kernel(LinArgs p) {
     const int xrow_base = wm * WM + li;
     const int koff = lg * KP;
 
-    const int nk = (p.K + BK - 1) / BK;
-    gload(0);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    gload(kbeg);
     lstore(0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) gload((kt + 1) * BK);
+        if (kt + 1 < nk) gload(kbeg + (kt + 1) * BK);
         const T* wsb = Ws + cur * BN * PITCH;
         const T* xsb = Xs + cur * BM * PITCH;
 #pragma unroll
@@ -162,6 +166,20 @@ __global__ __launch_bounds__(256) void linear_nt_kernel(LinArgs p) {
     const T* __restrict__ auxg = reinterpret_cast<const T*>(p.aux);
     const T* __restrict__ resg = reinterpret_cast<const T*>(p.res);
     const int ncol0 = n0 + wn * WN + lg * (4 * NT);
+    if (p.part) {                                          // split-K: raw fp32 partial sums, epilogue runs later
+        float* pp = p.part + (size_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+            const int m = m0 + wm * WM + a * 16 + li;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                const int n = ncol0 + b * 4;
+                if (n + 4 <= p.N) *reinterpret_cast<f32x4*>(pp + (size_t)m * p.N + n) = acc[a][b];
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < MT; ++a) {
         const int m = m0 + wm * WM + a * 16 + li;
@@ -221,9 +239,34 @@ int launch_nt(const LinArgs& a, hipStream_t st) {
     LinArgs p = a;
     p.tiles_n = (a.N + BN - 1) / BN;
     const int tiles_m = (a.M + BM - 1) / BM;
-    hipLaunchKernelGGL((linear_nt_kernel<T, BM, BN, BK>), dim3(tiles_m * p.tiles_n), dim3(256), lds, st, p);
+    const int splits = a.ksplit ? (a.K + a.ksplit - 1) / a.ksplit : 1;
+    hipLaunchKernelGGL((linear_nt_kernel<T, BM, BN, BK>), dim3(tiles_m * p.tiles_n, splits), dim3(256), lds, st, p);
     FMMT_CHECK_LAUNCH();
     return 0;
+}
+
+// y = T(sum_s part[s] + bias) for the split-K path
+template <typename T>
+__global__ void splitk_finish_kernel(const float* __restrict__ part, int splits, int M, int N, const float* __restrict__ bias,
+                                     T* __restrict__ y, int ldy) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)M * N) return;
+    const int m = (int)(i / N), n = (int)(i - (size_t)m * N);
+    float t = bias ? bias[n] : 0.f;
+    for (int s = 0; s < splits; ++s) t += part[(size_t)s * M * N + i];
+    y[(size_t)m * ldy + n] = from_f32<T>(t);
+}
+
+// split-K plan for skinny problems (the 37632 -> 512 head): few output tiles, very long K
+int splitk_plan(int M, int N, int K, int* ksplit) {
+    const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    if (tiles >= 128 || K < 4096) { *ksplit = 0; return 1; }
+    int splits = 512 / tiles;
+    if (splits > 32) splits = 32;
+    int ks = (K + splits - 1) / splits;
+    ks = (ks + 63) / 64 * 64;
+    *ksplit = ks;
+    return (K + ks - 1) / ks;
 }
 
 template <typename T>
@@ -399,12 +442,17 @@ __global__ __launch_bounds__(256) void linear_tn_kernel(TnArgs p) {
     }
 }
 
-__global__ void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n, int splits) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// out[i] = sum_s part[s][i] : 256 threads = 64 outputs x 4 split groups, fixed-order tree (deterministic)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n, int splits) {
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const size_t i = (size_t)blockIdx.x * 64 + tx;
     float t = 0.f;
-    for (int s = 0; s < splits; ++s) t += part[(size_t)s * n + i];
-    out[i] = t;
+    if (i < n)
+        for (int s = ty; s < splits; s += 4) t += part[(size_t)s * n + i];
+    red[ty][tx] = t;
+    __syncthreads();
+    if (ty == 0 && i < n) out[i] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
 }
 
 struct TnPlan { int tiles_n, tiles_k, splits, chunk; size_t bytes; };
@@ -414,7 +462,7 @@ TnPlan tn_plan(int M, int N, int K) {
     pl.tiles_n = (N + 127) / 128;
     pl.tiles_k = (K + 127) / 128;
     const int tiles = pl.tiles_n * pl.tiles_k;
-    int splits = (1024 + tiles - 1) / tiles;
+    int splits = (768 + tiles - 1) / tiles;
     const int max_by_rows = (M + 255) / 256;
     if (splits > max_by_rows) splits = max_by_rows;
     if (splits < 1) splits = 1;
@@ -448,9 +496,40 @@ extern "C" int fmmt_linear_fwd(int dtype, int M, int N, int K,
     if (!aligned16(x) || !aligned16(w) || !aligned16(y) || (bias && !aligned16(bias)) ||
         (res && !aligned16(res)) || (aux && !aligned16(aux)) || (y_pre && !aligned16(y_pre)))
         return FMMT_EALIGN;
-    LinArgs a{M, N, K, x, ldx, w, ldw, bias, y, ldy, y_pre, epi, aux, ldaux, res, ldres, rowscale, rows_per_scale, 0};
+    LinArgs a{M, N, K, x, ldx, w, ldw, bias, y, ldy, y_pre, epi, aux, ldaux, res, ldres, rowscale, rows_per_scale, 0, 0, nullptr};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     return dtype == FMMT_BF16 ? dispatch_nt<bf16>(a, st) : dispatch_nt<float>(a, st);
+}
+
+extern "C" size_t fmmt_linear_splitk_workspace(int M, int N, int K) {
+    int ks;
+    const int splits = splitk_plan(M, N, K, &ks);
+    return ks ? (size_t)splits * M * N * sizeof(float) : 0;
+}
+
+extern "C" int fmmt_linear_fwd_splitk(int dtype, int M, int N, int K, const void* x, int ldx, const void* w, int ldw,
+                                      const float* bias, void* y, int ldy, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0) return FMMT_EINVAL;
+    if (dtype != FMMT_BF16 && dtype != FMMT_F32) return FMMT_EINVAL;
+    const int vec = dtype == FMMT_BF16 ? 8 : 4;
+    if (K % vec || N % 4 || ldx % vec || ldw % vec) return FMMT_EINVAL;
+    if (!aligned16(x) || !aligned16(w) || !aligned16(workspace)) return FMMT_EALIGN;
+    int ks;
+    const int splits = splitk_plan(M, N, K, &ks);
+    if (!ks) return FMMT_EINVAL;                            // not a split-K shape: use fmmt_linear_fwd
+    if (workspace_bytes < (size_t)splits * M * N * sizeof(float)) return FMMT_EWORKSPACE;
+    LinArgs a{M, N, K, x, ldx, w, ldw, nullptr, nullptr, N, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 1, 0, ks,
+              reinterpret_cast<float*>(workspace)};
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (int rc = (dtype == FMMT_BF16 ? dispatch_nt<bf16>(a, st) : dispatch_nt<float>(a, st))) return rc;
+    const size_t total = (size_t)M * N;
+    if (dtype == FMMT_BF16)
+        hipLaunchKernelGGL(splitk_finish_kernel<bf16>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.part, splits, M, N, bias, (bf16*)y, ldy);
+    else
+        hipLaunchKernelGGL(splitk_finish_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.part, splits, M, N, bias, (float*)y, ldy);
+    FMMT_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" size_t fmmt_linear_wgrad_workspace(int M, int N, int K) {
@@ -479,10 +558,10 @@ extern "C" int fmmt_linear_wgrad(int dtype, int M, int N, int K,
     else hipLaunchKernelGGL(linear_tn_kernel<float>, grid, dim3(256), 0, st, a);
     FMMT_CHECK_LAUNCH();
     const size_t nw = (size_t)N * K;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, part_w, dw, nw, pl.splits);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nw + 63) / 64)), dim3(256), 0, st, part_w, dw, nw, pl.splits);
     FMMT_CHECK_LAUNCH();
     if (db) {
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 255) / 256), dim3(256), 0, st, part_b, db, (size_t)N, pl.splits);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 63) / 64), dim3(256), 0, st, part_b, db, (size_t)N, pl.splits);
         FMMT_CHECK_LAUNCH();
     }
     return 0;

@@ -1,0 +1,432 @@
+// (Shifted-)window attention core on the matrix cores -- bf16 throughput path (gfx950).
+//
+// One wave owns one (window, head) problem: 49 tokens (padded to 64) x head_dim 32.
+//   S^T = K . Q^T      16 x mfma_f32_16x16x32_bf16 (K, Q fragments are 16-byte loads straight from the
+//                      token-order qkv matrix: an MFMA fragment row IS 8 contiguous channels of one token)
+//   softmax            computed on S^T: a lane holds ONE query column (its 16 keys per query tile), so the
+//                      row max / sum need only two cross-lane steps (xor 16, xor 32)
+//   O^T = V^T . P^T    16 x MFMA; P^T is consumed from the registers it was produced in (the k-slot order of
+//                      the contraction is free, so it is chosen to match the accumulator layout); V^T comes
+//                      from a natural-layout LDS tile through the LDS transpose read (ds_read_b64_tr_b16),
+//                      with the output-channel permutation that makes every lane store 8 contiguous channels.
+// roll / window_partition / window_reverse are address arithmetic, as in attn.hip.  A workgroup (4 waves)
+// is pinned to one head and walks windows, so that head's dense 49x49 bias sits in LDS.
+//
+// Backward recomputes P from the saved log-sum-exp twice: once with lanes owning query columns (dQ, d bias
+// accumulated in registers across windows) and once with lanes owning key columns (dK, dV) -- cheaper than
+// transposing P / dS through LDS.  d(bias table) is reduced through per-wave partials in a fixed order.
+#include "fmmt_common.h"
+#include "../../include/fmmt.h"
+#include "wattn_args.h"
+
+namespace {
+
+constexpr int TOK = 49, WS = 7, HD = 32;
+constexpr int TP = 40;       // LDS tile pitch in bf16 (80 B rows: 16-byte aligned, spreads banks)
+constexpr int BPM = 64;      // LDS bias pitch (floats)
+constexpr float NEG_BIG = -1.0e30f;
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ bf16x8 ld_frag(const bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
+
+__device__ __forceinline__ bf16x8 zero_frag() {
+    bf16x8 z;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) z[e] = (bf16)0.f;
+    return z;
+}
+
+// A-operand fragment of X^T for X stored [row][HD] in LDS: MFMA row i <-> channel (i>>2)*8 + dt*4 + (i&3),
+// k-slot (g, e) <-> row r0 + e (e < 4), r0 + 16 + (e - 4) (e >= 4)   with r0 = 32*ks + 4*g
+__device__ __forceinline__ bf16x8 tr_fragT(const bf16* tile, int r0, int dt, int li) {
+    const bf16* a0 = tile + (r0 + (li >> 2)) * TP + (li & 3) * 8 + dt * 4;
+    union { struct { s16x4 lo, hi; } s; bf16x8 v; } u;
+    u.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
+    u.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 16 * TP));
+    return u.v;
+}
+
+__device__ __forceinline__ bf16x8 pack8(const float* lo4, const float* hi4) {
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = (bf16)lo4[e]; v[4 + e] = (bf16)hi4[e]; }
+    return v;
+}
+
+__device__ __forceinline__ float xor_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float xor_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+struct LaneGeom {
+    int di[4], dj[4];        // window-local (row, col) of slot t*16 + li (clamped to slot 48)
+    bool valid[4];
+    unsigned nearH, nearW;   // bit (t*4 + r): slot 16t + 4g + r lies in the "near" part (i < 7 - shift) -- std mask
+    unsigned ownH, ownW;     // bit t: own slot 16t + li in the near part
+};
+
+__device__ __forceinline__ LaneGeom lane_geom(int li, int lg, int shift) {
+    LaneGeom G;
+    G.nearH = G.nearW = G.ownH = G.ownW = 0u;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int slot = t * 16 + li;
+        G.valid[t] = slot < TOK;
+        const int cs = slot < TOK ? slot : TOK - 1;
+        G.di[t] = cs / WS;
+        G.dj[t] = cs - G.di[t] * WS;
+        if (G.di[t] < WS - shift) G.ownH |= 1u << t;
+        if (G.dj[t] < WS - shift) G.ownW |= 1u << t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int s2 = t * 16 + lg * 4 + r;
+            s2 = s2 < TOK ? s2 : TOK - 1;
+            const int i2 = s2 / WS, j2 = s2 - i2 * WS;
+            if (i2 < WS - shift) G.nearH |= 1u << (t * 4 + r);
+            if (j2 < WS - shift) G.nearW |= 1u << (t * 4 + r);
+        }
+    }
+    return G;
+}
+
+struct WinPos { int img, wy, wx, w; bool lastrow, lastcol; };
+
+__device__ __forceinline__ WinPos win_pos(const WaArgs& p, int b_) {
+    const int nWx = p.W / WS, nWy = p.H / WS, nW = nWx * nWy;
+    WinPos P;
+    P.img = b_ / nW;
+    P.w = b_ - P.img * nW;
+    P.wy = P.w / nWx;
+    P.wx = P.w - P.wy * nWx;
+    P.lastrow = P.wy == nWy - 1;
+    P.lastcol = P.wx == nWx - 1;
+    return P;
+}
+
+__device__ __forceinline__ size_t tok_of(const WaArgs& p, const WinPos& P, int di, int dj) {
+    int hh = P.wy * WS + di + p.shift;
+    if (hh >= p.H) hh -= p.H;
+    int ww = P.wx * WS + dj + p.shift;
+    if (ww >= p.W) ww -= p.W;
+    return (size_t)P.img * p.H * p.W + (size_t)hh * p.W + ww;
+}
+
+// 16-bit mask of "other" slots (bit t*4+r <-> slot 16t+4g+r) that sit in a different shift-region than
+// the lane's own slot of tile `t_own`
+__device__ __forceinline__ unsigned std_mask_bits(const LaneGeom& G, const WinPos& P, int t_own) {
+    unsigned m = 0u;
+    if (P.lastrow) m |= ((G.ownH >> t_own) & 1u) ? ~G.nearH : G.nearH;
+    if (P.lastcol) m |= ((G.ownW >> t_own) & 1u) ? ~G.nearW : G.nearW;
+    return m & 0xFFFFu;
+}
+
+__device__ __forceinline__ void fill_bias_mfma(const WaArgs& p, int head, float* Bs) {
+    for (int t = threadIdx.x; t < 64 * BPM; t += 256) {
+        const int q = t / BPM, k = t - q * BPM;
+        Bs[t] = (q < TOK && k < TOK) ? p.table[p.index[q * TOK + k] * p.nH + head] : NEG_BIG;
+    }
+}
+
+// =============================================================================================
+template <int DUMMY>
+__global__ __launch_bounds__(256) void wattn_mfma_fwd_kernel(WaArgs p) {
+    __shared__ __attribute__((aligned(16))) bf16 Vt[4][64 * TP];
+    __shared__ __attribute__((aligned(16))) float Bs[64 * BPM];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int head = blockIdx.x / p.groups_per_head, grp = blockIdx.x - head * p.groups_per_head;
+    const int nW = (p.H / WS) * (p.W / WS), B_ = p.n_img * nW;
+    const int stride = p.groups_per_head * 4;
+    const bf16* __restrict__ qkv = reinterpret_cast<const bf16*>(p.qkv);
+    bf16* __restrict__ out = reinterpret_cast<bf16*>(p.out);
+    const LaneGeom G = lane_geom(li, lg, p.shift);
+    bf16* vt = Vt[wave];
+
+    fill_bias_mfma(p, head, Bs);
+    const int iters = (B_ + stride - 1) / stride;
+    for (int it = 0; it < iters; ++it) {
+        const int b_raw = it * stride + grp * 4 + wave;
+        const bool wactive = b_raw < B_;
+        const int b_ = wactive ? b_raw : B_ - 1;
+        const WinPos P = win_pos(p, b_);
+        size_t tok[4];
+        bf16x8 qf[4], kf[4];
+        __syncthreads();                                   // previous iteration's reads of Vt are done
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            tok[t] = tok_of(p, P, G.di[t], G.dj[t]);
+            const bf16* row = qkv + tok[t] * 3 * p.C + head * HD + lg * 8;
+            qf[t] = ld_frag(row);
+            kf[t] = ld_frag(row + p.C);
+            const bf16x8 vv = G.valid[t] ? ld_frag(row + 2 * p.C) : zero_frag();
+            *reinterpret_cast<bf16x8*>(vt + (t * 16 + li) * TP + lg * 8) = vv;
+        }
+        __syncthreads();
+        bf16x8 vT[2][2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) vT[ks][dt] = tr_fragT(vt, 32 * ks + 4 * lg, dt, li);
+
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+            const int q = qt * 16 + li;
+            float s[16];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(&Bs[q * BPM + kt * 16 + lg * 4]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[kt * 4 + r] = a[r] * p.scale + b[r];
+            }
+            if (p.mask) {
+                if (p.mask_is_shift) {
+                    const unsigned mb = std_mask_bits(G, P, qt);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) s[e] += ((mb >> e) & 1u) ? -100.0f : 0.0f;
+                } else if (q < TOK) {
+                    const float* mrow = p.mask + ((size_t)(b_ % p.nW_mask) * TOK + q) * TOK;
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int key = kt * 16 + lg * 4 + r;
+                            if (key < TOK) s[kt * 4 + r] += mrow[key];
+                        }
+                }
+            }
+            float m = s[0];
+#pragma unroll
+            for (int e = 1; e < 16; ++e) m = fmaxf(m, s[e]);
+            m = xor_max(m);
+            float l = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                s[e] = __expf(s[e] - m);
+                l += s[e];
+            }
+            l = xor_sum(l);
+            const float inv = 1.0f / l;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[e] *= inv;
+            const bf16x8 pb0 = pack8(&s[0], &s[4]), pb1 = pack8(&s[8], &s[12]);
+            f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+            o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vT[0][0], pb0, o0, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vT[1][0], pb1, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vT[0][1], pb0, o1, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vT[1][1], pb1, o1, 0, 0, 0);
+            if (wactive && G.valid[qt]) {
+                bf16x8 ob;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { ob[r] = (bf16)o0[r]; ob[4 + r] = (bf16)o1[r]; }
+                *reinterpret_cast<bf16x8*>(out + tok[qt] * p.C + head * HD + lg * 8) = ob;
+                if (lg == 0) p.lse[((size_t)b_ * p.nH + head) * TOK + q] = m + __logf(l);
+            }
+        }
+    }
+}
+
+// =============================================================================================
+template <int DUMMY>
+__global__ __launch_bounds__(256) void wattn_mfma_bwd_kernel(WaArgs p) {
+    __shared__ __attribute__((aligned(16))) bf16 Kt[4][64 * TP];
+    __shared__ __attribute__((aligned(16))) bf16 Qt[4][64 * TP];
+    __shared__ __attribute__((aligned(16))) bf16 Gt[4][64 * TP];
+    __shared__ __attribute__((aligned(16))) float Ls[4][64];
+    __shared__ __attribute__((aligned(16))) float Dl[4][64];
+    __shared__ __attribute__((aligned(16))) float Bs[64 * BPM];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int head = blockIdx.x / p.groups_per_head, grp = blockIdx.x - head * p.groups_per_head;
+    const int nW = (p.H / WS) * (p.W / WS), B_ = p.n_img * nW;
+    const int stride = p.groups_per_head * 4;
+    const bf16* __restrict__ qkv = reinterpret_cast<const bf16*>(p.qkv);
+    const bf16* __restrict__ og = reinterpret_cast<const bf16*>(p.out);
+    const bf16* __restrict__ dog = reinterpret_cast<const bf16*>(p.dout);
+    bf16* __restrict__ dqkv = reinterpret_cast<bf16*>(p.dqkv);
+    const LaneGeom G = lane_geom(li, lg, p.shift);
+    bf16 *kt_ = Kt[wave], *qt_ = Qt[wave], *gt_ = Gt[wave];
+
+    fill_bias_mfma(p, head, Bs);
+    f32x4 dbias[4][4];                               // [qt][kt], lane = query column layout
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) dbias[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int iters = (B_ + stride - 1) / stride;
+    for (int it = 0; it < iters; ++it) {
+        const int b_raw = it * stride + grp * 4 + wave;
+        const bool wactive = b_raw < B_;
+        const int b_ = wactive ? b_raw : B_ - 1;
+        const WinPos P = win_pos(p, b_);
+        const float* mbase = (p.mask && !p.mask_is_shift) ? p.mask + (size_t)(b_ % p.nW_mask) * TOK * TOK : nullptr;
+        size_t tok[4];
+        bf16x8 qf[4], kf[4], vf[4], gf[4];
+        float ls[4], dl[4];
+        __syncthreads();                                   // previous iteration finished with the LDS tiles
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            tok[t] = tok_of(p, P, G.di[t], G.dj[t]);
+            const bf16* row = qkv + tok[t] * 3 * p.C + head * HD + lg * 8;
+            qf[t] = ld_frag(row);
+            kf[t] = ld_frag(row + p.C);
+            vf[t] = ld_frag(row + 2 * p.C);
+            gf[t] = ld_frag(dog + tok[t] * p.C + head * HD + lg * 8);
+            const bf16x8 of = ld_frag(og + tok[t] * p.C + head * HD + lg * 8);
+            float d = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d += (float)gf[t][e] * (float)of[e];
+            dl[t] = xor_sum(d);
+            const int q = t * 16 + li;
+            ls[t] = p.lse[((size_t)b_ * p.nH + head) * TOK + (q < TOK ? q : TOK - 1)];
+            const int off = (t * 16 + li) * TP + lg * 8;
+            *reinterpret_cast<bf16x8*>(kt_ + off) = G.valid[t] ? kf[t] : zero_frag();
+            *reinterpret_cast<bf16x8*>(qt_ + off) = G.valid[t] ? qf[t] : zero_frag();
+            *reinterpret_cast<bf16x8*>(gt_ + off) = G.valid[t] ? gf[t] : zero_frag();
+            if (lg == 0) {
+                Ls[wave][q] = ls[t];
+                Dl[wave][q] = dl[t];
+            }
+        }
+        __syncthreads();
+
+        // ------------------------------------------------ pass 1: lanes own query columns -> dQ, d bias
+        {
+            bf16x8 kT[2][2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) kT[ks][dt] = tr_fragT(kt_, 32 * ks + 4 * lg, dt, li);
+#pragma unroll
+            for (int qt = 0; qt < 4; ++qt) {
+                const int q = qt * 16 + li;
+                float ds[16];
+                const unsigned mb = (p.mask && p.mask_is_shift) ? std_mask_bits(G, P, qt) : 0u;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[kt], gf[qt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(&Bs[q * BPM + kt * 16 + lg * 4]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float s = a[r] * p.scale + b[r];
+                        if ((mb >> (kt * 4 + r)) & 1u) s -= 100.0f;
+                        if (mbase) {
+                            const int key = kt * 16 + lg * 4 + r;
+                            if (q < TOK && key < TOK) s += mbase[q * TOK + key];
+                        }
+                        const float pij = __expf(s - ls[qt]);
+                        const float d = pij * (dp[r] - dl[qt]);
+                        ds[kt * 4 + r] = d;
+                        if (wactive) dbias[qt][kt][r] += d;
+                    }
+                }
+                const bf16x8 d0 = pack8(&ds[0], &ds[4]), d1 = pack8(&ds[8], &ds[12]);
+                f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+                a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT[0][0], d0, a0, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT[1][0], d1, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT[0][1], d0, a1, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT[1][1], d1, a1, 0, 0, 0);
+                if (wactive && G.valid[qt]) {
+                    bf16x8 ob;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { ob[r] = (bf16)(a0[r] * p.scale); ob[4 + r] = (bf16)(a1[r] * p.scale); }
+                    *reinterpret_cast<bf16x8*>(dqkv + tok[qt] * 3 * p.C + head * HD + lg * 8) = ob;
+                }
+            }
+        }
+
+        // ------------------------------------------------ pass 2: lanes own key columns -> dK, dV
+        {
+            bf16x8 gT[2][2], qT[2][2];
+#pragma unroll
+            for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    gT[qs][dt] = tr_fragT(gt_, 32 * qs + 4 * lg, dt, li);
+                    qT[qs][dt] = tr_fragT(qt_, 32 * qs + 4 * lg, dt, li);
+                }
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const int key = kt * 16 + li;
+                float pp[16], ds[16];
+                const unsigned mb = (p.mask && p.mask_is_shift) ? std_mask_bits(G, P, kt) : 0u;
+#pragma unroll
+                for (int qt = 0; qt < 4; ++qt) {
+                    const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[qt], kf[kt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[qt], vf[kt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    const f32x4 lq = *reinterpret_cast<const f32x4*>(&Ls[wave][qt * 16 + lg * 4]);
+                    const f32x4 dq = *reinterpret_cast<const f32x4*>(&Dl[wave][qt * 16 + lg * 4]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int q = qt * 16 + lg * 4 + r;
+                        float s = a[r] * p.scale + Bs[q * BPM + key];
+                        if ((mb >> (qt * 4 + r)) & 1u) s -= 100.0f;
+                        if (mbase) {
+                            if (q < TOK && key < TOK) s += mbase[q * TOK + key];
+                        }
+                        const float pij = __expf(s - lq[r]);
+                        pp[qt * 4 + r] = pij;
+                        ds[qt * 4 + r] = pij * (dp[r] - dq[r]);
+                    }
+                }
+                const bf16x8 p0 = pack8(&pp[0], &pp[4]), p1 = pack8(&pp[8], &pp[12]);
+                const bf16x8 d0 = pack8(&ds[0], &ds[4]), d1 = pack8(&ds[8], &ds[12]);
+                f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f}, k0 = {0.f, 0.f, 0.f, 0.f}, k1 = {0.f, 0.f, 0.f, 0.f};
+                v0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gT[0][0], p0, v0, 0, 0, 0);
+                v0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gT[1][0], p1, v0, 0, 0, 0);
+                v1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gT[0][1], p0, v1, 0, 0, 0);
+                v1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gT[1][1], p1, v1, 0, 0, 0);
+                k0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT[0][0], d0, k0, 0, 0, 0);
+                k0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT[1][0], d1, k0, 0, 0, 0);
+                k1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT[0][1], d0, k1, 0, 0, 0);
+                k1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT[1][1], d1, k1, 0, 0, 0);
+                if (wactive && G.valid[kt]) {
+                    bf16x8 kb, vb;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        kb[r] = (bf16)(k0[r] * p.scale); kb[4 + r] = (bf16)(k1[r] * p.scale);
+                        vb[r] = (bf16)v0[r]; vb[4 + r] = (bf16)v1[r];
+                    }
+                    bf16* dst = dqkv + tok[kt] * 3 * p.C + head * HD + lg * 8;
+                    *reinterpret_cast<bf16x8*>(dst + p.C) = kb;
+                    *reinterpret_cast<bf16x8*>(dst + 2 * p.C) = vb;
+                }
+            }
+        }
+    }
+    // per-wave partial of d(bias): [q][key], lane holds q = qt*16 + li, key = kt*16 + 4g + r
+    float* part = p.part + ((size_t)head * stride + grp * 4 + wave) * TOK * TOK;
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+        const int q = qt * 16 + li;
+        if (q >= TOK) continue;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * 16 + lg * 4 + r;
+                if (key < TOK) part[q * TOK + key] = dbias[qt][kt][r];
+            }
+    }
+}
+
+}  // namespace
+
+int fmmt_wattn_mfma_fwd_launch(const WaArgs& a, int grid, hipStream_t st) {
+    hipLaunchKernelGGL(wattn_mfma_fwd_kernel<0>, dim3(grid), dim3(256), 0, st, a);
+    FMMT_CHECK_LAUNCH();
+    return 0;
+}
+
+int fmmt_wattn_mfma_bwd_launch(const WaArgs& a, int grid, hipStream_t st) {
+    hipLaunchKernelGGL(wattn_mfma_bwd_kernel<0>, dim3(grid), dim3(256), 0, st, a);
+    FMMT_CHECK_LAUNCH();
+    return 0;
+}

@@ -126,12 +126,13 @@ class WindowAttention(nn.Module):
         _require(not self.training or (self.attn_drop.p == 0.0 and self.proj_drop.p == 0.0),
                  "attention / projection dropout p > 0 in training")
 
-    def forward_tokens(self, x, n_img, H, W, shift, mask, res=None, rowscale=None):
-        """x: (n_img, H*W, C) in token order -> same shape; `res + rowscale * attn(x)` if res is given."""
+    def forward_tokens(self, x, n_img, H, W, shift, mask, res=None, rowscale=None, mask_is_shift=False):
+        """x: (n_img, H*W, C) in token order -> same shape; `res + rowscale * attn(x)` if res is given.
+        mask_is_shift: the caller guarantees `mask` is the standard SW-MSA mask of (H, W, shift)."""
         self._check()
         qkv = ops.linear(x, self.qkv.weight, self.qkv.bias)
         o = ops.window_attn_core(qkv.view(-1, 3 * self.dim), self.relative_position_bias_table, self._index(x.device),
-                                 mask, n_img, H, W, self.num_heads, shift, float(self.scale))
+                                 mask, n_img, H, W, self.num_heads, shift, float(self.scale), mask_is_shift)
         return ops.linear(o.view(n_img, H * W, self.dim), self.proj.weight, self.proj.bias, res, rowscale, H * W)
 
     def forward(self, x, mask=None):
@@ -189,6 +190,20 @@ class SwinTransformerBlock(nn.Module):
             H, W = self.input_resolution
             attn_mask = build_shift_mask(H, W, self.window_size, self.shift_size)
         self.register_buffer("attn_mask", attn_mask)
+        self._mask_checked = None      # (data_ptr, version) of the attn_mask buffer last verified to be the standard mask
+
+    def _mask_is_standard(self) -> bool:
+        """True iff the attn_mask buffer (possibly overwritten by load_state_dict) equals the mask the
+        constructor builds; verified once per buffer version, so the kernel may derive it arithmetically."""
+        m = self.attn_mask
+        if m is None:
+            return False
+        key = (m.data_ptr(), m._version)
+        if self._mask_checked is None or self._mask_checked[0] != key:
+            H, W = self.input_resolution
+            ok = bool(torch.equal(m.detach().float().cpu(), build_shift_mask(H, W, self.window_size, self.shift_size)))
+            self._mask_checked = (key, ok)
+        return self._mask_checked[1]
 
     def _scale(self, n, device):
         return self.drop_path.sample_scale(n, device) if isinstance(self.drop_path, DropPath) else None
@@ -198,7 +213,8 @@ class SwinTransformerBlock(nn.Module):
         B, L, C = x.shape
         assert L == H * W, "input feature has wrong size"
         xn = ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        x = self.attn.forward_tokens(xn, B, H, W, self.shift_size, self.attn_mask, res=x, rowscale=self._scale(B, x.device))
+        x = self.attn.forward_tokens(xn, B, H, W, self.shift_size, self.attn_mask, res=x, rowscale=self._scale(B, x.device),
+                                     mask_is_shift=self._mask_is_standard())
         xn = ops.layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         return self.mlp(xn, res=x, rowscale=self._scale(B, x.device), rows_per_scale=L)
 

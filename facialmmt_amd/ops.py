@@ -40,6 +40,14 @@ def linear_raw(x2, w, bias, *, epi=EPI_NONE, y_pre=None, aux=None, res=None, row
     N = w.shape[0]
     y = torch.empty((M, N), dtype=x2.dtype, device=x2.device)
     lib = _lib.load()
+    if epi == EPI_NONE and res is None and rowscale is None and K >= 4096:
+        nbytes = lib.fmmt_linear_splitk_workspace(M, N, K)
+        if nbytes:                                       # skinny, very long K (embedding head): split-K kernel
+            ws = _ws(nbytes, x2.device)
+            rc = lib.fmmt_linear_fwd_splitk(dtype_code(x2.dtype), M, N, K, _p(x2), K, _p(w), K, _p(bias), _p(y), N,
+                                            _p(ws), nbytes, _st())
+            check(rc, f"fmmt_linear_fwd_splitk(M={M},N={N},K={K})")
+            return y
     rc = lib.fmmt_linear_fwd(dtype_code(x2.dtype), M, N, K, _p(x2), K, _p(w), K, _p(bias), _p(y), N, _p(y_pre),
                              epi, _p(aux), N, _p(res), N, _p(rowscale), rows_per_scale, _st())
     check(rc, f"fmmt_linear_fwd(M={M},N={N},K={K})")
@@ -199,7 +207,7 @@ def layer_norm(x, gamma, beta, eps=1e-5, merge_hw=0):
 # ------------------------------------------------------------------------------------------------
 class WindowAttnCoreFn(Function):
     @staticmethod
-    def forward(ctx, qkv, table, index_i32, mask, n_img, H, W, num_heads, shift, scale):
+    def forward(ctx, qkv, table, index_i32, mask, n_img, H, W, num_heads, shift, scale, mask_is_shift):
         _need_cuda(qkv, "window_attention")
         lib = _lib.load()
         qkv = qkv.contiguous()
@@ -211,16 +219,16 @@ class WindowAttnCoreFn(Function):
         m = mask.detach().float().contiguous() if mask is not None else None
         nWm = m.shape[0] if m is not None else 0
         rc = lib.fmmt_window_attn_fwd(dtype_code(qkv.dtype), n_img, H, W, C, num_heads, shift, _p(qkv), _p(tab),
-                                      _p(index_i32), _p(m), nWm, scale, _p(out), _p(lse), _st())
+                                      _p(index_i32), _p(m), nWm, int(mask_is_shift), scale, _p(out), _p(lse), _st())
         check(rc, f"fmmt_window_attn_fwd(n={n_img},H={H},W={W},C={C},heads={num_heads},shift={shift})")
         ctx.save_for_backward(qkv, out, lse, tab, index_i32, m)
-        ctx.cfg = (n_img, H, W, C, num_heads, shift, scale, nWm)
+        ctx.cfg = (n_img, H, W, C, num_heads, shift, scale, nWm, int(mask_is_shift))
         return out
 
     @staticmethod
     def backward(ctx, dout):
         qkv, out, lse, tab, index_i32, m = ctx.saved_tensors
-        n_img, H, W, C, num_heads, shift, scale, nWm = ctx.cfg
+        n_img, H, W, C, num_heads, shift, scale, nWm, mis = ctx.cfg
         lib = _lib.load()
         dout = dout.contiguous()
         dqkv = torch.empty_like(qkv)
@@ -228,14 +236,14 @@ class WindowAttnCoreFn(Function):
         nbytes = lib.fmmt_window_attn_bwd_workspace(num_heads)
         ws = _ws(nbytes, qkv.device)
         rc = lib.fmmt_window_attn_bwd(dtype_code(qkv.dtype), n_img, H, W, C, num_heads, shift, _p(qkv), _p(out), _p(dout),
-                                      _p(lse), _p(tab), _p(index_i32), _p(m), nWm, scale, _p(dqkv), _p(dtable),
+                                      _p(lse), _p(tab), _p(index_i32), _p(m), nWm, mis, scale, _p(dqkv), _p(dtable),
                                       _p(ws), nbytes, _st())
         check(rc, "fmmt_window_attn_bwd")
-        return dqkv, dtable, None, None, None, None, None, None, None, None
+        return dqkv, dtable, None, None, None, None, None, None, None, None, None
 
 
-def window_attn_core(qkv, table, index_i32, mask, n_img, H, W, num_heads, shift, scale):
-    return WindowAttnCoreFn.apply(qkv, table, index_i32, mask, n_img, H, W, num_heads, shift, scale)
+def window_attn_core(qkv, table, index_i32, mask, n_img, H, W, num_heads, shift, scale, mask_is_shift=False):
+    return WindowAttnCoreFn.apply(qkv, table, index_i32, mask, n_img, H, W, num_heads, shift, scale, mask_is_shift)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -59,6 +59,15 @@ int fmmt_linear_fwd(int dtype, int M, int N, int K,
                     const void* res, int ldres, const float* rowscale, int rows_per_scale,
                     void* stream);
 
+/* Split-K variant for skinny problems (few output tiles, very long K: the 49*768 -> 512 embedding head,
+ * Swin_Transformer.py:493).  y = x . w^T + bias only (no activation / residual).  The K range is cut
+ * across workgroups into fp32 partials in `workspace` and summed in a fixed order.
+ * fmmt_linear_splitk_workspace returns 0 when the shape is not a split-K shape (use fmmt_linear_fwd). */
+size_t fmmt_linear_splitk_workspace(int M, int N, int K);
+int fmmt_linear_fwd_splitk(int dtype, int M, int N, int K, const void* x, int ldx, const void* w, int ldw,
+                           const float* bias, void* y, int ldy, void* workspace, size_t workspace_bytes,
+                           void* stream);
+
 /* Weight/bias gradients of the same layers (autograd of F.linear):
  *   dw[N,K] (fp32) = sum_m s_m * dy[m,N]^T x[m,K],   db[N] (fp32) = sum_m s_m * dy[m,N]   (db may be NULL)
  * with s_m = rowscale[m / rows_per_scale] (NULL -> 1).  The contraction over M is split across
@@ -103,12 +112,15 @@ int fmmt_layernorm_bwd(int dtype, int M, int C, const void* dy, const void* x, c
  * out : [n_img * H * W, C]  token order, head h occupies channels [h*hd, (h+1)*hd), hd = C/num_heads (== 32)
  * lse : fp32 [n_img * nW * num_heads * 49] log-sum-exp per query row (saved for backward)
  * table: fp32 [(2*7-1)^2, num_heads]; index: int32 [49*49]; mask: fp32 [nW_mask,49,49] or NULL,
- *        window b_ uses mask[b_ % nW_mask] (WindowAttention.forward's broadcast, :131-134)
+ *        window b_ uses mask[b_ % nW_mask] (WindowAttention.forward's broadcast, :131-134);
+ *        mask_is_shift != 0 asserts that `mask` is exactly the SW-MSA mask SwinTransformerBlock builds for
+ *        (H, W, shift) (:208-227, values {0,-100}): the bf16 kernel then derives it from window coordinates
+ *        instead of reading 9.6 KB per window (the fp32 kernel always reads the tensor).
  * window size is 7 (swin_conf.yaml:20); H, W multiples of 7; shift in [0,7).
  */
 int fmmt_window_attn_fwd(int dtype, int n_img, int H, int W, int C, int num_heads, int shift,
                          const void* qkv, const float* table, const int32_t* index,
-                         const float* mask, int nW_mask, float scale,
+                         const float* mask, int nW_mask, int mask_is_shift, float scale,
                          void* out, float* lse, void* stream);
 
 /* dqkv [n_img*H*W, 3C] (dtype, every element written); dtable fp32 [(169), num_heads] (overwritten).
@@ -117,7 +129,7 @@ size_t fmmt_window_attn_bwd_workspace(int num_heads);
 int fmmt_window_attn_bwd(int dtype, int n_img, int H, int W, int C, int num_heads, int shift,
                          const void* qkv, const void* out, const void* dout, const float* lse,
                          const float* table, const int32_t* index, const float* mask, int nW_mask,
-                         float scale, void* dqkv, float* dtable,
+                         int mask_is_shift, float scale, void* dqkv, float* dtable,
                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

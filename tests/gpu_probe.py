@@ -139,21 +139,23 @@ def _wattn_ref(qkv, table, mask, n_img, H, C, nh, shift):
 def t_wattn():
     index = OS.relative_position_index(7).to(dev).int().contiguous()
     for dt, tol in ((torch.float32, 2e-5), (torch.bfloat16, 2e-2)):
-        for (n_img, H, C, nh, shift) in [(2, 14, 96, 3, 0), (2, 14, 96, 3, 3), (1, 28, 192, 6, 3), (3, 7, 768, 24, 0), (5, 14, 384, 12, 3)]:
-            qkv = rnd("qkv", (n_img * H * H, 3 * C), 1, dtype=dt).requires_grad_(True)
-            table = (rnd("tab", (169, nh), 2) * 0.5).requires_grad_(True)
-            mask = OS.shift_mask(H, H, 7, shift).to(dev) if shift else None
-            out = ops.window_attn_core(qkv, table, index, mask, n_img, H, H, nh, shift, 32 ** -0.5)
-            q64 = qkv.detach().double().requires_grad_(True)
-            t64 = table.detach().double().requires_grad_(True)
-            ref = _wattn_ref(q64, t64, mask.double() if mask is not None else None, n_img, H, C, nh, shift)
-            tag = f"{dt} n{n_img} H{H} C{C} s{shift}"
-            report(f"wattn fwd {tag}", out, ref, tol)
-            dy = rnd("dy", (n_img * H * H, C), 3, dtype=dt)
-            out.backward(dy)
-            ref.backward(dy.double())
-            report(f"wattn bwd dqkv {tag}", qkv.grad, q64.grad, tol * 2)
-            report(f"wattn bwd dtable {tag}", table.grad, t64.grad, tol * 2)
+        for (n_img, H, C, nh, shift) in [(2, 14, 96, 3, 0), (2, 14, 96, 3, 3), (1, 28, 192, 6, 3), (3, 7, 768, 24, 0), (5, 14, 384, 12, 3),
+                                         (1, 56, 96, 3, 3), (2, 21, 96, 3, 2)]:
+            for mis in ((False, True) if shift else (False,)):
+                qkv = rnd("qkv", (n_img * H * H, 3 * C), 1, dtype=dt).requires_grad_(True)
+                table = (rnd("tab", (169, nh), 2) * 0.5).requires_grad_(True)
+                mask = OS.shift_mask(H, H, 7, shift).to(dev) if shift else None
+                out = ops.window_attn_core(qkv, table, index, mask, n_img, H, H, nh, shift, 32 ** -0.5, mis)
+                q64 = qkv.detach().double().requires_grad_(True)
+                t64 = table.detach().double().requires_grad_(True)
+                ref = _wattn_ref(q64, t64, mask.double() if mask is not None else None, n_img, H, C, nh, shift)
+                tag = f"{dt} n{n_img} H{H} C{C} s{shift} std{int(mis)}"
+                report(f"wattn fwd {tag}", out, ref, tol)
+                dy = rnd("dy", (n_img * H * H, C), 3, dtype=dt)
+                out.backward(dy)
+                ref.backward(dy.double())
+                report(f"wattn bwd dqkv {tag}", qkv.grad, q64.grad, tol * 2)
+                report(f"wattn bwd dtable {tag}", table.grad, t64.grad, tol * 2)
 
 
 def t_mha():
@@ -246,8 +248,8 @@ def t_speed():
         qkv = torch.randn(n_img * H * H, 3 * C, device=dev, dtype=dt).requires_grad_(True)
         table = torch.randn(169, nh, device=dev).requires_grad_(True)
         mask = OS.shift_mask(H, H, 7, 3).to(dev) if H > 7 else None
-        t = timeit(lambda: ops.window_attn_core(qkv, table, index, mask, n_img, H, H, nh, 3 if H > 7 else 0, 32 ** -0.5), 5)
-        out = ops.window_attn_core(qkv, table, index, mask, n_img, H, H, nh, 3 if H > 7 else 0, 32 ** -0.5)
+        t = timeit(lambda: ops.window_attn_core(qkv, table, index, mask, n_img, H, H, nh, 3 if H > 7 else 0, 32 ** -0.5, True), 5)
+        out = ops.window_attn_core(qkv, table, index, mask, n_img, H, H, nh, 3 if H > 7 else 0, 32 ** -0.5, True)
         dy = torch.randn_like(out)
         t2 = timeit(lambda: torch.autograd.grad(out, (qkv, table), dy, retain_graph=True), 5)
         print(f"     wattn n{n_img} H{H} C{C}: fwd {t*1e3:8.3f} ms | bwd {t2*1e3:8.3f} ms", flush=True)
