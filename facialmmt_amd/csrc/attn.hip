@@ -22,7 +22,7 @@ constexpr int WS = 7;        // window side
 constexpr int HD = 32;       // head dim of every Swin-tiny stage
 constexpr int KP = 36;       // LDS row pitch (floats) of a 49 x 32 tile: 16-byte aligned rows
 constexpr int BP = 50;       // LDS row pitch of the 49 x 49 bias tile
-constexpr int WA_BWD_WAVES_PER_HEAD_MAX = 256;
+constexpr int WA_BWD_WAVES_PER_HEAD_MAX = 256;   // partial d(bias) tiles per head (waves for the fp32 kernel, workgroups for the MFMA kernel)
 
 
 template <typename T> __device__ __forceinline__ void load_row32(const T* p, float* r) {
@@ -277,14 +277,20 @@ __global__ __launch_bounds__(256) void wattn_bwd_kernel(WaArgs p) {
 // d(bias table), deterministic two-stage reduction of the per-wave partials:
 //   dense[h][e] = sum_w part[h][w][e]           (one thread per (h, e): coalesced over e)
 //   dtable[r][h] = sum_{e : index[e] == r} dense[h][e]
-__global__ void wattn_dense_kernel(const float* __restrict__ part, int nH, int waves, float* __restrict__ dense) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nH * TOK * TOK) return;
-    const int h = t / (TOK * TOK), e = t - h * TOK * TOK;
-    const float* pe = part + (size_t)h * waves * TOK * TOK + e;
+__global__ __launch_bounds__(256) void wattn_dense_kernel(const float* __restrict__ part, int nH, int waves, float* __restrict__ dense) {
+    // 256 threads = 64 entries x 4 partial groups; fixed-order tree
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + tx;
     float a = 0.f;
-    for (int w = 0; w < waves; ++w) a += pe[(size_t)w * TOK * TOK];
-    dense[t] = a;
+    if (t < nH * TOK * TOK) {
+        const int h = t / (TOK * TOK), e = t - h * TOK * TOK;
+        const float* pe = part + (size_t)h * waves * TOK * TOK + e;
+        for (int w = ty; w < waves; w += 4) a += pe[(size_t)w * TOK * TOK];
+    }
+    red[ty][tx] = a;
+    __syncthreads();
+    if (ty == 0 && t < nH * TOK * TOK) dense[t] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
 }
 
 __global__ __launch_bounds__(64) void wattn_dtable_kernel(const float* __restrict__ dense, const int32_t* __restrict__ index,
@@ -299,12 +305,13 @@ __global__ __launch_bounds__(64) void wattn_dtable_kernel(const float* __restric
     if (threadIdx.x == 0) dtable[t] = a;
 }
 
-int wa_groups_per_head(int B_, int nH, bool bwd) {
-    // ~8 workgroups per CU over the whole grid, at least 1, at most what the windows can feed
-    int g = (2048 + nH - 1) / nH;
+int wa_groups_per_head(int B_, int nH, bool bwd, bool mfma) {
+    // persistent workgroups pinned to a head: ~3 per CU for the (fast) MFMA kernels, ~8 per CU otherwise
+    int g = ((mfma ? 768 : 2048) + nH - 1) / nH;
     const int maxg = (B_ + 3) / 4;
     if (g > maxg) g = maxg;
-    if (bwd && g > WA_BWD_WAVES_PER_HEAD_MAX / 4) g = WA_BWD_WAVES_PER_HEAD_MAX / 4;
+    const int cap = mfma ? WA_BWD_WAVES_PER_HEAD_MAX : WA_BWD_WAVES_PER_HEAD_MAX / 4;
+    if (bwd && g > cap) g = cap;
     return g < 1 ? 1 : g;
 }
 
@@ -569,7 +576,7 @@ extern "C" int fmmt_window_attn_fwd(int dtype, int n_img, int H, int W, int C, i
     a.n_img = n_img; a.H = H; a.W = W; a.C = C; a.nH = num_heads; a.shift = shift; a.qkv = qkv; a.table = table;
     a.index = index; a.mask = mask; a.nW_mask = nW_mask; a.mask_is_shift = mask_is_shift; a.scale = scale; a.out = out; a.lse = lse;
     const int B_ = n_img * (H / WS) * (W / WS);
-    a.groups_per_head = wa_groups_per_head(B_, num_heads, false);
+    a.groups_per_head = wa_groups_per_head(B_, num_heads, false, dtype == FMMT_BF16);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid(num_heads * a.groups_per_head);
     if (dtype == FMMT_BF16) return fmmt_wattn_mfma_fwd_launch(a, (int)grid.x, st);     // matrix-core path
@@ -595,7 +602,7 @@ extern "C" int fmmt_window_attn_bwd(int dtype, int n_img, int H, int W, int C, i
     a.index = index; a.mask = mask; a.nW_mask = nW_mask; a.mask_is_shift = mask_is_shift; a.scale = scale; a.out = const_cast<void*>(out);
     a.lse = const_cast<float*>(lse); a.dout = dout; a.dqkv = dqkv; a.part = reinterpret_cast<float*>(workspace);
     const int B_ = n_img * (H / WS) * (W / WS);
-    a.groups_per_head = wa_groups_per_head(B_, num_heads, true);
+    a.groups_per_head = wa_groups_per_head(B_, num_heads, true, dtype == FMMT_BF16);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid(num_heads * a.groups_per_head);
     if (dtype == FMMT_BF16) {
@@ -607,7 +614,8 @@ extern "C" int fmmt_window_attn_bwd(int dtype, int n_img, int H, int W, int C, i
     const int nt = (2 * WS - 1) * (2 * WS - 1) * num_heads;
     float* dense = a.part + (size_t)num_heads * WA_BWD_WAVES_PER_HEAD_MAX * TOK * TOK;
     const int nd = num_heads * TOK * TOK;
-    hipLaunchKernelGGL(wattn_dense_kernel, dim3((nd + 255) / 256), dim3(256), 0, st, a.part, num_heads, a.groups_per_head * 4, dense);
+    hipLaunchKernelGGL(wattn_dense_kernel, dim3((nd + 63) / 64), dim3(256), 0, st, a.part, num_heads,
+                       dtype == FMMT_BF16 ? a.groups_per_head : a.groups_per_head * 4, dense);
     FMMT_CHECK_LAUNCH();
     hipLaunchKernelGGL(wattn_dtable_kernel, dim3(nt), dim3(64), 0, st, dense, index, num_heads, dtable);
     FMMT_CHECK_LAUNCH();

@@ -133,7 +133,8 @@ __device__ __forceinline__ void fill_bias_mfma(const WaArgs& p, int head, float*
 }
 
 // =============================================================================================
-template <int DUMMY>
+// MM: 0 = no mask, 1 = standard SW-MSA mask derived from window coordinates, 2 = arbitrary (nW,49,49) tensor
+template <int MM>
 __global__ __launch_bounds__(256) void wattn_mfma_fwd_kernel(WaArgs p) {
     __shared__ __attribute__((aligned(16))) bf16 Vt[4][64 * TP];
     __shared__ __attribute__((aligned(16))) float Bs[64 * BPM];
@@ -184,21 +185,19 @@ __global__ __launch_bounds__(256) void wattn_mfma_fwd_kernel(WaArgs p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) s[kt * 4 + r] = a[r] * p.scale + b[r];
             }
-            if (p.mask) {
-                if (p.mask_is_shift) {
-                    const unsigned mb = std_mask_bits(G, P, qt);
+            if constexpr (MM == 1) {
+                const unsigned mb = std_mask_bits(G, P, qt);
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) s[e] += ((mb >> e) & 1u) ? -100.0f : 0.0f;
-                } else if (q < TOK) {
-                    const float* mrow = p.mask + ((size_t)(b_ % p.nW_mask) * TOK + q) * TOK;
+                for (int e = 0; e < 16; ++e) s[e] += ((mb >> e) & 1u) ? -100.0f : 0.0f;
+            } else if constexpr (MM == 2) {
+                const float* mrow = p.mask + ((size_t)(b_ % p.nW_mask) * TOK + (q < TOK ? q : TOK - 1)) * TOK;
 #pragma unroll
-                    for (int kt = 0; kt < 4; ++kt)
+                for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int key = kt * 16 + lg * 4 + r;
-                            if (key < TOK) s[kt * 4 + r] += mrow[key];
-                        }
-                }
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kt * 16 + lg * 4 + r;
+                        s[kt * 4 + r] += mrow[key < TOK ? key : TOK - 1];      // clamped, branch-free (pad keys are -1e30 already)
+                    }
             }
             float m = s[0];
 #pragma unroll
@@ -232,7 +231,7 @@ __global__ __launch_bounds__(256) void wattn_mfma_fwd_kernel(WaArgs p) {
 }
 
 // =============================================================================================
-template <int DUMMY>
+template <int MM>
 __global__ __launch_bounds__(256) void wattn_mfma_bwd_kernel(WaArgs p) {
     __shared__ __attribute__((aligned(16))) bf16 Kt[4][64 * TP];
     __shared__ __attribute__((aligned(16))) bf16 Qt[4][64 * TP];
@@ -265,7 +264,7 @@ __global__ __launch_bounds__(256) void wattn_mfma_bwd_kernel(WaArgs p) {
         const bool wactive = b_raw < B_;
         const int b_ = wactive ? b_raw : B_ - 1;
         const WinPos P = win_pos(p, b_);
-        const float* mbase = (p.mask && !p.mask_is_shift) ? p.mask + (size_t)(b_ % p.nW_mask) * TOK * TOK : nullptr;
+        const float* mbase = (MM == 2) ? p.mask + (size_t)(b_ % p.nW_mask) * TOK * TOK : nullptr;
         size_t tok[4];
         bf16x8 qf[4], kf[4], vf[4], gf[4];
         float ls[4], dl[4];
@@ -307,7 +306,7 @@ __global__ __launch_bounds__(256) void wattn_mfma_bwd_kernel(WaArgs p) {
             for (int qt = 0; qt < 4; ++qt) {
                 const int q = qt * 16 + li;
                 float ds[16];
-                const unsigned mb = (p.mask && p.mask_is_shift) ? std_mask_bits(G, P, qt) : 0u;
+                const unsigned mb = (MM == 1) ? std_mask_bits(G, P, qt) : 0u;
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt) {
                     const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
@@ -316,10 +315,10 @@ __global__ __launch_bounds__(256) void wattn_mfma_bwd_kernel(WaArgs p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float s = a[r] * p.scale + b[r];
-                        if ((mb >> (kt * 4 + r)) & 1u) s -= 100.0f;
-                        if (mbase) {
+                        if constexpr (MM == 1) s += ((mb >> (kt * 4 + r)) & 1u) ? -100.0f : 0.0f;
+                        if constexpr (MM == 2) {
                             const int key = kt * 16 + lg * 4 + r;
-                            if (q < TOK && key < TOK) s += mbase[q * TOK + key];
+                            s += mbase[(q < TOK ? q : TOK - 1) * TOK + (key < TOK ? key : TOK - 1)];
                         }
                         const float pij = __expf(s - ls[qt]);
                         const float d = pij * (dp[r] - dl[qt]);
@@ -356,7 +355,7 @@ __global__ __launch_bounds__(256) void wattn_mfma_bwd_kernel(WaArgs p) {
             for (int kt = 0; kt < 4; ++kt) {
                 const int key = kt * 16 + li;
                 float pp[16], ds[16];
-                const unsigned mb = (p.mask && p.mask_is_shift) ? std_mask_bits(G, P, kt) : 0u;
+                const unsigned mb = (MM == 1) ? std_mask_bits(G, P, kt) : 0u;
 #pragma unroll
                 for (int qt = 0; qt < 4; ++qt) {
                     const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[qt], kf[kt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
@@ -367,10 +366,8 @@ __global__ __launch_bounds__(256) void wattn_mfma_bwd_kernel(WaArgs p) {
                     for (int r = 0; r < 4; ++r) {
                         const int q = qt * 16 + lg * 4 + r;
                         float s = a[r] * p.scale + Bs[q * BPM + key];
-                        if ((mb >> (qt * 4 + r)) & 1u) s -= 100.0f;
-                        if (mbase) {
-                            if (q < TOK && key < TOK) s += mbase[q * TOK + key];
-                        }
+                        if constexpr (MM == 1) s += ((mb >> (qt * 4 + r)) & 1u) ? -100.0f : 0.0f;
+                        if constexpr (MM == 2) s += mbase[(q < TOK ? q : TOK - 1) * TOK + (key < TOK ? key : TOK - 1)];
                         const float pij = __expf(s - lq[r]);
                         pp[qt * 4 + r] = pij;
                         ds[qt * 4 + r] = pij * (dp[r] - dq[r]);
@@ -401,32 +398,51 @@ __global__ __launch_bounds__(256) void wattn_mfma_bwd_kernel(WaArgs p) {
             }
         }
     }
-    // per-wave partial of d(bias): [q][key], lane holds q = qt*16 + li, key = kt*16 + 4g + r
-    float* part = p.part + ((size_t)head * stride + grp * 4 + wave) * TOK * TOK;
+    // d(bias) of the workgroup: the 4 waves add their register accumulators into one LDS tile in wave order
+    // (deterministic), then the tile is written as this workgroup's partial [q][key].
+    // lane holds q = qt*16 + li, key = kt*16 + 4g + r
+    float* acc = reinterpret_cast<float*>(&Kt[0][0]);           // 20 KB >= 49*49 floats
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
 #pragma unroll
-    for (int qt = 0; qt < 4; ++qt) {
-        const int q = qt * 16 + li;
-        if (q >= TOK) continue;
+            for (int qt = 0; qt < 4; ++qt) {
+                const int q = qt * 16 + li;
+                if (q >= TOK) continue;
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+                for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kt * 16 + lg * 4 + r;
-                if (key < TOK) part[q * TOK + key] = dbias[qt][kt][r];
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kt * 16 + lg * 4 + r;
+                        if (key < TOK) {
+                            const float v = dbias[qt][kt][r];
+                            acc[q * TOK + key] = (w == 0) ? v : acc[q * TOK + key] + v;
+                        }
+                    }
             }
+        }
     }
+    __syncthreads();
+    float* part = p.part + ((size_t)head * p.groups_per_head + grp) * TOK * TOK;
+    for (int t = threadIdx.x; t < TOK * TOK; t += 256) part[t] = acc[t];
 }
 
 }  // namespace
 
 int fmmt_wattn_mfma_fwd_launch(const WaArgs& a, int grid, hipStream_t st) {
-    hipLaunchKernelGGL(wattn_mfma_fwd_kernel<0>, dim3(grid), dim3(256), 0, st, a);
+    const int mm = !a.mask ? 0 : (a.mask_is_shift ? 1 : 2);
+    if (mm == 0) hipLaunchKernelGGL(wattn_mfma_fwd_kernel<0>, dim3(grid), dim3(256), 0, st, a);
+    else if (mm == 1) hipLaunchKernelGGL(wattn_mfma_fwd_kernel<1>, dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(wattn_mfma_fwd_kernel<2>, dim3(grid), dim3(256), 0, st, a);
     FMMT_CHECK_LAUNCH();
     return 0;
 }
 
 int fmmt_wattn_mfma_bwd_launch(const WaArgs& a, int grid, hipStream_t st) {
-    hipLaunchKernelGGL(wattn_mfma_bwd_kernel<0>, dim3(grid), dim3(256), 0, st, a);
+    const int mm = !a.mask ? 0 : (a.mask_is_shift ? 1 : 2);
+    if (mm == 0) hipLaunchKernelGGL(wattn_mfma_bwd_kernel<0>, dim3(grid), dim3(256), 0, st, a);
+    else if (mm == 1) hipLaunchKernelGGL(wattn_mfma_bwd_kernel<1>, dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(wattn_mfma_bwd_kernel<2>, dim3(grid), dim3(256), 0, st, a);
     FMMT_CHECK_LAUNCH();
     return 0;
 }

@@ -69,10 +69,26 @@ def wgrad_raw(dy2, x2, want_bias, rowscale=None, rows_per_scale=1):
     return dw, db
 
 
-def _lp(w: torch.Tensor, dtype) -> torch.Tensor:
-    """parameter in the activation dtype (fp32 master -> bf16 shadow in throughput mode)"""
+_CAST_CACHE: dict = {}
+
+
+def _lp(w: torch.Tensor, dtype, transpose: bool = False) -> torch.Tensor:
+    """Parameter in the activation dtype (fp32 master -> bf16 shadow in throughput mode), optionally
+    transposed+contiguous (the input-gradient GEMM wants W^T row-major).  Shadows of leaf parameters are
+    cached per (storage, version): they are rebuilt only after an optimizer step touched the master copy."""
     w = w.detach()
-    return w if w.dtype == dtype else w.to(dtype)
+    if w.dtype == dtype and not transpose:
+        return w.contiguous()
+    key = (w.data_ptr(), tuple(w.shape), dtype, transpose)
+    hit = _CAST_CACHE.get(key)
+    if hit is not None and hit[0] == w._version:
+        return hit[1]
+    out = w.to(dtype)
+    out = out.t().contiguous() if transpose else out.contiguous()
+    if len(_CAST_CACHE) > 4096:
+        _CAST_CACHE.clear()
+    _CAST_CACHE[key] = (w._version, out)
+    return out
 
 
 # ------------------------------------------------------------------------------------------------
@@ -84,11 +100,11 @@ class LinearFn(Function):
         _need_cuda(x, "linear")
         K = x.shape[-1]
         x2 = x.reshape(-1, K).contiguous()
-        w = _lp(weight, x.dtype).contiguous()
+        w = _lp(weight, x.dtype)
         res2 = res.reshape(-1, weight.shape[0]).contiguous() if res is not None else None
         y = linear_raw(x2, w, bias.detach() if bias is not None else None, res=res2, rowscale=rowscale,
                        rows_per_scale=rows_per_scale)
-        ctx.save_for_backward(x2, w, rowscale)
+        ctx.save_for_backward(x2, weight, rowscale)
         ctx.has_bias = bias is not None
         ctx.has_res = res is not None
         ctx.rps = rows_per_scale
@@ -97,12 +113,12 @@ class LinearFn(Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x2, w, rowscale = ctx.saved_tensors
-        N = w.shape[0]
+        x2, weight, rowscale = ctx.saved_tensors
+        N = weight.shape[0]
         dy2 = dy.reshape(-1, N).contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = linear_raw(dy2, w.t().contiguous(), None, rowscale=rowscale, rows_per_scale=ctx.rps).reshape(ctx.xshape)
+            dx = linear_raw(dy2, _lp(weight, dy2.dtype, transpose=True), None, rowscale=rowscale, rows_per_scale=ctx.rps).reshape(ctx.xshape)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw, db = wgrad_raw(dy2, x2, ctx.has_bias, rowscale, ctx.rps)
         dres = dy if ctx.has_res else None
@@ -123,13 +139,13 @@ class MlpFn(Function):
         _need_cuda(x, "mlp")
         K = x.shape[-1]
         x2 = x.reshape(-1, K).contiguous()
-        w1l, w2l = _lp(w1, x.dtype).contiguous(), _lp(w2, x.dtype).contiguous()
+        w1l, w2l = _lp(w1, x.dtype), _lp(w2, x.dtype)
         train = any(ctx.needs_input_grad)      # grad mode is off inside Function.forward; this is the reliable signal
         h_pre = torch.empty((x2.shape[0], w1.shape[0]), dtype=x.dtype, device=x.device) if train else None
         h = linear_raw(x2, w1l, b1.detach(), epi=EPI_GELU, y_pre=h_pre)
         res2 = res.reshape(-1, w2.shape[0]).contiguous() if res is not None else None
         y = linear_raw(h, w2l, b2.detach(), res=res2, rowscale=rowscale, rows_per_scale=rows_per_scale)
-        ctx.save_for_backward(x2, w1l, w2l, h_pre, h, rowscale)
+        ctx.save_for_backward(x2, w1, w2, h_pre, h, rowscale)
         ctx.rps = rows_per_scale
         ctx.has_res = res is not None
         ctx.xshape = x.shape
@@ -137,13 +153,13 @@ class MlpFn(Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x2, w1l, w2l, h_pre, h, rowscale = ctx.saved_tensors
-        dy2 = dy.reshape(-1, w2l.shape[0]).contiguous()
+        x2, w1, w2, h_pre, h, rowscale = ctx.saved_tensors
+        dy2 = dy.reshape(-1, w2.shape[0]).contiguous()
         # d(h_pre) = (s * dy @ W2) * gelu'(h_pre)   [fused epilogue]
-        dh = linear_raw(dy2, w2l.t().contiguous(), None, epi=EPI_GELU_BWD, aux=h_pre, rowscale=rowscale,
+        dh = linear_raw(dy2, _lp(w2, dy2.dtype, transpose=True), None, epi=EPI_GELU_BWD, aux=h_pre, rowscale=rowscale,
                         rows_per_scale=ctx.rps)
         dw2, db2 = wgrad_raw(dy2, h, True, rowscale, ctx.rps)
-        dx = linear_raw(dh, w1l.t().contiguous(), None).reshape(ctx.xshape) if ctx.needs_input_grad[0] else None
+        dx = linear_raw(dh, _lp(w1, dy2.dtype, transpose=True), None).reshape(ctx.xshape) if ctx.needs_input_grad[0] else None
         dw1, db1 = wgrad_raw(dh, x2, True)
         return dx, dw1, db1, dw2, db2, (dy if ctx.has_res else None), None, None
 
