@@ -8,6 +8,7 @@
 // epilogue (bias, GELU, residual, DropPath scale) works on contiguous vectors and stores rows.
 #include "fmmt_common.h"
 #include "../../include/fmmt.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -49,17 +50,21 @@ struct LinArgs {
     const void* aux; int ldaux;
     const void* res; int ldres;
     const float* rowscale; int rows_per_scale;
-    int tiles_n;
+    int tiles_n, tiles_m, reserved;
     int ksplit;        // K range per blockIdx.y (split-K); 0 = no split
     float* part;       // split-K: fp32 partials [split][M][N] instead of the epilogue
 };
 
 // ---------------------------------------------------------------------------------------------
 // NT kernel: 256 threads = 4 waves (2 along M x 2 along N); block tile BM x BN, K step BK.
-// LDS: double-buffered weight tile [BN][BK+pad] and activation tile [BM][BK+pad]; one barrier per
-// K step; the next tile's global loads are in flight while the MFMAs of the current one run.
+//  * K pipeline: while tile k is multiplied out of LDS, tile k+1 is in flight into registers; two LDS
+//    buffers, one barrier per K step.  BK = 64 makes every global load instruction fetch whole 128-byte
+//    rows.  K == 96 (Swin stage 0) is a single step (NBUF = 1).  (A second register stage was measured
+//    and lost: occupancy beats prefetch depth on this chip for these shapes -- tests/gpu_gemm_bench.py.)
+//  * one output tile per workgroup.  (A persistent variant that issues the next tile's first K step under
+//    the epilogue was measured and lost as well: +60..100 VGPRs -> one wave per SIMD.)
 // ---------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int BK>
+template <typename T, int BM, int BN, int BK, int NBUF>
 __global__ __launch_bounds__(256) void linear_nt_kernel(LinArgs p) {
     constexpr int VEC = Vec<T>::N;
     constexpr int PITCH = BK + VEC;
@@ -68,34 +73,38 @@ __global__ __launch_bounds__(256) void linear_nt_kernel(LinArgs p) {
     constexpr int KV = BK / VEC;                        // 16-byte vectors per tile row
     constexpr int W_VECS = BN * KV, X_VECS = BM * KV;
     constexpr int WV = (W_VECS + 255) / 256, XV = (X_VECS + 255) / 256;
+    constexpr int CW = 4 * NT;                          // consecutive channels owned by a lane in the epilogue
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* Ws = reinterpret_cast<T*>(smem);                 // [2][BN][PITCH]
-    T* Xs = Ws + 2 * BN * PITCH;                        // [2][BM][PITCH]
+    T* Ws = reinterpret_cast<T*>(smem);                 // [NBUF][BN][PITCH]
+    T* Xs = Ws + NBUF * BN * PITCH;                     // [NBUF][BM][PITCH]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 15, lg = lane >> 4;
 
-    const int logical = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_m = logical / p.tiles_n, tile_n = logical % p.tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-
     const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
     const T* __restrict__ wg = reinterpret_cast<const T*>(p.w);
+    T* __restrict__ yg = reinterpret_cast<T*>(p.y);
+    T* __restrict__ ypre = reinterpret_cast<T*>(p.y_pre);
+    const T* __restrict__ auxg = reinterpret_cast<const T*>(p.aux);
+    const T* __restrict__ resg = reinterpret_cast<const T*>(p.res);
 
-    Vec<T> wreg[WV], xreg[XV];
     const int kbeg = p.ksplit ? blockIdx.y * p.ksplit : 0;
     const int kend = p.ksplit ? min(p.K, kbeg + p.ksplit) : p.K;
+    const int nk = (kend - kbeg + BK - 1) / BK;
 
-    auto gload = [&](int k0) {
+    struct Stage { Vec<T> w[WV], x[XV]; };
+    Stage R0;
+
+    auto gload = [&](Stage& R, int k0, int m0, int n0) {
 #pragma unroll
         for (int i = 0; i < WV; ++i) {
             const int v = tid + i * 256;
             if (v < W_VECS) {
                 const int row = v / KV, kc = (v % KV) * VEC;
                 const int n = min(n0 + row, p.N - 1);
-                wreg[i] = (k0 + kc < kend) ? ldvec<T>(wg + (size_t)n * p.ldw + k0 + kc) : zerovec<T>();
+                R.w[i] = (k0 + kc < kend) ? ldvec<T>(wg + (size_t)n * p.ldw + k0 + kc) : zerovec<T>();
             }
         }
 #pragma unroll
@@ -104,30 +113,26 @@ __global__ __launch_bounds__(256) void linear_nt_kernel(LinArgs p) {
             if (v < X_VECS) {
                 const int row = v / KV, kc = (v % KV) * VEC;
                 const int m = min(m0 + row, p.M - 1);
-                xreg[i] = (k0 + kc < kend) ? ldvec<T>(xg + (size_t)m * p.ldx + k0 + kc) : zerovec<T>();
+                R.x[i] = (k0 + kc < kend) ? ldvec<T>(xg + (size_t)m * p.ldx + k0 + kc) : zerovec<T>();
             }
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](const Stage& R, int buf) {
         T* wsb = Ws + buf * BN * PITCH;
         T* xsb = Xs + buf * BM * PITCH;
 #pragma unroll
         for (int i = 0; i < WV; ++i) {
             const int v = tid + i * 256;
-            if (v < W_VECS) stvec<T>(wsb + (v / KV) * PITCH + (v % KV) * VEC, wreg[i]);
+            if (v < W_VECS) stvec<T>(wsb + (v / KV) * PITCH + (v % KV) * VEC, R.w[i]);
         }
 #pragma unroll
         for (int i = 0; i < XV; ++i) {
             const int v = tid + i * 256;
-            if (v < X_VECS) stvec<T>(xsb + (v / KV) * PITCH + (v % KV) * VEC, xreg[i]);
+            if (v < X_VECS) stvec<T>(xsb + (v / KV) * PITCH + (v % KV) * VEC, R.x[i]);
         }
     };
 
     f32x4 acc[MT][NT];
-#pragma unroll
-    for (int a = 0; a < MT; ++a)
-#pragma unroll
-        for (int b = 0; b < NT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // weight-row permutation inside a wave tile: MFMA row i of n-tile nt is output channel
     // (i>>2)*(4*NT) + nt*4 + (i&3), so that a lane's accumulators cover 4*NT consecutive channels.
@@ -135,15 +140,9 @@ __global__ __launch_bounds__(256) void linear_nt_kernel(LinArgs p) {
     const int xrow_base = wm * WM + li;
     const int koff = lg * KP;
 
-    const int nk = (kend - kbeg + BK - 1) / BK;
-    gload(kbeg);
-    lstore(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) gload(kbeg + (kt + 1) * BK);
-        const T* wsb = Ws + cur * BN * PITCH;
-        const T* xsb = Xs + cur * BM * PITCH;
+    auto compute = [&](int buf) {
+        const T* wsb = Ws + buf * BN * PITCH;
+        const T* xsb = Xs + buf * BM * PITCH;
 #pragma unroll
         for (int kk = 0; kk < BK / KM; ++kk) {
             typename Mma<T>::frag wf[NT], xf[MT];
@@ -156,93 +155,157 @@ __global__ __launch_bounds__(256) void linear_nt_kernel(LinArgs p) {
 #pragma unroll
                 for (int b = 0; b < NT; ++b) acc[a][b] = Mma<T>::mma(wf[b], xf[a], acc[a][b]);
         }
-        if (kt + 1 < nk) lstore(cur ^ 1);
-        __syncthreads();
-    }
+    };
 
-    // ------------------------------------------------------------------ epilogue
-    T* __restrict__ yg = reinterpret_cast<T*>(p.y);
-    T* __restrict__ ypre = reinterpret_cast<T*>(p.y_pre);
-    const T* __restrict__ auxg = reinterpret_cast<const T*>(p.aux);
-    const T* __restrict__ resg = reinterpret_cast<const T*>(p.res);
-    const int ncol0 = n0 + wn * WN + lg * (4 * NT);
-    if (p.part) {                                          // split-K: raw fp32 partial sums, epilogue runs later
-        float* pp = p.part + (size_t)blockIdx.y * p.M * p.N;
+    auto epilogue = [&](int m0, int n0) {
+        const int ncol0 = n0 + wn * WN + lg * CW;
+        if (p.part) {                                      // split-K: raw fp32 partial sums, finished by another kernel
+            float* pp = p.part + (size_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+                const int m = m0 + wm * WM + a * 16 + li;
+                if (m >= p.M) continue;
+#pragma unroll
+                for (int b = 0; b < NT; ++b) {
+                    const int n = ncol0 + b * 4;
+                    if (n + 4 <= p.N) *reinterpret_cast<f32x4*>(pp + (size_t)m * p.N + n) = acc[a][b];
+                }
+            }
+            return;
+        }
+        // a lane owns CW consecutive channels of row m: chunks of VEC (one 16-byte access per operand)
+        // with a 4-wide tail when CW % VEC != 0
 #pragma unroll
         for (int a = 0; a < MT; ++a) {
             const int m = m0 + wm * WM + a * 16 + li;
             if (m >= p.M) continue;
+            const float rs = row_scale(p.rowscale, m, p.rows_per_scale);
 #pragma unroll
-            for (int b = 0; b < NT; ++b) {
-                const int n = ncol0 + b * 4;
-                if (n + 4 <= p.N) *reinterpret_cast<f32x4*>(pp + (size_t)m * p.N + n) = acc[a][b];
-            }
-        }
-        return;
-    }
+            for (int c0 = 0; c0 < CW; c0 += VEC) {
+                const int n = ncol0 + c0;
+                const int w = (CW - c0 >= VEC) ? VEC : 4;      // chunk width (compile-time after unrolling)
+                if (n + w > p.N) continue;
+                float v[VEC];
 #pragma unroll
-    for (int a = 0; a < MT; ++a) {
-        const int m = m0 + wm * WM + a * 16 + li;
-        if (m >= p.M) continue;
-        const float rs = row_scale(p.rowscale, m, p.rows_per_scale);
+                for (int e = 0; e < VEC; ++e) v[e] = (e < w) ? acc[a][(c0 + e) >> 2][(c0 + e) & 3] : 0.f;
+                if (p.bias) {
 #pragma unroll
-        for (int b = 0; b < NT; ++b) {
-            const int n = ncol0 + b * 4;
-            if (n + 4 > p.N) continue;
-            float v[4];
+                    for (int e4 = 0; e4 < VEC; e4 += 4)
+                        if (e4 < w) {
+                            const f32x4 bb = *reinterpret_cast<const f32x4*>(p.bias + n + e4);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r];
-            if (p.bias) {
-                const f32x4 bb = *reinterpret_cast<const f32x4*>(p.bias + n);
+                            for (int r = 0; r < 4; ++r) v[e4 + r] += bb[r];
+                        }
+                }
+                auto load_chunk = [&](const T* base, int ld, float* out) {
+                    if (w == VEC) {
+                        const Vec<T> t = ldvec<T>(base + (size_t)m * ld + n);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += bb[r];
-            }
-            if (p.epi == FMMT_EPI_GELU) {
-                if (ypre) {
-                    T o[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(v[r]);
-                    if constexpr (sizeof(T) == 2) {
-                        *reinterpret_cast<uint2*>(ypre + (size_t)m * p.ldy + n) = *reinterpret_cast<const uint2*>(o);
+                        for (int e = 0; e < VEC; ++e) out[e] = t.get(e);
                     } else {
-                        *reinterpret_cast<uint4*>(ypre + (size_t)m * p.ldy + n) = *reinterpret_cast<const uint4*>(o);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) out[e] = to_f32(base[(size_t)m * ld + n + e]);
                     }
+                };
+                auto store_chunk = [&](T* base, int ld, const float* in) {
+                    if (w == VEC) {
+                        Vec<T> t;
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) t.set(e, in[e]);
+                        stvec<T>(base + (size_t)m * ld + n, t);
+                    } else {
+                        T o[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = from_f32<T>(in[e]);
+                        *reinterpret_cast<uint2*>(base + (size_t)m * ld + n) = *reinterpret_cast<const uint2*>(o);   // bf16 only (VEC == 8)
+                    }
+                };
+                if (p.epi == FMMT_EPI_GELU) {
+                    if (ypre) store_chunk(ypre, p.ldy, v);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) v[e] = gelu_f(v[e]);
+                } else if (p.epi == FMMT_EPI_GELU_BWD) {
+                    float ax[VEC];
+                    load_chunk(auxg, p.ldaux, ax);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) v[e] *= (e < w) ? gelu_grad_f(ax[e]) : 0.f;
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
-            } else if (p.epi == FMMT_EPI_GELU_BWD) {
+                for (int e = 0; e < VEC; ++e) v[e] *= rs;
+                if (resg) {
+                    float rx[VEC];
+                    load_chunk(resg, p.ldres, rx);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_f(to_f32(auxg[(size_t)m * p.ldaux + n + r]));
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] *= rs;
-            if (resg) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += to_f32(resg[(size_t)m * p.ldres + n + r]);
-            }
-            T o[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(v[r]);
-            if constexpr (sizeof(T) == 2) {
-                *reinterpret_cast<uint2*>(yg + (size_t)m * p.ldy + n) = *reinterpret_cast<const uint2*>(o);
-            } else {
-                *reinterpret_cast<uint4*>(yg + (size_t)m * p.ldy + n) = *reinterpret_cast<const uint4*>(o);
+                    for (int e = 0; e < VEC; ++e) v[e] += (e < w) ? rx[e] : 0.f;
+                }
+                store_chunk(yg, p.ldy, v);
             }
         }
+    };
+
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (logical / p.tiles_n) * BM, n0 = (logical % p.tiles_n) * BN;
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gload(R0, kbeg, m0, n0);
+    lstore(R0, 0);
+    __syncthreads();
+    if constexpr (NBUF == 1) {
+        compute(0);
+    } else {
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) gload(R0, kbeg + (kt + 1) * BK, m0, n0);
+            compute(cur);
+            if (kt + 1 < nk) lstore(R0, cur ^ 1);
+            __syncthreads();
+        }
+    }
+    epilogue(m0, n0);
+}
+
+template <typename T, int BM, int BN, int BK, int NBUF>
+int launch_nt(const LinArgs& a, hipStream_t st) {
+    constexpr int VEC = Vec<T>::N;
+    constexpr size_t lds = (size_t)NBUF * (BM + BN) * (BK + VEC) * sizeof(T);
+    static bool attr_set = false;
+    if (lds > 65536 && !attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_nt_kernel<T, BM, BN, BK, NBUF>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    LinArgs p = a;
+    p.tiles_n = (a.N + BN - 1) / BN;
+    p.tiles_m = (a.M + BM - 1) / BM;
+    const int grid = p.tiles_m * p.tiles_n;
+    const int splits = a.ksplit ? (a.K + a.ksplit - 1) / a.ksplit : 1;
+    hipLaunchKernelGGL((linear_nt_kernel<T, BM, BN, BK, NBUF>), dim3(grid, splits), dim3(256), lds, st, p);
+    FMMT_CHECK_LAUNCH();
+    return 0;
+}
+
+template <typename T, int BN>
+int dispatch_nt_bk(const LinArgs& a, hipStream_t st) {
+    if constexpr (sizeof(T) == 2) {
+        if (!a.ksplit && a.K == 96) return launch_nt<T, 128, BN, 96, 1>(a, st);     // Swin stage 0: one K step
+        if (!a.ksplit && a.K <= 64) return launch_nt<T, 128, BN, 64, 1>(a, st);     // PatchEmbed (K = 48)
+        // measured on MI355X (tests/gpu_gemm_bench.py, sum over the bench shapes): BK=64 5.33 ms vs BK=32 5.88 ms
+        if (a.K % 64 == 0 && (!a.ksplit || a.ksplit % 64 == 0)) return launch_nt<T, 128, BN, 64, 2>(a, st);
+        return launch_nt<T, 128, BN, 32, 2>(a, st);
+    } else {
+        return launch_nt<T, 128, BN, 16, 2>(a, st);                                 // fp32 parity path
     }
 }
 
-template <typename T, int BM, int BN, int BK>
-int launch_nt(const LinArgs& a, hipStream_t st) {
-    constexpr int VEC = Vec<T>::N;
-    constexpr size_t lds = (size_t)2 * (BM + BN) * (BK + VEC) * sizeof(T);
-    LinArgs p = a;
-    p.tiles_n = (a.N + BN - 1) / BN;
-    const int tiles_m = (a.M + BM - 1) / BM;
-    const int splits = a.ksplit ? (a.K + a.ksplit - 1) / a.ksplit : 1;
-    hipLaunchKernelGGL((linear_nt_kernel<T, BM, BN, BK>), dim3(tiles_m * p.tiles_n, splits), dim3(256), lds, st, p);
-    FMMT_CHECK_LAUNCH();
-    return 0;
+template <typename T>
+int dispatch_nt(const LinArgs& a, hipStream_t st) {
+    // BN = 96 when it tiles N exactly and 128 would not (C = 96, 288, 192, 576 ...)
+    const bool n96 = (a.N % 96 == 0) && (a.N % 128 != 0);
+    if (n96) return dispatch_nt_bk<T, 96>(a, st);
+    return dispatch_nt_bk<T, 128>(a, st);
 }
 
 // y = T(sum_s part[s] + bias) for the split-K path
@@ -267,15 +330,6 @@ int splitk_plan(int M, int N, int K, int* ksplit) {
     ks = (ks + 63) / 64 * 64;
     *ksplit = ks;
     return (K + ks - 1) / ks;
-}
-
-template <typename T>
-int dispatch_nt(const LinArgs& a, hipStream_t st) {
-    constexpr int BK = sizeof(T) == 2 ? 32 : 16;
-    // BN = 96 when it tiles N exactly and 128 would not (C = 96, 288, 192, 576 ...)
-    const bool n96 = (a.N % 96 == 0) && (a.N % 128 != 0);
-    if (n96) return launch_nt<T, 128, 96, BK>(a, st);
-    return launch_nt<T, 128, 128, BK>(a, st);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -309,17 +363,18 @@ __device__ __forceinline__ bf16x8 lds_tr_frag(const bf16* s, int pitch, int c0, 
     return u.v;
 }
 
-template <typename T>
+template <typename T, int BMS>
 __global__ __launch_bounds__(256) void linear_tn_kernel(TnArgs p) {
     constexpr int VEC = Vec<T>::N;
-    constexpr int BMS = sizeof(T) == 2 ? 32 : 16;       // token rows per step
     constexpr int PITCH = 128 + VEC;
     constexpr int CV = 128 / VEC;                       // vectors per tile row
-    constexpr int NV = BMS * CV / 256;                  // vectors per thread per operand (= 2)
+    constexpr int NV = BMS * CV / 256;                  // vectors per thread per operand
+    constexpr int KM = sizeof(T) == 2 ? 32 : 4;         // token rows consumed per MFMA
 
-    __shared__ __attribute__((aligned(16))) T As[2][BMS * PITCH];
-    __shared__ __attribute__((aligned(16))) T Bs[2][BMS * PITCH];
-    __shared__ float bsum[16][128];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* As = reinterpret_cast<T*>(smem);                 // [2][BMS][PITCH]
+    T* Bs = As + 2 * BMS * PITCH;                       // [2][BMS][PITCH]
+    float* bsum = reinterpret_cast<float*>(Bs + 2 * BMS * PITCH);   // [256/CV][128]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 1, wk = wave & 1;
@@ -363,8 +418,8 @@ __global__ __launch_bounds__(256) void linear_tn_kernel(TnArgs p) {
         for (int i = 0; i < NV; ++i) {
             const int v = tid + i * 256;
             const int row = v / CV, c = (v % CV) * VEC;
-            stvec<T>(&As[buf][row * PITCH + c], areg[i]);
-            stvec<T>(&Bs[buf][row * PITCH + c], breg[i]);
+            stvec<T>(As + (buf * BMS + row) * PITCH + c, areg[i]);
+            stvec<T>(Bs + (buf * BMS + row) * PITCH + c, breg[i]);
             if (do_bias) {
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) colsum[e] += areg[i].get(e);
@@ -387,24 +442,26 @@ __global__ __launch_bounds__(256) void linear_tn_kernel(TnArgs p) {
     for (int s = 0; s < nsteps; ++s) {
         const int cur = s & 1;
         if (s + 1 < nsteps) gload(mbeg + (s + 1) * BMS);
-        if constexpr (sizeof(T) == 2) {
-            bf16x8 af[4], bf_[4];
+        const T* asb = As + cur * BMS * PITCH;
+        const T* bsb = Bs + cur * BMS * PITCH;
 #pragma unroll
-            for (int a = 0; a < 4; ++a) af[a] = lds_tr_frag(reinterpret_cast<const bf16*>(As[cur]), PITCH, wn * 64 + a * 16, li, lg);
+        for (int kk = 0; kk < BMS / KM; ++kk) {
+            if constexpr (sizeof(T) == 2) {
+                bf16x8 af[4], bf_[4];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) bf_[b] = lds_tr_frag(reinterpret_cast<const bf16*>(Bs[cur]), PITCH, wk * 64 + b * 16, li, lg);
+                for (int a = 0; a < 4; ++a) af[a] = lds_tr_frag(reinterpret_cast<const bf16*>(asb) + kk * 32 * PITCH, PITCH, wn * 64 + a * 16, li, lg);
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+                for (int b = 0; b < 4; ++b) bf_[b] = lds_tr_frag(reinterpret_cast<const bf16*>(bsb) + kk * 32 * PITCH, PITCH, wk * 64 + b * 16, li, lg);
 #pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf_[b], acc[a][b], 0, 0, 0);
-        } else {
+                for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int kk = 0; kk < BMS / 4; ++kk) {
+                    for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf_[b], acc[a][b], 0, 0, 0);
+            } else {
                 float af[4], bf_[4];
 #pragma unroll
-                for (int a = 0; a < 4; ++a) af[a] = As[cur][(kk * 4 + lg) * PITCH + wn * 64 + a * 16 + li];
+                for (int a = 0; a < 4; ++a) af[a] = asb[(kk * 4 + lg) * PITCH + wn * 64 + a * 16 + li];
 #pragma unroll
-                for (int b = 0; b < 4; ++b) bf_[b] = Bs[cur][(kk * 4 + lg) * PITCH + wk * 64 + b * 16 + li];
+                for (int b = 0; b < 4; ++b) bf_[b] = bsb[(kk * 4 + lg) * PITCH + wk * 64 + b * 16 + li];
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -432,14 +489,30 @@ __global__ __launch_bounds__(256) void linear_tn_kernel(TnArgs p) {
         // thread's column chunk is (tid % CV) for every vector it staged; 256/CV threads share it
         const int cchunk = tid % CV, rowgrp = tid / CV;   // rowgrp < 256/CV (16 for bf16, 8 for f32)
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) bsum[rowgrp][cchunk * VEC + e] = colsum[e];
+        for (int e = 0; e < VEC; ++e) bsum[rowgrp * 128 + cchunk * VEC + e] = colsum[e];
         __syncthreads();
         if (tid < 128) {
             float t = 0.f;
-            for (int g = 0; g < 256 / CV; ++g) t += bsum[g][tid];
+            for (int g = 0; g < 256 / CV; ++g) t += bsum[g * 128 + tid];
             if (n0 + tid < p.N) p.part_b[(size_t)split * p.N + n0 + tid] = t;
         }
     }
+}
+
+template <typename T, int BMS>
+int launch_tn(const TnArgs& a, dim3 grid, hipStream_t st) {
+    constexpr int VEC = Vec<T>::N;
+    constexpr size_t lds = (size_t)4 * BMS * (128 + VEC) * sizeof(T) + (256 / (128 / VEC)) * 128 * sizeof(float);
+    static bool attr_set = false;
+    if (lds > 65536 && !attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_tn_kernel<T, BMS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((linear_tn_kernel<T, BMS>), grid, dim3(256), lds, st, a);
+    FMMT_CHECK_LAUNCH();
+    return 0;
 }
 
 // out[i] = sum_s part[s][i] : 256 threads = 64 outputs x 4 split groups, fixed-order tree (deterministic)
@@ -469,7 +542,7 @@ TnPlan tn_plan(int M, int N, int K) {
     // keep the partial buffer under 512 MiB
     while (splits > 1 && (size_t)splits * N * K * 4 > ((size_t)512 << 20)) --splits;
     int chunk = (M + splits - 1) / splits;
-    chunk = (chunk + 31) / 32 * 32;
+    chunk = (chunk + 63) / 64 * 64;
     pl.splits = (M + chunk - 1) / chunk;
     pl.chunk = chunk;
     pl.bytes = (size_t)pl.splits * ((size_t)N * K + N) * sizeof(float);
@@ -496,7 +569,7 @@ extern "C" int fmmt_linear_fwd(int dtype, int M, int N, int K,
     if (!aligned16(x) || !aligned16(w) || !aligned16(y) || (bias && !aligned16(bias)) ||
         (res && !aligned16(res)) || (aux && !aligned16(aux)) || (y_pre && !aligned16(y_pre)))
         return FMMT_EALIGN;
-    LinArgs a{M, N, K, x, ldx, w, ldw, bias, y, ldy, y_pre, epi, aux, ldaux, res, ldres, rowscale, rows_per_scale, 0, 0, nullptr};
+    LinArgs a{M, N, K, x, ldx, w, ldw, bias, y, ldy, y_pre, epi, aux, ldaux, res, ldres, rowscale, rows_per_scale, 0, 0, 1, 0, nullptr};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     return dtype == FMMT_BF16 ? dispatch_nt<bf16>(a, st) : dispatch_nt<float>(a, st);
 }
@@ -519,7 +592,7 @@ extern "C" int fmmt_linear_fwd_splitk(int dtype, int M, int N, int K, const void
     const int splits = splitk_plan(M, N, K, &ks);
     if (!ks) return FMMT_EINVAL;                            // not a split-K shape: use fmmt_linear_fwd
     if (workspace_bytes < (size_t)splits * M * N * sizeof(float)) return FMMT_EWORKSPACE;
-    LinArgs a{M, N, K, x, ldx, w, ldw, nullptr, nullptr, N, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 1, 0, ks,
+    LinArgs a{M, N, K, x, ldx, w, ldw, nullptr, nullptr, N, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 1, 0, 0, 1, ks,
               reinterpret_cast<float*>(workspace)};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (int rc = (dtype == FMMT_BF16 ? dispatch_nt<bf16>(a, st) : dispatch_nt<float>(a, st))) return rc;
@@ -554,9 +627,14 @@ extern "C" int fmmt_linear_wgrad(int dtype, int M, int N, int K,
     float* part_b = db ? part_w + (size_t)pl.splits * N * K : nullptr;
     TnArgs a{M, N, K, dy, lddy, x, ldx, part_w, part_b, rowscale, rows_per_scale, pl.tiles_k, pl.chunk};
     dim3 grid(pl.tiles_n * pl.tiles_k, pl.splits);
-    if (dtype == FMMT_BF16) hipLaunchKernelGGL(linear_tn_kernel<bf16>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(linear_tn_kernel<float>, grid, dim3(256), 0, st, a);
-    FMMT_CHECK_LAUNCH();
+    static const int tn_cfg = getenv("FMMT_TN_CFG") ? atoi(getenv("FMMT_TN_CFG")) : 0;
+    int rc;
+    // measured (tests/gpu_gemm_bench.py): 64-token steps win for the compute-heavy stage-2/3 shapes (+15-25 %),
+    // 32-token steps (3 workgroups per CU) win for the HBM-bound multi-million-token stage-0/1 shapes
+    const bool bms64 = tn_cfg == 2 || (tn_cfg == 0 && M <= 262144);
+    if (dtype == FMMT_BF16) rc = bms64 ? launch_tn<bf16, 64>(a, grid, st) : launch_tn<bf16, 32>(a, grid, st);
+    else rc = launch_tn<float, 16>(a, grid, st);
+    if (rc) return rc;
     const size_t nw = (size_t)N * K;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nw + 63) / 64)), dim3(256), 0, st, part_w, dw, nw, pl.splits);
     FMMT_CHECK_LAUNCH();

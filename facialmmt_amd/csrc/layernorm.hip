@@ -10,7 +10,7 @@
 
 namespace {
 
-constexpr int LN_BWD_MAX_BLOCKS = 256;   // one partial per CU
+constexpr int LN_BWD_MAX_BLOCKS = 1024;  // four partial blocks per CU: the kernel is HBM-bound and needs the occupancy
 
 struct LnArgs {
     int M, C;

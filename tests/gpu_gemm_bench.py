@@ -1,0 +1,22 @@
+"""Development micro-benchmark of the Linear kernels at the bench shapes (bf16)."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from facialmmt_amd import ops
+dev = torch.device("cuda:0")
+def timeit(fn, n=10):
+    fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n
+SHAPES = [(2007040, 288, 96), (2007040, 96, 96), (2007040, 384, 96), (2007040, 96, 384), (2007040, 96, 288),
+          (501760, 576, 192), (501760, 768, 192), (501760, 192, 768), (125440, 1152, 384), (125440, 1536, 384), (125440, 384, 1536),
+          (31360, 2304, 768), (31360, 3072, 768), (31360, 768, 3072), (664, 768, 768), (1280, 3072, 768)]
+print("cfg", os.environ.get("FMMT_NT_CFG", "0"))
+tot = 0
+for (M, N, K) in SHAPES:
+    x = torch.randn(M, K, device=dev, dtype=torch.bfloat16); w = torch.randn(N, K, device=dev, dtype=torch.bfloat16); b = torch.randn(N, device=dev)
+    t = timeit(lambda: ops.linear_raw(x, w, b)); tot += t
+    dy = torch.randn(M, N, device=dev, dtype=torch.bfloat16)
+    t2 = timeit(lambda: ops.wgrad_raw(dy, x, True))
+    print(f"  {M:8d}x{N:5d}x{K:5d}: nt {t*1e3:7.3f} ms {2.0*M*N*K/t/1e12:6.1f} TF/s {(M*K+M*N+N*K)*2/t/1e9:6.0f} GB/s | tn {t2*1e3:7.3f} ms {2.0*M*N*K/t2/1e12:6.1f} TF/s", flush=True)
+print(f"  sum nt {tot*1e3:.3f} ms")
