@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--frames", type=int, default=160, help="face frames per utterance (vision_max_utt_len)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-ddp", action="store_true", help="wrap in DDP even with one process (exercises the N>1 code path on one GPU)")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames in the CPU-baseline Swin sample")
     return ap.parse_args()
 
@@ -196,7 +197,9 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the hot path has no CPU fallback)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or args.force_ddp:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
@@ -205,8 +208,8 @@ def main():
     from facialmmt_amd.train_step import TargetStep
     cfg = default_args(get_vision_utt_max_lens=args.frames, trg_accumulation_steps=1)
     swin, mm = build_models(args, dev, cfg)
-    ddp = wrap_ddp(mm, dev) if world > 1 else None
-    opt = torch.optim.AdamW(mm.parameters(), lr=cfg.trg_lr, weight_decay=cfg.weight_decay)
+    ddp = wrap_ddp(mm, dev) if (world > 1 or args.force_ddp) else None
+    opt = torch.optim.AdamW(mm.parameters(), lr=cfg.trg_lr, weight_decay=cfg.weight_decay, fused=True)
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: min(1.0, (s + 1) / 100.0))
     step = TargetStep(swin, mm, opt, sched, cfg, autocast_dtype=torch.bfloat16 if args.dtype == "bf16" else None, ddp_model=ddp)
     batch = synth_batch(args, dev, rank, cfg)
@@ -266,7 +269,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, cfg)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -191,18 +191,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnArgs p) {
     }
 }
 
-// [nblocks][2][C] partials -> dgamma/dbeta.  256 threads = 64 columns x 4 partial groups; fixed-order tree.
-__global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict__ part, int nblocks, int C, float* dgamma, float* dbeta) {
-    __shared__ float red[4][64];
+// [nblocks][2][C] partials -> dgamma/dbeta.  1024 threads = 64 columns x 16 partial groups; fixed-order tree.
+__global__ __launch_bounds__(1024) void ln_reduce_kernel(const float* __restrict__ part, int nblocks, int C, float* dgamma, float* dbeta) {
+    __shared__ float red[16][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + tx;
     float a = 0.f;
     if (i < 2 * C)
-        for (int b = ty; b < nblocks; b += 4) a += part[(size_t)b * 2 * C + i];
+        for (int b = ty; b < nblocks; b += 16) a += part[(size_t)b * 2 * C + i];
     red[ty][tx] = a;
     __syncthreads();
     if (ty == 0 && i < 2 * C) {
-        a = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+        a = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) a += red[g][tx];
         if (i < C) { if (dgamma) dgamma[i] = a; }
         else { if (dbeta) dbeta[i - C] = a; }
     }
@@ -294,7 +296,7 @@ extern "C" int fmmt_layernorm_bwd(int dtype, int M, int C, const void* dy, const
     if (dtype == FMMT_BF16) rc = merge_hw ? launch_ln<bf16, true, true>(a, g, nch, grid, st) : launch_ln<bf16, false, true>(a, g, nch, grid, st);
     else rc = merge_hw ? launch_ln<float, true, true>(a, g, nch, grid, st) : launch_ln<float, false, true>(a, g, nch, grid, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(ln_reduce_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, st, a.part, grid, C, dgamma, dbeta);
+    hipLaunchKernelGGL(ln_reduce_kernel, dim3((2 * C + 63) / 64), dim3(1024), 0, st, a.part, grid, C, dgamma, dbeta);
     FMMT_CHECK_LAUNCH();
     return 0;
 }

@@ -57,7 +57,11 @@ class TransformerEncoderLayer(nn.Module):
         if self.attn_mask:
             raise NotImplementedError("facialmmt_amd HIP path: future mask (attn_mask=True is never used by the model)")
         fused = not self.training or (self.res_dropout == 0.0 and self.gelu_dropout == 0.0)
-        xn = self._ln(0, x)
+        ln0, ln1 = self.layer_norms[0], self.layer_norms[1]
+        if fused:
+            x, xn = ops.residual_layer_norm(x, ln0.weight, ln0.bias, ln0.eps)
+        else:
+            xn = self._ln(0, x)
         if x_k is None and x_v is None:
             kn = vn = xn
         else:
@@ -65,7 +69,8 @@ class TransformerEncoderLayer(nn.Module):
             vn = kn if x_v is x_k else self._ln(0, x_v)
         if fused:
             x = self.self_attn.attend(xn, kn, vn, res=x)
-            return ops.mlp(self._ln(1, x), self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, res=x)
+            x, xn = ops.residual_layer_norm(x, ln1.weight, ln1.bias, ln1.eps)
+            return ops.mlp(xn, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, res=x)
         # non-zero residual / gelu dropouts (not used by the model's configuration): un-fused epilogues
         a = self.self_attn.attend(xn, kn, vn)
         x = x + F.dropout(a, p=self.res_dropout, training=True)

@@ -212,10 +212,10 @@ class SwinTransformerBlock(nn.Module):
         H, W = self.input_resolution
         B, L, C = x.shape
         assert L == H * W, "input feature has wrong size"
-        xn = ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        x, xn = ops.residual_layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         x = self.attn.forward_tokens(xn, B, H, W, self.shift_size, self.attn_mask, res=x, rowscale=self._scale(B, x.device),
                                      mask_is_shift=self._mask_is_standard())
-        xn = ops.layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        x, xn = ops.residual_layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         return self.mlp(xn, res=x, rowscale=self._scale(B, x.device), rows_per_scale=L)
 
     def extra_repr(self) -> str:

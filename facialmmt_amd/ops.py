@@ -218,6 +218,51 @@ def layer_norm(x, gamma, beta, eps=1e-5, merge_hw=0):
     return LayerNormFn.apply(x, gamma, beta, eps, merge_hw)
 
 
+class ResidualLayerNormFn(Function):
+    """(x, LN(x)) for pre-norm residual blocks `x + f(LN(x))`: the residual branch takes the first output,
+    f the second.  Backward receives both incoming gradients at once, so the residual-gradient add is the
+    `add` operand of the LayerNorm-backward kernel instead of a separate elementwise pass."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        _need_cuda(x, "layer_norm")
+        lib = _lib.load()
+        x = x.contiguous()
+        C = x.shape[-1]
+        M = x.numel() // C
+        y = torch.empty_like(x)
+        mean = torch.empty(M, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+        g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        rc = lib.fmmt_layernorm_fwd(dtype_code(x.dtype), M, C, _p(x), _p(g), _p(b), eps, _p(y), _p(mean), _p(rstd), 0, _st())
+        check(rc, f"fmmt_layernorm_fwd(M={M},C={C})")
+        ctx.save_for_backward(x, mean, rstd, g)
+        ctx.dims = (M, C)
+        return x.view_as(x), y
+
+    @staticmethod
+    def backward(ctx, dres, dy):
+        x, mean, rstd, g = ctx.saved_tensors
+        M, C = ctx.dims
+        lib = _lib.load()
+        dy = dy.contiguous()
+        add = dres.contiguous() if dres is not None else None
+        dx = torch.empty_like(x)
+        dg = torch.empty(C, dtype=torch.float32, device=x.device)
+        db = torch.empty(C, dtype=torch.float32, device=x.device)
+        nbytes = lib.fmmt_layernorm_bwd_workspace(C)
+        ws = _ws(nbytes, x.device)
+        rc = lib.fmmt_layernorm_bwd(dtype_code(x.dtype), M, C, _p(dy), _p(x), _p(mean), _p(rstd), _p(g), _p(add), _p(dx),
+                                    _p(dg), _p(db), 0, _p(ws), nbytes, _st())
+        check(rc, f"fmmt_layernorm_bwd(M={M},C={C},add)")
+        return dx, dg, db, None
+
+
+def residual_layer_norm(x, gamma, beta, eps=1e-5):
+    """returns (x, LN(x)); use the returned x as the residual input of the block's last GEMM"""
+    return ResidualLayerNormFn.apply(x, gamma, beta, eps)
+
+
 # ------------------------------------------------------------------------------------------------
 # (shifted-)window attention core on token-order qkv
 # ------------------------------------------------------------------------------------------------
