@@ -14,6 +14,7 @@
 #include "fmmt_common.h"
 #include "../../include/fmmt.h"
 #include "wattn_args.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -306,8 +307,13 @@ __global__ __launch_bounds__(64) void wattn_dtable_kernel(const float* __restric
 }
 
 int wa_groups_per_head(int B_, int nH, bool bwd, bool mfma) {
-    // persistent workgroups pinned to a head: ~3 per CU for the (fast) MFMA kernels, ~8 per CU otherwise
-    int g = ((mfma ? 768 : 2048) + nH - 1) / nH;
+    // Persistent workgroups pinned to a head.  The grid must not exceed what is co-resident (a second
+    // round of workgroups would find its share of windows already sized for the full grid):
+    //   MFMA fwd: 36 KB LDS, 116 VGPR -> 4 per CU (1024);  MFMA bwd: 80 KB LDS, 256 VGPR -> 2 per CU (512);
+    //   fp32 VALU kernels: ~8 / 1-2 per CU, parity path only.
+    static const int fwd_wgs = getenv("FMMT_WA_FWD_WGS") ? atoi(getenv("FMMT_WA_FWD_WGS")) : 1024;
+    const int target = mfma ? (bwd ? 512 : fwd_wgs) : 2048;
+    int g = target / nH;
     const int maxg = (B_ + 3) / 4;
     if (g > maxg) g = maxg;
     const int cap = mfma ? WA_BWD_WAVES_PER_HEAD_MAX : WA_BWD_WAVES_PER_HEAD_MAX / 4;

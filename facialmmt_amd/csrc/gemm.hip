@@ -134,9 +134,18 @@ __global__ __launch_bounds__(256) void linear_nt_kernel(LinArgs p) {
 
     f32x4 acc[MT][NT];
 
-    // weight-row permutation inside a wave tile: MFMA row i of n-tile nt is output channel
-    // (i>>2)*(4*NT) + nt*4 + (i&3), so that a lane's accumulators cover 4*NT consecutive channels.
-    const int wrow_base = wn * WN + (li >> 2) * (4 * NT) + (li & 3);
+    // weight-row permutation inside a wave tile.  MFMA row i = 4*g + r of n-tile nt becomes output channel
+    //   full 8-wide chunk c = (4*nt)/8 :  c*32 + g*8 + (4*nt)%8 + r     (4 lanes x 16 B = 64 contiguous bytes per row)
+    //   4-wide tail (CW % 8 != 0)      :  (CW/8)*32 + g*4 + r
+    // so that every epilogue access of a lane is a 16-byte vector and the four lanes that share a token
+    // row cover one contiguous 64-byte span per store instruction.
+    auto chan_of = [&](int nt, int g, int r) {
+        const int t0 = nt * 4;
+        return (t0 < (CW / 8) * 8) ? (t0 / 8) * 32 + g * 8 + (t0 % 8) + r : (CW / 8) * 32 + g * 4 + r;
+    };
+    int wrow[NT];
+#pragma unroll
+    for (int b = 0; b < NT; ++b) wrow[b] = wn * WN + chan_of(b, li >> 2, li & 3);
     const int xrow_base = wm * WM + li;
     const int koff = lg * KP;
 
@@ -147,7 +156,7 @@ __global__ __launch_bounds__(256) void linear_nt_kernel(LinArgs p) {
         for (int kk = 0; kk < BK / KM; ++kk) {
             typename Mma<T>::frag wf[NT], xf[MT];
 #pragma unroll
-            for (int b = 0; b < NT; ++b) wf[b] = Mma<T>::load(wsb + (wrow_base + b * 4) * PITCH + kk * KM + koff);
+            for (int b = 0; b < NT; ++b) wf[b] = Mma<T>::load(wsb + wrow[b] * PITCH + kk * KM + koff);
 #pragma unroll
             for (int a = 0; a < MT; ++a) xf[a] = Mma<T>::load(xsb + (xrow_base + a * 16) * PITCH + kk * KM + koff);
 #pragma unroll
@@ -158,7 +167,7 @@ __global__ __launch_bounds__(256) void linear_nt_kernel(LinArgs p) {
     };
 
     auto epilogue = [&](int m0, int n0) {
-        const int ncol0 = n0 + wn * WN + lg * CW;
+        const int nbase = n0 + wn * WN;
         if (p.part) {                                      // split-K: raw fp32 partial sums, finished by another kernel
             float* pp = p.part + (size_t)blockIdx.y * p.M * p.N;
 #pragma unroll
@@ -167,27 +176,28 @@ __global__ __launch_bounds__(256) void linear_nt_kernel(LinArgs p) {
                 if (m >= p.M) continue;
 #pragma unroll
                 for (int b = 0; b < NT; ++b) {
-                    const int n = ncol0 + b * 4;
+                    const int n = nbase + chan_of(b, lg, 0);
                     if (n + 4 <= p.N) *reinterpret_cast<f32x4*>(pp + (size_t)m * p.N + n) = acc[a][b];
                 }
             }
             return;
         }
-        // a lane owns CW consecutive channels of row m: chunks of VEC (one 16-byte access per operand)
-        // with a 4-wide tail when CW % VEC != 0
+        // per lane and token row: CW/VEC vector chunks (fp32: one n-tile = 4 channels = 16 B; bf16: two
+        // n-tiles = 8 channels = 16 B) plus, for bf16 with odd NT, a 4-channel (8-byte) tail
+        constexpr int TPC = VEC / 4;                       // n-tiles per 16-byte chunk
 #pragma unroll
         for (int a = 0; a < MT; ++a) {
             const int m = m0 + wm * WM + a * 16 + li;
             if (m >= p.M) continue;
             const float rs = row_scale(p.rowscale, m, p.rows_per_scale);
 #pragma unroll
-            for (int c0 = 0; c0 < CW; c0 += VEC) {
-                const int n = ncol0 + c0;
-                const int w = (CW - c0 >= VEC) ? VEC : 4;      // chunk width (compile-time after unrolling)
+            for (int b0 = 0; b0 < NT; b0 += TPC) {
+                const int w = (NT - b0 >= TPC) ? VEC : 4;      // chunk width (compile-time after unrolling)
+                const int n = nbase + chan_of(b0, lg, 0);
                 if (n + w > p.N) continue;
                 float v[VEC];
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) v[e] = (e < w) ? acc[a][(c0 + e) >> 2][(c0 + e) & 3] : 0.f;
+                for (int e = 0; e < VEC; ++e) v[e] = (e < w) ? acc[a][b0 + (e >> 2)][e & 3] : 0.f;
                 if (p.bias) {
 #pragma unroll
                     for (int e4 = 0; e4 < VEC; e4 += 4)
@@ -290,7 +300,9 @@ int launch_nt(const LinArgs& a, hipStream_t st) {
 template <typename T, int BN>
 int dispatch_nt_bk(const LinArgs& a, hipStream_t st) {
     if constexpr (sizeof(T) == 2) {
-        if (!a.ksplit && a.K == 96) return launch_nt<T, 128, BN, 96, 1>(a, st);     // Swin stage 0: one K step
+        // Swin stage 0: one K step.  (64- and 256-row tiles measured: no gain / -35 %.  These launches are bound by
+        // HBM *write* bandwidth, ~2.3 TB/s on this part: time tracks bytes written, not tile shape or store pattern.)
+        if (!a.ksplit && a.K == 96) return launch_nt<T, 128, BN, 96, 1>(a, st);
         if (!a.ksplit && a.K <= 64) return launch_nt<T, 128, BN, 64, 1>(a, st);     // PatchEmbed (K = 48)
         // measured on MI355X (tests/gpu_gemm_bench.py, sum over the bench shapes): BK=64 5.33 ms vs BK=32 5.88 ms
         if (a.K % 64 == 0 && (!a.ksplit || a.ksplit % 64 == 0)) return launch_nt<T, 128, BN, 64, 2>(a, st);
