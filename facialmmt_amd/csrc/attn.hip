@@ -14,6 +14,7 @@
 #include "fmmt_common.h"
 #include "../../include/fmmt.h"
 #include "wattn_args.h"
+#include "mha_args.h"
 #include <stdlib.h>
 
 namespace {
@@ -332,15 +333,6 @@ int wa_check(int dtype, int n_img, int H, int W, int C, int nH, int shift) {
 // =============================================================================================
 // Cross-modal multi-head attention (head_dim 64 or 32), time-major operands.
 // =============================================================================================
-struct MhaArgs {
-    int Lq, Lk, B, E, nH;
-    const void* q; int ldq;
-    const void* k; const void* v; int ldkv;
-    float scale, drop_p; uint64_t seed;
-    void* out; int ldo; float* lse;
-    const void* dout;
-    void* dq; int lddq; void* dk; void* dv; int lddkv;
-};
 
 template <typename T, int D> __device__ __forceinline__ void load_row(const T* p, float* r) {
     constexpr int VEC = Vec<T>::N;
@@ -656,6 +648,8 @@ extern "C" int fmmt_mha_fwd(int dtype, int Lq, int Lk, int B, int E, int num_hea
     a.Lq = Lq; a.Lk = Lk; a.B = B; a.E = E; a.nH = num_heads; a.q = q; a.ldq = ldq; a.k = k; a.v = v; a.ldkv = ldkv;
     a.scale = scale; a.drop_p = dropout_p; a.seed = seed; a.out = out; a.ldo = ldo; a.lse = lse;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == FMMT_BF16 && E / num_heads == 64 && ldq % 8 == 0 && ldkv % 8 == 0 && ldo % 8 == 0)
+        return fmmt_mha_mfma_fwd_launch(a, st);                      // matrix-core path
     FMMT_MHA_DISPATCH(K_FWD, (Lq + 63) / 64);
     return 0;
 }
@@ -671,6 +665,8 @@ extern "C" int fmmt_mha_bwd(int dtype, int Lq, int Lk, int B, int E, int num_hea
     a.scale = scale; a.drop_p = dropout_p; a.seed = seed; a.out = const_cast<void*>(out); a.ldo = ldo;
     a.lse = const_cast<float*>(lse); a.dout = dout; a.dq = dq; a.lddq = lddq; a.dk = dk; a.dv = dv; a.lddkv = lddkv;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == FMMT_BF16 && E / num_heads == 64 && ldq % 8 == 0 && ldkv % 8 == 0 && ldo % 8 == 0 && lddq % 8 == 0 && lddkv % 8 == 0)
+        return fmmt_mha_mfma_bwd_launch(a, st);                      // matrix-core path
     FMMT_MHA_DISPATCH(K_DQ, (Lq + 63) / 64);
     FMMT_MHA_DISPATCH(K_DV, (Lk + 63) / 64);
     FMMT_MHA_DISPATCH(K_DK, (Lk + 63) / 64);

@@ -1,0 +1,18 @@
+// Launch arguments shared by the two multi-head-attention formulations (attn.hip: fp32-exact VALU path and
+// head_dim 32; mha_mfma.hip: bf16 MFMA path for head_dim 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct MhaArgs {
+    int Lq, Lk, B, E, nH;
+    const void* q; int ldq;
+    const void* k; const void* v; int ldkv;
+    float scale, drop_p; uint64_t seed;
+    void* out; int ldo; float* lse;
+    const void* dout;
+    void* dq; int lddq; void* dk; void* dv; int lddkv;
+};
+
+int fmmt_mha_mfma_fwd_launch(const MhaArgs& a, hipStream_t st);
+int fmmt_mha_mfma_bwd_launch(const MhaArgs& a, hipStream_t st);

@@ -125,3 +125,25 @@ def test_multimodal_model_logits(golden, dev, plm):
     inp = [t.to(dev) for t in synth_multimodal_inputs(synth, B=3, T=64, La=24, Lv=20)]
     with torch.no_grad():
         golden.check("multimodal", f"mm/{plm}", mm(*inp), **TOL)
+
+
+def test_mfma_attention_dropout_matches_fp32_kernel(dev):
+    """the bf16 MFMA attention and the fp32 VALU attention draw the same keep-mask from (seed, element):
+    with identical inputs (bf16-representable) forward and backward agree to bf16 accuracy"""
+    from facialmmt_amd import ops
+    torch.manual_seed(4)
+    q16 = torch.randn(100, 3, 768, device=dev).bfloat16()
+    kv16 = torch.randn(130, 3, 1536, device=dev).bfloat16()
+    w16 = torch.randn(100, 3, 768, device=dev).bfloat16()
+    outs = []
+    for dt in (torch.float32, torch.bfloat16):
+        q = q16.to(dt).requires_grad_(True)
+        kv = kv16.to(dt).requires_grad_(True)
+        o = ops.mha_core(q, kv, None, 12, 0.125, 0.2, 991)
+        (o * w16.to(dt)).sum().backward()
+        outs.append((o.detach().float(), q.grad.float(), kv.grad.float()))
+    for a, b in zip(*outs):
+        assert (a - b).abs().max().item() <= 3e-2 * a.abs().max().item()
+    # and the mask really drops ~20 % of the probabilities
+    o0 = ops.mha_core(q16, kv16, None, 12, 0.125, 0.0, 0).float()
+    assert (o0 - outs[1][0]).abs().max().item() > 1e-2
