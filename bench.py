@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--frames", type=int, default=160, help="face frames per utterance (vision_max_utt_len)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graphs", type=int, default=1, help="capture the multimodal model (fwd+bwd) as HIP graphs (1) or launch eagerly (0)")
     ap.add_argument("--force-ddp", action="store_true", help="wrap in DDP even with one process (exercises the N>1 code path on one GPU)")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames in the CPU-baseline Swin sample")
     return ap.parse_args()
@@ -208,11 +209,20 @@ def main():
     from facialmmt_amd.train_step import TargetStep
     cfg = default_args(get_vision_utt_max_lens=args.frames, trg_accumulation_steps=1)
     swin, mm = build_models(args, dev, cfg)
+    batch = synth_batch(args, dev, rank, cfg)
+    if args.graphs:
+        from facialmmt_amd.train_step import graph_multimodal, select_frames
+        with torch.no_grad():
+            preds = swin(batch[8][:8], is_trg_task=True).float().repeat(batch[8].shape[0] // 8, 1)
+        vis, nmask = select_frames(preds, batch[5], batch[6], batch[9], cfg.FacialEmoImpor_threshold)
+        sample = (batch[0], batch[1], batch[2], batch[3], batch[4], vis.detach().requires_grad_(True), nmask, batch[10])
+        mm = graph_multimodal(mm, sample, torch.bfloat16 if args.dtype == "bf16" else None)
+        mm.zero_grad(set_to_none=True)
+        swin.zero_grad(set_to_none=True)
     ddp = wrap_ddp(mm, dev) if (world > 1 or args.force_ddp) else None
     opt = torch.optim.AdamW(mm.parameters(), lr=cfg.trg_lr, weight_decay=cfg.weight_decay, fused=True)
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: min(1.0, (s + 1) / 100.0))
     step = TargetStep(swin, mm, opt, sched, cfg, autocast_dtype=torch.bfloat16 if args.dtype == "bf16" else None, ddp_model=ddp)
-    batch = synth_batch(args, dev, rank, cfg)
     timer = KernelTimer()
     timer.install()
 
@@ -225,9 +235,11 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     timer.enabled = rank == 0
+    step.host_ms = {}
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, kept = step(batch)
+    issue_s = time.perf_counter() - t0                      # host time to enqueue the steps (GPU still running)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -262,7 +274,9 @@ def main():
                                    f"batch {args.utts} utterances/GPU, {args.dtype}, fwd+bwd+AdamW every step",
                        "global_batch": args.utts * world, "frames_per_step_per_gpu": args.utts * args.frames,
                        "parallelism": f"dp{world}", "kept_frame_fraction": round(float(kept.mean().item()), 3),
-                       "model_tflops_per_s_per_gpu": round(flops_step / (ms * 1e-3) / 1e12, 1)},
+                       "model_tflops_per_s_per_gpu": round(flops_step / (ms * 1e-3) / 1e12, 1),
+                       "host_enqueue_ms_per_step": round(issue_s / args.steps * 1e3, 1), "hip_graphs": bool(args.graphs),
+                       "host_ms_per_phase": {k: round(v / args.steps, 1) for k, v in step.host_ms.items()}},
             "roofline": roof,
             "cpu_baseline": None,
         }

@@ -394,7 +394,8 @@ __device__ __forceinline__ void stage_rows(const T* base, int ld, int B, int b, 
 __device__ __forceinline__ float keep_scale(const MhaArgs& p, int bh, int i, int j) {
     if (p.drop_p <= 0.f) return 1.f;
     const uint64_t idx = ((uint64_t)bh * p.Lq + i) * p.Lk + j;
-    return hash_uniform(p.seed, idx) >= p.drop_p ? 1.0f / (1.0f - p.drop_p) : 0.f;
+    const uint64_t seed = p.seed_dev ? *p.seed_dev : p.seed;
+    return hash_uniform(seed, idx) >= p.drop_p ? 1.0f / (1.0f - p.drop_p) : 0.f;
 }
 
 // forward: lane owns a query row; keys/values streamed through LDS in tiles of MT; online softmax
@@ -641,12 +642,12 @@ extern "C" int fmmt_window_attn_bwd(int dtype, int n_img, int H, int W, int C, i
 
 extern "C" int fmmt_mha_fwd(int dtype, int Lq, int Lk, int B, int E, int num_heads,
                             const void* q, int ldq, const void* k, const void* v, int ldkv, float scale,
-                            float dropout_p, uint64_t seed, void* out, int ldo, float* lse, void* stream) {
+                            float dropout_p, uint64_t seed, const uint64_t* seed_dev, void* out, int ldo, float* lse, void* stream) {
     if (int e = mha_check(dtype, Lq, Lk, B, E, num_heads)) return e;
     if (dropout_p < 0.f || dropout_p >= 1.f) return FMMT_EINVAL;
     MhaArgs a{};
     a.Lq = Lq; a.Lk = Lk; a.B = B; a.E = E; a.nH = num_heads; a.q = q; a.ldq = ldq; a.k = k; a.v = v; a.ldkv = ldkv;
-    a.scale = scale; a.drop_p = dropout_p; a.seed = seed; a.out = out; a.ldo = ldo; a.lse = lse;
+    a.scale = scale; a.drop_p = dropout_p; a.seed = seed; a.seed_dev = seed_dev; a.out = out; a.ldo = ldo; a.lse = lse;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == FMMT_BF16 && E / num_heads == 64 && ldq % 8 == 0 && ldkv % 8 == 0 && ldo % 8 == 0)
         return fmmt_mha_mfma_fwd_launch(a, st);                      // matrix-core path
@@ -656,13 +657,13 @@ extern "C" int fmmt_mha_fwd(int dtype, int Lq, int Lk, int B, int E, int num_hea
 
 extern "C" int fmmt_mha_bwd(int dtype, int Lq, int Lk, int B, int E, int num_heads,
                             const void* q, int ldq, const void* k, const void* v, int ldkv, float scale,
-                            float dropout_p, uint64_t seed, const void* out, const void* dout, int ldo,
+                            float dropout_p, uint64_t seed, const uint64_t* seed_dev, const void* out, const void* dout, int ldo,
                             const float* lse, void* dq, int lddq, void* dk, void* dv, int lddkv, void* stream) {
     if (int e = mha_check(dtype, Lq, Lk, B, E, num_heads)) return e;
     if (dropout_p < 0.f || dropout_p >= 1.f) return FMMT_EINVAL;
     MhaArgs a{};
     a.Lq = Lq; a.Lk = Lk; a.B = B; a.E = E; a.nH = num_heads; a.q = q; a.ldq = ldq; a.k = k; a.v = v; a.ldkv = ldkv;
-    a.scale = scale; a.drop_p = dropout_p; a.seed = seed; a.out = const_cast<void*>(out); a.ldo = ldo;
+    a.scale = scale; a.drop_p = dropout_p; a.seed = seed; a.seed_dev = seed_dev; a.out = const_cast<void*>(out); a.ldo = ldo;
     a.lse = const_cast<float*>(lse); a.dout = dout; a.dq = dq; a.lddq = lddq; a.dk = dk; a.dv = dv; a.lddkv = lddkv;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == FMMT_BF16 && E / num_heads == 64 && ldq % 8 == 0 && ldkv % 8 == 0 && ldo % 8 == 0 && lddq % 8 == 0 && lddkv % 8 == 0)

@@ -8,7 +8,7 @@ struct MhaArgs {
     int Lq, Lk, B, E, nH;
     const void* q; int ldq;
     const void* k; const void* v; int ldkv;
-    float scale, drop_p; uint64_t seed;
+    float scale, drop_p; uint64_t seed; const uint64_t* seed_dev;
     void* out; int ldo; float* lse;
     const void* dout;
     void* dq; int lddq; void* dk; void* dv; int lddkv;

@@ -56,7 +56,8 @@ __device__ __forceinline__ bf16x8 tr_fragT(const bf16* tile, int r0, int dt, int
 __device__ __forceinline__ float keep_scale(const MhaArgs& p, int bh, int i, int j) {
     if (p.drop_p <= 0.f) return 1.f;
     const uint64_t idx = ((uint64_t)bh * p.Lq + i) * p.Lk + j;
-    return hash_uniform(p.seed, idx) >= p.drop_p ? 1.0f / (1.0f - p.drop_p) : 0.f;
+    const uint64_t seed = p.seed_dev ? *p.seed_dev : p.seed;
+    return hash_uniform(seed, idx) >= p.drop_p ? 1.0f / (1.0f - p.drop_p) : 0.f;
 }
 
 // stage 64 rows [r0, r0+64) of a time-major tensor as a natural-layout bf16 tile; rows >= L are zero

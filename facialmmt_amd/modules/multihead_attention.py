@@ -64,7 +64,8 @@ class MultiheadAttention(nn.Module):
         assert key.size() == value.size()
         E = self.embed_dim
         p = self.attn_dropout if self.training else 0.0
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0     # CPU generator: no device sync
+        # fresh seed per call, drawn on the device: no host sync, and a captured hipGraph re-draws it on replay
+        seed = torch.randint(0, 2 ** 62, (1,), device=query.device, dtype=torch.int64) if p > 0 else 0
         q = self.in_proj_q(query)
         if key is value or (key.data_ptr() == value.data_ptr() and key.shape == value.shape):
             kv = self.in_proj_kv(key)                                           # one GEMM, N = 2E, [k | v]

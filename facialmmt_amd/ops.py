@@ -79,12 +79,15 @@ def _lp(w: torch.Tensor, dtype, transpose: bool = False) -> torch.Tensor:
     w = w.detach()
     if w.dtype == dtype and not transpose:
         return w.contiguous()
+    capturing = w.is_cuda and torch.cuda.is_current_stream_capturing()
     key = (w.data_ptr(), tuple(w.shape), dtype, transpose)
-    hit = _CAST_CACHE.get(key)
+    hit = None if capturing else _CAST_CACHE.get(key)       # inside a hipGraph the cast must be part of the graph
     if hit is not None and hit[0] == w._version:
         return hit[1]
     out = w.to(dtype)
     out = out.t().contiguous() if transpose else out.contiguous()
+    if capturing:
+        return out
     if len(_CAST_CACHE) > 4096:
         _CAST_CACHE.clear()
     _CAST_CACHE[key] = (w._version, out)
@@ -330,16 +333,18 @@ class MhaCoreFn(Function):
             kp, vp = k.data_ptr(), v.data_ptr()
         out = torch.empty_like(q)
         lse = torch.empty((B * num_heads * Lq,), dtype=torch.float32, device=q.device)
+        seed_t = seed if isinstance(seed, torch.Tensor) else None          # device int64 word: graph-replay safe
+        seed_i = 0 if seed_t is not None else int(seed)
         rc = lib.fmmt_mha_fwd(dtype_code(q.dtype), Lq, Lk, B, E, num_heads, _p(q), E, kp, vp, ldkv, scale,
-                              dropout_p, seed, _p(out), E, _p(lse), _st())
+                              dropout_p, seed_i, _p(seed_t), _p(out), E, _p(lse), _st())
         check(rc, f"fmmt_mha_fwd(Lq={Lq},Lk={Lk},B={B},E={E},heads={num_heads})")
-        ctx.save_for_backward(q, k, v, out, lse)
-        ctx.cfg = (Lq, Lk, B, E, num_heads, scale, dropout_p, seed, packed, ldkv)
+        ctx.save_for_backward(q, k, v, out, lse, seed_t)
+        ctx.cfg = (Lq, Lk, B, E, num_heads, scale, dropout_p, seed_i, packed, ldkv)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        q, k, v, out, lse = ctx.saved_tensors
+        q, k, v, out, lse, seed_t = ctx.saved_tensors
         Lq, Lk, B, E, num_heads, scale, dropout_p, seed, packed, ldkv = ctx.cfg
         lib = _lib.load()
         dout = dout.contiguous()
@@ -352,13 +357,14 @@ class MhaCoreFn(Function):
             dv = torch.empty_like(v)
             kp, vp, dkp, dvp = k.data_ptr(), v.data_ptr(), dk.data_ptr(), dv.data_ptr()
         rc = lib.fmmt_mha_bwd(dtype_code(q.dtype), Lq, Lk, B, E, num_heads, _p(q), E, kp, vp, ldkv, scale, dropout_p,
-                              seed, _p(out), _p(dout), E, _p(lse), _p(dq), E, dkp, dvp, ldkv, _st())
+                              seed, _p(seed_t), _p(out), _p(dout), E, _p(lse), _p(dq), E, dkp, dvp, ldkv, _st())
         check(rc, "fmmt_mha_bwd")
         return dq, dk, dv, None, None, None, None
 
 
 def mha_core(q, k, v, num_heads, scale, dropout_p=0.0, seed=0):
-    return MhaCoreFn.apply(q, k, v, num_heads, scale, float(dropout_p), int(seed))
+    """seed: python int, or a 1-element int64 CUDA tensor read by the kernel at run time"""
+    return MhaCoreFn.apply(q, k, v, num_heads, scale, float(dropout_p), seed if isinstance(seed, torch.Tensor) else int(seed))
 
 
 # ------------------------------------------------------------------------------------------------

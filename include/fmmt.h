@@ -138,15 +138,16 @@ int fmmt_window_attn_bwd(int dtype, int n_img, int H, int W, int C, int num_head
  * :128 (head merge).  Time-major operands: q [Lq, B, E], k / v [Lk, B, ldkv] (k and v may be column
  * slices of one packed projection: pass the slice pointers and the shared row pitch ldkv).
  * head_dim = E / num_heads must be 64 or 32.  Dropout: keep-mask = hash(seed, element) >= p, kept
- * probabilities scaled by 1/(1-p); p == 0 disables.  The head-averaged weights the reference also
+ * probabilities scaled by 1/(1-p); p == 0 disables.  If seed_dev != NULL the seed is read from that device
+ * word at kernel run time (so a captured hipGraph draws a fresh mask on every replay) and `seed` is ignored.  The head-averaged weights the reference also
  * returns (:133-134) are discarded by every caller (CrossmodalTransformer.py:147,151) and are not produced.
  */
 int fmmt_mha_fwd(int dtype, int Lq, int Lk, int B, int E, int num_heads,
                  const void* q, int ldq, const void* k, const void* v, int ldkv, float scale,
-                 float dropout_p, uint64_t seed, void* out, int ldo, float* lse, void* stream);
+                 float dropout_p, uint64_t seed, const uint64_t* seed_dev, void* out, int ldo, float* lse, void* stream);
 int fmmt_mha_bwd(int dtype, int Lq, int Lk, int B, int E, int num_heads,
                  const void* q, int ldq, const void* k, const void* v, int ldkv, float scale,
-                 float dropout_p, uint64_t seed, const void* out, const void* dout, int ldo,
+                 float dropout_p, uint64_t seed, const uint64_t* seed_dev, const void* out, const void* dout, int ldo,
                  const float* lse, void* dq, int lddq, void* dk, void* dv, int lddkv, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
