@@ -113,6 +113,7 @@ class KernelTimer:
             # same dispatch as csrc/gemm.hip::dispatch_nt: <BN, BK, LDS buffers>
             bn = 96 if (N % 96 == 0 and N % 128 != 0) else 128
             bn = f"{bn},96,1" if K == 96 else f"{bn},64,1" if K <= 64 else f"{bn},64,2" if K % 64 == 0 else f"{bn},32,2"
+            bn = f"{64 if M <= 4096 else 128},{bn}"
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             y = raw(x2, w, bias, **kw)
@@ -259,9 +260,18 @@ def main():
         if fams:
             bn, (cnt, fl, by, sec) = max(fams.items(), key=lambda kv: kv[1][3])
             achieved = fl / sec / 1e12
-            roof = {"bound": "mfma", "kernel": f"linear_nt_kernel<bf16,128,{bn}>", "achieved": round(achieved, 1),
+            kname = f"linear_nt_kernel<bf16,{bn}>"
+            traffic = None                       # PMC counters cannot be read in-process: taken from the committed PMC summary
+            try:
+                with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                    t = json.load(f).get(kname)
+                if t:
+                    traffic = (2 * t["fetch_size_kb"] + t["write_size_kb"]) * 1024
+            except OSError:
+                pass
+            roof = {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 1),
                     "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                    "traffic": None, "launches_per_step": cnt // args.steps,
+                    "traffic": traffic, "algorithmic_bytes_per_launch": round(by / cnt), "launches_per_step": cnt // args.steps,
                     "avg_launch_us": round(sec / cnt * 1e6, 1), "algorithmic_GB_per_s": round(by / sec / 1e9, 0),
                     "share_of_step": round(sec / elapsed, 3)}
         flops_step = args.utts * (args.frames * SWIN_FWD_GFLOP_PER_FRAME * 3 + (335 + 29.7) * 3) * 1e9

@@ -297,18 +297,18 @@ int launch_nt(const LinArgs& a, hipStream_t st) {
     return 0;
 }
 
-template <typename T, int BN>
+template <typename T, int BM, int BN>
 int dispatch_nt_bk(const LinArgs& a, hipStream_t st) {
     if constexpr (sizeof(T) == 2) {
         // Swin stage 0: one K step.  (64- and 256-row tiles measured: no gain / -35 %.  These launches are bound by
         // HBM *write* bandwidth, ~2.3 TB/s on this part: time tracks bytes written, not tile shape or store pattern.)
-        if (!a.ksplit && a.K == 96) return launch_nt<T, 128, BN, 96, 1>(a, st);
-        if (!a.ksplit && a.K <= 64) return launch_nt<T, 128, BN, 64, 1>(a, st);     // PatchEmbed (K = 48)
+        if (!a.ksplit && a.K == 96) return launch_nt<T, BM, BN, 96, 1>(a, st);
+        if (!a.ksplit && a.K <= 64) return launch_nt<T, BM, BN, 64, 1>(a, st);     // PatchEmbed (K = 48)
         // measured on MI355X (tests/gpu_gemm_bench.py, sum over the bench shapes): BK=64 5.33 ms vs BK=32 5.88 ms
-        if (a.K % 64 == 0 && (!a.ksplit || a.ksplit % 64 == 0)) return launch_nt<T, 128, BN, 64, 2>(a, st);
-        return launch_nt<T, 128, BN, 32, 2>(a, st);
+        if (a.K % 64 == 0 && (!a.ksplit || a.ksplit % 64 == 0)) return launch_nt<T, BM, BN, 64, 2>(a, st);
+        return launch_nt<T, BM, BN, 32, 2>(a, st);
     } else {
-        return launch_nt<T, 128, BN, 16, 2>(a, st);                                 // fp32 parity path
+        return launch_nt<T, BM, BN, 16, 2>(a, st);                                 // fp32 parity path
     }
 }
 
@@ -316,8 +316,10 @@ template <typename T>
 int dispatch_nt(const LinArgs& a, hipStream_t st) {
     // BN = 96 when it tiles N exactly and 128 would not (C = 96, 288, 192, 576 ...)
     const bool n96 = (a.N % 96 == 0) && (a.N % 128 != 0);
-    if (n96) return dispatch_nt_bk<T, 96>(a, st);
-    return dispatch_nt_bk<T, 128>(a, st);
+    // few-token problems (cross-modal encoder: 152..1280 rows; embedding head: 640 rows) use 64-row tiles so
+    // that twice as many workgroups share the work; the multi-million-token Swin GEMMs use 128-row tiles
+    if (a.M <= 4096) return n96 ? dispatch_nt_bk<T, 64, 96>(a, st) : dispatch_nt_bk<T, 64, 128>(a, st);
+    return n96 ? dispatch_nt_bk<T, 128, 96>(a, st) : dispatch_nt_bk<T, 128, 128>(a, st);
 }
 
 // y = T(sum_s part[s] + bias) for the split-K path
@@ -334,7 +336,8 @@ __global__ void splitk_finish_kernel(const float* __restrict__ part, int splits,
 
 // split-K plan for skinny problems (the 37632 -> 512 head): few output tiles, very long K
 int splitk_plan(int M, int N, int K, int* ksplit) {
-    const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    const int bm = M <= 4096 ? 64 : 128;
+    const int tiles = ((M + bm - 1) / bm) * ((N + 127) / 128);
     if (tiles >= 128 || K < 4096) { *ksplit = 0; return 1; }
     int splits = 512 / tiles;
     if (splits > 32) splits = 32;
