@@ -119,3 +119,25 @@ class TargetStep:
             mark("optimizer")
         self.swin.zero_grad(set_to_none=True)
         return loss.detach(), new_mask
+
+
+class AuxStep:
+    """One auxiliary-task (Aff-Wild2 frame classification) step, train.py:15-41: Swin -> logits (no Gumbel)
+    -> cross-entropy -> backward -> clip (0.8) -> AdamW on the Swin model (aux_lr 5e-5) every
+    `aux_accumulation_steps`.  BASELINE.json configs[4] alternates these steps with target steps per epoch."""
+
+    def __init__(self, swin_model, optimizer, scheduler, args):
+        self.swin, self.opt, self.sched, self.args = swin_model, optimizer, scheduler, args
+        self.i_batch = 0
+
+    def __call__(self, images, labels):
+        loss = self.swin(images, False, labels, F.cross_entropy) / self.args.aux_accumulation_steps
+        loss.backward()
+        self.i_batch += 1
+        if self.i_batch % self.args.aux_accumulation_steps == 0:
+            torch.nn.utils.clip_grad_norm_(self.swin.parameters(), self.args.clip)
+            self.opt.step()
+            if self.sched is not None:
+                self.sched.step()
+            self.opt.zero_grad(set_to_none=True)
+        return loss.detach()

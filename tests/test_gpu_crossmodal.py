@@ -147,3 +147,37 @@ def test_mfma_attention_dropout_matches_fp32_kernel(dev):
     # and the mask really drops ~20 % of the probabilities
     o0 = ops.mha_core(q16, kv16, None, 12, 0.125, 0.0, 0).float()
     assert (o0 - outs[1][0]).abs().max().item() > 1e-2
+
+
+def test_hip_graph_replay_matches_eager(dev):
+    """train_step.graph_multimodal: forward and backward replayed from HIP graphs equal the eager launches
+    (dropout off so the comparison is deterministic); replaying twice with new inputs tracks the inputs."""
+    from facialmmt_amd import models
+    from facialmmt_amd.config import default_args
+    from facialmmt_amd.train_step import graph_multimodal
+    from oracle.gen_golden import synth_multimodal_inputs
+    cfg = default_args(get_audio_utt_max_lens=24, get_vision_utt_max_lens=20, plm_module=synth.make_standin_plm(),
+                       hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
+                       crossmodal_attn_dropout_TA=0.0, crossmodal_attn_dropout_TA_V=0.0)
+    mm = models.MultiModalTransformerForClassification(cfg)
+    synth.fill_state_dict(mm, seed=200)
+    mm.to(dev).train()
+    inp = [t.to(dev) for t in synth_multimodal_inputs(synth, B=3, T=64, La=24, Lv=20)]
+
+    def run(model, scale):
+        for p in model.parameters():
+            p.grad = None
+        vis = (inp[5] * scale).clone().requires_grad_(True)
+        out = model(inp[0], inp[1], inp[2], inp[3], inp[4], vis, inp[6], inp[7])
+        out.square().sum().backward()
+        g = model.CrossModalTrans_TA.layers[0].fc1.weight.grad.clone()
+        return out.detach().clone(), vis.grad.clone(), g
+
+    eager = [run(mm, s) for s in (1.0, 0.5)]
+    sample = (inp[0], inp[1], inp[2], inp[3], inp[4], inp[5].clone().requires_grad_(True), inp[6], inp[7])
+    gm = graph_multimodal(mm, sample)
+    graphed = [run(gm, s) for s in (1.0, 0.5)]
+    for e, g in zip(eager, graphed):
+        for a, b in zip(e, g):
+            assert torch.allclose(a, b, atol=1e-5 * max(1.0, a.abs().max().item()), rtol=1e-4)
+    assert not torch.allclose(graphed[0][0], graphed[1][0])
