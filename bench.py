@@ -113,7 +113,7 @@ class KernelTimer:
             # same dispatch as csrc/gemm.hip::dispatch_nt: <BN, BK, LDS buffers>
             bn = 96 if (N % 96 == 0 and N % 128 != 0) else 128
             bn = f"{bn},96,1" if K == 96 else f"{bn},64,1" if K <= 64 else f"{bn},64,2" if K % 64 == 0 else f"{bn},32,2"
-            bn = f"{64 if M <= 4096 else 128},{bn}"
+            bn = f"{64 if M <= 4096 else 128},{bn}" + (",glds" if (K % 64 == 0 and K > 64) else "")
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             y = raw(x2, w, bias, **kw)
