@@ -114,6 +114,8 @@ class KernelTimer:
             bn = 96 if (N % 96 == 0 and N % 128 != 0) else 128
             bn = f"{bn},96,1" if K == 96 else f"{bn},64,1" if K <= 64 else f"{bn},64,2" if K % 64 == 0 else f"{bn},32,2"
             bn = f"{64 if M <= 4096 else 128},{bn}" + (",glds" if (K % 64 == 0 and K > 64) else "")
+            if M >= 65536 and N % 128 == 0 and K % 64 == 0 and K >= 256:
+                bn = "deep256x128x64"
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             y = raw(x2, w, bias, **kw)
@@ -260,7 +262,7 @@ def main():
         if fams:
             bn, (cnt, fl, by, sec) = max(fams.items(), key=lambda kv: kv[1][3])
             achieved = fl / sec / 1e12
-            kname = f"linear_nt_kernel<bf16,{bn}>"
+            kname = "linear_nt_deep_kernel" if bn.startswith("deep") else f"linear_nt_kernel<bf16,{bn}>"
             traffic = None                       # PMC counters cannot be read in-process: taken from the committed PMC summary
             try:
                 with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:

@@ -55,141 +55,35 @@ struct LinArgs {
     float* part;       // split-K: fp32 partials [split][M][N] instead of the epilogue
 };
 
-// ---------------------------------------------------------------------------------------------
-// NT kernel: 256 threads = 4 waves (2 along M x 2 along N); block tile BM x BN, K step BK.
-//  * K pipeline: while tile k is multiplied out of LDS, tile k+1 is in flight into registers; two LDS
-//    buffers, one barrier per K step.  BK = 64 makes every global load instruction fetch whole 128-byte
-//    rows.  K == 96 (Swin stage 0) is a single step (NBUF = 1).  (A second register stage was measured
-//    and lost: occupancy beats prefetch depth on this chip for these shapes -- tests/gpu_gemm_bench.py.)
-//  * one output tile per workgroup.  (A persistent variant that issues the next tile's first K step under
-//    the epilogue was measured and lost as well: +60..100 VGPRs -> one wave per SIMD.)
-// ---------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int BK, int NBUF, bool GLDS>
-__global__ __launch_bounds__(256) void linear_nt_kernel(LinArgs p) {
+// Output-channel permutation of a wave tile.  MFMA row i = 4*g + r of n-tile nt becomes output channel
+//   full 8-wide chunk c = (4*nt)/8 :  c*32 + g*8 + (4*nt)%8 + r     (4 lanes x 16 B = 64 contiguous bytes per row)
+//   4-wide tail (CW % 8 != 0)      :  (CW/8)*32 + g*4 + r
+// so that every epilogue access of a lane is a 16-byte vector and the four lanes that share a token row
+// cover one contiguous 64-byte span per store instruction.
+template <int CW>
+__device__ __forceinline__ int chan_of(int nt, int g, int r) {
+    const int t0 = nt * 4;
+    return (t0 < (CW / 8) * 8) ? (t0 / 8) * 32 + g * 8 + (t0 % 8) + r : (CW / 8) * 32 + g * 4 + r;
+}
+
+// Epilogue of one wave tile (MT x NT MFMA tiles at rows mbase.., channels nbase..): bias, GELU / GELU',
+// DropPath row scale, residual, 16-byte stores; or raw fp32 partials for the split-K path.
+template <typename T, int MT, int NT>
+__device__ __forceinline__ void nt_epilogue(const LinArgs& p, f32x4 (&acc)[MT][NT], int mbase, int nbase, int li, int lg) {
     constexpr int VEC = Vec<T>::N;
-    // GLDS: tiles are filled by direct global->LDS DMA (global_load_lds_dwordx4): the LDS image of a wave
-    // instruction is lane-linear, so rows are unpadded (128 B) and bank conflicts are removed by an XOR
-    // swizzle applied to the *source* chunk index and again on the fragment read (key = (row >> 1) & 7).
-    constexpr int PITCH = GLDS ? BK : BK + VEC;
-    constexpr int KM = Mma<T>::KM, KP = Mma<T>::KP;
-    constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 16, NT = WN / 16;
-    constexpr int KV = BK / VEC;                        // 16-byte vectors per tile row
-    constexpr int W_VECS = BN * KV, X_VECS = BM * KV;
-    constexpr int WV = (W_VECS + 255) / 256, XV = (X_VECS + 255) / 256;
-    constexpr int CW = 4 * NT;                          // consecutive channels owned by a lane in the epilogue
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* Ws = reinterpret_cast<T*>(smem);                 // [NBUF][BN][PITCH]
-    T* Xs = Ws + NBUF * BN * PITCH;                     // [NBUF][BM][PITCH]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int li = lane & 15, lg = lane >> 4;
-
-    const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
-    const T* __restrict__ wg = reinterpret_cast<const T*>(p.w);
     T* __restrict__ yg = reinterpret_cast<T*>(p.y);
     T* __restrict__ ypre = reinterpret_cast<T*>(p.y_pre);
     const T* __restrict__ auxg = reinterpret_cast<const T*>(p.aux);
     const T* __restrict__ resg = reinterpret_cast<const T*>(p.res);
-
-    const int kbeg = p.ksplit ? blockIdx.y * p.ksplit : 0;
-    const int kend = p.ksplit ? min(p.K, kbeg + p.ksplit) : p.K;
-    const int nk = (kend - kbeg + BK - 1) / BK;
-
-    struct Stage { Vec<T> w[WV], x[XV]; };
-    Stage R0;
-
-    auto gload = [&](Stage& R, int k0, int m0, int n0) {
-#pragma unroll
-        for (int i = 0; i < WV; ++i) {
-            const int v = tid + i * 256;
-            if (v < W_VECS) {
-                const int row = v / KV, kc = (v % KV) * VEC;
-                const int n = min(n0 + row, p.N - 1);
-                R.w[i] = (k0 + kc < kend) ? ldvec<T>(wg + (size_t)n * p.ldw + k0 + kc) : zerovec<T>();
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < XV; ++i) {
-            const int v = tid + i * 256;
-            if (v < X_VECS) {
-                const int row = v / KV, kc = (v % KV) * VEC;
-                const int m = min(m0 + row, p.M - 1);
-                R.x[i] = (k0 + kc < kend) ? ldvec<T>(xg + (size_t)m * p.ldx + k0 + kc) : zerovec<T>();
-            }
-        }
-    };
-    auto lstore = [&](const Stage& R, int buf) {
-        T* wsb = Ws + buf * BN * PITCH;
-        T* xsb = Xs + buf * BM * PITCH;
-#pragma unroll
-        for (int i = 0; i < WV; ++i) {
-            const int v = tid + i * 256;
-            if (v < W_VECS) stvec<T>(wsb + (v / KV) * PITCH + (v % KV) * VEC, R.w[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < XV; ++i) {
-            const int v = tid + i * 256;
-            if (v < X_VECS) stvec<T>(xsb + (v / KV) * PITCH + (v % KV) * VEC, R.x[i]);
-        }
-    };
-
-    f32x4 acc[MT][NT];
-
-    // weight-row permutation inside a wave tile.  MFMA row i = 4*g + r of n-tile nt becomes output channel
-    //   full 8-wide chunk c = (4*nt)/8 :  c*32 + g*8 + (4*nt)%8 + r     (4 lanes x 16 B = 64 contiguous bytes per row)
-    //   4-wide tail (CW % 8 != 0)      :  (CW/8)*32 + g*4 + r
-    // so that every epilogue access of a lane is a 16-byte vector and the four lanes that share a token
-    // row cover one contiguous 64-byte span per store instruction.
-    auto chan_of = [&](int nt, int g, int r) {
-        const int t0 = nt * 4;
-        return (t0 < (CW / 8) * 8) ? (t0 / 8) * 32 + g * 8 + (t0 % 8) + r : (CW / 8) * 32 + g * 4 + r;
-    };
-    int wrow[NT];
-#pragma unroll
-    for (int b = 0; b < NT; ++b) wrow[b] = wn * WN + chan_of(b, li >> 2, li & 3);
-    const int xrow_base = wm * WM + li;
-    const int koff = lg * KP;
-
-    auto compute = [&](int buf) {
-        const T* wsb = Ws + buf * BN * PITCH;
-        const T* xsb = Xs + buf * BM * PITCH;
-#pragma unroll
-        for (int kk = 0; kk < BK / KM; ++kk) {
-            typename Mma<T>::frag wf[NT], xf[MT];
-            if constexpr (GLDS) {
-#pragma unroll
-                for (int b = 0; b < NT; ++b) wf[b] = Mma<T>::load(wsb + wrow[b] * PITCH + (((kk * 4 + lg) ^ ((wrow[b] >> 1) & 7)) << 3));
-#pragma unroll
-                for (int a = 0; a < MT; ++a) {
-                    const int r = xrow_base + a * 16;
-                    xf[a] = Mma<T>::load(xsb + r * PITCH + (((kk * 4 + lg) ^ ((r >> 1) & 7)) << 3));
-                }
-            } else {
-#pragma unroll
-                for (int b = 0; b < NT; ++b) wf[b] = Mma<T>::load(wsb + wrow[b] * PITCH + kk * KM + koff);
-#pragma unroll
-                for (int a = 0; a < MT; ++a) xf[a] = Mma<T>::load(xsb + (xrow_base + a * 16) * PITCH + kk * KM + koff);
-            }
-#pragma unroll
-            for (int a = 0; a < MT; ++a)
-#pragma unroll
-                for (int b = 0; b < NT; ++b) acc[a][b] = Mma<T>::mma(wf[b], xf[a], acc[a][b]);
-        }
-    };
-
-    auto epilogue = [&](int m0, int n0) {
-        const int nbase = n0 + wn * WN;
         if (p.part) {                                      // split-K: raw fp32 partial sums, finished by another kernel
             float* pp = p.part + (size_t)blockIdx.y * p.M * p.N;
 #pragma unroll
             for (int a = 0; a < MT; ++a) {
-                const int m = m0 + wm * WM + a * 16 + li;
+                const int m = mbase + a * 16 + li;
                 if (m >= p.M) continue;
 #pragma unroll
                 for (int b = 0; b < NT; ++b) {
-                    const int n = nbase + chan_of(b, lg, 0);
+                    const int n = nbase + chan_of<4 * NT>(b, lg, 0);
                     if (n + 4 <= p.N) *reinterpret_cast<f32x4*>(pp + (size_t)m * p.N + n) = acc[a][b];
                 }
             }
@@ -200,13 +94,13 @@ __global__ __launch_bounds__(256) void linear_nt_kernel(LinArgs p) {
         constexpr int TPC = VEC / 4;                       // n-tiles per 16-byte chunk
 #pragma unroll
         for (int a = 0; a < MT; ++a) {
-            const int m = m0 + wm * WM + a * 16 + li;
+            const int m = mbase + a * 16 + li;
             if (m >= p.M) continue;
             const float rs = row_scale(p.rowscale, m, p.rows_per_scale);
 #pragma unroll
             for (int b0 = 0; b0 < NT; b0 += TPC) {
                 const int w = (NT - b0 >= TPC) ? VEC : 4;      // chunk width (compile-time after unrolling)
-                const int n = nbase + chan_of(b0, lg, 0);
+                const int n = nbase + chan_of<4 * NT>(b0, lg, 0);
                 if (n + w > p.N) continue;
                 float v[VEC];
 #pragma unroll
@@ -264,7 +158,121 @@ __global__ __launch_bounds__(256) void linear_nt_kernel(LinArgs p) {
                 store_chunk(yg, p.ldy, v);
             }
         }
+}
+
+// ---------------------------------------------------------------------------------------------
+// NT kernel: 256 threads = 4 waves (2 along M x 2 along N); block tile BM x BN, K step BK.
+//  * K pipeline: while tile k is multiplied out of LDS, tile k+1 is in flight into registers; two LDS
+//    buffers, one barrier per K step.  BK = 64 makes every global load instruction fetch whole 128-byte
+//    rows.  K == 96 (Swin stage 0) is a single step (NBUF = 1).  (A second register stage was measured
+//    and lost: occupancy beats prefetch depth on this chip for these shapes -- tests/gpu_gemm_bench.py.)
+//  * one output tile per workgroup.  (A persistent variant that issues the next tile's first K step under
+//    the epilogue was measured and lost as well: +60..100 VGPRs -> one wave per SIMD.)
+// ---------------------------------------------------------------------------------------------
+template <typename T, int BM, int BN, int BK, int NBUF, bool GLDS>
+__global__ __launch_bounds__(256) void linear_nt_kernel(LinArgs p) {
+    constexpr int VEC = Vec<T>::N;
+    // GLDS: tiles are filled by direct global->LDS DMA (global_load_lds_dwordx4): the LDS image of a wave
+    // instruction is lane-linear, so rows are unpadded (128 B) and bank conflicts are removed by an XOR
+    // swizzle applied to the *source* chunk index and again on the fragment read (key = (row >> 1) & 7).
+    constexpr int PITCH = GLDS ? BK : BK + VEC;
+    constexpr int KM = Mma<T>::KM, KP = Mma<T>::KP;
+    constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 16, NT = WN / 16;
+    constexpr int KV = BK / VEC;                        // 16-byte vectors per tile row
+    constexpr int W_VECS = BN * KV, X_VECS = BM * KV;
+    constexpr int WV = (W_VECS + 255) / 256, XV = (X_VECS + 255) / 256;
+    constexpr int CW = 4 * NT;                          // consecutive channels owned by a lane in the epilogue
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* Ws = reinterpret_cast<T*>(smem);                 // [NBUF][BN][PITCH]
+    T* Xs = Ws + NBUF * BN * PITCH;                     // [NBUF][BM][PITCH]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 15, lg = lane >> 4;
+
+    const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
+    const T* __restrict__ wg = reinterpret_cast<const T*>(p.w);
+
+    const int kbeg = p.ksplit ? blockIdx.y * p.ksplit : 0;
+    const int kend = p.ksplit ? min(p.K, kbeg + p.ksplit) : p.K;
+    const int nk = (kend - kbeg + BK - 1) / BK;
+
+    struct Stage { Vec<T> w[WV], x[XV]; };
+    Stage R0;
+
+    auto gload = [&](Stage& R, int k0, int m0, int n0) {
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            const int v = tid + i * 256;
+            if (v < W_VECS) {
+                const int row = v / KV, kc = (v % KV) * VEC;
+                const int n = min(n0 + row, p.N - 1);
+                R.w[i] = (k0 + kc < kend) ? ldvec<T>(wg + (size_t)n * p.ldw + k0 + kc) : zerovec<T>();
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            const int v = tid + i * 256;
+            if (v < X_VECS) {
+                const int row = v / KV, kc = (v % KV) * VEC;
+                const int m = min(m0 + row, p.M - 1);
+                R.x[i] = (k0 + kc < kend) ? ldvec<T>(xg + (size_t)m * p.ldx + k0 + kc) : zerovec<T>();
+            }
+        }
     };
+    auto lstore = [&](const Stage& R, int buf) {
+        T* wsb = Ws + buf * BN * PITCH;
+        T* xsb = Xs + buf * BM * PITCH;
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            const int v = tid + i * 256;
+            if (v < W_VECS) stvec<T>(wsb + (v / KV) * PITCH + (v % KV) * VEC, R.w[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            const int v = tid + i * 256;
+            if (v < X_VECS) stvec<T>(xsb + (v / KV) * PITCH + (v % KV) * VEC, R.x[i]);
+        }
+    };
+
+    f32x4 acc[MT][NT];
+
+    // weight-row permutation inside a wave tile: see chan_of()
+    int wrow[NT];
+#pragma unroll
+    for (int b = 0; b < NT; ++b) wrow[b] = wn * WN + chan_of<CW>(b, li >> 2, li & 3);
+    const int xrow_base = wm * WM + li;
+    const int koff = lg * KP;
+
+    auto compute = [&](int buf) {
+        const T* wsb = Ws + buf * BN * PITCH;
+        const T* xsb = Xs + buf * BM * PITCH;
+#pragma unroll
+        for (int kk = 0; kk < BK / KM; ++kk) {
+            typename Mma<T>::frag wf[NT], xf[MT];
+            if constexpr (GLDS) {
+#pragma unroll
+                for (int b = 0; b < NT; ++b) wf[b] = Mma<T>::load(wsb + wrow[b] * PITCH + (((kk * 4 + lg) ^ ((wrow[b] >> 1) & 7)) << 3));
+#pragma unroll
+                for (int a = 0; a < MT; ++a) {
+                    const int r = xrow_base + a * 16;
+                    xf[a] = Mma<T>::load(xsb + r * PITCH + (((kk * 4 + lg) ^ ((r >> 1) & 7)) << 3));
+                }
+            } else {
+#pragma unroll
+                for (int b = 0; b < NT; ++b) wf[b] = Mma<T>::load(wsb + wrow[b] * PITCH + kk * KM + koff);
+#pragma unroll
+                for (int a = 0; a < MT; ++a) xf[a] = Mma<T>::load(xsb + (xrow_base + a * 16) * PITCH + kk * KM + koff);
+            }
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b) acc[a][b] = Mma<T>::mma(wf[b], xf[a], acc[a][b]);
+        }
+    };
+
+    auto epilogue = [&](int m0, int n0) { nt_epilogue<T, MT, NT>(p, acc, m0 + wm * WM, n0 + wn * WN, li, lg); };
 
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (logical / p.tiles_n) * BM, n0 = (logical % p.tiles_n) * BN;
@@ -319,6 +327,93 @@ __global__ __launch_bounds__(256) void linear_nt_kernel(LinArgs p) {
     epilogue(m0, n0);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Deep-pipelined NT kernel for the compute-heavy shapes (bf16, K % 64 == 0, N % 128 == 0):
+// 512 threads = 8 waves (4 along M x 2 along N), block tile 256 x 128, K step 64, THREE LDS buffers
+// filled by direct global->LDS DMA.  Two tiles are in flight while one is multiplied: each wave waits
+// only for its own six DMA instructions of the tile about to be used (counted s_waitcnt vmcnt(6)), then
+// a raw s_barrier publishes the tile; the buffer freed by that barrier is refilled immediately.
+// LDS 3 x 48 KB = 144 KB: one workgroup (8 waves, 2 per SIMD) per CU.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void linear_nt_deep_kernel(LinArgs p) {
+    using T = bf16;
+    constexpr int BM = 256, BN = 128, BK = 64, PITCH = 64, MT = 4, NT = 4, CW = 16;
+    constexpr int STAGE = (BM + BN) * PITCH;               // elements per buffer
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* S = reinterpret_cast<T*>(smem);                     // [3][BN rows of W | BM rows of X][64]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 15, lg = lane >> 4;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (logical / p.tiles_n) * BM, n0 = (logical % p.tiles_n) * BN;
+    const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
+    const T* __restrict__ wg = reinterpret_cast<const T*>(p.w);
+    const int nk = p.K / BK;
+
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    const int r8 = lane >> 3, c = lane & 7;
+    auto issue = [&](int buf, int k0) {
+        T* base = S + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < BN / 64; ++i) {                // 2 DMA instructions per wave for W
+            const int grp = i * 8 + wave, row = grp * 8 + r8;
+            const T* src = wg + (size_t)min(n0 + row, p.N - 1) * p.ldw + k0 + ((c ^ ((row >> 1) & 7)) << 3);
+            __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(base + grp * 8 * PITCH), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < BM / 64; ++i) {                // 4 DMA instructions per wave for X
+            const int grp = i * 8 + wave, row = grp * 8 + r8;
+            const T* src = xg + (size_t)min(m0 + row, p.M - 1) * p.ldx + k0 + ((c ^ ((row >> 1) & 7)) << 3);
+            __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(base + (BN + grp * 8) * PITCH), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int wrow[NT];
+#pragma unroll
+    for (int b = 0; b < NT; ++b) wrow[b] = wn * 64 + chan_of<CW>(b, li >> 2, li & 3);
+    const int xrow_base = wm * 64 + li;
+
+    auto compute = [&](int buf) {
+        const T* wsb = S + buf * STAGE;
+        const T* xsb = wsb + BN * PITCH;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 wf[NT], xf[MT];
+#pragma unroll
+            for (int b = 0; b < NT; ++b) wf[b] = *reinterpret_cast<const bf16x8*>(wsb + wrow[b] * PITCH + (((kk * 4 + lg) ^ ((wrow[b] >> 1) & 7)) << 3));
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+                const int r = xrow_base + a * 16;
+                xf[a] = *reinterpret_cast<const bf16x8*>(xsb + r * PITCH + (((kk * 4 + lg) ^ ((r >> 1) & 7)) << 3));
+            }
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b], xf[a], acc[a][b], 0, 0, 0);
+        }
+    };
+
+    issue(0, 0);
+    if (nk > 1) issue(1, BK);
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // tile kt landed (this wave's part); tile kt+1 may fly
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                         // every wave's part of tile kt is in LDS
+        if (kt + 2 < nk) issue(cur == 0 ? 2 : cur - 1, (kt + 2) * BK);        // refill the buffer last read in step kt-1
+        compute(cur);
+        cur = cur == 2 ? 0 : cur + 1;
+    }
+    nt_epilogue<T, MT, NT>(p, acc, m0 + wm * 64, n0 + wn * 64, li, lg);
+}
+
 template <typename T, int BM, int BN, int BK, int NBUF, bool GLDS = false>
 int launch_nt(const LinArgs& a, hipStream_t st) {
     constexpr int VEC = Vec<T>::N;
@@ -366,6 +461,27 @@ int dispatch_nt(const LinArgs& a, hipStream_t st) {
     // few-token problems (cross-modal encoder: 152..1280 rows; embedding head: 640 rows) use 64-row tiles so
     // that twice as many workgroups share the work; the multi-million-token Swin GEMMs use 128-row tiles
     if (a.M <= 4096) return n96 ? dispatch_nt_bk<T, 64, 96>(a, st) : dispatch_nt_bk<T, 64, 128>(a, st);
+    if constexpr (sizeof(T) == 2) {
+        // measured (tests/gpu_gemm_bench.py): +8 % on the 125440-token stage-2 shapes (K = 384: 496 -> 540 TF/s),
+        // -4 % on the 31360-token stage-3 shapes (tile quantisation at one workgroup per CU) -> only for M >= 65536
+        static const int deep = getenv("FMMT_NT_DEEP") ? atoi(getenv("FMMT_NT_DEEP")) : 1;
+        if (deep && a.M >= 65536 && !a.ksplit && a.N % 128 == 0 && a.K % 64 == 0 && a.K >= 256 && a.ldx % 8 == 0 && a.ldw % 8 == 0) {
+            constexpr size_t lds = (size_t)3 * (256 + 128) * 64 * 2;
+            static bool attr_set = false;
+            if (!attr_set) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_nt_deep_kernel),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return (int)e;
+                attr_set = true;
+            }
+            LinArgs p = a;
+            p.tiles_n = a.N / 128;
+            p.tiles_m = (a.M + 255) / 256;
+            hipLaunchKernelGGL(linear_nt_deep_kernel, dim3(p.tiles_m * p.tiles_n), dim3(512), lds, st, p);
+            FMMT_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     // (256-row tiles with 4 waves measured: -30 % on the stage-2/3 shapes -- one workgroup per CU)
     return n96 ? dispatch_nt_bk<T, 128, 96>(a, st) : dispatch_nt_bk<T, 128, 128>(a, st);
 }
