@@ -124,6 +124,23 @@ class KernelTimer:
             return y
 
         ops.linear_raw = timed_linear_raw
+        raw_w = ops.wgrad_raw
+
+        def timed_wgrad_raw(dy2, x2, want_bias, rowscale=None, rows_per_scale=1):
+            if not timer.enabled or dy2.dtype != torch.bfloat16:
+                return raw_w(dy2, x2, want_bias, rowscale, rows_per_scale)
+            M, N = dy2.shape
+            K = x2.shape[1]
+            # same dispatch as csrc/gemm.hip::fmmt_linear_wgrad (the split-reduction kernels are not included)
+            name = "linear_tn_kernel<bf16,32,few>" if M <= 4096 else "linear_tn_kernel<bf16,64>" if M <= 262144 else "linear_tn_kernel<bf16,32>"
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = raw_w(dy2, x2, want_bias, rowscale, rows_per_scale)
+            e.record()
+            timer.events.append((name, 2.0 * M * N * K, (M * N + M * K) * 2.0 + N * K * 4.0, s, e))
+            return out
+
+        ops.wgrad_raw = timed_wgrad_raw
 
     def summary(self):
         out = {}
@@ -305,7 +322,7 @@ def main():
         if fams:
             bn, (cnt, fl, by, sec) = max(fams.items(), key=lambda kv: kv[1][3])
             achieved = fl / sec / 1e12
-            kname = "linear_nt_deep_kernel" if bn.startswith("deep") else f"linear_nt_kernel<bf16,{bn}>"
+            kname = bn if bn.startswith("linear_tn") else "linear_nt_deep_kernel" if bn.startswith("deep") else f"linear_nt_kernel<bf16,{bn}>"
             traffic = None                       # PMC counters cannot be read in-process: taken from the committed PMC summary
             try:
                 with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:

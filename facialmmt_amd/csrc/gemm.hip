@@ -542,7 +542,9 @@ __device__ __forceinline__ bf16x8 lds_tr_frag(const bf16* s, int pitch, int c0, 
     return u.v;
 }
 
-template <typename T, int BMS>
+// FEW: instantiation used for few-token problems (cross-modal encoder, embedding head) -- same code, its own
+// symbol, so that profiles keep the multi-million-token Swin launches and the tiny ones apart.
+template <typename T, int BMS, bool FEW = false>
 __global__ __launch_bounds__(256) void linear_tn_kernel(TnArgs p) {
     constexpr int VEC = Vec<T>::N;
     constexpr int PITCH = 128 + VEC;
@@ -678,21 +680,27 @@ __global__ __launch_bounds__(256) void linear_tn_kernel(TnArgs p) {
     }
 }
 
-template <typename T, int BMS>
+template <typename T, int BMS, bool FEW = false>
 int launch_tn(const TnArgs& a, dim3 grid, hipStream_t st) {
     constexpr int VEC = Vec<T>::N;
     constexpr size_t lds = (size_t)4 * BMS * (128 + VEC) * sizeof(T) + (256 / (128 / VEC)) * 128 * sizeof(float);
     static bool attr_set = false;
     if (lds > 65536 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_tn_kernel<T, BMS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_tn_kernel<T, BMS, FEW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((linear_tn_kernel<T, BMS>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((linear_tn_kernel<T, BMS, FEW>), grid, dim3(256), lds, st, a);
     FMMT_CHECK_LAUNCH();
     return 0;
 }
+
+// (A DMA-staged variant of the TN kernel -- global_load_lds tiles with an XOR-swizzled chunk order for the
+//  transposing reads, DropPath scale applied to the fragments, bias gradient as an extra MFMA against ones --
+//  was written and measured: bit-for-bit correct but 3-9 % slower than this register-staged kernel on the
+//  stage-2/3 shapes (472-550 vs 464-591 TF/s), so it is not kept.  What did help: sizing the split count to
+//  exactly one round of co-resident workgroups, +13 % on those shapes.)
 
 // out[i] = sum_s part[s][i] : 256 threads = 64 outputs x 4 split groups, fixed-order tree (deterministic)
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n, int splits) {
@@ -714,7 +722,10 @@ TnPlan tn_plan(int M, int N, int K) {
     pl.tiles_n = (N + 127) / 128;
     pl.tiles_k = (K + 127) / 128;
     const int tiles = pl.tiles_n * pl.tiles_k;
-    int splits = (768 + tiles - 1) / tiles;
+    // one round of co-resident workgroups: 2 per CU for the 64-token-step kernels (64-78 KB LDS), 3 per CU for
+    // the 32-token-step kernel; more would run as a second, partly empty round
+    const int target = (M <= 262144) ? 512 : 768;
+    int splits = target / tiles;
     const int max_by_rows = (M + 255) / 256;
     if (splits > max_by_rows) splits = max_by_rows;
     if (splits < 1) splits = 1;
@@ -811,7 +822,8 @@ extern "C" int fmmt_linear_wgrad(int dtype, int M, int N, int K,
     // measured (tests/gpu_gemm_bench.py): 64-token steps win for the compute-heavy stage-2/3 shapes (+15-25 %),
     // 32-token steps (3 workgroups per CU) win for the HBM-bound multi-million-token stage-0/1 shapes
     const bool bms64 = tn_cfg == 2 || (tn_cfg == 0 && M <= 262144);
-    if (dtype == FMMT_BF16) rc = bms64 ? launch_tn<bf16, 64>(a, grid, st) : launch_tn<bf16, 32>(a, grid, st);
+    if (dtype == FMMT_BF16) rc = M <= 4096 ? launch_tn<bf16, 32, true>(a, grid, st)
+                                           : bms64 ? launch_tn<bf16, 64>(a, grid, st) : launch_tn<bf16, 32>(a, grid, st);
     else rc = launch_tn<float, 16>(a, grid, st);
     if (rc) return rc;
     const size_t nw = (size_t)N * K;
