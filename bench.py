@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graphs", type=int, default=1, help="capture the multimodal model (fwd+bwd) as HIP graphs (1) or launch eagerly (0)")
     ap.add_argument("--force-ddp", action="store_true", help="wrap in DDP even with one process (exercises the N>1 code path on one GPU)")
+    ap.add_argument("--shape-report", default=None, help="write a per-GEMM-shape timing table to this file (development aid)")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames in the CPU-baseline Swin sample")
     return ap.parse_args()
 
@@ -120,7 +121,8 @@ class KernelTimer:
             s.record()
             y = raw(x2, w, bias, **kw)
             e.record()
-            timer.events.append((bn, 2.0 * M * N * K, (M * K + N * K + M * N) * 2.0, s, e))
+            timer.events.append((bn, 2.0 * M * N * K, (M * K + N * K + M * N) * 2.0, s, e,
+                                 ("nt", M, N, K, kw.get("epi", 0), kw.get("y_pre") is not None, kw.get("res") is not None)))
             return y
 
         ops.linear_raw = timed_linear_raw
@@ -137,20 +139,35 @@ class KernelTimer:
             s.record()
             out = raw_w(dy2, x2, want_bias, rowscale, rows_per_scale)
             e.record()
-            timer.events.append((name, 2.0 * M * N * K, (M * N + M * K) * 2.0 + N * K * 4.0, s, e))
+            timer.events.append((name, 2.0 * M * N * K, (M * N + M * K) * 2.0 + N * K * 4.0, s, e,
+                                 ("tn", M, N, K, 0, bool(want_bias), rowscale is not None)))
             return out
 
         ops.wgrad_raw = timed_wgrad_raw
 
     def summary(self):
         out = {}
-        for bn, fl, by, s, e in self.events:
+        for bn, fl, by, s, e, _ in self.events:
             d = out.setdefault(bn, [0, 0.0, 0.0, 0.0])
             d[0] += 1
             d[1] += fl
             d[2] += by
             d[3] += s.elapsed_time(e) * 1e-3
         return out
+
+    def shape_report(self, steps):
+        """per problem shape: launches/step, ms/step, TFLOP/s, algorithmic GB/s (development aid: --shape-report)"""
+        out = {}
+        for bn, fl, by, s, e, shape in self.events:
+            d = out.setdefault((bn,) + shape, [0, 0.0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += fl
+            d[2] += by
+            d[3] += s.elapsed_time(e) * 1e-3
+        lines = ["ms/step launches/step TFLOP/s GB/s kernel kind M N K epi flag1 flag2"]
+        for k, (cnt, fl, by, sec) in sorted(out.items(), key=lambda kv: -kv[1][3]):
+            lines.append(f"{sec / steps * 1e3:8.3f} {cnt / steps:6.1f} {fl / sec / 1e12:7.1f} {by / sec / 1e9:7.0f}  " + " ".join(str(v) for v in k))
+        return "\n".join(lines)
 
 
 def cpu_baseline(args, cfg):
@@ -318,6 +335,9 @@ def main():
         ms = elapsed / args.steps * 1e3
         value = args.utts * world * args.steps / elapsed
         fams = timer.summary()
+        if args.shape_report:
+            with open(args.shape_report, "w") as f:
+                f.write(timer.shape_report(args.steps) + "\n")
         roof = None
         if fams:
             bn, (cnt, fl, by, sec) = max(fams.items(), key=lambda kv: kv[1][3])

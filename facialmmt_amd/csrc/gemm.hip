@@ -38,6 +38,17 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
+// Banded variant: the grid is cut into bands of 8*S consecutive tiles; inside a band XCD x owns S consecutive
+// tiles.  All eight XCDs then advance through the same narrow region of the output (one compact HBM write front)
+// while an XCD's L2 still sees S neighbouring tiles.  The last, partial band falls back to identity.
+__device__ __forceinline__ int xcd_remap_banded(int bid, int nwg, int S) {
+    const int band = 8 * S, b = bid / band, o = bid - b * band;
+    if ((b + 1) * band > nwg) return bid;
+    return b * band + (o & 7) * S + (o >> 3);
+}
+__device__ __forceinline__ int tile_remap(int bid, int nwg, int mode) {
+    return mode == 0 ? xcd_remap(bid, nwg) : mode == 1 ? bid : xcd_remap_banded(bid, nwg, mode);
+}
 
 struct LinArgs {
     int M, N, K;
@@ -139,13 +150,13 @@ __device__ __forceinline__ void nt_epilogue(const LinArgs& p, f32x4 (&acc)[MT][N
                 };
                 if (p.epi == FMMT_EPI_GELU) {
                     if (ypre) store_chunk(ypre, p.ldy, v);
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) v[e] = gelu_f(v[e]);
+                    gelu_inplace<T>(v, VEC);
                 } else if (p.epi == FMMT_EPI_GELU_BWD) {
                     float ax[VEC];
                     load_chunk(auxg, p.ldaux, ax);
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) v[e] *= (e < w) ? gelu_grad_f(ax[e]) : 0.f;
+                    for (int e = 0; e < VEC; ++e) ax[e] = (e < w) ? ax[e] : 0.f;
+                    gelu_grad_mul_inplace<T>(v, ax, VEC);
                 }
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) v[e] *= rs;
@@ -169,8 +180,13 @@ __device__ __forceinline__ void nt_epilogue(const LinArgs& p, f32x4 (&acc)[MT][N
 //  * one output tile per workgroup.  (A persistent variant that issues the next tile's first K step under
 //    the epilogue was measured and lost as well: +60..100 VGPRs -> one wave per SIMD.)
 // ---------------------------------------------------------------------------------------------
+// Register budget: the K = 96 single-step kernels are latency-bound (load -> LDS -> MFMA -> store with nothing to
+// overlap inside a workgroup), so they need the three workgroups per CU that their 43-53 KB of LDS allows, i.e.
+// <= 168 VGPRs+AGPRs; the double-buffered 128-row kernels are LDS-limited to two per CU (<= 256 registers).
+template <int BM, int NBUF> struct NtWaves { static constexpr int value = (BM == 128) ? (NBUF == 1 ? 3 : 2) : 4; };
 template <typename T, int BM, int BN, int BK, int NBUF, bool GLDS>
-__global__ __launch_bounds__(256) void linear_nt_kernel(LinArgs p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NtWaves<BM, NBUF>::value)))
+void linear_nt_kernel(LinArgs p) {
     constexpr int VEC = Vec<T>::N;
     // GLDS: tiles are filled by direct global->LDS DMA (global_load_lds_dwordx4): the LDS image of a wave
     // instruction is lane-linear, so rows are unpadded (128 B) and bank conflicts are removed by an XOR
@@ -274,7 +290,7 @@ __global__ __launch_bounds__(256) void linear_nt_kernel(LinArgs p) {
 
     auto epilogue = [&](int m0, int n0) { nt_epilogue<T, MT, NT>(p, acc, m0 + wm * WM, n0 + wn * WN, li, lg); };
 
-    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int logical = tile_remap(blockIdx.x, gridDim.x, p.reserved);
     const int m0 = (logical / p.tiles_n) * BM, n0 = (logical % p.tiles_n) * BN;
 #pragma unroll
     for (int a = 0; a < MT; ++a)
@@ -428,6 +444,8 @@ int launch_nt(const LinArgs& a, hipStream_t st) {
     LinArgs p = a;
     p.tiles_n = (a.N + BN - 1) / BN;
     p.tiles_m = (a.M + BM - 1) / BM;
+    static const int remap = getenv("FMMT_NT_REMAP") ? atoi(getenv("FMMT_NT_REMAP")) : 0;
+    p.reserved = remap;
     const int grid = p.tiles_m * p.tiles_n;
     const int splits = a.ksplit ? (a.K + a.ksplit - 1) / a.ksplit : 1;
     hipLaunchKernelGGL((linear_nt_kernel<T, BM, BN, BK, NBUF, GLDS>), dim3(grid, splits), dim3(256), lds, st, p);
@@ -570,6 +588,7 @@ __global__ __launch_bounds__(256) void linear_tn_kernel(TnArgs p) {
     const bool do_bias = (p.part_b != nullptr) && (tile_k == 0);
 
     Vec<T> areg[NV], breg[NV];
+    float sreg[NV];
     float colsum[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) colsum[e] = 0.f;
@@ -581,16 +600,10 @@ __global__ __launch_bounds__(256) void linear_tn_kernel(TnArgs p) {
             const int row = v / CV, c = (v % CV) * VEC;
             const int m = mb + row;
             const bool mv = m < mend;
-            if (mv && n0 + c < p.N) {
-                areg[i] = ldvec<T>(dyg + (size_t)m * p.lddy + n0 + c);
-                if (p.rowscale) {
-                    const float s = p.rowscale[m / p.rows_per_scale];
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) areg[i].set(e, areg[i].get(e) * s);
-                }
-            } else {
-                areg[i] = zerovec<T>();
-            }
+            // the DropPath scale is only *fetched* here and applied in lstore(), after the MFMA block: applying it
+            // right away makes every tile load wait for two dependent HBM round trips (measured: 2x slower launches)
+            areg[i] = (mv && n0 + c < p.N) ? ldvec<T>(dyg + (size_t)m * p.lddy + n0 + c) : zerovec<T>();
+            if (p.rowscale) sreg[i] = mv ? p.rowscale[m / p.rows_per_scale] : 0.f;
             breg[i] = (mv && k0 + c < p.K) ? ldvec<T>(xg + (size_t)m * p.ldx + k0 + c) : zerovec<T>();
         }
     };
@@ -599,6 +612,10 @@ __global__ __launch_bounds__(256) void linear_tn_kernel(TnArgs p) {
         for (int i = 0; i < NV; ++i) {
             const int v = tid + i * 256;
             const int row = v / CV, c = (v % CV) * VEC;
+            if (p.rowscale) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) areg[i].set(e, areg[i].get(e) * sreg[i]);
+            }
             stvec<T>(As + (buf * BMS + row) * PITCH + c, areg[i]);
             stvec<T>(Bs + (buf * BMS + row) * PITCH + c, breg[i]);
             if (do_bias) {

@@ -12,11 +12,25 @@ SHAPES = [(2007040, 288, 96), (2007040, 96, 96), (2007040, 384, 96), (2007040, 9
           (501760, 576, 192), (501760, 768, 192), (501760, 192, 768), (125440, 1152, 384), (125440, 1536, 384), (125440, 384, 1536),
           (31360, 2304, 768), (31360, 3072, 768), (31360, 768, 3072), (664, 768, 768), (1280, 3072, 768)]
 print("cfg", os.environ.get("FMMT_NT_CFG", "0"))
+from facialmmt_amd._lib import EPI_GELU, EPI_GELU_BWD
 tot = 0
 for (M, N, K) in SHAPES:
     x = torch.randn(M, K, device=dev, dtype=torch.bfloat16); w = torch.randn(N, K, device=dev, dtype=torch.bfloat16); b = torch.randn(N, device=dev)
     t = timeit(lambda: ops.linear_raw(x, w, b)); tot += t
     dy = torch.randn(M, N, device=dev, dtype=torch.bfloat16)
+    rs = torch.full((M // 49,), 1.25, device=dev)
     t2 = timeit(lambda: ops.wgrad_raw(dy, x, True))
-    print(f"  {M:8d}x{N:5d}x{K:5d}: nt {t*1e3:7.3f} ms {2.0*M*N*K/t/1e12:6.1f} TF/s {(M*K+M*N+N*K)*2/t/1e9:6.0f} GB/s | tn {t2*1e3:7.3f} ms {2.0*M*N*K/t2/1e12:6.1f} TF/s", flush=True)
+    t3 = timeit(lambda: ops.wgrad_raw(dy, x, True, rs, 49))
+    line = f"  {M:8d}x{N:5d}x{K:5d}: nt {t*1e3:7.3f} ms {2.0*M*N*K/t/1e12:6.1f} TF/s {(M*K+M*N+N*K)*2/t/1e9:6.0f} GB/s | tn {t2*1e3:7.3f} ms {2.0*M*N*K/t2/1e12:6.1f} TF/s | tn+rowscale {t3*1e3:7.3f} ms"
+    if N == 4 * K:      # fc1 forward (GELU, pre-activation saved) and fc2 input gradient (GELU')
+        pre = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        t4 = timeit(lambda: ops.linear_raw(x, w, b, epi=EPI_GELU, y_pre=pre))
+        t5 = timeit(lambda: ops.linear_raw(x, w, None, epi=EPI_GELU_BWD, aux=pre))
+        line += f" | gelu+pre {t4*1e3:7.3f} ms | gelu' {t5*1e3:7.3f} ms"
+    if K == 4 * N or K == N:      # fc2 / proj forward: residual + DropPath scale
+        res = torch.randn(M, N, device=dev, dtype=torch.bfloat16)
+        t6 = timeit(lambda: ops.linear_raw(x, w, b, res=res, rowscale=rs, rows_per_scale=49))
+        line += f" | res+scale {t6*1e3:7.3f} ms"
+    print(line, flush=True)
+    del x, w, dy
 print(f"  sum nt {tot*1e3:.3f} ms")
