@@ -30,8 +30,8 @@ SIGNATURES = {
     "fmmt_window_attn_fwd": (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _i, _f, _p, _p, _p]),
     "fmmt_window_attn_bwd_workspace": (_sz, [_i]),
     "fmmt_window_attn_bwd": (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p, _p, _p, _sz, _p]),
-    "fmmt_mha_fwd": (_i, [_i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i, _f, _f, _u64, _p, _p, _i, _p, _p]),
-    "fmmt_mha_bwd": (_i, [_i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i, _f, _f, _u64, _p, _p, _p, _i, _p, _p, _i, _p, _p, _i, _p]),
+    "fmmt_mha_fwd": (_i, [_i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i, _f, _p, _f, _u64, _p, _p, _i, _p, _p]),
+    "fmmt_mha_bwd": (_i, [_i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i, _f, _p, _f, _u64, _p, _p, _p, _i, _p, _p, _i, _p, _p, _i, _p]),
     "fmmt_patch_im2col": (_i, [_i, _i, _p, _p, _p]),
     "fmmt_patch_col2im": (_i, [_i, _i, _p, _p, _p]),
     "fmmt_batchnorm1d_fwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p]),

@@ -397,6 +397,10 @@ __device__ __forceinline__ float keep_scale(const MhaArgs& p, int bh, int i, int
     const uint64_t seed = p.seed_dev ? *p.seed_dev : p.seed;
     return hash_uniform(seed, idx) >= p.drop_p ? 1.0f / (1.0f - p.drop_p) : 0.f;
 }
+// additive logit bias of key j (the BERT-style "(1 - mask) * -10000" extended attention mask); 0 if absent
+__device__ __forceinline__ float key_bias(const MhaArgs& p, int b, int j) {
+    return p.key_bias ? p.key_bias[(size_t)b * p.Lk + min(j, p.Lk - 1)] : 0.f;
+}
 
 // forward: lane owns a query row; keys/values streamed through LDS in tiles of MT; online softmax
 template <typename T, int D>
@@ -427,7 +431,7 @@ __global__ __launch_bounds__(64) void mha_fwd_kernel(MhaArgs p) {
             float tmax = -INFINITY;
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
-                s[jj] = (j0 + js + jj < p.Lk) ? ldot<D>(Ks + (js + jj) * P, q) : -INFINITY;
+                s[jj] = (j0 + js + jj < p.Lk) ? ldot<D>(Ks + (js + jj) * P, q) + key_bias(p, b, j0 + js + jj) : -INFINITY;
                 tmax = fmaxf(tmax, s[jj]);
             }
             const float mnew = fmaxf(m, tmax);
@@ -486,7 +490,7 @@ __global__ __launch_bounds__(64) void mha_bwd_dq_kernel(MhaArgs p) {
 #pragma unroll 2
         for (int j = 0; j < MT; ++j) {
             if (j0 + j >= p.Lk) break;
-            const float pij = __expf(ldot<D>(Ks + j * P, q) - lse);
+            const float pij = __expf(ldot<D>(Ks + j * P, q) + key_bias(p, b, j0 + j) - lse);
             const float dP = ldot<D>(Vs + j * P, dO) * keep_scale(p, bh, i, j0 + j);
             laxpy<D>(dq, pij * (dP - delta), Ks + j * P);
         }
@@ -514,6 +518,7 @@ __global__ __launch_bounds__(64) void mha_bwd_dkv_kernel(MhaArgs p) {
     load_row<T, D>(reinterpret_cast<const T*>(p.k) + ((size_t)j * p.B + b) * p.ldkv + h * D, kreg);
 #pragma unroll
     for (int d = 0; d < D; ++d) acc[d] = 0.f;
+    const float kb = key_bias(p, b, j);
     float vreg[WHICH == 1 ? D : 1];
     if constexpr (WHICH == 1) load_row<T, D>(reinterpret_cast<const T*>(p.v) + ((size_t)j * p.B + b) * p.ldkv + h * D, vreg);
     const T* og = reinterpret_cast<const T*>(p.out);
@@ -539,7 +544,7 @@ __global__ __launch_bounds__(64) void mha_bwd_dkv_kernel(MhaArgs p) {
 #pragma unroll 2
         for (int ii = 0; ii < MT; ++ii) {
             if (i0 + ii >= p.Lq) break;
-            const float pij = __expf(ldot<D>(Qs + ii * P, kreg) - Ls[ii]);
+            const float pij = __expf(ldot<D>(Qs + ii * P, kreg) + kb - Ls[ii]);
             const float ks = keep_scale(p, bh, i0 + ii, j);
             if constexpr (WHICH == 0) {
                 laxpy<D>(acc, pij * ks, Gs + ii * P);
@@ -641,13 +646,13 @@ extern "C" int fmmt_window_attn_bwd(int dtype, int n_img, int H, int W, int C, i
 #define K_DK(T, D) mha_bwd_dkv_kernel<T, D, 1>
 
 extern "C" int fmmt_mha_fwd(int dtype, int Lq, int Lk, int B, int E, int num_heads,
-                            const void* q, int ldq, const void* k, const void* v, int ldkv, float scale,
+                            const void* q, int ldq, const void* k, const void* v, int ldkv, float scale, const float* key_bias,
                             float dropout_p, uint64_t seed, const uint64_t* seed_dev, void* out, int ldo, float* lse, void* stream) {
     if (int e = mha_check(dtype, Lq, Lk, B, E, num_heads)) return e;
     if (dropout_p < 0.f || dropout_p >= 1.f) return FMMT_EINVAL;
     MhaArgs a{};
     a.Lq = Lq; a.Lk = Lk; a.B = B; a.E = E; a.nH = num_heads; a.q = q; a.ldq = ldq; a.k = k; a.v = v; a.ldkv = ldkv;
-    a.scale = scale; a.drop_p = dropout_p; a.seed = seed; a.seed_dev = seed_dev; a.out = out; a.ldo = ldo; a.lse = lse;
+    a.scale = scale; a.key_bias = key_bias; a.drop_p = dropout_p; a.seed = seed; a.seed_dev = seed_dev; a.out = out; a.ldo = ldo; a.lse = lse;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == FMMT_BF16 && E / num_heads == 64 && ldq % 8 == 0 && ldkv % 8 == 0 && ldo % 8 == 0)
         return fmmt_mha_mfma_fwd_launch(a, st);                      // matrix-core path
@@ -656,14 +661,14 @@ extern "C" int fmmt_mha_fwd(int dtype, int Lq, int Lk, int B, int E, int num_hea
 }
 
 extern "C" int fmmt_mha_bwd(int dtype, int Lq, int Lk, int B, int E, int num_heads,
-                            const void* q, int ldq, const void* k, const void* v, int ldkv, float scale,
+                            const void* q, int ldq, const void* k, const void* v, int ldkv, float scale, const float* key_bias,
                             float dropout_p, uint64_t seed, const uint64_t* seed_dev, const void* out, const void* dout, int ldo,
                             const float* lse, void* dq, int lddq, void* dk, void* dv, int lddkv, void* stream) {
     if (int e = mha_check(dtype, Lq, Lk, B, E, num_heads)) return e;
     if (dropout_p < 0.f || dropout_p >= 1.f) return FMMT_EINVAL;
     MhaArgs a{};
     a.Lq = Lq; a.Lk = Lk; a.B = B; a.E = E; a.nH = num_heads; a.q = q; a.ldq = ldq; a.k = k; a.v = v; a.ldkv = ldkv;
-    a.scale = scale; a.drop_p = dropout_p; a.seed = seed; a.seed_dev = seed_dev; a.out = const_cast<void*>(out); a.ldo = ldo;
+    a.scale = scale; a.key_bias = key_bias; a.drop_p = dropout_p; a.seed = seed; a.seed_dev = seed_dev; a.out = const_cast<void*>(out); a.ldo = ldo;
     a.lse = const_cast<float*>(lse); a.dout = dout; a.dq = dq; a.lddq = lddq; a.dk = dk; a.dv = dv; a.lddkv = lddkv;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == FMMT_BF16 && E / num_heads == 64 && ldq % 8 == 0 && ldkv % 8 == 0 && ldo % 8 == 0 && lddq % 8 == 0 && lddkv % 8 == 0)

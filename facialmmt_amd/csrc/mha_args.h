@@ -9,6 +9,7 @@ struct MhaArgs {
     const void* q; int ldq;
     const void* k; const void* v; int ldkv;
     float scale, drop_p; uint64_t seed; const uint64_t* seed_dev;
+    const float* key_bias;          // optional additive logit bias per (batch, key): [B][Lk] fp32, nullptr = none
     void* out; int ldo; float* lse;
     const void* dout;
     void* dq; int lddq; void* dk; void* dv; int lddkv;

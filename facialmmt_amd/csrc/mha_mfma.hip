@@ -60,6 +60,11 @@ __device__ __forceinline__ float keep_scale(const MhaArgs& p, int bh, int i, int
     return hash_uniform(seed, idx) >= p.drop_p ? 1.0f / (1.0f - p.drop_p) : 0.f;
 }
 
+// additive logit bias of key j ("(1 - mask) * -10000" extended attention mask of the self-attention encoders); 0 if absent
+__device__ __forceinline__ float key_bias(const MhaArgs& p, int b, int j) {
+    return p.key_bias ? p.key_bias[(size_t)b * p.Lk + min(j, p.Lk - 1)] : 0.f;
+}
+
 // stage 64 rows [r0, r0+64) of a time-major tensor as a natural-layout bf16 tile; rows >= L are zero
 __device__ __forceinline__ void stage_tile(const bf16* base, int ld, int B, int b, int h, int r0, int L, bf16* tile, int li, int lg) {
 #pragma unroll
@@ -129,6 +134,9 @@ __global__ __launch_bounds__(64) void mha_mfma_fwd_kernel(MhaArgs p) {
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) vT[ks][dt] = tr_fragT(Vt, 32 * ks + 4 * lg, dt, li);
+        float kb[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) kb[e] = key_bias(p, b, j0 + (e >> 2) * 16 + lg * 4 + (e & 3));
 #pragma unroll
         for (int qt = 0; qt < 4; ++qt) {
             const int q = q0 + qt * 16 + li;
@@ -141,7 +149,7 @@ __global__ __launch_bounds__(64) void mha_mfma_fwd_kernel(MhaArgs p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = j0 + kt * 16 + lg * 4 + r;
-                    const float v = key < p.Lk ? a[r] * p.scale : NEG_BIG;
+                    const float v = key < p.Lk ? a[r] * p.scale + kb[kt * 4 + r] : NEG_BIG;
                     s[kt * 4 + r] = v;
                     tmax = fmaxf(tmax, v);
                 }
@@ -234,6 +242,9 @@ __global__ __launch_bounds__(64) void mha_mfma_bwd_dq_kernel(MhaArgs p) {
             }
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) kT[dt] = tr_fragT(Kt, 32 * ks2 + 4 * lg, dt, li);
+            float kb[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) kb[e] = key_bias(p, b, j0 + (2 * ks2 + (e >> 2)) * 16 + lg * 4 + (e & 3));
 #pragma unroll
             for (int qt = 0; qt < 4; ++qt) {
                 const int q = min(q0 + qt * 16 + li, p.Lq - 1);
@@ -247,7 +258,7 @@ __global__ __launch_bounds__(64) void mha_mfma_bwd_dq_kernel(MhaArgs p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int key = j0 + (2 * ks2 + u) * 16 + lg * 4 + r;
-                        const float pij = key < p.Lk ? __expf(a[r] * p.scale - ls[qt]) : 0.f;
+                        const float pij = key < p.Lk ? __expf(a[r] * p.scale + kb[u * 4 + r] - ls[qt]) : 0.f;
                         const float ksc = p.drop_p > 0.f ? keep_scale(p, bh, q, min(key, p.Lk - 1)) : 1.f;
                         ds[u * 4 + r] = pij * (dp[r] * ksc - dl[qt]);
                     }
@@ -282,9 +293,11 @@ __global__ __launch_bounds__(64) void mha_mfma_bwd_dkv_kernel(MhaArgs p) {
 
     bf16x8 kf[2][2], vf[2][2];
     f32x4 dk[2][4], dv[2][4];
+    float kbk[2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
         const int key = min(k0 + kt * 16 + li, p.Lk - 1);
+        kbk[kt] = key_bias(p, b, key);
         const size_t off = ((size_t)key * p.B + b) * p.ldkv + h * D + lg * 8;
         kf[kt][0] = ldg8(kg + off);
         kf[kt][1] = ldg8(kg + off + 32);
@@ -334,7 +347,7 @@ __global__ __launch_bounds__(64) void mha_mfma_bwd_dkv_kernel(MhaArgs p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int q = i0 + qt * 16 + lg * 4 + r;
-                    const float pij = q < p.Lq ? __expf(a[r] * p.scale - lq[r]) : 0.f;
+                    const float pij = q < p.Lq ? __expf(a[r] * p.scale + kbk[kt] - lq[r]) : 0.f;
                     const float ksc = p.drop_p > 0.f ? keep_scale(p, bh, min(q, p.Lq - 1), min(key, p.Lk - 1)) : 1.f;
                     pp[qt * 4 + r] = pij * ksc;
                     ds[qt * 4 + r] = pij * (dp[r] * ksc - dq[r]);

@@ -1,7 +1,10 @@
 """Task models; host-side mirror of the reference's src/models.py (callers of
 the hot path, API preserved): same class names, constructor arguments (an argparse-style namespace),
-attribute names / state_dict keys and forward signatures.  The Swin backbone and the two cross-modal
-encoders run on libfmmt_hip; the text encoder stays the HuggingFace RoBERTa/BERT on PyTorch-ROCm.
+attribute names / state_dict keys and forward signatures.  The Swin backbone, the two cross-modal encoders,
+the per-modality self-attention encoders and the P-projection of the additive-attention pooling run on
+libfmmt_hip; the text encoder stays the HuggingFace RoBERTa/BERT on PyTorch-ROCm, and the three input
+projections whose widths the kernels' 16-byte alignment excludes (audio 300, vision 519, classifier -> 7)
+stay nn.Linear.
 
 Differences from the reference, on purpose:
   * no hard-coded .cuda() (ref src/models.py:114-115): buffers are created on the input's device;
@@ -119,6 +122,8 @@ class MultiModalTransformerForClassification(nn.Module):
                                                                  self.crossmodal_layers_TA_V, self.crossmodal_attn_dropout_TA_V)
         self.dropout = nn.Dropout(config.hidden_dropout_prob)
         self.classifier = nn.Linear(self.hidden_size, self.num_labels)
+        for m in (self.audio_utt_transformer, self.vision_utt_transformer, self.attention):
+            m.compute_dtype = self.compute_dtype
 
     def _build_plm(self, config):
         """HF from_pretrained as in the reference (:72-77); `config.plm_config` (a transformers config
@@ -180,6 +185,7 @@ class meld_utt_transformer(nn.Module):
         self.attention = AdditiveAttention(self.hidden_size, self.hidden_size)
         self.mm_dropout = nn.Dropout(self.hidden_dropout_prob)
         self.classifier = nn.Linear(self.hidden_size, args.num_labels)
+        self.utt_transformer.compute_dtype = self.attention.compute_dtype = getattr(args, "compute_dtype", None)
 
     def forward(self, inputs=None, utt_mask=None):
         ext = utt_mask.unsqueeze(1).unsqueeze(2).to(dtype=next(self.parameters()).dtype)

@@ -1,8 +1,22 @@
 """Per-modality self-attention encoder (BERT-style, post-LN, TF LayerNorm) and additive-attention
-pooling; host-side mirror of the reference's modules/Transformer.py with identical class names and
-state_dict keys.  SURVEY.md 8f rank 1: this stack is *next* in line for native kernels; in round 1 it
-runs as stock PyTorch-ROCm ops on the GPU (it is on the logits path but outside the section-8 hot path),
-written device-agnostically (the reference hard-codes .cuda(), ref :213)."""
+pooling on the HIP path; host-side mirror of the reference's modules/Transformer.py with identical class
+names, constructor signatures and state_dict keys.
+
+Every Linear / LayerNorm / attention core below is a libfmmt_hip kernel (ops.linear, ops.mlp,
+ops.layer_norm, ops.mha_core with the extended attention mask as its `key_bias`); like the rest of the hot
+path there is no PyTorch / CPU formulation behind it -- CPU tensors raise FmmtError.  What stays as torch
+elementwise ops on (B, L)-sized tensors: the position-embedding add, hidden-state dropout (p = 0.1 between a
+dense layer and its residual add, ref :121,134) and the tanh / masked-softmax / weighted-sum tail of
+AdditiveAttention.
+
+Layout: the reference is batch-major (B, L, H); the attention kernel is time-major (row t of (L, B, H) at
+(t*B + b)*ld), so MELDTransEncoder transposes once on entry and once on exit and runs its layers time-major
+(all other ops are per-token and layout-agnostic).  The sub-modules keep the reference's batch-major
+`forward` signatures for API compatibility and expose the time-major body as `forward_tm`.
+
+Compute dtype: `compute_dtype` (set by the owning model from `config.compute_dtype`; None = the input's
+dtype) selects bf16 (throughput) or fp32 (parity) for the kernels; the result is returned in the input's dtype.
+The reference hard-codes .cuda() for the position ids (ref :213); here they follow the input's device."""
 from __future__ import annotations
 
 import copy
@@ -11,6 +25,19 @@ import math
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from .. import ops
+
+
+def _key_bias(attention_mask, B, L):
+    """(B,1,1,L) extended attention mask ((1-m) * -10000, src/models.py:157,164) -> (B, L) fp32 logit bias"""
+    if attention_mask is None:
+        return None
+    kb = attention_mask.reshape(-1, attention_mask.shape[-1]).to(torch.float32)
+    if kb.shape[0] == 1 and B > 1:
+        kb = kb.expand(B, L)
+    assert kb.shape == (B, L), f"attention_mask must broadcast over heads and queries: expected (B,1,1,L) = ({B},1,1,{L})"
+    return kb.contiguous()
 
 
 class AdditiveAttention(nn.Module):
@@ -23,20 +50,26 @@ class AdditiveAttention(nn.Module):
         self.P = nn.Linear(inputs_dim, hidden_dim)
         self.Q = nn.Linear(inputs_dim, hidden_dim)
         self.tanh = nn.Tanh()
+        self.compute_dtype = None
 
     def forward(self, inputs, mask=None):
         B, L, _ = inputs.size()
         if L == 1:
             return inputs.squeeze(), 1
-        scores = self.value(self.tanh(self.P(inputs) + self.Q(self.query_vector))).squeeze(-1)     # (B, L)
+        cd = self.compute_dtype or inputs.dtype
+        # P h_t: the one real GEMM of the pooling (B*L x H x H) on the HIP path; Q query_vector is a single row
+        ph = ops.linear(inputs.to(cd), self.P.weight, self.P.bias).to(inputs.dtype)
+        qq = ops.linear(self.query_vector.to(cd).unsqueeze(0), self.Q.weight, self.Q.bias).to(inputs.dtype)
+        scores = F.linear(torch.tanh(ph + qq), self.value.weight.to(inputs.dtype), self.value.bias.to(inputs.dtype)).squeeze(-1)
         if mask is not None:
             scores = scores.masked_fill(mask == 0., float('-inf'))
-        alpha = F.softmax(scores, dim=-1).view(B, 1, L)
+        alpha = F.softmax(scores.float(), dim=-1).to(inputs.dtype).view(B, 1, L)
         return torch.bmm(alpha, inputs).squeeze(dim=1), alpha
 
 
 class LayerNorm(nn.Module):
-    """TF-style layer norm, epsilon inside the square root (ref :48-61)."""
+    """TF-style layer norm, epsilon inside the square root (ref :48-61) -- the same arithmetic as
+    fmmt_layernorm_fwd's rsqrt(var + eps)."""
 
     def __init__(self, hidden_size, eps=None):
         super().__init__()
@@ -45,7 +78,7 @@ class LayerNorm(nn.Module):
         self.variance_epsilon = eps
 
     def forward(self, x):
-        return F.layer_norm(x, x.shape[-1:], self.weight, self.bias, self.variance_epsilon)
+        return ops.layer_norm(x, self.weight, self.bias, self.variance_epsilon)
 
 
 class SelfAttention(nn.Module):
@@ -62,17 +95,20 @@ class SelfAttention(nn.Module):
         self.value = nn.Linear(config.hidden_size, self.all_head_size)
         self.dropout = nn.Dropout(config.attention_probs_dropout_prob)
 
-    def transpose_for_scores(self, x):
-        return x.view(*x.shape[:-1], self.num_attention_heads, self.attention_head_size).permute(0, 2, 1, 3)
+    def forward_tm(self, x, key_bias):
+        """x (L, B, H) time-major; key_bias (B, L) or None.  softmax(q k^T / sqrt(d) + mask) v with dropout on the
+        probabilities (ref :86-103); the (B, nH, L, L) tensors are never materialised."""
+        q = ops.linear(x, self.query.weight, self.query.bias)
+        k = ops.linear(x, self.key.weight, self.key.bias)
+        v = ops.linear(x, self.value.weight, self.value.bias)
+        p = self.dropout.p if self.training else 0.0
+        seed = torch.randint(0, 2 ** 62, (1,), device=x.device, dtype=torch.int64) if p > 0 else 0
+        return ops.mha_core(q, k, v, self.num_attention_heads, 1.0 / math.sqrt(self.attention_head_size), p, seed, key_bias)
 
     def forward(self, hidden_states, attention_mask):
-        q = self.transpose_for_scores(self.query(hidden_states))
-        k = self.transpose_for_scores(self.key(hidden_states))
-        v = self.transpose_for_scores(self.value(hidden_states))
-        scores = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(self.attention_head_size) + attention_mask
-        probs = self.dropout(torch.softmax(scores, dim=-1))
-        ctx = torch.matmul(probs, v).permute(0, 2, 1, 3).contiguous()
-        return ctx.view(*ctx.shape[:-2], self.all_head_size)
+        B, L, _ = hidden_states.shape
+        out = self.forward_tm(hidden_states.transpose(0, 1).contiguous(), _key_bias(attention_mask, B, L))
+        return out.transpose(0, 1).contiguous()
 
 
 def gelu(x):
@@ -86,7 +122,8 @@ class TransformerIntermediate(nn.Module):
         self.intermediate_act_fn = gelu
 
     def forward(self, hidden_states):
-        return self.intermediate_act_fn(self.dense(hidden_states))
+        # standalone use only: inside the encoder layer the erf GELU is the epilogue of this GEMM (ops.mlp)
+        return self.intermediate_act_fn(ops.linear(hidden_states, self.dense.weight, self.dense.bias))
 
 
 class Residual_Norm(nn.Module):
@@ -97,7 +134,10 @@ class Residual_Norm(nn.Module):
         self.dropout = nn.Dropout(config.hidden_dropout_prob)
 
     def forward(self, hidden_states, input_tensor):
-        return self.LayerNorm(self.dropout(self.dense(hidden_states)) + input_tensor)
+        if self.training and self.dropout.p > 0:
+            return self.LayerNorm(self.dropout(ops.linear(hidden_states, self.dense.weight, self.dense.bias)) + input_tensor)
+        # no dropout between dense and residual: the residual add is the GEMM epilogue
+        return self.LayerNorm(ops.linear(hidden_states, self.dense.weight, self.dense.bias, res=input_tensor))
 
 
 class Output_Residual_Norm(nn.Module):
@@ -108,7 +148,9 @@ class Output_Residual_Norm(nn.Module):
         self.dropout = nn.Dropout(config.hidden_dropout_prob)
 
     def forward(self, hidden_states, input_tensor):
-        return self.LayerNorm(self.dropout(self.dense(hidden_states)) + input_tensor)
+        if self.training and self.dropout.p > 0:
+            return self.LayerNorm(self.dropout(ops.linear(hidden_states, self.dense.weight, self.dense.bias)) + input_tensor)
+        return self.LayerNorm(ops.linear(hidden_states, self.dense.weight, self.dense.bias, res=input_tensor))
 
 
 class MultiHeadSelfAttention(nn.Module):
@@ -116,6 +158,9 @@ class MultiHeadSelfAttention(nn.Module):
         super().__init__()
         self.selfatt = SelfAttention(config)
         self.dense_norm = Residual_Norm(config)
+
+    def forward_tm(self, x, key_bias):
+        return self.dense_norm(self.selfatt.forward_tm(x, key_bias), x)
 
     def forward(self, input_tensor, attention_mask):
         return self.dense_norm(self.selfatt(input_tensor, attention_mask), input_tensor)
@@ -128,9 +173,20 @@ class TransformerEnoderLayer(nn.Module):      # (sic) the reference's spelling i
         self.intermediate = TransformerIntermediate(config)
         self.output = Output_Residual_Norm(config)
 
+    def _ffn(self, a):
+        """LN(dropout(dense2(gelu(dense1(a)))) + a)  (ref :109-137): fc1 + erf GELU + fc2 as ops.mlp (GELU in fc1's
+        epilogue, GELU' in the epilogue of fc2's input-gradient GEMM)."""
+        out, inter = self.output, self.intermediate
+        if self.training and out.dropout.p > 0:
+            h = ops.mlp(a, inter.dense.weight, inter.dense.bias, out.dense.weight, out.dense.bias)
+            return out.LayerNorm(out.dropout(h) + a)
+        return out.LayerNorm(ops.mlp(a, inter.dense.weight, inter.dense.bias, out.dense.weight, out.dense.bias, res=a))
+
+    def forward_tm(self, x, key_bias):
+        return self._ffn(self.transformer_self_attention.forward_tm(x, key_bias))
+
     def forward(self, inputs, attention_mask):
-        a = self.transformer_self_attention(inputs, attention_mask)
-        return self.output(self.intermediate(a), a)
+        return self._ffn(self.transformer_self_attention(inputs, attention_mask))
 
 
 class MELDTransEncoder(nn.Module):
@@ -139,11 +195,14 @@ class MELDTransEncoder(nn.Module):
         self.position_embeddings = nn.Embedding(get_max_lens, hidden_size)
         layer = TransformerEnoderLayer(config)
         self.layer = nn.ModuleList([copy.deepcopy(layer) for _ in range(layer_num)])
+        self.compute_dtype = None
 
     def forward(self, feature_input, attention_mask, output_all_encoded_layers=False):
-        L = feature_input.shape[1]
+        B, L, _ = feature_input.shape
         pos = self.position_embeddings(torch.arange(L, dtype=torch.long, device=feature_input.device))
-        x = feature_input + pos.unsqueeze(0)
+        cd = self.compute_dtype or feature_input.dtype
+        x = (feature_input + pos.unsqueeze(0)).transpose(0, 1).contiguous().to(cd)          # (L, B, H) time-major
+        kb = _key_bias(attention_mask, B, L)
         for layer_module in self.layer:
-            x = layer_module(x, attention_mask)
-        return x
+            x = layer_module.forward_tm(x, kb)
+        return x.transpose(0, 1).to(feature_input.dtype)

@@ -317,7 +317,7 @@ class MhaCoreFn(Function):
     """q: (Lq,B,E); kv: either a packed (Lk,B,2E) tensor [k | v] (v is None) or separate k, v (Lk,B,E)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, num_heads, scale, dropout_p, seed):
+    def forward(ctx, q, k, v, num_heads, scale, dropout_p, seed, key_bias=None):
         _need_cuda(q, "multihead_attention")
         lib = _lib.load()
         q = q.contiguous()
@@ -335,16 +335,19 @@ class MhaCoreFn(Function):
         lse = torch.empty((B * num_heads * Lq,), dtype=torch.float32, device=q.device)
         seed_t = seed if isinstance(seed, torch.Tensor) else None          # device int64 word: graph-replay safe
         seed_i = 0 if seed_t is not None else int(seed)
-        rc = lib.fmmt_mha_fwd(dtype_code(q.dtype), Lq, Lk, B, E, num_heads, _p(q), E, kp, vp, ldkv, scale,
+        if key_bias is not None:
+            key_bias = key_bias.detach().to(torch.float32).contiguous()
+            assert key_bias.shape == (B, Lk), f"key_bias must be (B, Lk) = ({B}, {Lk}), got {tuple(key_bias.shape)}"
+        rc = lib.fmmt_mha_fwd(dtype_code(q.dtype), Lq, Lk, B, E, num_heads, _p(q), E, kp, vp, ldkv, scale, _p(key_bias),
                               dropout_p, seed_i, _p(seed_t), _p(out), E, _p(lse), _st())
         check(rc, f"fmmt_mha_fwd(Lq={Lq},Lk={Lk},B={B},E={E},heads={num_heads})")
-        ctx.save_for_backward(q, k, v, out, lse, seed_t)
+        ctx.save_for_backward(q, k, v, out, lse, seed_t, key_bias)
         ctx.cfg = (Lq, Lk, B, E, num_heads, scale, dropout_p, seed_i, packed, ldkv)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        q, k, v, out, lse, seed_t = ctx.saved_tensors
+        q, k, v, out, lse, seed_t, key_bias = ctx.saved_tensors
         Lq, Lk, B, E, num_heads, scale, dropout_p, seed, packed, ldkv = ctx.cfg
         lib = _lib.load()
         dout = dout.contiguous()
@@ -356,15 +359,16 @@ class MhaCoreFn(Function):
         else:
             dv = torch.empty_like(v)
             kp, vp, dkp, dvp = k.data_ptr(), v.data_ptr(), dk.data_ptr(), dv.data_ptr()
-        rc = lib.fmmt_mha_bwd(dtype_code(q.dtype), Lq, Lk, B, E, num_heads, _p(q), E, kp, vp, ldkv, scale, dropout_p,
-                              seed, _p(seed_t), _p(out), _p(dout), E, _p(lse), _p(dq), E, dkp, dvp, ldkv, _st())
+        rc = lib.fmmt_mha_bwd(dtype_code(q.dtype), Lq, Lk, B, E, num_heads, _p(q), E, kp, vp, ldkv, scale, _p(key_bias),
+                              dropout_p, seed, _p(seed_t), _p(out), _p(dout), E, _p(lse), _p(dq), E, dkp, dvp, ldkv, _st())
         check(rc, "fmmt_mha_bwd")
-        return dq, dk, dv, None, None, None, None
+        return dq, dk, dv, None, None, None, None, None
 
 
-def mha_core(q, k, v, num_heads, scale, dropout_p=0.0, seed=0):
-    """seed: python int, or a 1-element int64 CUDA tensor read by the kernel at run time"""
-    return MhaCoreFn.apply(q, k, v, num_heads, scale, float(dropout_p), seed if isinstance(seed, torch.Tensor) else int(seed))
+def mha_core(q, k, v, num_heads, scale, dropout_p=0.0, seed=0, key_bias=None):
+    """seed: python int, or a 1-element int64 CUDA tensor read by the kernel at run time.
+    key_bias: optional (B, Lk) additive logit bias (extended attention mask), no gradient."""
+    return MhaCoreFn.apply(q, k, v, num_heads, scale, float(dropout_p), seed if isinstance(seed, torch.Tensor) else int(seed), key_bias)
 
 
 # ------------------------------------------------------------------------------------------------

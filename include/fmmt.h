@@ -141,12 +141,16 @@ int fmmt_window_attn_bwd(int dtype, int n_img, int H, int W, int C, int num_head
  * probabilities scaled by 1/(1-p); p == 0 disables.  If seed_dev != NULL the seed is read from that device
  * word at kernel run time (so a captured hipGraph draws a fresh mask on every replay) and `seed` is ignored.  The head-averaged weights the reference also
  * returns (:133-134) are discarded by every caller (CrossmodalTransformer.py:147,151) and are not produced.
+ * key_bias (fp32 [B, Lk], may be NULL): added to the scaled logits of key j of batch b before the softmax.  The
+ * cross-modal encoder passes NULL (it has no key-padding mask at all); the per-modality self-attention encoders
+ * (modules/Transformer.py:93-95 `attention_scores + attention_mask`, mask built at src/models.py:157,164 as
+ * (1 - m) * -10000) pass their extended attention mask squeezed to [B, Lk].  No gradient is produced for it.
  */
 int fmmt_mha_fwd(int dtype, int Lq, int Lk, int B, int E, int num_heads,
-                 const void* q, int ldq, const void* k, const void* v, int ldkv, float scale,
+                 const void* q, int ldq, const void* k, const void* v, int ldkv, float scale, const float* key_bias,
                  float dropout_p, uint64_t seed, const uint64_t* seed_dev, void* out, int ldo, float* lse, void* stream);
 int fmmt_mha_bwd(int dtype, int Lq, int Lk, int B, int E, int num_heads,
-                 const void* q, int ldq, const void* k, const void* v, int ldkv, float scale,
+                 const void* q, int ldq, const void* k, const void* v, int ldkv, float scale, const float* key_bias,
                  float dropout_p, uint64_t seed, const uint64_t* seed_dev, const void* out, const void* dout, int ldo,
                  const float* lse, void* dq, int lddq, void* dk, void* dv, int lddkv, void* stream);
 

@@ -177,6 +177,30 @@ def t_mha():
             ref.backward(dy.double())
             report(f"mha bwd dq {tag}", q.grad, q64.grad, tol * 2)
             report(f"mha bwd dkv {tag}", kv.grad, kv64.grad, tol * 2)
+        # additive key bias (extended attention mask of the self-attention encoders): separate k, v, self-attention
+        # lengths incl. ragged tails, -10000 on padded keys plus a smooth bias to exercise the general case
+        for (L, B, E, nh) in [(128, 4, 768, 12), (37, 3, 768, 12), (160, 2, 768, 12), (70, 2, 256, 8)]:
+            hd = E // nh
+            q = rnd("q", (L, B, E), 1, dtype=dt).requires_grad_(True)
+            k = rnd("k", (L, B, E), 2, dtype=dt).requires_grad_(True)
+            v = rnd("v", (L, B, E), 3, dtype=dt).requires_grad_(True)
+            kb = rnd("kb", (B, L), 4) * 0.5
+            for b in range(B):
+                kb[b, L - 1 - 7 * b:] += -10000.0
+            out = ops.mha_core(q, k, v, nh, hd ** -0.5, 0.0, 0, kb)
+            q64, k64, v64 = (t.detach().double().requires_grad_(True) for t in (q, k, v))
+            def hs(t):
+                return t.reshape(L, B, nh, hd).permute(1, 2, 0, 3)
+            sc = hs(q64) @ hs(k64).transpose(-1, -2) * hd ** -0.5 + kb.double()[:, None, None, :]
+            ref = (torch.softmax(sc, -1) @ hs(v64)).permute(2, 0, 1, 3).reshape(L, B, E)
+            tag = f"{dt} L{L} B{B} E{E} key_bias"
+            report(f"mha fwd {tag}", out, ref, tol)
+            dy = rnd("dy", (L, B, E), 5, dtype=dt)
+            out.backward(dy)
+            ref.backward(dy.double())
+            report(f"mha bwd dq {tag}", q.grad, q64.grad, tol * 2)
+            report(f"mha bwd dk {tag}", k.grad, k64.grad, tol * 2)
+            report(f"mha bwd dv {tag}", v.grad, v64.grad, tol * 2)
         # separate k, v tensors + dropout statistics
         q = rnd("q", (64, 2, 768), 1, dtype=dt)
         k = rnd("k", (96, 2, 768), 2, dtype=dt)

@@ -181,3 +181,76 @@ def test_hip_graph_replay_matches_eager(dev):
         for a, b in zip(e, g):
             assert torch.allclose(a, b, atol=1e-5 * max(1.0, a.abs().max().item()), rtol=1e-4)
     assert not torch.allclose(graphed[0][0], graphed[1][0])
+
+
+# ------------------------------------------------------------------------------------------------
+# per-modality self-attention encoder (modules/Transformer.py) on the HIP path  -- SURVEY.md 8f rank 1
+# ------------------------------------------------------------------------------------------------
+def test_meld_utt_logits_golden(golden, dev):
+    """meld_utt_transformer (V-only classifier: MELDTransEncoder + AdditiveAttention) against the reference's
+    golden logits, fp32 kernels; the bf16 kernels stay within bf16 tolerance of them."""
+    from facialmmt_amd import models
+    from facialmmt_amd.config import default_args
+    x = synth.tensor("vfeat", (2, 20, 512), seed=12).to(dev)
+    vmask = torch.ones(2, 20, device=dev)
+    vmask[1, 14:] = 0
+    m = models.meld_utt_transformer(default_args(get_vision_utt_max_lens=20)).eval()
+    synth.fill_state_dict(m, seed=201)
+    m.to(dev)
+    with torch.no_grad():
+        out = m(x, vmask)
+    golden.check("multimodal", "meld_utt", out, **TOL)
+    m16 = models.meld_utt_transformer(default_args(get_vision_utt_max_lens=20, compute_dtype=torch.bfloat16)).eval()
+    synth.fill_state_dict(m16, seed=201)
+    m16.to(dev)
+    with torch.no_grad():
+        out16 = m16(x, vmask)
+    assert (out16.float() - out).abs().max().item() <= 5e-2 * max(1.0, out.abs().max().item())
+
+
+def test_meld_encoder_forward_backward_vs_oracle(dev):
+    """MELDTransEncoder (2 layers, padded keys masked with -10000) forward and every gradient against the oracle
+    (oracle/multimodal.py::meld_encoder differentiated by autograd on the CPU); dropout disabled."""
+    from facialmmt_amd.config import default_args
+    from facialmmt_amd.modules.Transformer import MELDTransEncoder
+    from oracle import multimodal as OM
+    cfg = default_args(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    B, L = 3, 37
+    enc = MELDTransEncoder(cfg, 2, 40, 768)
+    synth.fill_state_dict(enc, seed=77, prefix="meld.")
+    sd = {"e." + k: v.detach().clone().requires_grad_(True) for k, v in enc.state_dict().items()}
+    x = synth.tensor("meld_x", (B, L, 768), seed=78)
+    mask = torch.ones(B, L)
+    mask[1, 20:] = 0
+    mask[2, 5:] = 0
+    ext = (1.0 - mask[:, None, None]) * -10000.0
+    wgt = synth.tensor("meld_w", (B, L, 768), seed=79)
+    x_ref = x.clone().requires_grad_(True)
+    ref = OM.meld_encoder(sd, "e.", x_ref, ext, 2, cfg.num_attention_heads, cfg.layer_norm_eps)
+    (ref * wgt).sum().backward()
+
+    enc.to(dev).train()                               # train mode with p = 0: exercises the unfused residual path
+    x_dev = x.to(dev).requires_grad_(True)
+    out = enc(x_dev, ext.to(dev))
+    (out * wgt.to(dev)).sum().backward()
+    assert torch.allclose(out.detach().cpu(), ref.detach(), atol=2e-3, rtol=2e-3)
+    assert torch.allclose(x_dev.grad.cpu(), x_ref.grad, atol=3e-3, rtol=3e-3)
+    for k, p in enc.named_parameters():
+        g_ref = sd["e." + k].grad
+        scale = max(1.0, g_ref.abs().max().item())
+        err = (p.grad.cpu() - g_ref).abs().max().item()
+        assert err <= 3e-3 * scale, (k, err, scale)
+    enc.eval()                                        # eval: residual add fused into the GEMM epilogue -- same numbers
+    with torch.no_grad():
+        out_eval = enc(x.to(dev), ext.to(dev))
+    assert torch.allclose(out_eval.cpu(), ref.detach(), atol=2e-3, rtol=2e-3)
+
+
+def test_meld_encoder_rejects_cpu():
+    """no CPU / PyTorch formulation behind the encoder: CPU tensors raise"""
+    from facialmmt_amd._lib import FmmtError
+    from facialmmt_amd.config import default_args
+    from facialmmt_amd.modules.Transformer import MELDTransEncoder
+    enc = MELDTransEncoder(default_args(), 1, 8, 768)
+    with pytest.raises(FmmtError):
+        enc(torch.zeros(1, 8, 768), torch.zeros(1, 1, 1, 8))

@@ -36,7 +36,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert lib.fmmt_linear_fwd(7, 10, 96, 96, None, 96, None, 96, None, None, 96, None, 0, None, 96, None, 96, None, 1, None) == -1
     assert lib.fmmt_window_attn_fwd(1, 1, 15, 14, 96, 3, 0, None, None, None, None, 0, 0, 1.0, None, None, None) == -1
     assert lib.fmmt_window_attn_fwd(1, 1, 14, 14, 96, 4, 0, None, None, None, None, 0, 0, 1.0, None, None, None) == -1
-    assert lib.fmmt_mha_fwd(1, 8, 8, 1, 500, 4, None, 500, None, None, 500, 1.0, 0.0, 0, None, None, 500, None, None) == -1
+    assert lib.fmmt_mha_fwd(1, 8, 8, 1, 500, 4, None, 500, None, None, 500, 1.0, None, 0.0, 0, None, None, 500, None, None) == -1
     assert lib.fmmt_layernorm_fwd(1, 8, 100, None, None, None, 1e-5, None, None, None, 0, None) == -1
     assert lib.fmmt_linear_wgrad_workspace(2007040, 288, 96) > 0
     assert lib.fmmt_window_attn_bwd_workspace(3) == 3 * 257 * 49 * 49 * 4
