@@ -430,6 +430,114 @@ __global__ __launch_bounds__(512) void linear_nt_deep_kernel(LinArgs p) {
     nt_epilogue<T, MT, NT>(p, acc, m0 + wm * 64, n0 + wn * 64, li, lg);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Same 256 x 128 tile with K step 32: three 24 KB buffers = 72 KB, so TWO workgroups (16 waves) share a CU and
+// one workgroup's epilogue (GELU, stores) overlaps the other's MFMA loop.  A DMA instruction now covers 16 rows
+// x 64 B; the bank swizzle is chunk ^ ((row >> 3) & 3) for the channel-permuted weight rows and
+// chunk ^ ((row >> 2) & 3) for the token rows (each makes the 16 lanes of a fragment read hit 16 distinct
+// 16-byte slots of the 256-byte bank window).
+// ---------------------------------------------------------------------------------------------
+// NK: compile-time number of K steps (6 for the K = 192 stage-1 problems, which are HBM-bound and get their own
+// fully unrolled instantiation), 0 = run-time.
+template <int NK>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4)))
+void linear_nt_deep32_kernel(LinArgs p) {
+    using T = bf16;
+    constexpr int BM = 256, BN = 128, BK = 32, PITCH = 32, MT = 4, NT = 4, CW = 16;
+    constexpr int STAGE = (BM + BN) * PITCH;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* S = reinterpret_cast<T*>(smem);                     // [3][BN rows of W | BM rows of X][32]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 15, lg = lane >> 4;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (logical / p.tiles_n) * BM, n0 = (logical % p.tiles_n) * BN;
+    const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
+    const T* __restrict__ wg = reinterpret_cast<const T*>(p.w);
+    const int nk = NK ? NK : p.K / BK;
+
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    const int r16 = lane >> 2, c = lane & 3;
+    auto issue = [&](int buf, int k0) {
+        T* base = S + buf * STAGE;
+        {                                                  // 1 DMA instruction per wave for W (8 x 16 rows)
+            const int row = wave * 16 + r16;
+            const T* src = wg + (size_t)min(n0 + row, p.N - 1) * p.ldw + k0 + ((c ^ ((row >> 3) & 3)) << 3);
+            __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(base + wave * 16 * PITCH), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {                      // 2 DMA instructions per wave for X (16 x 16 rows)
+            const int grp = i * 8 + wave, row = grp * 16 + r16;
+            const T* src = xg + (size_t)min(m0 + row, p.M - 1) * p.ldx + k0 + ((c ^ ((row >> 2) & 3)) << 3);
+            __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(base + (BN + grp * 16) * PITCH), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int woff[NT], xoff[MT];
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+        const int r = wn * 64 + chan_of<CW>(b, li >> 2, li & 3);
+        woff[b] = r * PITCH + ((lg ^ ((r >> 3) & 3)) << 3);
+    }
+#pragma unroll
+    for (int a = 0; a < MT; ++a) {
+        const int r = wm * 64 + a * 16 + li;
+        xoff[a] = (BN + r) * PITCH + ((lg ^ ((r >> 2) & 3)) << 3);
+    }
+
+    auto compute = [&](int buf) {
+        const T* sb = S + buf * STAGE;
+        bf16x8 wf[NT], xf[MT];
+#pragma unroll
+        for (int b = 0; b < NT; ++b) wf[b] = *reinterpret_cast<const bf16x8*>(sb + woff[b]);
+#pragma unroll
+        for (int a = 0; a < MT; ++a) xf[a] = *reinterpret_cast<const bf16x8*>(sb + xoff[a]);
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b], xf[a], acc[a][b], 0, 0, 0);
+    };
+
+    issue(0, 0);
+    if (nk > 1) issue(1, BK);
+    if constexpr (NK > 0) {
+#pragma unroll
+        for (int kt = 0; kt < NK; ++kt) {
+            if (kt + 1 < NK) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 2 < NK) issue((kt + 2) % 3, (kt + 2) * BK);
+            compute(kt % 3);
+        }
+    } else {
+        int cur = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 2 < nk) issue(cur == 0 ? 2 : cur - 1, (kt + 2) * BK);
+            compute(cur);
+            cur = cur == 2 ? 0 : cur + 1;
+        }
+    }
+    nt_epilogue<T, MT, NT>(p, acc, m0 + wm * 64, n0 + wn * 64, li, lg);
+}
+
+// (A "wide-wave" variant -- the same 256 x 128 block computed by four waves with 128 x 64 wave tiles, 0.375 KB of
+//  LDS reads per MFMA instead of 0.5 KB -- was measured on the 125440-token shapes: 0.98-1.02x, i.e. LDS bandwidth is
+//  not what bounds these kernels.  What does: bytes in flight.  A K step's MFMA work (~0.1 us per wave) is far
+//  shorter than the ~2 us L2/HBM latency of the DMA that feeds it, and 160 KB of LDS holds ~100 KB of in-flight
+//  tiles per CU, so a CU can pull ~50 GB/s = 12.8 TB/s chip-wide; at 85 FLOP per loaded byte (256 x 128 tile)
+//  that caps the kernel near 1.1 PFLOP/s, and the measured 0.8 PFLOP/s on K = 1536 is 72 % of that cap.  The next
+//  step up is a 256 x 256 tile (128 FLOP/B) with persistent scheduling for the tile-count quantisation.)
+
 template <typename T, int BM, int BN, int BK, int NBUF, bool GLDS = false>
 int launch_nt(const LinArgs& a, hipStream_t st) {
     constexpr int VEC = Vec<T>::N;
@@ -483,19 +591,35 @@ int dispatch_nt(const LinArgs& a, hipStream_t st) {
         // measured (tests/gpu_gemm_bench.py): +8 % on the 125440-token stage-2 shapes (K = 384: 496 -> 540 TF/s),
         // -4 % on the 31360-token stage-3 shapes (tile quantisation at one workgroup per CU) -> only for M >= 65536
         static const int deep = getenv("FMMT_NT_DEEP") ? atoi(getenv("FMMT_NT_DEEP")) : 1;
-        if (deep && a.M >= 65536 && !a.ksplit && a.N % 128 == 0 && a.K % 64 == 0 && a.K >= 256 && a.ldx % 8 == 0 && a.ldw % 8 == 0) {
+        static const int deep_mink = getenv("FMMT_NT_DEEP_MINK") ? atoi(getenv("FMMT_NT_DEEP_MINK")) : 192;
+        if (deep && a.M >= 65536 && !a.ksplit && a.N % 128 == 0 && a.K % 32 == 0 && a.K >= deep_mink && a.ldx % 8 == 0 && a.ldw % 8 == 0 &&
+            (a.K % 64 == 0 || deep == 1 || deep == 2)) {
             constexpr size_t lds = (size_t)3 * (256 + 128) * 64 * 2;
             static bool attr_set = false;
             if (!attr_set) {
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_nt_deep_kernel),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (e != hipSuccess) return (int)e;
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_nt_deep32_kernel<0>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds / 2);
+                if (e != hipSuccess) return (int)e;
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_nt_deep32_kernel<6>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds / 2);
+                if (e != hipSuccess) return (int)e;
                 attr_set = true;
             }
             LinArgs p = a;
             p.tiles_n = a.N / 128;
             p.tiles_m = (a.M + 255) / 256;
-            hipLaunchKernelGGL(linear_nt_deep_kernel, dim3(p.tiles_m * p.tiles_n), dim3(512), lds, st, p);
+            // measured (tests/gpu_gemm_bench.py, 125440 tokens): the K-step-32 kernel with two workgroups per CU wins
+            // where the epilogue is a large share of a tile's life -- GELU / GELU' launches (0.388 -> 0.340 ms) and
+            // K = 384 (384x384: 0.069 -> 0.057 ms); the K-step-64 kernel keeps a 2-4 % edge on plain K >= 1152.
+            // FMMT_NT_DEEP: 1 = this policy, 2 = always K step 32, 4 = always K step 64, 0 = 128-row kernels only
+            if (deep == 2 || (deep == 1 && (a.epi != 0 || a.K <= 512)) || a.K % 64 != 0)
+                if (a.K == 192) hipLaunchKernelGGL(linear_nt_deep32_kernel<6>, dim3(p.tiles_m * p.tiles_n), dim3(512), lds / 2, st, p);
+                else hipLaunchKernelGGL(linear_nt_deep32_kernel<0>, dim3(p.tiles_m * p.tiles_n), dim3(512), lds / 2, st, p);
+            else
+                hipLaunchKernelGGL(linear_nt_deep_kernel, dim3(p.tiles_m * p.tiles_n), dim3(512), lds, st, p);
             FMMT_CHECK_LAUNCH();
             return 0;
         }

@@ -8,9 +8,10 @@ def timeit(fn, n=10):
     fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n
-SHAPES = [(2007040, 288, 96), (2007040, 96, 96), (2007040, 384, 96), (2007040, 96, 384), (2007040, 96, 288),
-          (501760, 576, 192), (501760, 768, 192), (501760, 192, 768), (125440, 1152, 384), (125440, 1536, 384), (125440, 384, 1536),
+SHAPES_ALL = [(2007040, 288, 96), (2007040, 96, 96), (2007040, 384, 96), (2007040, 96, 384), (2007040, 96, 288),
+          (501760, 576, 192), (501760, 768, 192), (501760, 192, 768), (125440, 1152, 384), (125440, 1536, 384), (125440, 384, 1536), (125440, 384, 384), (125440, 384, 1152),
           (31360, 2304, 768), (31360, 3072, 768), (31360, 768, 3072), (664, 768, 768), (1280, 3072, 768)]
+SHAPES = [sh for sh in SHAPES_ALL if not os.environ.get("GEMM_BENCH_M") or sh[0] == int(os.environ["GEMM_BENCH_M"])]
 print("cfg", os.environ.get("FMMT_NT_CFG", "0"))
 from facialmmt_amd._lib import EPI_GELU, EPI_GELU_BWD
 tot = 0
@@ -31,6 +32,10 @@ for (M, N, K) in SHAPES:
         res = torch.randn(M, N, device=dev, dtype=torch.bfloat16)
         t6 = timeit(lambda: ops.linear_raw(x, w, b, res=res, rowscale=rs, rows_per_scale=49))
         line += f" | res+scale {t6*1e3:7.3f} ms"
+    if os.environ.get("GEMM_BENCH_VENDOR"):        # vendor-library reference points (hipBLASLt via torch), same operands
+        tv = timeit(lambda: torch.nn.functional.linear(x, w))
+        tv2 = timeit(lambda: torch.matmul(dy.t(), x))
+        line += f" || hipblaslt nt {tv*1e3:7.3f} ms {2.0*M*N*K/tv/1e12:6.1f} TF/s  tn {tv2*1e3:7.3f} ms {2.0*M*N*K/tv2/1e12:6.1f} TF/s"
     print(line, flush=True)
     del x, w, dy
 print(f"  sum nt {tot*1e3:.3f} ms")

@@ -69,6 +69,32 @@ def t_linear():
         report(f"linear gelu_bwd {dt}", y, (x.double() @ w.double().t()) * g, tol)
 
 
+def t_linear_large():
+    """many-token bf16 problems (>= 65536 rows: the 256-row deep-pipelined kernels; FMMT_NT_DEEP selects the
+    variant) with ragged M, every epilogue, against fp32 torch matmuls of the same bf16 operands"""
+    dt, tol = torch.bfloat16, 2e-2
+    for (M, N, K) in [(65536 + 77, 384, 384), (70000, 1536, 384), (65536, 384, 1536), (66000, 128, 256), (65600, 768, 192)]:
+        x = rnd("x", (M, K), 1, dtype=dt)
+        w = rnd("w", (N, K), 2, K ** -0.5, dtype=dt)
+        b = rnd("b", (N,), 3, 0.1)
+        pre = x.float() @ w.float().t() + b
+        report(f"linear large {M}x{N}x{K}", ops.linear_raw(x, w, b), pre, tol)
+        ypre = torch.empty((M, N), dtype=dt, device=dev)
+        y = ops.linear_raw(x, w, b, epi=EPI_GELU, y_pre=ypre)
+        report(f"linear large gelu {M}x{N}x{K}", y, torch.nn.functional.gelu(pre), tol)
+        report(f"linear large gelu pre {M}x{N}x{K}", ypre, pre, tol)
+        res = rnd("res", (M, N), 4, dtype=dt)
+        rs = rnd("rs", (M // 196 + 1,), 5).abs() + 0.5
+        y = ops.linear_raw(x, w, b, res=res, rowscale=rs, rows_per_scale=196)
+        report(f"linear large res+rowscale {M}x{N}x{K}", y, res.float() + rs.repeat_interleave(196)[:M, None] * pre, tol)
+        aux = rnd("aux", (M, N), 6, dtype=dt)
+        a32 = aux.float().requires_grad_(True)
+        g = torch.autograd.grad(torch.nn.functional.gelu(a32).sum(), a32)[0]
+        y = ops.linear_raw(x, w, None, epi=EPI_GELU_BWD, aux=aux)
+        report(f"linear large gelu_bwd {M}x{N}x{K}", y, (x.float() @ w.float().t()) * g, tol)
+        del x, w, pre, y, ypre, res, aux, a32, g
+
+
 def t_wgrad():
     for dt, tol in ((torch.float32, 2e-5), (torch.bfloat16, 2e-2)):
         for (M, N, K) in [(500, 96, 96), (3136, 288, 96), (777, 384, 96), (1000, 96, 384), (100, 512, 1024), (6272, 96, 48)]:
