@@ -319,7 +319,13 @@ int wa_groups_per_head(int B_, int nH, bool bwd, bool mfma) {
     if (g > maxg) g = maxg;
     const int cap = mfma ? WA_BWD_WAVES_PER_HEAD_MAX : WA_BWD_WAVES_PER_HEAD_MAX / 4;
     if (bwd && g > cap) g = cap;
+    if (mfma && g >= 8) g &= ~7;          // multiple of 8: lets the kernel keep a window group's heads on one XCD
     return g < 1 ? 1 : g;
+}
+
+int wa_xcd_grouped(int groups_per_head, bool mfma) {
+    static const int on = getenv("FMMT_WA_XCD") ? atoi(getenv("FMMT_WA_XCD")) : 1;
+    return (on && mfma && groups_per_head % 8 == 0) ? 1 : 0;
 }
 
 int wa_check(int dtype, int n_img, int H, int W, int C, int nH, int shift) {
@@ -581,6 +587,7 @@ extern "C" int fmmt_window_attn_fwd(int dtype, int n_img, int H, int W, int C, i
     a.index = index; a.mask = mask; a.nW_mask = nW_mask; a.mask_is_shift = mask_is_shift; a.scale = scale; a.out = out; a.lse = lse;
     const int B_ = n_img * (H / WS) * (W / WS);
     a.groups_per_head = wa_groups_per_head(B_, num_heads, false, dtype == FMMT_BF16);
+    a.xcd_grouped = wa_xcd_grouped(a.groups_per_head, dtype == FMMT_BF16);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid(num_heads * a.groups_per_head);
     if (dtype == FMMT_BF16) return fmmt_wattn_mfma_fwd_launch(a, (int)grid.x, st);     // matrix-core path
@@ -607,6 +614,7 @@ extern "C" int fmmt_window_attn_bwd(int dtype, int n_img, int H, int W, int C, i
     a.lse = const_cast<float*>(lse); a.dout = dout; a.dqkv = dqkv; a.part = reinterpret_cast<float*>(workspace);
     const int B_ = n_img * (H / WS) * (W / WS);
     a.groups_per_head = wa_groups_per_head(B_, num_heads, true, dtype == FMMT_BF16);
+    a.xcd_grouped = wa_xcd_grouped(a.groups_per_head, dtype == FMMT_BF16);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid(num_heads * a.groups_per_head);
     if (dtype == FMMT_BF16) {

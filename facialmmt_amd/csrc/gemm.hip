@@ -297,7 +297,7 @@ void linear_nt_kernel(LinArgs p) {
 #pragma unroll
         for (int b = 0; b < NT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (GLDS) {
-        static_assert(BK == 64 && NBUF == 2 && sizeof(T) == 2, "direct-to-LDS path: bf16, BK = 64, two buffers");
+        static_assert(BK == 64 && (NBUF == 2 || NBUF == 4) && sizeof(T) == 2, "direct-to-LDS path: bf16, BK = 64, two or four buffers");
         typedef __attribute__((address_space(1))) const void gptr_t;
         typedef __attribute__((address_space(3))) void lptr_t;
         auto issue = [&](int buf, int k0) {
@@ -315,6 +315,27 @@ void linear_nt_kernel(LinArgs p) {
                 __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(Xs + (buf * BM + grp * 8) * PITCH), 16, 0, 0);
             }
         };
+        if constexpr (NBUF == 4) {
+            // Few-token problems (one workgroup per CU at most, K loop of 12-48 steps that is pure latency): a ring of
+            // four buffers keeps three K steps in flight; each wave waits only for its own DI DMA instructions of the
+            // step about to be used (counted vmcnt), a raw s_barrier publishes it and frees the buffer read last step.
+            constexpr int DI = BN / 32 + BM / 32;
+            static_assert(2 * DI <= 63, "vmcnt immediate");
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+                if (s < nk) issue(s, kbeg + s * BK);
+            for (int kt = 0; kt < nk; ++kt) {
+                const int ahead = min(nk - 1 - kt, 2);     // steps issued after step kt that may still be in flight
+                if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DI) : "memory");
+                else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DI) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (kt + 3 < nk) issue((kt + 3) & 3, kbeg + (kt + 3) * BK);
+                compute(kt & 3);
+            }
+            epilogue(m0, n0);
+            return;
+        }
         issue(0, kbeg);
         __syncthreads();                                   // the compiler drains vmcnt(0) in front of the barrier
         for (int kt = 0; kt < nk; ++kt) {
@@ -572,7 +593,16 @@ int dispatch_nt_bk(const LinArgs& a, hipStream_t st) {
         // direct global->LDS DMA staging: measured +7 % over register staging summed over the bench shapes, up to
         // +25 % on the K >= 768 ones (971 TF/s on 31360x768x3072); FMMT_NT_GLDS=0 selects the register-staged kernel
         static const int glds = getenv("FMMT_NT_GLDS") ? atoi(getenv("FMMT_NT_GLDS")) : 1;
-        if (glds && a.K % 64 == 0 && !a.ksplit && a.ldx % 8 == 0 && a.ldw % 8 == 0) return launch_nt<T, BM, BN, 64, 2, true>(a, st);
+        if (glds && a.K % 64 == 0 && !a.ksplit && a.ldx % 8 == 0 && a.ldw % 8 == 0) {
+            // four-buffer ring for few-token problems with a long K loop and at most one workgroup per CU (fc2 of the
+            // encoder FFNs, 512-1328 tokens x 768 x 3072: 32 -> 25 us); with more tiles than CUs the 96 KB ring costs
+            // co-residency (1328 x 3072 x 768: 15 -> 21 us), and at K = 768 it is a wash.  FMMT_NT_GLDS=2: never.
+            if constexpr (BM == 64) {
+                const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+                if (glds != 2 && a.K >= 2048 && tiles <= 256) return launch_nt<T, BM, BN, 64, 4, true>(a, st);
+            }
+            return launch_nt<T, BM, BN, 64, 2, true>(a, st);
+        }
         if (a.K % 64 == 0 && (!a.ksplit || a.ksplit % 64 == 0)) return launch_nt<T, BM, BN, 64, 2>(a, st);
         return launch_nt<T, BM, BN, 32, 2>(a, st);
     } else {
@@ -669,6 +699,8 @@ struct TnArgs {
     const float* rowscale; int rows_per_scale;
     int tiles_k;
     int chunk;          // rows of m per split (multiple of the m step)
+    int tiles_n;
+    int xcd;            // 1: chunked XCD remap of the (split, tile) work list
 };
 
 __device__ __forceinline__ bf16x8 lds_tr_frag(const bf16* s, int pitch, int c0, int li, int lg) {
@@ -702,9 +734,14 @@ __global__ __launch_bounds__(256) void linear_tn_kernel(TnArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 1, wk = wave & 1;
     const int li = lane & 15, lg = lane >> 4;
-    const int tile_n = blockIdx.x / p.tiles_k, tile_k = blockIdx.x % p.tiles_k;
+    // 1-D grid of tiles x splits.  All output tiles of one split read the same token rows of dy and x, so a split's
+    // tiles are kept on one XCD (chunked XCD remap over the split-major work list): with the head-major order each
+    // XCD's L2 fetched every operand slab again (FETCH_SIZE 1.9x the algorithmic bytes on the stage-2 launches).
+    const int tiles = p.tiles_n * p.tiles_k;
+    const int logical = p.xcd ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int split = logical / tiles, tile = logical - split * tiles;
+    const int tile_n = tile / p.tiles_k, tile_k = tile % p.tiles_k;
     const int n0 = tile_n * 128, k0 = tile_k * 128;
-    const int split = blockIdx.y;
     const int mbeg = split * p.chunk, mend = min(p.M, mbeg + p.chunk);
 
     const T* __restrict__ dyg = reinterpret_cast<const T*>(p.dy);
@@ -941,38 +978,57 @@ extern "C" size_t fmmt_linear_wgrad_workspace(int M, int N, int K) {
     return tn_plan(M, N, K).bytes;
 }
 
-extern "C" int fmmt_linear_wgrad(int dtype, int M, int N, int K,
-                                 const void* dy, int lddy, const void* x, int ldx,
-                                 float* dw, float* db, const float* rowscale, int rows_per_scale,
-                                 void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int fmmt_linear_wgrad_partials(int dtype, int M, int N, int K,
+                                          const void* dy, int lddy, const void* x, int ldx, int want_bias,
+                                          const float* rowscale, int rows_per_scale,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0) return FMMT_EINVAL;
     if (dtype != FMMT_BF16 && dtype != FMMT_F32) return FMMT_EINVAL;
     const int vec = dtype == FMMT_BF16 ? 8 : 4;
     if (N % vec || K % vec || lddy % vec || ldx % vec) return FMMT_EINVAL;
     if (rowscale && rows_per_scale <= 0) return FMMT_EINVAL;
-    if (!aligned16(dy) || !aligned16(x) || !aligned16(dw) || !aligned16(workspace)) return FMMT_EALIGN;
+    if (!aligned16(dy) || !aligned16(x) || !aligned16(workspace)) return FMMT_EALIGN;
     const TnPlan pl = tn_plan(M, N, K);
     if (workspace_bytes < pl.bytes) return FMMT_EWORKSPACE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     float* part_w = reinterpret_cast<float*>(workspace);
-    float* part_b = db ? part_w + (size_t)pl.splits * N * K : nullptr;
-    TnArgs a{M, N, K, dy, lddy, x, ldx, part_w, part_b, rowscale, rows_per_scale, pl.tiles_k, pl.chunk};
-    dim3 grid(pl.tiles_n * pl.tiles_k, pl.splits);
+    float* part_b = want_bias ? part_w + (size_t)pl.splits * N * K : nullptr;
+    static const int tn_xcd = getenv("FMMT_TN_XCD") ? atoi(getenv("FMMT_TN_XCD")) : 1;
+    TnArgs a{M, N, K, dy, lddy, x, ldx, part_w, part_b, rowscale, rows_per_scale, pl.tiles_k, pl.chunk, pl.tiles_n, tn_xcd};
+    dim3 grid(pl.tiles_n * pl.tiles_k * pl.splits);
     static const int tn_cfg = getenv("FMMT_TN_CFG") ? atoi(getenv("FMMT_TN_CFG")) : 0;
-    int rc;
     // measured (tests/gpu_gemm_bench.py): 64-token steps win for the compute-heavy stage-2/3 shapes (+15-25 %),
     // 32-token steps (3 workgroups per CU) win for the HBM-bound multi-million-token stage-0/1 shapes
     const bool bms64 = tn_cfg == 2 || (tn_cfg == 0 && M <= 262144);
-    if (dtype == FMMT_BF16) rc = M <= 4096 ? launch_tn<bf16, 32, true>(a, grid, st)
-                                           : bms64 ? launch_tn<bf16, 64>(a, grid, st) : launch_tn<bf16, 32>(a, grid, st);
-    else rc = launch_tn<float, 16>(a, grid, st);
-    if (rc) return rc;
+    if (dtype == FMMT_BF16) return M <= 4096 ? launch_tn<bf16, 32, true>(a, grid, st)
+                                             : bms64 ? launch_tn<bf16, 64>(a, grid, st) : launch_tn<bf16, 32>(a, grid, st);
+    return launch_tn<float, 16>(a, grid, st);
+}
+
+extern "C" int fmmt_linear_wgrad_finish(int M, int N, int K, float* dw, float* db,
+                                        const void* workspace, size_t workspace_bytes, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || !dw) return FMMT_EINVAL;
+    if (!aligned16(dw) || !aligned16(workspace)) return FMMT_EALIGN;
+    const TnPlan pl = tn_plan(M, N, K);
+    if (workspace_bytes < pl.bytes) return FMMT_EWORKSPACE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const float* part_w = reinterpret_cast<const float*>(workspace);
     const size_t nw = (size_t)N * K;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nw + 63) / 64)), dim3(256), 0, st, part_w, dw, nw, pl.splits);
     FMMT_CHECK_LAUNCH();
     if (db) {
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 63) / 64), dim3(256), 0, st, part_b, db, (size_t)N, pl.splits);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 63) / 64), dim3(256), 0, st, part_w + (size_t)pl.splits * N * K, db, (size_t)N, pl.splits);
         FMMT_CHECK_LAUNCH();
     }
     return 0;
+}
+
+extern "C" int fmmt_linear_wgrad(int dtype, int M, int N, int K,
+                                 const void* dy, int lddy, const void* x, int ldx,
+                                 float* dw, float* db, const float* rowscale, int rows_per_scale,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    if (!aligned16(dw)) return FMMT_EALIGN;
+    if (int rc = fmmt_linear_wgrad_partials(dtype, M, N, K, dy, lddy, x, ldx, db != nullptr, rowscale, rows_per_scale,
+                                            workspace, workspace_bytes, stream)) return rc;
+    return fmmt_linear_wgrad_finish(M, N, K, dw, db, workspace, workspace_bytes, stream);
 }

@@ -20,6 +20,7 @@ struct WaArgs {
     void* dqkv;
     float* part;           // [nH][waves_per_head][49*49]
     int groups_per_head;   // workgroups per head
+    int xcd_grouped;       // block numbering keeps the heads of a window group on one XCD (groups_per_head % 8 == 0)
 };
 
 int fmmt_wattn_mfma_fwd_launch(const WaArgs& a, int grid, hipStream_t st);

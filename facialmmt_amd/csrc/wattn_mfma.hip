@@ -132,6 +132,22 @@ __device__ __forceinline__ void fill_bias_mfma(const WaArgs& p, int head, float*
     }
 }
 
+// blockIdx -> (head, window group).  The hardware places block b on XCD b % 8, and each XCD has its own L2.  A head
+// slice of a token is 64 B, half an L2 line, so the heads of one window group should run on the SAME XCD at about the
+// same time: with groups_per_head a multiple of 8 (the launcher rounds it), blocks are numbered
+// b = (grp / 8) * 8 * nH + head * 8 + grp % 8, i.e. b % 8 == grp % 8 for every head.  (FMMT_WA_XCD=0: head-major.)
+__device__ __forceinline__ void head_group_of_block(const WaArgs& p, int& head, int& grp) {
+    const int b = blockIdx.x;
+    if (p.xcd_grouped) {
+        const int band = 8 * p.nH, q = b / band, o = b - q * band;
+        head = o >> 3;
+        grp = q * 8 + (o & 7);
+    } else {
+        head = b / p.groups_per_head;
+        grp = b - head * p.groups_per_head;
+    }
+}
+
 // =============================================================================================
 // MM: 0 = no mask, 1 = standard SW-MSA mask derived from window coordinates, 2 = arbitrary (nW,49,49) tensor
 template <int MM>
@@ -140,7 +156,8 @@ __global__ __launch_bounds__(256) void wattn_mfma_fwd_kernel(WaArgs p) {
     __shared__ __attribute__((aligned(16))) float Bs[64 * BPM];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lg = lane >> 4;
-    const int head = blockIdx.x / p.groups_per_head, grp = blockIdx.x - head * p.groups_per_head;
+    int head, grp;
+    head_group_of_block(p, head, grp);
     const int nW = (p.H / WS) * (p.W / WS), B_ = p.n_img * nW;
     const int stride = p.groups_per_head * 4;
     const bf16* __restrict__ qkv = reinterpret_cast<const bf16*>(p.qkv);
@@ -241,7 +258,8 @@ __global__ __launch_bounds__(256) void wattn_mfma_bwd_kernel(WaArgs p) {
     __shared__ __attribute__((aligned(16))) float Bs[64 * BPM];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lg = lane >> 4;
-    const int head = blockIdx.x / p.groups_per_head, grp = blockIdx.x - head * p.groups_per_head;
+    int head, grp;
+    head_group_of_block(p, head, grp);
     const int nW = (p.H / WS) * (p.W / WS), B_ = p.n_img * nW;
     const int stride = p.groups_per_head * 4;
     const bf16* __restrict__ qkv = reinterpret_cast<const bf16*>(p.qkv);

@@ -54,6 +54,15 @@ def linear_raw(x2, w, bias, *, epi=EPI_NONE, y_pre=None, aux=None, res=None, row
     return y
 
 
+def wgrad_partials_raw(dy2, x2, want_bias, ws, nbytes, rowscale=None, rows_per_scale=1):
+    """the split contraction of the weight gradient (one MFMA kernel launch) into fp32 partials in `ws`"""
+    M, N = dy2.shape
+    K = x2.shape[1]
+    rc = _lib.load().fmmt_linear_wgrad_partials(dtype_code(dy2.dtype), M, N, K, _p(dy2), N, _p(x2), K, 1 if want_bias else 0,
+                                                _p(rowscale), rows_per_scale, _p(ws), nbytes, _st())
+    check(rc, f"fmmt_linear_wgrad_partials(M={M},N={N},K={K})")
+
+
 def wgrad_raw(dy2, x2, want_bias, rowscale=None, rows_per_scale=1):
     """dw[N,K] fp32 = (s*dy2)^T @ x2 ; db[N] fp32 = colsum(s*dy2)."""
     M, N = dy2.shape
@@ -63,9 +72,9 @@ def wgrad_raw(dy2, x2, want_bias, rowscale=None, rows_per_scale=1):
     db = torch.empty((N,), dtype=torch.float32, device=dy2.device) if want_bias else None
     nbytes = lib.fmmt_linear_wgrad_workspace(M, N, K)
     ws = _ws(nbytes, dy2.device)
-    rc = lib.fmmt_linear_wgrad(dtype_code(dy2.dtype), M, N, K, _p(dy2), N, _p(x2), K, _p(dw), _p(db),
-                               _p(rowscale), rows_per_scale, _p(ws), nbytes, _st())
-    check(rc, f"fmmt_linear_wgrad(M={M},N={N},K={K})")
+    wgrad_partials_raw(dy2, x2, want_bias, ws, nbytes, rowscale, rows_per_scale)
+    rc = lib.fmmt_linear_wgrad_finish(M, N, K, _p(dw), _p(db), _p(ws), nbytes, _st())
+    check(rc, f"fmmt_linear_wgrad_finish(M={M},N={N},K={K})")
     return dw, db
 
 

@@ -78,6 +78,16 @@ int fmmt_linear_wgrad(int dtype, int M, int N, int K,
                       const void* dy, int lddy, const void* x, int ldx,
                       float* dw, float* db, const float* rowscale, int rows_per_scale,
                       void* workspace, size_t workspace_bytes, void* stream);
+/* The same operation as its two launches, for callers that want to time or overlap them separately:
+ *   _partials: the split contraction (MFMA kernel) -> fp32 partials in `workspace` (want_bias != 0: also the bias partials);
+ *   _finish  : fixed-order sum of the partials into dw (and db, which requires the partials call to have had want_bias).
+ * Both must be given the same (M, N, K) and workspace. */
+int fmmt_linear_wgrad_partials(int dtype, int M, int N, int K,
+                               const void* dy, int lddy, const void* x, int ldx, int want_bias,
+                               const float* rowscale, int rows_per_scale,
+                               void* workspace, size_t workspace_bytes, void* stream);
+int fmmt_linear_wgrad_finish(int M, int N, int K, float* dw, float* db,
+                             const void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm.  Replaces nn.LayerNorm (eps 1e-5) at Swin_Transformer.py:198,204,239,268 (norm1/2),

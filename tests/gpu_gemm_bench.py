@@ -12,6 +12,8 @@ SHAPES_ALL = [(2007040, 288, 96), (2007040, 96, 96), (2007040, 384, 96), (200704
           (501760, 576, 192), (501760, 768, 192), (501760, 192, 768), (125440, 1152, 384), (125440, 1536, 384), (125440, 384, 1536), (125440, 384, 384), (125440, 384, 1152),
           (31360, 2304, 768), (31360, 3072, 768), (31360, 768, 3072), (664, 768, 768), (1280, 3072, 768)]
 SHAPES = [sh for sh in SHAPES_ALL if not os.environ.get("GEMM_BENCH_M") or sh[0] == int(os.environ["GEMM_BENCH_M"])]
+if os.environ.get("GEMM_BENCH_FEW"):
+    SHAPES = []
 print("cfg", os.environ.get("FMMT_NT_CFG", "0"))
 from facialmmt_amd._lib import EPI_GELU, EPI_GELU_BWD
 tot = 0
@@ -39,3 +41,27 @@ for (M, N, K) in SHAPES:
     print(line, flush=True)
     del x, w, dy
 print(f"  sum nt {tot*1e3:.3f} ms")
+
+# few-token problems (cross-modal / self-attention encoders): GPU time per launch from a captured graph of 20 launches
+def graph_time(fn, reps=20):
+    fn(); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        fn()
+        with torch.cuda.graph(g, stream=s):
+            for _ in range(reps): fn()
+    g.replay(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5): g.replay()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / 5 / reps
+if not os.environ.get("GEMM_BENCH_M"):
+    print("few-token (graph-replayed, per launch):")
+    for (M, N, K) in [(152, 768, 768), (512, 768, 768), (640, 768, 768), (1328, 768, 768), (664, 1536, 768), (512, 3072, 768), (512, 768, 3072), (1328, 3072, 768), (1328, 768, 3072)]:
+        x = torch.randn(M, K, device=dev, dtype=torch.bfloat16); w = torch.randn(N, K, device=dev, dtype=torch.bfloat16); b = torch.randn(N, device=dev)
+        dy = torch.randn(M, N, device=dev, dtype=torch.bfloat16)
+        t = graph_time(lambda: ops.linear_raw(x, w, b))
+        t2 = graph_time(lambda: ops.wgrad_raw(dy, x, True))
+        tv = graph_time(lambda: torch.nn.functional.linear(x, w, b.bfloat16()))
+        print(f"  {M:6d}x{N:5d}x{K:5d}: nt {t*1e6:6.1f} us {2.0*M*N*K/t/1e12:6.1f} TF/s | tn(+reduce) {t2*1e6:6.1f} us | hipblaslt nt {tv*1e6:6.1f} us", flush=True)

@@ -28,7 +28,7 @@ def stats(d, steps):
     print(f"# rocprofv3 --kernel-trace --stats: per-kernel GPU time ({steps} steps incl. warm-up profiled)\n")
     print(f"total kernel time: {tot / 1e6:.2f} ms = {tot / 1e6 / steps:.2f} ms/step\n")
     print("| ms/step | % | calls/step | avg us | min us | max us | kernel |\n|---:|---:|---:|---:|---:|---:|---|")
-    for r in rows[:45]:
+    for r in rows[:int(os.environ.get("PROF_ROWS", "45"))]:
         print(f"| {float(r['TotalDurationNs']) / 1e6 / steps:.3f} | {float(r['Percentage']):.2f} | {int(r['Calls']) / steps:.1f} | "
               f"{float(r['AverageNs']) / 1e3:.1f} | {float(r['MinNs']) / 1e3:.1f} | {float(r['MaxNs']) / 1e3:.1f} | `{short(r['Name'])}` |")
 
