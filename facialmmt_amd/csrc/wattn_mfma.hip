@@ -445,6 +445,234 @@ __global__ __launch_bounds__(256) void wattn_mfma_bwd_kernel(WaArgs p) {
     for (int t = threadIdx.x; t < TOK * TOK; t += 256) part[t] = acc[t];
 }
 
+
+// =============================================================================================
+// Backward, two waves per (window, head).  The one-wave kernel above needs 344-412 registers (64 for d(bias),
+// 64 for the q/k/v/dO fragments of all four token tiles, ...), i.e. one wave per SIMD and nothing to hide the
+// global-load -> LDS -> MFMA -> store chain behind.  Here wave h of a pair owns token tiles {2h, 2h+1}: as
+// QUERY tiles in pass 1 (dQ, d(bias): 2 x 4 accumulator tiles instead of 4 x 4) and as KEY tiles in pass 2
+// (dK, dV).  Fragments of the partner's tiles come from the pair's natural-layout LDS tiles (K, Q, dO,
+// V).  A workgroup (2 pairs) walks two windows per iteration with 57 KB of LDS: two workgroups per CU, two
+// waves per SIMD.
+// =============================================================================================
+struct Slot { int di, dj; bool valid; };
+__device__ __forceinline__ Slot slot_of(int slot) {
+    Slot S;
+    S.valid = slot < TOK;
+    const int cs = S.valid ? slot : TOK - 1;
+    S.di = cs / WS;
+    S.dj = cs - S.di * WS;
+    return S;
+}
+
+template <int MM>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+void wattn_mfma_bwd2_kernel(WaArgs p) {
+    __shared__ __attribute__((aligned(16))) bf16 Kt[2][64 * TP];
+    __shared__ __attribute__((aligned(16))) bf16 Qt[2][64 * TP];
+    __shared__ __attribute__((aligned(16))) bf16 Gt[2][64 * TP];
+    __shared__ __attribute__((aligned(16))) bf16 Vt[2][64 * TP];
+    __shared__ __attribute__((aligned(16))) float Ls[2][64];
+    __shared__ __attribute__((aligned(16))) float Dl[2][64];
+    __shared__ __attribute__((aligned(16))) float Bs[64 * BPM];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pair = wave >> 1, h = wave & 1;
+    const int li = lane & 15, lg = lane >> 4;
+    int head, grp;
+    head_group_of_block(p, head, grp);
+    const int nW = (p.H / WS) * (p.W / WS), B_ = p.n_img * nW;
+    const int stride = p.groups_per_head * 2;
+    const bf16* __restrict__ qkv = reinterpret_cast<const bf16*>(p.qkv);
+    const bf16* __restrict__ og = reinterpret_cast<const bf16*>(p.out);
+    const bf16* __restrict__ dog = reinterpret_cast<const bf16*>(p.dout);
+    bf16* __restrict__ dqkv = reinterpret_cast<bf16*>(p.dqkv);
+    const LaneGeom G = lane_geom(li, lg, p.shift);
+    bf16 *kt_ = Kt[pair], *qt_ = Qt[pair], *gt_ = Gt[pair], *vt_ = Vt[pair];
+    const Slot own[2] = {slot_of((2 * h) * 16 + li), slot_of((2 * h + 1) * 16 + li)};
+
+    fill_bias_mfma(p, head, Bs);
+    f32x4 dbias[2][4];                               // [own query tile][key tile], lane = query column layout
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) dbias[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int iters = (B_ + stride - 1) / stride;
+    for (int it = 0; it < iters; ++it) {
+        const int b_raw = it * stride + grp * 2 + pair;
+        const bool wactive = b_raw < B_;
+        const int b_ = wactive ? b_raw : B_ - 1;
+        const WinPos P = win_pos(p, b_);
+        const float* mbase = (MM == 2) ? p.mask + (size_t)(b_ % p.nW_mask) * TOK * TOK : nullptr;
+        size_t tok[2];
+        bf16x8 qf[2], kf[2], gf[2];
+        float ls[2], dl[2];
+        __syncthreads();                                   // previous iteration finished with the LDS tiles
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int slot = (2 * h + a) * 16 + li;
+            tok[a] = tok_of(p, P, own[a].di, own[a].dj);
+            const bf16* row = qkv + tok[a] * 3 * p.C + head * HD + lg * 8;
+            qf[a] = ld_frag(row);
+            kf[a] = ld_frag(row + p.C);
+            const bf16x8 vv = ld_frag(row + 2 * p.C);
+            gf[a] = ld_frag(dog + tok[a] * p.C + head * HD + lg * 8);
+            const bf16x8 of = ld_frag(og + tok[a] * p.C + head * HD + lg * 8);
+            float d = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d += (float)gf[a][e] * (float)of[e];
+            dl[a] = xor_sum(d);
+            ls[a] = p.lse[((size_t)b_ * p.nH + head) * TOK + (slot < TOK ? slot : TOK - 1)];
+            const int off = slot * TP + lg * 8;
+            *reinterpret_cast<bf16x8*>(kt_ + off) = own[a].valid ? kf[a] : zero_frag();
+            *reinterpret_cast<bf16x8*>(qt_ + off) = own[a].valid ? qf[a] : zero_frag();
+            *reinterpret_cast<bf16x8*>(gt_ + off) = own[a].valid ? gf[a] : zero_frag();
+            *reinterpret_cast<bf16x8*>(vt_ + off) = own[a].valid ? vv : zero_frag();
+            if (lg == 0) {
+                Ls[pair][slot] = ls[a];
+                Dl[pair][slot] = dl[a];
+            }
+        }
+        __syncthreads();
+
+        // ------------------------------------------------ pass 1: own QUERY tiles -> dQ, d bias
+        {
+            bf16x8 kT[2][2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) kT[ks][dt] = tr_fragT(kt_, 32 * ks + 4 * lg, dt, li);
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int qt = 2 * h + a;
+                const int q = qt * 16 + li;
+                float ds[16];
+                const unsigned mb = (MM == 1) ? std_mask_bits(G, P, qt) : 0u;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    const bf16x8 kfk = ld_frag(kt_ + (kt * 16 + li) * TP + lg * 8);
+                    const f32x4 sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfk, qf[a], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    const bf16x8 vfk = ld_frag(vt_ + (kt * 16 + li) * TP + lg * 8);
+                    const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfk, gf[a], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(&Bs[q * BPM + kt * 16 + lg * 4]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float s = sa[r] * p.scale + b[r];
+                        if constexpr (MM == 1) s += ((mb >> (kt * 4 + r)) & 1u) ? -100.0f : 0.0f;
+                        if constexpr (MM == 2) {
+                            const int key = kt * 16 + lg * 4 + r;
+                            s += mbase[(q < TOK ? q : TOK - 1) * TOK + (key < TOK ? key : TOK - 1)];
+                        }
+                        const float pij = __expf(s - ls[a]);
+                        const float d = pij * (dp[r] - dl[a]);
+                        ds[kt * 4 + r] = d;
+                        if (wactive) dbias[a][kt][r] += d;
+                    }
+                }
+                const bf16x8 d0 = pack8(&ds[0], &ds[4]), d1 = pack8(&ds[8], &ds[12]);
+                f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+                a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT[0][0], d0, a0, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT[1][0], d1, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT[0][1], d0, a1, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT[1][1], d1, a1, 0, 0, 0);
+                if (wactive && own[a].valid) {
+                    bf16x8 ob;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { ob[r] = (bf16)(a0[r] * p.scale); ob[4 + r] = (bf16)(a1[r] * p.scale); }
+                    *reinterpret_cast<bf16x8*>(dqkv + tok[a] * 3 * p.C + head * HD + lg * 8) = ob;
+                }
+            }
+        }
+
+        // ------------------------------------------------ pass 2: own KEY tiles -> dK, dV
+        {
+            bf16x8 gT[2][2], qT[2][2];
+#pragma unroll
+            for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    gT[qs][dt] = tr_fragT(gt_, 32 * qs + 4 * lg, dt, li);
+                    qT[qs][dt] = tr_fragT(qt_, 32 * qs + 4 * lg, dt, li);
+                }
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int kt = 2 * h + a;
+                const int key = kt * 16 + li;
+                const bf16x8 vfk = ld_frag(vt_ + (kt * 16 + li) * TP + lg * 8);
+                float pp[16], ds[16];
+                const unsigned mb = (MM == 1) ? std_mask_bits(G, P, kt) : 0u;
+#pragma unroll
+                for (int qt = 0; qt < 4; ++qt) {
+                    const bf16x8 qfq = ld_frag(qt_ + (qt * 16 + li) * TP + lg * 8);
+                    const bf16x8 gfq = ld_frag(gt_ + (qt * 16 + li) * TP + lg * 8);
+                    const f32x4 sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfq, kf[a], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gfq, vfk, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    const f32x4 lq = *reinterpret_cast<const f32x4*>(&Ls[pair][qt * 16 + lg * 4]);
+                    const f32x4 dq = *reinterpret_cast<const f32x4*>(&Dl[pair][qt * 16 + lg * 4]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int q = qt * 16 + lg * 4 + r;
+                        float s = sa[r] * p.scale + Bs[q * BPM + key];
+                        if constexpr (MM == 1) s += ((mb >> (qt * 4 + r)) & 1u) ? -100.0f : 0.0f;
+                        if constexpr (MM == 2) s += mbase[(q < TOK ? q : TOK - 1) * TOK + (key < TOK ? key : TOK - 1)];
+                        const float pij = __expf(s - lq[r]);
+                        pp[qt * 4 + r] = pij;
+                        ds[qt * 4 + r] = pij * (dp[r] - dq[r]);
+                    }
+                }
+                const bf16x8 p0 = pack8(&pp[0], &pp[4]), p1 = pack8(&pp[8], &pp[12]);
+                const bf16x8 d0 = pack8(&ds[0], &ds[4]), d1 = pack8(&ds[8], &ds[12]);
+                f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f}, k0 = {0.f, 0.f, 0.f, 0.f}, k1 = {0.f, 0.f, 0.f, 0.f};
+                v0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gT[0][0], p0, v0, 0, 0, 0);
+                v0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gT[1][0], p1, v0, 0, 0, 0);
+                v1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gT[0][1], p0, v1, 0, 0, 0);
+                v1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gT[1][1], p1, v1, 0, 0, 0);
+                k0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT[0][0], d0, k0, 0, 0, 0);
+                k0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT[1][0], d1, k0, 0, 0, 0);
+                k1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT[0][1], d0, k1, 0, 0, 0);
+                k1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT[1][1], d1, k1, 0, 0, 0);
+                if (wactive && own[a].valid) {
+                    bf16x8 kb, vb;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        kb[r] = (bf16)(k0[r] * p.scale); kb[4 + r] = (bf16)(k1[r] * p.scale);
+                        vb[r] = (bf16)v0[r]; vb[4 + r] = (bf16)v1[r];
+                    }
+                    bf16* dst = dqkv + tok[a] * 3 * p.C + head * HD + lg * 8;
+                    *reinterpret_cast<bf16x8*>(dst + p.C) = kb;
+                    *reinterpret_cast<bf16x8*>(dst + 2 * p.C) = vb;
+                }
+            }
+        }
+    }
+    // d(bias) of the workgroup: waves add their register accumulators into one LDS tile in wave order (deterministic).
+    // Wave w holds query rows of half (w & 1); waves 0 and 1 write their rows first, waves 2 and 3 add to them.
+    float* acc = reinterpret_cast<float*>(&Kt[0][0]);           // Kt: 2 x 5 KB >= 49*49 floats
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int q = (2 * h + a) * 16 + li;
+                if (q >= TOK) continue;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kt * 16 + lg * 4 + r;
+                        if (key < TOK) {
+                            const float v = dbias[a][kt][r];
+                            acc[q * TOK + key] = (w < 2) ? v : acc[q * TOK + key] + v;
+                        }
+                    }
+            }
+        }
+    }
+    __syncthreads();
+    float* part = p.part + ((size_t)head * p.groups_per_head + grp) * TOK * TOK;
+    for (int t = threadIdx.x; t < TOK * TOK; t += 256) part[t] = acc[t];
+}
+
 }  // namespace
 
 int fmmt_wattn_mfma_fwd_launch(const WaArgs& a, int grid, hipStream_t st) {
@@ -458,6 +686,13 @@ int fmmt_wattn_mfma_fwd_launch(const WaArgs& a, int grid, hipStream_t st) {
 
 int fmmt_wattn_mfma_bwd_launch(const WaArgs& a, int grid, hipStream_t st) {
     const int mm = !a.mask ? 0 : (a.mask_is_shift ? 1 : 2);
+    if (a.bwd_two_wave) {
+        if (mm == 0) hipLaunchKernelGGL(wattn_mfma_bwd2_kernel<0>, dim3(grid), dim3(256), 0, st, a);
+        else if (mm == 1) hipLaunchKernelGGL(wattn_mfma_bwd2_kernel<1>, dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(wattn_mfma_bwd2_kernel<2>, dim3(grid), dim3(256), 0, st, a);
+        FMMT_CHECK_LAUNCH();
+        return 0;
+    }
     if (mm == 0) hipLaunchKernelGGL(wattn_mfma_bwd_kernel<0>, dim3(grid), dim3(256), 0, st, a);
     else if (mm == 1) hipLaunchKernelGGL(wattn_mfma_bwd_kernel<1>, dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(wattn_mfma_bwd_kernel<2>, dim3(grid), dim3(256), 0, st, a);
