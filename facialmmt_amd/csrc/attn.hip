@@ -307,11 +307,6 @@ __global__ __launch_bounds__(64) void wattn_dtable_kernel(const float* __restric
     if (threadIdx.x == 0) dtable[t] = a;
 }
 
-int wa_bwd_two_wave() {
-    static const int on = getenv("FMMT_WA_BWD2") ? atoi(getenv("FMMT_WA_BWD2")) : 1;
-    return on;
-}
-
 int wa_groups_per_head(int B_, int nH, bool bwd, bool mfma) {
     // Persistent workgroups pinned to a head.  The grid must not exceed what is co-resident (a second
     // round of workgroups would find its share of windows already sized for the full grid):
@@ -321,7 +316,7 @@ int wa_groups_per_head(int B_, int nH, bool bwd, bool mfma) {
     static const int fwd_wgs = getenv("FMMT_WA_FWD_WGS") ? atoi(getenv("FMMT_WA_FWD_WGS")) : 1024;
     const int target = mfma ? (bwd ? 512 : fwd_wgs) : 2048;
     int g = target / nH;
-    const int wpi = (mfma && bwd && wa_bwd_two_wave()) ? 2 : 4;      // windows per workgroup iteration
+    const int wpi = (mfma && bwd) ? 2 : 4;      // windows per workgroup iteration (MFMA backward: two waves per window)
     const int maxg = (B_ + wpi - 1) / wpi;
     if (g > maxg) g = maxg;
     const int cap = mfma ? WA_BWD_WAVES_PER_HEAD_MAX : WA_BWD_WAVES_PER_HEAD_MAX / 4;
@@ -622,7 +617,6 @@ extern "C" int fmmt_window_attn_bwd(int dtype, int n_img, int H, int W, int C, i
     const int B_ = n_img * (H / WS) * (W / WS);
     a.groups_per_head = wa_groups_per_head(B_, num_heads, true, dtype == FMMT_BF16);
     a.xcd_grouped = wa_xcd_grouped(a.groups_per_head, dtype == FMMT_BF16);
-    a.bwd_two_wave = wa_bwd_two_wave();
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid(num_heads * a.groups_per_head);
     if (dtype == FMMT_BF16) {

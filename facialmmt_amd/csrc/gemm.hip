@@ -880,11 +880,20 @@ int launch_tn(const TnArgs& a, dim3 grid, hipStream_t st) {
 //  stage-2/3 shapes (472-550 vs 464-591 TF/s), so it is not kept.  What did help: sizing the split count to
 //  exactly one round of co-resident workgroups, +13 % on those shapes.)
 
-// out[i] = sum_s part[s][i] : 256 threads = 64 outputs x 4 split groups, fixed-order tree (deterministic)
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n, int splits) {
+// out[i] = sum_s part[s][i] : 256 threads = 64 outputs x 4 split groups, fixed-order tree (deterministic).
+// One launch finishes both the weight gradient (blocks [0, wblocks)) and, if present, the bias gradient.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n, int splits,
+                                                              int wblocks, const float* __restrict__ part2, float* __restrict__ out2, size_t n2) {
     __shared__ float red[4][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const size_t i = (size_t)blockIdx.x * 64 + tx;
+    int blk = blockIdx.x;
+    if (blk >= wblocks) {                                  // bias gradient blocks
+        blk -= wblocks;
+        part = part2;
+        out = out2;
+        n = n2;
+    }
+    const size_t i = (size_t)blk * 64 + tx;
     float t = 0.f;
     if (i < n)
         for (int s = ty; s < splits; s += 4) t += part[(size_t)s * n + i];
@@ -1014,12 +1023,10 @@ extern "C" int fmmt_linear_wgrad_finish(int M, int N, int K, float* dw, float* d
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const float* part_w = reinterpret_cast<const float*>(workspace);
     const size_t nw = (size_t)N * K;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nw + 63) / 64)), dim3(256), 0, st, part_w, dw, nw, pl.splits);
+    const int wblocks = (int)((nw + 63) / 64), bblocks = db ? (N + 63) / 64 : 0;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(wblocks + bblocks), dim3(256), 0, st, part_w, dw, nw, pl.splits,
+                       wblocks, part_w + (size_t)pl.splits * N * K, db, (size_t)N);
     FMMT_CHECK_LAUNCH();
-    if (db) {
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 63) / 64), dim3(256), 0, st, part_w + (size_t)pl.splits * N * K, db, (size_t)N, pl.splits);
-        FMMT_CHECK_LAUNCH();
-    }
     return 0;
 }
 

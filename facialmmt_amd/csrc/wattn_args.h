@@ -20,7 +20,6 @@ struct WaArgs {
     void* dqkv;
     float* part;           // [nH][waves_per_head][49*49]
     int groups_per_head;   // workgroups per head
-    int bwd_two_wave;      // backward: two waves per (window, head) (wattn_mfma_bwd2_kernel), two windows per workgroup iteration
     int xcd_grouped;       // block numbering keeps the heads of a window group on one XCD (groups_per_head % 8 == 0)
 };
 

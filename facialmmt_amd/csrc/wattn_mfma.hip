@@ -13,8 +13,9 @@
 // is pinned to one head and walks windows, so that head's dense 49x49 bias sits in LDS.
 //
 // Backward recomputes P from the saved log-sum-exp twice: once with lanes owning query columns (dQ, d bias
-// accumulated in registers across windows) and once with lanes owning key columns (dK, dV) -- cheaper than
-// transposing P / dS through LDS.  d(bias table) is reduced through per-wave partials in a fixed order.
+// accumulated in registers across windows) and once with lanes owning key columns (dK, dV); two waves share a
+// (window, head) problem, each owning half of the token tiles in both passes.  d(bias table) is reduced
+// through per-workgroup partials in a fixed order.
 #include "fmmt_common.h"
 #include "../../include/fmmt.h"
 #include "wattn_args.h"
@@ -248,208 +249,10 @@ __global__ __launch_bounds__(256) void wattn_mfma_fwd_kernel(WaArgs p) {
 }
 
 // =============================================================================================
-template <int MM>
-__global__ __launch_bounds__(256) void wattn_mfma_bwd_kernel(WaArgs p) {
-    __shared__ __attribute__((aligned(16))) bf16 Kt[4][64 * TP];
-    __shared__ __attribute__((aligned(16))) bf16 Qt[4][64 * TP];
-    __shared__ __attribute__((aligned(16))) bf16 Gt[4][64 * TP];
-    __shared__ __attribute__((aligned(16))) float Ls[4][64];
-    __shared__ __attribute__((aligned(16))) float Dl[4][64];
-    __shared__ __attribute__((aligned(16))) float Bs[64 * BPM];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int li = lane & 15, lg = lane >> 4;
-    int head, grp;
-    head_group_of_block(p, head, grp);
-    const int nW = (p.H / WS) * (p.W / WS), B_ = p.n_img * nW;
-    const int stride = p.groups_per_head * 4;
-    const bf16* __restrict__ qkv = reinterpret_cast<const bf16*>(p.qkv);
-    const bf16* __restrict__ og = reinterpret_cast<const bf16*>(p.out);
-    const bf16* __restrict__ dog = reinterpret_cast<const bf16*>(p.dout);
-    bf16* __restrict__ dqkv = reinterpret_cast<bf16*>(p.dqkv);
-    const LaneGeom G = lane_geom(li, lg, p.shift);
-    bf16 *kt_ = Kt[wave], *qt_ = Qt[wave], *gt_ = Gt[wave];
-
-    fill_bias_mfma(p, head, Bs);
-    f32x4 dbias[4][4];                               // [qt][kt], lane = query column layout
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) dbias[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int iters = (B_ + stride - 1) / stride;
-    for (int it = 0; it < iters; ++it) {
-        const int b_raw = it * stride + grp * 4 + wave;
-        const bool wactive = b_raw < B_;
-        const int b_ = wactive ? b_raw : B_ - 1;
-        const WinPos P = win_pos(p, b_);
-        const float* mbase = (MM == 2) ? p.mask + (size_t)(b_ % p.nW_mask) * TOK * TOK : nullptr;
-        size_t tok[4];
-        bf16x8 qf[4], kf[4], vf[4], gf[4];
-        float ls[4], dl[4];
-        __syncthreads();                                   // previous iteration finished with the LDS tiles
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            tok[t] = tok_of(p, P, G.di[t], G.dj[t]);
-            const bf16* row = qkv + tok[t] * 3 * p.C + head * HD + lg * 8;
-            qf[t] = ld_frag(row);
-            kf[t] = ld_frag(row + p.C);
-            vf[t] = ld_frag(row + 2 * p.C);
-            gf[t] = ld_frag(dog + tok[t] * p.C + head * HD + lg * 8);
-            const bf16x8 of = ld_frag(og + tok[t] * p.C + head * HD + lg * 8);
-            float d = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) d += (float)gf[t][e] * (float)of[e];
-            dl[t] = xor_sum(d);
-            const int q = t * 16 + li;
-            ls[t] = p.lse[((size_t)b_ * p.nH + head) * TOK + (q < TOK ? q : TOK - 1)];
-            const int off = (t * 16 + li) * TP + lg * 8;
-            *reinterpret_cast<bf16x8*>(kt_ + off) = G.valid[t] ? kf[t] : zero_frag();
-            *reinterpret_cast<bf16x8*>(qt_ + off) = G.valid[t] ? qf[t] : zero_frag();
-            *reinterpret_cast<bf16x8*>(gt_ + off) = G.valid[t] ? gf[t] : zero_frag();
-            if (lg == 0) {
-                Ls[wave][q] = ls[t];
-                Dl[wave][q] = dl[t];
-            }
-        }
-        __syncthreads();
-
-        // ------------------------------------------------ pass 1: lanes own query columns -> dQ, d bias
-        {
-            bf16x8 kT[2][2];
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) kT[ks][dt] = tr_fragT(kt_, 32 * ks + 4 * lg, dt, li);
-#pragma unroll
-            for (int qt = 0; qt < 4; ++qt) {
-                const int q = qt * 16 + li;
-                float ds[16];
-                const unsigned mb = (MM == 1) ? std_mask_bits(G, P, qt) : 0u;
-#pragma unroll
-                for (int kt = 0; kt < 4; ++kt) {
-                    const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                    const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[kt], gf[qt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(&Bs[q * BPM + kt * 16 + lg * 4]);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float s = a[r] * p.scale + b[r];
-                        if constexpr (MM == 1) s += ((mb >> (kt * 4 + r)) & 1u) ? -100.0f : 0.0f;
-                        if constexpr (MM == 2) {
-                            const int key = kt * 16 + lg * 4 + r;
-                            s += mbase[(q < TOK ? q : TOK - 1) * TOK + (key < TOK ? key : TOK - 1)];
-                        }
-                        const float pij = __expf(s - ls[qt]);
-                        const float d = pij * (dp[r] - dl[qt]);
-                        ds[kt * 4 + r] = d;
-                        if (wactive) dbias[qt][kt][r] += d;
-                    }
-                }
-                const bf16x8 d0 = pack8(&ds[0], &ds[4]), d1 = pack8(&ds[8], &ds[12]);
-                f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-                a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT[0][0], d0, a0, 0, 0, 0);
-                a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT[1][0], d1, a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT[0][1], d0, a1, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT[1][1], d1, a1, 0, 0, 0);
-                if (wactive && G.valid[qt]) {
-                    bf16x8 ob;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { ob[r] = (bf16)(a0[r] * p.scale); ob[4 + r] = (bf16)(a1[r] * p.scale); }
-                    *reinterpret_cast<bf16x8*>(dqkv + tok[qt] * 3 * p.C + head * HD + lg * 8) = ob;
-                }
-            }
-        }
-
-        // ------------------------------------------------ pass 2: lanes own key columns -> dK, dV
-        {
-            bf16x8 gT[2][2], qT[2][2];
-#pragma unroll
-            for (int qs = 0; qs < 2; ++qs)
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    gT[qs][dt] = tr_fragT(gt_, 32 * qs + 4 * lg, dt, li);
-                    qT[qs][dt] = tr_fragT(qt_, 32 * qs + 4 * lg, dt, li);
-                }
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                const int key = kt * 16 + li;
-                float pp[16], ds[16];
-                const unsigned mb = (MM == 1) ? std_mask_bits(G, P, kt) : 0u;
-#pragma unroll
-                for (int qt = 0; qt < 4; ++qt) {
-                    const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[qt], kf[kt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                    const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[qt], vf[kt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                    const f32x4 lq = *reinterpret_cast<const f32x4*>(&Ls[wave][qt * 16 + lg * 4]);
-                    const f32x4 dq = *reinterpret_cast<const f32x4*>(&Dl[wave][qt * 16 + lg * 4]);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int q = qt * 16 + lg * 4 + r;
-                        float s = a[r] * p.scale + Bs[q * BPM + key];
-                        if constexpr (MM == 1) s += ((mb >> (qt * 4 + r)) & 1u) ? -100.0f : 0.0f;
-                        if constexpr (MM == 2) s += mbase[(q < TOK ? q : TOK - 1) * TOK + (key < TOK ? key : TOK - 1)];
-                        const float pij = __expf(s - lq[r]);
-                        pp[qt * 4 + r] = pij;
-                        ds[qt * 4 + r] = pij * (dp[r] - dq[r]);
-                    }
-                }
-                const bf16x8 p0 = pack8(&pp[0], &pp[4]), p1 = pack8(&pp[8], &pp[12]);
-                const bf16x8 d0 = pack8(&ds[0], &ds[4]), d1 = pack8(&ds[8], &ds[12]);
-                f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f}, k0 = {0.f, 0.f, 0.f, 0.f}, k1 = {0.f, 0.f, 0.f, 0.f};
-                v0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gT[0][0], p0, v0, 0, 0, 0);
-                v0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gT[1][0], p1, v0, 0, 0, 0);
-                v1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gT[0][1], p0, v1, 0, 0, 0);
-                v1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gT[1][1], p1, v1, 0, 0, 0);
-                k0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT[0][0], d0, k0, 0, 0, 0);
-                k0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT[1][0], d1, k0, 0, 0, 0);
-                k1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT[0][1], d0, k1, 0, 0, 0);
-                k1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT[1][1], d1, k1, 0, 0, 0);
-                if (wactive && G.valid[kt]) {
-                    bf16x8 kb, vb;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        kb[r] = (bf16)(k0[r] * p.scale); kb[4 + r] = (bf16)(k1[r] * p.scale);
-                        vb[r] = (bf16)v0[r]; vb[4 + r] = (bf16)v1[r];
-                    }
-                    bf16* dst = dqkv + tok[kt] * 3 * p.C + head * HD + lg * 8;
-                    *reinterpret_cast<bf16x8*>(dst + p.C) = kb;
-                    *reinterpret_cast<bf16x8*>(dst + 2 * p.C) = vb;
-                }
-            }
-        }
-    }
-    // d(bias) of the workgroup: the 4 waves add their register accumulators into one LDS tile in wave order
-    // (deterministic), then the tile is written as this workgroup's partial [q][key].
-    // lane holds q = qt*16 + li, key = kt*16 + 4g + r
-    float* acc = reinterpret_cast<float*>(&Kt[0][0]);           // 20 KB >= 49*49 floats
-    for (int w = 0; w < 4; ++w) {
-        __syncthreads();
-        if (wave == w) {
-#pragma unroll
-            for (int qt = 0; qt < 4; ++qt) {
-                const int q = qt * 16 + li;
-                if (q >= TOK) continue;
-#pragma unroll
-                for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int key = kt * 16 + lg * 4 + r;
-                        if (key < TOK) {
-                            const float v = dbias[qt][kt][r];
-                            acc[q * TOK + key] = (w == 0) ? v : acc[q * TOK + key] + v;
-                        }
-                    }
-            }
-        }
-    }
-    __syncthreads();
-    float* part = p.part + ((size_t)head * p.groups_per_head + grp) * TOK * TOK;
-    for (int t = threadIdx.x; t < TOK * TOK; t += 256) part[t] = acc[t];
-}
-
-
-// =============================================================================================
-// Backward, two waves per (window, head).  The one-wave kernel above needs 344-412 registers (64 for d(bias),
-// 64 for the q/k/v/dO fragments of all four token tiles, ...), i.e. one wave per SIMD and nothing to hide the
-// global-load -> LDS -> MFMA -> store chain behind.  Here wave h of a pair owns token tiles {2h, 2h+1}: as
+// Backward, two waves per (window, head).  A one-wave-per-window formulation (measured: 6.5 ms/step against 5.3)
+// needs 344-412 registers (64 for d(bias), 64 for the q/k/v/dO fragments of all four token tiles, ...), i.e. one
+// wave per SIMD and nothing to hide the global-load -> LDS -> MFMA -> store chain behind; forcing it to 256
+// registers spills and is 2x slower.  Here wave h of a pair owns token tiles {2h, 2h+1}: as
 // QUERY tiles in pass 1 (dQ, d(bias): 2 x 4 accumulator tiles instead of 4 x 4) and as KEY tiles in pass 2
 // (dK, dV).  Fragments of the partner's tiles come from the pair's natural-layout LDS tiles (K, Q, dO,
 // V).  A workgroup (2 pairs) walks two windows per iteration with 57 KB of LDS: two workgroups per CU, two
@@ -467,7 +270,7 @@ __device__ __forceinline__ Slot slot_of(int slot) {
 
 template <int MM>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
-void wattn_mfma_bwd2_kernel(WaArgs p) {
+void wattn_mfma_bwd_kernel(WaArgs p) {
     __shared__ __attribute__((aligned(16))) bf16 Kt[2][64 * TP];
     __shared__ __attribute__((aligned(16))) bf16 Qt[2][64 * TP];
     __shared__ __attribute__((aligned(16))) bf16 Gt[2][64 * TP];
@@ -686,13 +489,6 @@ int fmmt_wattn_mfma_fwd_launch(const WaArgs& a, int grid, hipStream_t st) {
 
 int fmmt_wattn_mfma_bwd_launch(const WaArgs& a, int grid, hipStream_t st) {
     const int mm = !a.mask ? 0 : (a.mask_is_shift ? 1 : 2);
-    if (a.bwd_two_wave) {
-        if (mm == 0) hipLaunchKernelGGL(wattn_mfma_bwd2_kernel<0>, dim3(grid), dim3(256), 0, st, a);
-        else if (mm == 1) hipLaunchKernelGGL(wattn_mfma_bwd2_kernel<1>, dim3(grid), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(wattn_mfma_bwd2_kernel<2>, dim3(grid), dim3(256), 0, st, a);
-        FMMT_CHECK_LAUNCH();
-        return 0;
-    }
     if (mm == 0) hipLaunchKernelGGL(wattn_mfma_bwd_kernel<0>, dim3(grid), dim3(256), 0, st, a);
     else if (mm == 1) hipLaunchKernelGGL(wattn_mfma_bwd_kernel<1>, dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(wattn_mfma_bwd_kernel<2>, dim3(grid), dim3(256), 0, st, a);
