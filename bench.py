@@ -115,8 +115,11 @@ class KernelTimer:
             bn = 96 if (N % 96 == 0 and N % 128 != 0) else 128
             bn = f"{bn},96,1" if K == 96 else f"{bn},64,1" if K <= 64 else f"{bn},64,2" if K % 64 == 0 else f"{bn},32,2"
             bn = f"{64 if M <= 4096 else 128},{bn}" + (",glds" if (K % 64 == 0 and K > 64) else "")
-            if M >= 65536 and N % 128 == 0 and K % 32 == 0 and K >= 192:
-                bn = "deep256x128x32,nk6" if K == 192 else "deep256x128x32" if (kw.get("epi", 0) != 0 or K <= 512 or K % 64) else "deep256x128x64"
+            if M >= 65536 and K % 32 == 0 and K >= 192 and (N % 128 == 0 or N % 96 == 0):
+                if N % 128 == 0:
+                    bn = "deep256x128x32,nk6" if K == 192 else "deep256x128x32" if (kw.get("epi", 0) != 0 or K <= 512 or K % 64) else "deep256x128x64"
+                else:
+                    bn = "deep256x96x32,nk6" if K == 192 else "deep256x96x32"
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             y = raw(x2, w, bias, **kw)
@@ -342,7 +345,9 @@ def main():
         if fams:
             bn, (cnt, fl, by, sec) = max(fams.items(), key=lambda kv: kv[1][3])
             achieved = fl / sec / 1e12
-            kname = (bn if bn.startswith("linear_tn") else "linear_nt_deep32_kernel<6>" if bn == "deep256x128x32,nk6" else "linear_nt_deep32_kernel<0>" if bn == "deep256x128x32" else
+            kname = (bn if bn.startswith("linear_tn") else
+                     {"deep256x128x32,nk6": "linear_nt_deep32_kernel<6,128>", "deep256x128x32": "linear_nt_deep32_kernel<0,128>",
+                      "deep256x96x32,nk6": "linear_nt_deep32_kernel<6,96>", "deep256x96x32": "linear_nt_deep32_kernel<0,96>"}[bn] if bn.startswith("deep256") and bn.endswith(("x32", "nk6")) else
                      "linear_nt_deep_kernel" if bn.startswith("deep") else f"linear_nt_kernel<bf16,{bn}>")
             traffic = None                       # PMC counters cannot be read in-process: taken from the committed PMC summary
             try:

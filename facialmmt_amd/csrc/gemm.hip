@@ -454,17 +454,17 @@ __global__ __launch_bounds__(512) void linear_nt_deep_kernel(LinArgs p) {
 // ---------------------------------------------------------------------------------------------
 // Same 256 x 128 tile with K step 32: three 24 KB buffers = 72 KB, so TWO workgroups (16 waves) share a CU and
 // one workgroup's epilogue (GELU, stores) overlaps the other's MFMA loop.  A DMA instruction now covers 16 rows
-// x 64 B; the bank swizzle is chunk ^ ((row >> 3) & 3) for the channel-permuted weight rows and
-// chunk ^ ((row >> 2) & 3) for the token rows (each makes the 16 lanes of a fragment read hit 16 distinct
-// 16-byte slots of the 256-byte bank window).
+// x 64 B; one chunk swizzle serves token rows and channel-permuted weight rows (see swz below).  BN = 96 is the
+// same kernel for N = 96 / 192 / 288 / 576 (48-channel wave slabs, 67.5 KB of LDS).
 // ---------------------------------------------------------------------------------------------
 // NK: compile-time number of K steps (6 for the K = 192 stage-1 problems, which are HBM-bound and get their own
 // fully unrolled instantiation), 0 = run-time.
-template <int NK>
+template <int NK, int BN>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4)))
 void linear_nt_deep32_kernel(LinArgs p) {
     using T = bf16;
-    constexpr int BM = 256, BN = 128, BK = 32, PITCH = 32, MT = 4, NT = 4, CW = 16;
+    constexpr int BM = 256, BK = 32, PITCH = 32, MT = 4, NT = BN / 32, CW = 4 * NT, WN = BN / 2;
+    static_assert(BN == 128 || BN == 96, "block tile is 256 x 128 or 256 x 96");
     constexpr int STAGE = (BM + BN) * PITCH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* S = reinterpret_cast<T*>(smem);                     // [3][BN rows of W | BM rows of X][32]
@@ -481,17 +481,28 @@ void linear_nt_deep32_kernel(LinArgs p) {
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
     const int r16 = lane >> 2, c = lane & 3;
+    // bank swizzle of the four 16-byte chunks of a 64-byte row: ((row >> 3) ^ (row >> 2)) & 3 gives 16 distinct slots of
+    // the 256-byte bank window both for 16 consecutive rows (token rows, the 4-channel tail of a 48-channel wave slab)
+    // and for the channel-permuted weight rows {8g + q + c0}
+    auto swz = [](int row) { return ((row >> 3) ^ (row >> 2)) & 3; };
+    // DMA instructions this wave issues per stage (the counted vmcnt below): 2 for X, +1 if it owns a group of W rows
+    const bool w_owner = BN == 128 || wave < BN / 16;
+    auto wait_stage = [&](bool next_in_flight) {
+        if (!next_in_flight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (w_owner) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    };
     auto issue = [&](int buf, int k0) {
         T* base = S + buf * STAGE;
-        {                                                  // 1 DMA instruction per wave for W (8 x 16 rows)
+        if (BN == 128 || wave < BN / 16) {                 // W: BN / 16 groups of 16 rows, one DMA instruction each
             const int row = wave * 16 + r16;
-            const T* src = wg + (size_t)min(n0 + row, p.N - 1) * p.ldw + k0 + ((c ^ ((row >> 3) & 3)) << 3);
+            const T* src = wg + (size_t)min(n0 + row, p.N - 1) * p.ldw + k0 + ((c ^ swz(row)) << 3);
             __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(base + wave * 16 * PITCH), 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {                      // 2 DMA instructions per wave for X (16 x 16 rows)
             const int grp = i * 8 + wave, row = grp * 16 + r16;
-            const T* src = xg + (size_t)min(m0 + row, p.M - 1) * p.ldx + k0 + ((c ^ ((row >> 2) & 3)) << 3);
+            const T* src = xg + (size_t)min(m0 + row, p.M - 1) * p.ldx + k0 + ((c ^ swz(row)) << 3);
             __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(base + (BN + grp * 16) * PITCH), 16, 0, 0);
         }
     };
@@ -504,13 +515,13 @@ void linear_nt_deep32_kernel(LinArgs p) {
     int woff[NT], xoff[MT];
 #pragma unroll
     for (int b = 0; b < NT; ++b) {
-        const int r = wn * 64 + chan_of<CW>(b, li >> 2, li & 3);
-        woff[b] = r * PITCH + ((lg ^ ((r >> 3) & 3)) << 3);
+        const int r = wn * WN + chan_of<CW>(b, li >> 2, li & 3);
+        woff[b] = r * PITCH + ((lg ^ swz(r)) << 3);
     }
 #pragma unroll
     for (int a = 0; a < MT; ++a) {
         const int r = wm * 64 + a * 16 + li;
-        xoff[a] = (BN + r) * PITCH + ((lg ^ ((r >> 2) & 3)) << 3);
+        xoff[a] = (BN + r) * PITCH + ((lg ^ swz(r)) << 3);
     }
 
     auto compute = [&](int buf) {
@@ -531,8 +542,7 @@ void linear_nt_deep32_kernel(LinArgs p) {
     if constexpr (NK > 0) {
 #pragma unroll
         for (int kt = 0; kt < NK; ++kt) {
-            if (kt + 1 < NK) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wait_stage(kt + 1 < NK);
             __builtin_amdgcn_s_barrier();
             if (kt + 2 < NK) issue((kt + 2) % 3, (kt + 2) * BK);
             compute(kt % 3);
@@ -540,15 +550,14 @@ void linear_nt_deep32_kernel(LinArgs p) {
     } else {
         int cur = 0;
         for (int kt = 0; kt < nk; ++kt) {
-            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wait_stage(kt + 1 < nk);
             __builtin_amdgcn_s_barrier();
             if (kt + 2 < nk) issue(cur == 0 ? 2 : cur - 1, (kt + 2) * BK);
             compute(cur);
             cur = cur == 2 ? 0 : cur + 1;
         }
     }
-    nt_epilogue<T, MT, NT>(p, acc, m0 + wm * 64, n0 + wn * 64, li, lg);
+    nt_epilogue<T, MT, NT>(p, acc, m0 + wm * 64, n0 + wn * WN, li, lg);
 }
 
 // (A "wide-wave" variant -- the same 256 x 128 block computed by four waves with 128 x 64 wave tiles, 0.375 KB of
@@ -622,34 +631,45 @@ int dispatch_nt(const LinArgs& a, hipStream_t st) {
         // -4 % on the 31360-token stage-3 shapes (tile quantisation at one workgroup per CU) -> only for M >= 65536
         static const int deep = getenv("FMMT_NT_DEEP") ? atoi(getenv("FMMT_NT_DEEP")) : 1;
         static const int deep_mink = getenv("FMMT_NT_DEEP_MINK") ? atoi(getenv("FMMT_NT_DEEP_MINK")) : 192;
-        if (deep && a.M >= 65536 && !a.ksplit && a.N % 128 == 0 && a.K % 32 == 0 && a.K >= deep_mink && a.ldx % 8 == 0 && a.ldw % 8 == 0 &&
-            (a.K % 64 == 0 || deep == 1 || deep == 2)) {
+        static const int deep96 = getenv("FMMT_NT_DEEP96") ? atoi(getenv("FMMT_NT_DEEP96")) : 1;
+        const bool big = deep && a.M >= 65536 && !a.ksplit && a.K % 32 == 0 && a.K >= deep_mink && a.ldx % 8 == 0 && a.ldw % 8 == 0;
+        if (big && (a.N % 128 == 0 || (n96 && deep96)) && (a.K % 64 == 0 || deep == 1 || deep == 2)) {
             constexpr size_t lds = (size_t)3 * (256 + 128) * 64 * 2;
+            constexpr size_t lds96 = (size_t)3 * (256 + 96) * 32 * 2;
             static bool attr_set = false;
             if (!attr_set) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_nt_deep_kernel),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                if (e != hipSuccess) return (int)e;
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_nt_deep32_kernel<0>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds / 2);
-                if (e != hipSuccess) return (int)e;
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_nt_deep32_kernel<6>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds / 2);
-                if (e != hipSuccess) return (int)e;
+                const void* fns[] = {reinterpret_cast<const void*>(&linear_nt_deep_kernel),
+                                     reinterpret_cast<const void*>(&linear_nt_deep32_kernel<0, 128>),
+                                     reinterpret_cast<const void*>(&linear_nt_deep32_kernel<6, 128>),
+                                     reinterpret_cast<const void*>(&linear_nt_deep32_kernel<0, 96>),
+                                     reinterpret_cast<const void*>(&linear_nt_deep32_kernel<6, 96>)};
+                const int sizes[] = {(int)lds, (int)lds / 2, (int)lds / 2, (int)lds96, (int)lds96};
+                for (int i = 0; i < 5; ++i) {
+                    hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, sizes[i]);
+                    if (e != hipSuccess) return (int)e;
+                }
                 attr_set = true;
             }
             LinArgs p = a;
-            p.tiles_n = a.N / 128;
             p.tiles_m = (a.M + 255) / 256;
+            if (n96) {
+                p.tiles_n = a.N / 96;
+                if (a.K == 192) hipLaunchKernelGGL((linear_nt_deep32_kernel<6, 96>), dim3(p.tiles_m * p.tiles_n), dim3(512), lds96, st, p);
+                else hipLaunchKernelGGL((linear_nt_deep32_kernel<0, 96>), dim3(p.tiles_m * p.tiles_n), dim3(512), lds96, st, p);
+                FMMT_CHECK_LAUNCH();
+                return 0;
+            }
+            p.tiles_n = a.N / 128;
             // measured (tests/gpu_gemm_bench.py, 125440 tokens): the K-step-32 kernel with two workgroups per CU wins
             // where the epilogue is a large share of a tile's life -- GELU / GELU' launches (0.388 -> 0.340 ms) and
             // K = 384 (384x384: 0.069 -> 0.057 ms); the K-step-64 kernel keeps a 2-4 % edge on plain K >= 1152.
             // FMMT_NT_DEEP: 1 = this policy, 2 = always K step 32, 4 = always K step 64, 0 = 128-row kernels only
-            if (deep == 2 || (deep == 1 && (a.epi != 0 || a.K <= 512)) || a.K % 64 != 0)
-                if (a.K == 192) hipLaunchKernelGGL(linear_nt_deep32_kernel<6>, dim3(p.tiles_m * p.tiles_n), dim3(512), lds / 2, st, p);
-                else hipLaunchKernelGGL(linear_nt_deep32_kernel<0>, dim3(p.tiles_m * p.tiles_n), dim3(512), lds / 2, st, p);
-            else
+            if (deep == 2 || (deep == 1 && (a.epi != 0 || a.K <= 512)) || a.K % 64 != 0) {
+                if (a.K == 192) hipLaunchKernelGGL((linear_nt_deep32_kernel<6, 128>), dim3(p.tiles_m * p.tiles_n), dim3(512), lds / 2, st, p);
+                else hipLaunchKernelGGL((linear_nt_deep32_kernel<0, 128>), dim3(p.tiles_m * p.tiles_n), dim3(512), lds / 2, st, p);
+            } else {
                 hipLaunchKernelGGL(linear_nt_deep_kernel, dim3(p.tiles_m * p.tiles_n), dim3(512), lds, st, p);
+            }
             FMMT_CHECK_LAUNCH();
             return 0;
         }
