@@ -115,7 +115,7 @@ class KernelTimer:
             bn = 96 if (N % 96 == 0 and N % 128 != 0) else 128
             bn = f"{bn},96,1" if K == 96 else f"{bn},64,1" if K <= 64 else f"{bn},64,2" if K % 64 == 0 else f"{bn},32,2"
             bn = f"{64 if M <= 4096 else 128},{bn}" + (",glds" if (K % 64 == 0 and K > 64) else "")
-            if M >= 65536 and K % 32 == 0 and K >= 192 and (N % 128 == 0 or N % 96 == 0):
+            if M >= 65536 and K % 32 == 0 and K >= 96 and (N % 128 == 0 or N % 96 == 0) and not (K == 96 and kw.get("epi", 0) == 1):
                 if N % 128 == 0:
                     bn = "deep256x128x32,nk6" if K == 192 else "deep256x128x32" if (kw.get("epi", 0) != 0 or K <= 512 or K % 64) else "deep256x128x64"
                 else:

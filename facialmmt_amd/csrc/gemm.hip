@@ -630,9 +630,12 @@ int dispatch_nt(const LinArgs& a, hipStream_t st) {
         // measured (tests/gpu_gemm_bench.py): +8 % on the 125440-token stage-2 shapes (K = 384: 496 -> 540 TF/s),
         // -4 % on the 31360-token stage-3 shapes (tile quantisation at one workgroup per CU) -> only for M >= 65536
         static const int deep = getenv("FMMT_NT_DEEP") ? atoi(getenv("FMMT_NT_DEEP")) : 1;
-        static const int deep_mink = getenv("FMMT_NT_DEEP_MINK") ? atoi(getenv("FMMT_NT_DEEP_MINK")) : 192;
+        static const int deep_mink = getenv("FMMT_NT_DEEP_MINK") ? atoi(getenv("FMMT_NT_DEEP_MINK")) : 96;
         static const int deep96 = getenv("FMMT_NT_DEEP96") ? atoi(getenv("FMMT_NT_DEEP96")) : 1;
-        const bool big = deep && a.M >= 65536 && !a.ksplit && a.K % 32 == 0 && a.K >= deep_mink && a.ldx % 8 == 0 && a.ldw % 8 == 0;
+        // K = 96 (stage 0, three K steps): -5..7 % with the deep kernel except for the GELU + pre-activation launch
+        // (two output streams; measured +2 %), which keeps the single-step kernel
+        const bool big = deep && a.M >= 65536 && !a.ksplit && a.K % 32 == 0 && a.K >= deep_mink && a.ldx % 8 == 0 && a.ldw % 8 == 0 &&
+                         !(a.K == 96 && a.epi == FMMT_EPI_GELU);
         if (big && (a.N % 128 == 0 || (n96 && deep96)) && (a.K % 64 == 0 || deep == 1 || deep == 2)) {
             constexpr size_t lds = (size_t)3 * (256 + 128) * 64 * 2;
             constexpr size_t lds96 = (size_t)3 * (256 + 96) * 32 * 2;
