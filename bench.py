@@ -47,7 +47,8 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graphs", type=int, default=1, help="capture the multimodal model (fwd+bwd) as HIP graphs (1) or launch eagerly (0)")
-    ap.add_argument("--force-ddp", action="store_true", help="wrap in DDP even with one process (exercises the N>1 code path on one GPU)")
+    ap.add_argument("--overlap-text", type=int, default=1, help="replay the text-encoder graph on a second HIP stream, concurrently with Swin (needs --graphs 1)")
+    ap.add_argument("--force-ddp", action="store_true", help="run the data-parallel gradient exchange path even with one process (exercises the N>1 code path on one GPU)")
     ap.add_argument("--shape-report", default=None, help="write a per-GEMM-shape timing table to this file (development aid)")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames in the CPU-baseline Swin sample")
     return ap.parse_args()
@@ -280,6 +281,8 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the hot path has no CPU fallback)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if rank != 0:                                           # only rank 0 reports; keep other ranks' C-level banners out of stdout
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
     if world > 1 or args.force_ddp:
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", WORLD_SIZE="1")
@@ -287,7 +290,6 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
     from facialmmt_amd.config import default_args
-    from facialmmt_amd.parallel import wrap_ddp
     from facialmmt_amd.train_step import TargetStep
     cfg = default_args(get_vision_utt_max_lens=args.frames, trg_accumulation_steps=1)
     swin, mm = build_models(args, dev, cfg)
@@ -298,14 +300,23 @@ def main():
             preds = swin(batch[8][:8], is_trg_task=True).float().repeat(batch[8].shape[0] // 8, 1)
         vis, nmask = select_frames(preds, batch[5], batch[6], batch[9], cfg.FacialEmoImpor_threshold)
         sample = (batch[0], batch[1], batch[2], batch[3], batch[4], vis.detach().requires_grad_(True), nmask, batch[10])
-        mm = graph_multimodal(mm, sample, torch.bfloat16 if args.dtype == "bf16" else None)
+        mm = graph_multimodal(mm, sample, torch.bfloat16 if args.dtype == "bf16" else None, overlap_text=bool(args.overlap_text))
         mm.zero_grad(set_to_none=True)
         swin.zero_grad(set_to_none=True)
-    ddp = wrap_ddp(mm, dev) if (world > 1 or args.force_ddp) else None
+    averager = None
+    if world > 1 or args.force_ddp:
+        # gradient mean over ranks for the parameters this step's optimizer updates (parallel.GradientAverager); two
+        # stream groups: the text branch's gradients are produced on the second HIP stream
+        from facialmmt_amd.parallel import GradientAverager, broadcast_parameters
+        broadcast_parameters(mm)
+        plm = mm.roberta if mm.text_pretrained_model == "roberta" else mm.bert
+        text_params = list(plm.parameters()) + list(mm.text_linear.parameters())
+        text_ids = set(map(id, text_params))
+        averager = GradientAverager(None, groups=[[p for p in mm.parameters() if id(p) not in text_ids], text_params])
     # (bf16 text-encoder parameters with fp32 masters in the optimizer were measured: 113.4 vs 110.4 ms -- no gain)
     opt = torch.optim.AdamW(mm.parameters(), lr=cfg.trg_lr, weight_decay=cfg.weight_decay, fused=True)
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: min(1.0, (s + 1) / 100.0))
-    step = TargetStep(swin, mm, opt, sched, cfg, autocast_dtype=torch.bfloat16 if args.dtype == "bf16" else None, ddp_model=ddp)
+    step = TargetStep(swin, mm, opt, sched, cfg, autocast_dtype=torch.bfloat16 if args.dtype == "bf16" else None, averager=averager)
     timer = KernelTimer()
     timer.install()
 
@@ -333,6 +344,24 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # After the timed region (not part of `value`): the same kernels with the text encoder back on the main stream.
+    # During the timed steps the text-encoder graph shares the CUs with Swin's launches, which stretches every Swin
+    # kernel; two extra steps without that overlap give the kernel's own rate next to the live one.
+    iso = None
+    if args.graphs and args.overlap_text and getattr(mm, "text_stream", None) is not None:
+        timed_events, timer.events = timer.events, []
+        side, mm.text_stream = mm.text_stream, None
+        step(batch)
+        timer.enabled = rank == 0
+        for _ in range(2):
+            step(batch)
+        torch.cuda.synchronize()
+        timer.enabled = False
+        mm.text_stream = side
+        iso, timer.events = timer.summary(), timed_events
+        if world > 1:
+            dist.barrier()
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -362,6 +391,10 @@ def main():
                     "traffic": traffic, "algorithmic_bytes_per_launch": round(by / cnt), "launches_per_step": cnt // args.steps,
                     "avg_launch_us": round(sec / cnt * 1e6, 1), "algorithmic_GB_per_s": round(by / sec / 1e9, 0),
                     "share_of_step": round(sec / elapsed, 3)}
+            if iso and bn in iso:
+                icnt, ifl, iby, isec = iso[bn]
+                roof["without_text_stream_overlap"] = {"achieved": round(ifl / isec / 1e12, 1), "frac": round(ifl / isec / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                                       "avg_launch_us": round(isec / icnt * 1e6, 1), "steps": 2}
         flops_step = args.utts * (args.frames * SWIN_FWD_GFLOP_PER_FRAME * 3 + (335 + 29.7) * 3) * 1e9
         line = {
             "metric": "utterances/sec T+A+V forward+bwd, 160-frame face seq, 1/2/4/8 GPU",
@@ -373,16 +406,25 @@ def main():
                        "global_batch": args.utts * world, "frames_per_step_per_gpu": args.utts * args.frames,
                        "parallelism": f"dp{world}", "kept_frame_fraction": round(float(kept.mean().item()), 3),
                        "model_tflops_per_s_per_gpu": round(flops_step / (ms * 1e-3) / 1e12, 1),
-                       "host_enqueue_ms_per_step": round(issue_s / args.steps * 1e3, 1), "hip_graphs": bool(args.graphs),
+                       "host_enqueue_ms_per_step": round(issue_s / args.steps * 1e3, 1), "hip_graphs": bool(args.graphs), "text_encoder_on_second_stream": bool(args.graphs and args.overlap_text),
+                       "second_stream_pair_over_single": round(float(getattr(mm, "text_stream_concurrency", 0.0)), 2),
                        "host_ms_per_phase": {k: round(v / args.steps, 1) for k, v in step.host_ms.items()}},
             "roofline": roof,
             "cpu_baseline": None,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, cfg)
-        print(json.dumps(line), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints a version banner through C stdio (block-buffered when stdout is a pipe): flush it first so that
+        # the JSON line is the LAST line of this process's stdout
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

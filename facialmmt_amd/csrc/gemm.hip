@@ -634,7 +634,8 @@ int dispatch_nt(const LinArgs& a, hipStream_t st) {
         static const int deep96 = getenv("FMMT_NT_DEEP96") ? atoi(getenv("FMMT_NT_DEEP96")) : 1;
         // K = 96 (stage 0, three K steps): -5..7 % with the deep kernel except for the GELU + pre-activation launch
         // (two output streams; measured +2 %), which keeps the single-step kernel
-        const bool big = deep && a.M >= 65536 && !a.ksplit && a.K % 32 == 0 && a.K >= deep_mink && a.ldx % 8 == 0 && a.ldw % 8 == 0 &&
+        static const int deep_minm = getenv("FMMT_NT_DEEP_MINM") ? atoi(getenv("FMMT_NT_DEEP_MINM")) : 65536;
+        const bool big = deep && a.M >= deep_minm && !a.ksplit && a.K % 32 == 0 && a.K >= deep_mink && a.ldx % 8 == 0 && a.ldw % 8 == 0 &&
                          !(a.K == 96 && a.epi == FMMT_EPI_GELU);
         if (big && (a.N % 128 == 0 || (n96 && deep96)) && (a.K % 64 == 0 || deep == 1 || deep == 2)) {
             constexpr size_t lds = (size_t)3 * (256 + 128) * 64 * 2;

@@ -138,15 +138,17 @@ class MultiModalTransformerForClassification(nn.Module):
             return cls(plm_config, add_pooling_layer=False) if getattr(config, "plm_no_pooler", False) else cls(plm_config)
         return cls.from_pretrained(config.pretrainedtextmodel_path)
 
-    def forward(self, batch_text_input_ids=None, batch_text_input_mask=None, batch_text_sep_mask=None,
-                audio_inputs=None, audio_mask=None, vision_inputs=None, new_vision_mask=None, batchUtt_in_dia_idx=None):
+    # ---- the forward in two branches (the text branch does not depend on the visual path) ------------------
+    def text_branch(self, batch_text_input_ids, batch_text_input_mask, batch_text_sep_mask, batchUtt_in_dia_idx):
+        """PLM -> text_linear -> tokens of the target utterance (ref :95-150): (B, L_t, H), mask (B, L_t)"""
         plm = self.roberta if self.text_pretrained_model == 'roberta' else self.bert
         text_out = plm(batch_text_input_ids, batch_text_input_mask)[0]                   # (B, T, plm_hidden)
         text_utt_linear = self.text_linear(text_out.to(self.text_linear.weight.dtype))
-        text_feat, text_mask = slice_target_utterance(text_utt_linear, batch_text_sep_mask, batchUtt_in_dia_idx,
-                                                      self.get_text_utt_max_lens, self.text_pretrained_model == 'roberta')
-        del text_utt_linear
+        return slice_target_utterance(text_utt_linear, batch_text_sep_mask, batchUtt_in_dia_idx,
+                                      self.get_text_utt_max_lens, self.text_pretrained_model == 'roberta')
 
+    def fusion_branch(self, text_feat, text_mask, audio_inputs, audio_mask, vision_inputs, new_vision_mask):
+        """self-attention encoders, four cross-modal calls, pooling, classifier (ref :152-188)"""
         audio_ext = (1.0 - audio_mask.unsqueeze(1).unsqueeze(2)) * -10000.0
         audio_utt = self.audio_utt_transformer(self.audio_linear(audio_inputs), audio_ext)
         vision_ext = (1.0 - new_vision_mask.unsqueeze(1).unsqueeze(2)) * -10000.0
@@ -168,6 +170,41 @@ class MultiModalTransformerForClassification(nn.Module):
 
         pooled, _ = self.attention(final, final_mask)
         return self.classifier(self.dropout(pooled))
+
+    def launch_text(self, batch_text_input_ids, batch_text_input_mask, batch_text_sep_mask, batchUtt_in_dia_idx):
+        """Optional: issue the text branch NOW on `self.text_stream` (a second HIP stream) and let the next forward() pick
+        the result up.  A training step calls this before it enqueues the Swin forward: the text encoder's many small
+        launches then run concurrently with Swin's large ones, and -- because autograd replays a node on the stream of
+        its forward, and processes later-created nodes first -- its backward is issued right after Swin's backward has
+        been enqueued and overlaps with it as well.  Without a text stream this is a no-op."""
+        side = getattr(self, "text_stream", None)
+        if side is None or not batch_text_input_ids.is_cuda:
+            return
+        text_call = getattr(self, "_text_call", None) or self.text_branch
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self._pending_text = text_call(batch_text_input_ids, batch_text_input_mask, batch_text_sep_mask,
+                                           torch.as_tensor(batchUtt_in_dia_idx, device=batch_text_input_ids.device))
+
+    def forward(self, batch_text_input_ids=None, batch_text_input_mask=None, batch_text_sep_mask=None,
+                audio_inputs=None, audio_mask=None, vision_inputs=None, new_vision_mask=None, batchUtt_in_dia_idx=None):
+        """Same signature and result as the reference's forward.  `_text_call` / `_fusion_call` are the two branches
+        (replaced by their HIP-graph replays by train_step.graph_multimodal); a text branch already in flight on the
+        second stream (launch_text) is joined here."""
+        fusion_call = getattr(self, "_fusion_call", None) or self.fusion_branch
+        pending = getattr(self, "_pending_text", None)
+        if pending is not None:
+            self._pending_text = None
+            text_feat, text_mask = pending
+            main = torch.cuda.current_stream()
+            main.wait_stream(self.text_stream)
+            text_feat.record_stream(main)                      # produced on the text stream, consumed here
+            text_mask.record_stream(main)
+        else:
+            text_call = getattr(self, "_text_call", None) or self.text_branch
+            text_feat, text_mask = text_call(batch_text_input_ids, batch_text_input_mask, batch_text_sep_mask,
+                                             torch.as_tensor(batchUtt_in_dia_idx, device=batch_text_input_ids.device))
+        return fusion_call(text_feat, text_mask, audio_inputs, audio_mask, vision_inputs, new_vision_mask)
 
 
 class meld_utt_transformer(nn.Module):

@@ -56,17 +56,101 @@ def select_frames(preds, vision_inputs, vision_mask, num_imgs, threshold):
     return torch.cat((inputs, emo.to(inputs.dtype)), dim=-1), mask
 
 
-def graph_multimodal(mm, sample_args, autocast_dtype=None):
+def pick_concurrent_stream(device, candidates: int = 8, cycles: int = 4_000_000):
+    """A HIP stream that really runs concurrently with the current one.  HIP multiplexes streams onto a handful of
+    hardware queues (4 by default) and two streams that share a queue serialise; which queue a new stream lands on
+    depends on how many streams the process created before (RCCL, for one, creates several at process-group
+    initialisation -- measured: the text-encoder overlap vanished in every run that had called init_process_group).
+    So measure it: spin kernels on both streams, keep the first candidate whose pair finishes in about the time
+    of one.  Returns (stream, ratio) with ratio = t(pair) / t(single); falls back to the best candidate."""
+    import time
+    main = torch.cuda.current_stream(device)
+
+    def timed(fn):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize(device)
+        return time.perf_counter() - t0
+    torch.cuda._sleep(cycles)                              # warm up the spin kernel
+    single = min(timed(lambda: torch.cuda._sleep(cycles)) for _ in range(3))
+    best, best_ratio, keep = None, float("inf"), []
+    for _ in range(candidates):
+        s = torch.cuda.Stream(device=device)
+        keep.append(s)                                     # keep candidates alive so that the next one is a new stream
+
+        def pair():
+            s.wait_stream(main)
+            torch.cuda._sleep(cycles)
+            with torch.cuda.stream(s):
+                torch.cuda._sleep(cycles)
+        ratio = min(timed(pair) for _ in range(2)) / single
+        if ratio < best_ratio:
+            best, best_ratio = s, ratio
+        if ratio < 1.3:
+            break
+    return best, best_ratio
+
+
+class _Branch(torch.nn.Module):
+    """One branch of the multimodal forward as a module of its own, so that torch.cuda.make_graphed_callables sees
+    exactly the parameters it uses.  Shares the owner's sub-modules (same Parameter objects); never registered on the
+    owner, so state_dict keys are untouched."""
+
+    def __init__(self, owner, fn_name, submodules):
+        super().__init__()
+        self._fn = getattr(owner, fn_name)
+        for i, m in enumerate(submodules):
+            self.add_module(f"m{i}", m)
+
+    def forward(self, *args):
+        return self._fn(*args)
+
+
+def graph_multimodal(mm, sample_args, autocast_dtype=None, overlap_text=True):
     """Capture forward and backward of the multimodal model as HIP graphs (torch.cuda.make_graphed_callables):
     its ~4000 small launches per step (24 PLM layers, 7 self-attention layers, 8 cross-modal layer calls) are
     host-bound when issued one by one (measured: 112 ms of host time per step against 105 ms of GPU work).
     Everything on that path is capture-safe: no host synchronisation, dropout seeds drawn on the device,
     bf16 weight shadows re-cast inside the graph.  Shapes are static (fixed synthetic batch).
+
+    Two graphs are captured: the text branch (PLM -> text_linear -> slicing) and the fusion branch.  With
+    `overlap_text` the text branch replays on a second HIP stream (`mm.text_stream`): it does not depend on the
+    visual path, and its small launches fill the CUs that Swin's large launches leave idle between waves
+    (measured on an MI355X: text encoder 28.4 ms + Swin 52.9 ms = 82.8 ms back to back, 66.9 ms concurrently).
     Returns the module (its forward now replays the graphs)."""
     import contextlib
+    ids, attn_mask, sep_mask, audio, audio_mask, vision, vision_mask, utt_idx = sample_args
+    utt_idx = torch.as_tensor(utt_idx, device=ids.device)
+    plm = mm.roberta if mm.text_pretrained_model == 'roberta' else mm.bert
+    text = _Branch(mm, "text_branch", [plm, mm.text_linear])
+    fusion = _Branch(mm, "fusion_branch", [mm.audio_linear, mm.audio_utt_transformer, mm.vision_linear, mm.vision_utt_transformer,
+                                           mm.attention, mm.CrossModalTrans_TA, mm.CrossModalTrans_TA_V, mm.dropout, mm.classifier])
+    B = ids.shape[0]
+    act = autocast_dtype if autocast_dtype is not None else torch.float32
+    text_feat = torch.zeros(B, mm.get_text_utt_max_lens, mm.hidden_size, device=ids.device, dtype=act, requires_grad=True)
+    text_mask = torch.ones(B, mm.get_text_utt_max_lens, device=ids.device)
+    side = None
+    if overlap_text:
+        # The gradient accumulators of the text branch's parameters must live on the text stream too: autograd runs
+        # AccumulateGrad on the stream that was current when the node was created, and a node created on the main
+        # stream would make the main stream wait for the whole text backward before Swin's backward could start.
+        # Create them now, under the text stream, and keep them alive (DDP, wrapped later, finds these same nodes).
+        side, ratio = pick_concurrent_stream(ids.device)
+        mm.text_stream_concurrency = ratio                 # ~1.0: truly concurrent with the main stream; ~2.0: serialised
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            mm._text_grad_accumulators = [p.expand_as(p).grad_fn.next_functions[0][0] for p in text.parameters() if p.requires_grad]
+        torch.cuda.current_stream().wait_stream(side)
     ctx = torch.autocast("cuda", dtype=autocast_dtype, cache_enabled=False) if autocast_dtype is not None else contextlib.nullcontext()
     with ctx:
-        return torch.cuda.make_graphed_callables(mm, tuple(sample_args), num_warmup_iters=3)
+        gtext, gfusion = torch.cuda.make_graphed_callables(
+            (text, fusion),
+            ((ids, attn_mask, sep_mask, utt_idx), (text_feat, text_mask, audio, audio_mask, vision, vision_mask)),
+            num_warmup_iters=3)
+    mm._text_call, mm._fusion_call = gtext, gfusion
+    mm.text_stream = side
+    return mm
 
 
 class TargetStep:
@@ -75,10 +159,13 @@ class TargetStep:
     optimizer steps here; Swin receives gradients through the emotion features and is updated by the
     auxiliary task's optimizer (train.py:31), so its gradients are dropped after each step."""
 
-    def __init__(self, swin_model, multimodal_model, optimizer, scheduler, args, autocast_dtype=None, ddp_model=None):
+    def __init__(self, swin_model, multimodal_model, optimizer, scheduler, args, autocast_dtype=None, ddp_model=None, averager=None):
+        """Data parallel: pass `averager` (parallel.GradientAverager over the multimodal parameters) or, alternatively,
+        `ddp_model` (the module wrapped by torch's DistributedDataParallel)."""
         self.swin = swin_model
         self.mm = multimodal_model
         self.mm_call = ddp_model if ddp_model is not None else multimodal_model
+        self.exchange = averager if averager is not None else ddp_model
         self.opt = optimizer
         self.sched = scheduler
         self.args = args
@@ -95,6 +182,13 @@ class TargetStep:
         def mark(name):
             t.append(time.perf_counter())
             self.host_ms[name] = self.host_ms.get(name, 0.0) + (t[-1] - t[-2]) * 1e3
+        if getattr(self.mm, "text_stream", None) is not None:
+            # start the text branch on its own stream before the Swin forward is enqueued (models.launch_text)
+            if self.autocast_dtype is not None:
+                with torch.autocast("cuda", dtype=self.autocast_dtype):
+                    self.mm.launch_text(ids, attn_mask, sep_mask, utt_idx)
+            else:
+                self.mm.launch_text(ids, attn_mask, sep_mask, utt_idx)
         preds = self.swin(frames, is_trg_task=True)                                  # (sumF, 7), Gumbel-softmax
         mark("swin_fwd")
         vis_concat, new_mask = select_frames(preds.float(), vision_inputs, vision_mask, num_imgs, args.FacialEmoImpor_threshold)
@@ -106,16 +200,25 @@ class TargetStep:
             logits = self.mm_call(ids, attn_mask, sep_mask, audio, audio_mask, vis_concat, new_mask, utt_idx)
         mark("multimodal_fwd")
         loss = F.cross_entropy(logits.float(), labels) / args.trg_accumulation_steps
-        loss.backward()
-        mark("backward")
         self.i_batch += 1
-        if self.i_batch % args.trg_accumulation_steps == 0:
+        last = self.i_batch % args.trg_accumulation_steps == 0
+        from .parallel import GradientAverager, accumulate
+        with accumulate(self.exchange, last):                # gradient exchange only on the last micro-step
+            loss.backward()
+        mark("backward")
+        if last:
+            averager = self.exchange if isinstance(self.exchange, GradientAverager) else None
+            if averager is not None:
+                averager.finish()
             torch.nn.utils.clip_grad_norm_(self.mm.parameters(), args.clip)
             mark("clip")
             self.opt.step()
             if self.sched is not None:
                 self.sched.step()
-            self.opt.zero_grad(set_to_none=True)
+            if averager is not None:
+                averager.zero_grad()                         # the .grad views into the flat buckets must survive
+            else:
+                self.opt.zero_grad(set_to_none=True)
             mark("optimizer")
         self.swin.zero_grad(set_to_none=True)
         return loss.detach(), new_mask

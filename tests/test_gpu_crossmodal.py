@@ -168,10 +168,12 @@ def test_hip_graph_replay_matches_eager(dev):
         for p in model.parameters():
             p.grad = None
         vis = (inp[5] * scale).clone().requires_grad_(True)
+        model.launch_text(inp[0], inp[1], inp[2], inp[7])      # no-op before graphing; second HIP stream afterwards
         out = model(inp[0], inp[1], inp[2], inp[3], inp[4], vis, inp[6], inp[7])
         out.square().sum().backward()
         g = model.CrossModalTrans_TA.layers[0].fc1.weight.grad.clone()
-        return out.detach().clone(), vis.grad.clone(), g
+        gt = model.text_linear.weight.grad.clone()            # produced by the text branch (second stream when graphed)
+        return out.detach().clone(), vis.grad.clone(), g, gt
 
     eager = [run(mm, s) for s in (1.0, 0.5)]
     sample = (inp[0], inp[1], inp[2], inp[3], inp[4], inp[5].clone().requires_grad_(True), inp[6], inp[7])

@@ -80,6 +80,50 @@ def test_two_rank_gradient_equals_single_process():
             assert torch.allclose(ret[r][k], p.grad, atol=1e-5, rtol=1e-4), k
 
 
+def _worker_averager(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from facialmmt_amd.parallel import GradientAverager, accumulate, broadcast_parameters, shard_utterances
+    m = _model()
+    if rank == 1:                                           # rank 1 starts from different values: the broadcast must fix that
+        with torch.no_grad():
+            for p in m.parameters():
+                p.add_(1.0)
+    broadcast_parameters(m)
+    # two stream groups (as the text / fusion branches) and buckets of a few KB -> several buckets per group
+    avg = GradientAverager(None, bucket_mb=0, groups=[list(m.inp.parameters()), list(m.mid.parameters()) + list(m.cls.parameters())])
+    assert len(avg.buckets) >= 4
+    x, mask, y = _data()
+    idx = list(shard_utterances(8, rank, world))
+    half = len(idx) // 2
+    out = []
+    for step in range(2):                                   # two optimisation steps: the flat buffers are reused
+        avg.zero_grad()
+        for micro, sl in enumerate((idx[:half], idx[half:])):
+            with accumulate(avg, micro == 1):
+                (torch.nn.functional.cross_entropy(m(x[sl], mask[sl]), y[sl], reduction="sum") / 4.0).backward()
+        avg.finish()
+        out.append({k: p.grad.clone() for k, p in m.named_parameters()})
+    ret[rank] = out
+    dist.destroy_process_group()
+
+
+def test_gradient_averager_equals_single_process():
+    """parallel.GradientAverager (the exchange bench.py uses for N > 1): bucketed async all-reduce with no_sync
+    accumulation over 2 gloo ranks == the single-process gradient of the mean loss, on both of two consecutive steps"""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_averager, args=(world, _free_port(), ret), nprocs=world, join=True)
+    m = _model()
+    x, mask, y = _data()
+    (torch.nn.functional.cross_entropy(m(x, mask), y, reduction="sum") / 8.0).backward()
+    for k, p in m.named_parameters():
+        for r in range(world):
+            for step in range(2):
+                assert torch.allclose(ret[r][step][k], p.grad, atol=1e-5, rtol=1e-4), (k, r, step)
+
+
 def test_shard_utterances_partitions():
     from facialmmt_amd.parallel import shard_utterances
     for n, w in [(32, 8), (16, 4), (8, 8), (7, 4), (1, 2)]:
