@@ -457,8 +457,8 @@ __global__ __launch_bounds__(512) void linear_nt_deep_kernel(LinArgs p) {
 // x 64 B; one chunk swizzle serves token rows and channel-permuted weight rows (see swz below).  BN = 96 is the
 // same kernel for N = 96 / 192 / 288 / 576 (48-channel wave slabs, 67.5 KB of LDS).
 // ---------------------------------------------------------------------------------------------
-// NK: compile-time number of K steps (6 for the K = 192 stage-1 problems, which are HBM-bound and get their own
-// fully unrolled instantiation), 0 = run-time.
+// NK: compile-time number of K steps (3 / 6 for the K = 96 / 192 stage-0 / stage-1 problems, which are HBM streams and
+// get their own fully unrolled instantiations), 0 = run-time.
 template <int NK, int BN>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4)))
 void linear_nt_deep32_kernel(LinArgs p) {
@@ -645,10 +645,12 @@ int dispatch_nt(const LinArgs& a, hipStream_t st) {
                 const void* fns[] = {reinterpret_cast<const void*>(&linear_nt_deep_kernel),
                                      reinterpret_cast<const void*>(&linear_nt_deep32_kernel<0, 128>),
                                      reinterpret_cast<const void*>(&linear_nt_deep32_kernel<6, 128>),
+                                     reinterpret_cast<const void*>(&linear_nt_deep32_kernel<3, 128>),
                                      reinterpret_cast<const void*>(&linear_nt_deep32_kernel<0, 96>),
-                                     reinterpret_cast<const void*>(&linear_nt_deep32_kernel<6, 96>)};
-                const int sizes[] = {(int)lds, (int)lds / 2, (int)lds / 2, (int)lds96, (int)lds96};
-                for (int i = 0; i < 5; ++i) {
+                                     reinterpret_cast<const void*>(&linear_nt_deep32_kernel<6, 96>),
+                                     reinterpret_cast<const void*>(&linear_nt_deep32_kernel<3, 96>)};
+                const int sizes[] = {(int)lds, (int)lds / 2, (int)lds / 2, (int)lds / 2, (int)lds96, (int)lds96, (int)lds96};
+                for (int i = 0; i < 7; ++i) {
                     hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, sizes[i]);
                     if (e != hipSuccess) return (int)e;
                 }
@@ -659,6 +661,7 @@ int dispatch_nt(const LinArgs& a, hipStream_t st) {
             if (n96) {
                 p.tiles_n = a.N / 96;
                 if (a.K == 192) hipLaunchKernelGGL((linear_nt_deep32_kernel<6, 96>), dim3(p.tiles_m * p.tiles_n), dim3(512), lds96, st, p);
+                else if (a.K == 96) hipLaunchKernelGGL((linear_nt_deep32_kernel<3, 96>), dim3(p.tiles_m * p.tiles_n), dim3(512), lds96, st, p);
                 else hipLaunchKernelGGL((linear_nt_deep32_kernel<0, 96>), dim3(p.tiles_m * p.tiles_n), dim3(512), lds96, st, p);
                 FMMT_CHECK_LAUNCH();
                 return 0;
@@ -670,6 +673,7 @@ int dispatch_nt(const LinArgs& a, hipStream_t st) {
             // FMMT_NT_DEEP: 1 = this policy, 2 = always K step 32, 4 = always K step 64, 0 = 128-row kernels only
             if (deep == 2 || (deep == 1 && (a.epi != 0 || a.K <= 512)) || a.K % 64 != 0) {
                 if (a.K == 192) hipLaunchKernelGGL((linear_nt_deep32_kernel<6, 128>), dim3(p.tiles_m * p.tiles_n), dim3(512), lds / 2, st, p);
+                else if (a.K == 96) hipLaunchKernelGGL((linear_nt_deep32_kernel<3, 128>), dim3(p.tiles_m * p.tiles_n), dim3(512), lds / 2, st, p);
                 else hipLaunchKernelGGL((linear_nt_deep32_kernel<0, 128>), dim3(p.tiles_m * p.tiles_n), dim3(512), lds / 2, st, p);
             } else {
                 hipLaunchKernelGGL(linear_nt_deep_kernel, dim3(p.tiles_m * p.tiles_n), dim3(512), lds, st, p);
