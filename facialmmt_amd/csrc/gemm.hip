@@ -930,6 +930,9 @@ TnPlan tn_plan(int M, int N, int K) {
     // (leaving head-room for the concurrent text-encoder stream -- 448/672, 384/576 -- measured: no gain)
     const int target = (M <= 262144) ? 512 : 768;
     int splits = target / tiles;
+    // few-token problems (fusion stack: 152-664 rows): one pass over the tokens per output tile, written straight to
+    // dW / db by fmmt_linear_wgrad -- a second launch to add two or three partials costs as much as the contraction
+    if (M <= 768) splits = 1;
     const int max_by_rows = (M + 255) / 256;
     if (splits > max_by_rows) splits = max_by_rows;
     if (splits < 1) splits = 1;
@@ -1004,6 +1007,24 @@ extern "C" size_t fmmt_linear_wgrad_workspace(int M, int N, int K) {
     return tn_plan(M, N, K).bytes;
 }
 
+namespace {
+// the split contraction: part_w [splits][N][K], part_b [splits][N] or nullptr (splits == 1: these may be dw / db themselves)
+int launch_tn_plan(int dtype, int M, int N, int K, const void* dy, int lddy, const void* x, int ldx, float* part_w, float* part_b,
+                   const float* rowscale, int rows_per_scale, hipStream_t st) {
+    const TnPlan pl = tn_plan(M, N, K);
+    static const int tn_xcd = getenv("FMMT_TN_XCD") ? atoi(getenv("FMMT_TN_XCD")) : 1;
+    TnArgs a{M, N, K, dy, lddy, x, ldx, part_w, part_b, rowscale, rows_per_scale, pl.tiles_k, pl.chunk, pl.tiles_n, tn_xcd};
+    dim3 grid(pl.tiles_n * pl.tiles_k * pl.splits);
+    static const int tn_cfg = getenv("FMMT_TN_CFG") ? atoi(getenv("FMMT_TN_CFG")) : 0;
+    // measured (tests/gpu_gemm_bench.py): 64-token steps win for the compute-heavy stage-2/3 shapes (+15-25 %),
+    // 32-token steps (3 workgroups per CU) win for the HBM-bound multi-million-token stage-0/1 shapes
+    const bool bms64 = tn_cfg == 2 || (tn_cfg == 0 && M <= 262144);
+    if (dtype == FMMT_BF16) return M <= 4096 ? launch_tn<bf16, 32, true>(a, grid, st)
+                                             : bms64 ? launch_tn<bf16, 64>(a, grid, st) : launch_tn<bf16, 32>(a, grid, st);
+    return launch_tn<float, 16>(a, grid, st);
+}
+}  // namespace
+
 extern "C" int fmmt_linear_wgrad_partials(int dtype, int M, int N, int K,
                                           const void* dy, int lddy, const void* x, int ldx, int want_bias,
                                           const float* rowscale, int rows_per_scale,
@@ -1016,19 +1037,9 @@ extern "C" int fmmt_linear_wgrad_partials(int dtype, int M, int N, int K,
     if (!aligned16(dy) || !aligned16(x) || !aligned16(workspace)) return FMMT_EALIGN;
     const TnPlan pl = tn_plan(M, N, K);
     if (workspace_bytes < pl.bytes) return FMMT_EWORKSPACE;
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     float* part_w = reinterpret_cast<float*>(workspace);
     float* part_b = want_bias ? part_w + (size_t)pl.splits * N * K : nullptr;
-    static const int tn_xcd = getenv("FMMT_TN_XCD") ? atoi(getenv("FMMT_TN_XCD")) : 1;
-    TnArgs a{M, N, K, dy, lddy, x, ldx, part_w, part_b, rowscale, rows_per_scale, pl.tiles_k, pl.chunk, pl.tiles_n, tn_xcd};
-    dim3 grid(pl.tiles_n * pl.tiles_k * pl.splits);
-    static const int tn_cfg = getenv("FMMT_TN_CFG") ? atoi(getenv("FMMT_TN_CFG")) : 0;
-    // measured (tests/gpu_gemm_bench.py): 64-token steps win for the compute-heavy stage-2/3 shapes (+15-25 %),
-    // 32-token steps (3 workgroups per CU) win for the HBM-bound multi-million-token stage-0/1 shapes
-    const bool bms64 = tn_cfg == 2 || (tn_cfg == 0 && M <= 262144);
-    if (dtype == FMMT_BF16) return M <= 4096 ? launch_tn<bf16, 32, true>(a, grid, st)
-                                             : bms64 ? launch_tn<bf16, 64>(a, grid, st) : launch_tn<bf16, 32>(a, grid, st);
-    return launch_tn<float, 16>(a, grid, st);
+    return launch_tn_plan(dtype, M, N, K, dy, lddy, x, ldx, part_w, part_b, rowscale, rows_per_scale, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int fmmt_linear_wgrad_finish(int M, int N, int K, float* dw, float* db,
@@ -1052,6 +1063,15 @@ extern "C" int fmmt_linear_wgrad(int dtype, int M, int N, int K,
                                  float* dw, float* db, const float* rowscale, int rows_per_scale,
                                  void* workspace, size_t workspace_bytes, void* stream) {
     if (!aligned16(dw)) return FMMT_EALIGN;
+    if (M > 0 && N > 0 && K > 0 && tn_plan(M, N, K).splits == 1) {
+        // single split: the "partials" ARE the result -- let the contraction kernel write dw / db directly
+        const int vec = dtype == FMMT_BF16 ? 8 : 4;
+        if (dtype != FMMT_BF16 && dtype != FMMT_F32) return FMMT_EINVAL;
+        if (N % vec || K % vec || lddy % vec || ldx % vec) return FMMT_EINVAL;
+        if (rowscale && rows_per_scale <= 0) return FMMT_EINVAL;
+        if (!aligned16(dy) || !aligned16(x)) return FMMT_EALIGN;
+        return launch_tn_plan(dtype, M, N, K, dy, lddy, x, ldx, dw, db, rowscale, rows_per_scale, reinterpret_cast<hipStream_t>(stream));
+    }
     if (int rc = fmmt_linear_wgrad_partials(dtype, M, N, K, dy, lddy, x, ldx, db != nullptr, rowscale, rows_per_scale,
                                             workspace, workspace_bytes, stream)) return rc;
     return fmmt_linear_wgrad_finish(M, N, K, dw, db, workspace, workspace_bytes, stream);
