@@ -1,0 +1,72 @@
+"""GPU test of the step scheduling: the target-task step run (a) eagerly on one stream, (b) with the multimodal model
+as two HIP graphs and the text branch on a second HIP stream, (c) the same plus parallel.GradientAverager (persistent
+bucketed gradients, world size 1) must walk the same trajectory -- same losses, same updated parameters -- over three
+optimisation steps.  Dropout inside the multimodal model is off; Swin's DropPath / Gumbel noise replay from the seed."""
+import types
+
+import pytest
+import torch
+
+from facialmmt_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(dev, graphs, averager):
+    from facialmmt_amd import models
+    from facialmmt_amd.config import default_args
+    from facialmmt_amd.parallel import GradientAverager
+    from facialmmt_amd.train_step import TargetStep, graph_multimodal, select_frames
+    import bench
+    B, Lv = 2, 6
+    cfg = default_args(get_vision_utt_max_lens=Lv, get_audio_utt_max_lens=24, trg_accumulation_steps=1, plm_module=synth.make_standin_plm(),
+                       hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, crossmodal_attn_dropout_TA=0.0, crossmodal_attn_dropout_TA_V=0.0)
+    cfg.compute_dtype = torch.float32
+    swin = models.SwinForAffwildClassification(cfg)
+    mm = models.MultiModalTransformerForClassification(cfg)
+    synth.fill_state_dict(swin, seed=100)
+    synth.fill_state_dict(mm, seed=200)
+    swin.to(dev).train()
+    mm.to(dev).train()
+    args = types.SimpleNamespace(utts=B, frames=Lv, dtype="fp32")
+    batch = list(bench.synth_batch(args, dev, 0, cfg))
+    batch[0] = batch[0] % 1000                                  # ids within the stand-in encoder's vocabulary
+    batch = tuple(batch)
+    avg = None
+    if graphs:
+        with torch.no_grad():
+            preds = swin(batch[8], is_trg_task=True).float()
+        vis, nmask = select_frames(preds, batch[5], batch[6], batch[9], cfg.FacialEmoImpor_threshold)
+        sample = (batch[0], batch[1], batch[2], batch[3], batch[4], vis.detach().requires_grad_(True), nmask, batch[10])
+        mm = graph_multimodal(mm, sample, None, overlap_text=True)
+        mm.zero_grad(set_to_none=True)
+        swin.zero_grad(set_to_none=True)
+        assert mm.text_stream is not None
+    if averager:
+        plm = mm.roberta
+        text_params = list(plm.parameters()) + list(mm.text_linear.parameters())
+        ids = set(map(id, text_params))
+        avg = GradientAverager(None, bucket_mb=1, groups=[[p for p in mm.parameters() if id(p) not in ids], text_params])
+    opt = torch.optim.AdamW(mm.parameters(), lr=1e-3, weight_decay=0.0)
+    return TargetStep(swin, mm, opt, None, cfg, autocast_dtype=None, averager=avg), mm, batch
+
+
+@pytest.mark.parametrize("mode", ["graphs+second_stream", "graphs+second_stream+averager"])
+def test_scheduled_step_equals_eager_step(mode):
+    dev = torch.device("cuda:0")
+    runs = {}
+    for name, (graphs, averager) in {"eager": (False, False), mode: (True, "averager" in mode)}.items():
+        step, mm, batch = _build(dev, graphs, averager)
+        losses = []
+        for i in range(3):
+            torch.manual_seed(1234 + i)                          # Swin's DropPath masks and Gumbel noise
+            loss, _ = step(batch)
+            losses.append(loss.item())
+        torch.cuda.synchronize()
+        runs[name] = (losses, {k: v.detach().clone() for k, v in mm.named_parameters()})
+    (l0, p0), (l1, p1) = runs["eager"], runs[mode]
+    assert l0[0] != l0[2]                                        # the optimiser moved something
+    for a, b in zip(l0, l1):
+        assert abs(a - b) <= 2e-4 * max(1.0, abs(a)), (l0, l1)
+    for k in p0:
+        assert torch.allclose(p0[k], p1[k], atol=2e-4, rtol=2e-3), k
