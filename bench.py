@@ -26,6 +26,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # before the HIP runtime initialises: see facialmmt_amd/__init__.py
+
 import torch
 import torch.distributed as dist
 

@@ -5,6 +5,7 @@ the hot path.  Every op raises if the library is missing or a launch fails (no f
 from __future__ import annotations
 
 import math
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -84,28 +85,34 @@ def wgrad_raw(dy2, x2, want_bias, rowscale=None, rows_per_scale=1):
     return dw, db
 
 
-_CAST_CACHE: dict = {}
+_CAST_CACHE: dict = {}          # id(parameter) -> {(offset, shape, stride, dtype, transpose): (version, shadow)}
 
 
 def _lp(w: torch.Tensor, dtype, transpose: bool = False) -> torch.Tensor:
     """Parameter in the activation dtype (fp32 master -> bf16 shadow in throughput mode), optionally
-    transposed+contiguous (the input-gradient GEMM wants W^T row-major).  Shadows of leaf parameters are
-    cached per (storage, version): they are rebuilt only after an optimizer step touched the master copy."""
-    w = w.detach()
-    if w.dtype == dtype and not transpose:
-        return w.contiguous()
-    capturing = w.is_cuda and torch.cuda.is_current_stream_capturing()
-    key = (w.data_ptr(), tuple(w.shape), dtype, transpose)
-    hit = None if capturing else _CAST_CACHE.get(key)       # inside a hipGraph the cast must be part of the graph
-    if hit is not None and hit[0] == w._version:
-        return hit[1]
-    out = w.to(dtype)
+    transposed+contiguous (the input-gradient GEMM wants W^T row-major).  Shadows are cached per parameter OBJECT
+    (for a view such as in_proj_weight[a:b]: its base) and version, and dropped when that object dies -- an
+    address-based key would hand a new model the shadows of a freed one that happened to occupy the same memory.
+    They are rebuilt only after an optimizer step touched the master copy."""
+    base = w._base if w._base is not None else w
+    wd = w.detach()
+    if wd.dtype == dtype and not transpose:
+        return wd.contiguous()
+    capturing = wd.is_cuda and torch.cuda.is_current_stream_capturing()
+    key = (w.storage_offset(), tuple(w.shape), tuple(w.stride()), dtype, transpose)
+    sub = None if capturing else _CAST_CACHE.get(id(base))   # inside a hipGraph the cast must be part of the graph
+    if sub is not None:
+        hit = sub.get(key)
+        if hit is not None and hit[0] == w._version:
+            return hit[1]
+    out = wd.to(dtype)
     out = out.t().contiguous() if transpose else out.contiguous()
     if capturing:
         return out
-    if len(_CAST_CACHE) > 4096:
-        _CAST_CACHE.clear()
-    _CAST_CACHE[key] = (w._version, out)
+    if sub is None:
+        sub = _CAST_CACHE[id(base)] = {}
+        weakref.finalize(base, _CAST_CACHE.pop, id(base), None)
+    sub[key] = (w._version, out)
     return out
 
 

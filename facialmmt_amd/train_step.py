@@ -120,6 +120,11 @@ def graph_multimodal(mm, sample_args, autocast_dtype=None, overlap_text=True):
     (measured on an MI355X: text encoder 28.4 ms + Swin 52.9 ms = 82.8 ms back to back, 66.9 ms concurrently).
     Returns the module (its forward now replays the graphs)."""
     import contextlib
+    import os
+    if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "") != "0":
+        raise RuntimeError("graph_multimodal: DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 must be in the environment before the HIP runtime "
+                           "initialises (import facialmmt_amd before the first CUDA call, or export it): with ROCm 7.0's packet "
+                           "capture, gradients of replayed graphs are wrong from the third replay on")
     ids, attn_mask, sep_mask, audio, audio_mask, vision, vision_mask, utt_idx = sample_args
     utt_idx = torch.as_tensor(utt_idx, device=ids.device)
     plm = mm.roberta if mm.text_pretrained_model == 'roberta' else mm.bert
@@ -148,7 +153,9 @@ def graph_multimodal(mm, sample_args, autocast_dtype=None, overlap_text=True):
             (text, fusion),
             ((ids, attn_mask, sep_mask, utt_idx), (text_feat, text_mask, audio, audio_mask, vision, vision_mask)),
             num_warmup_iters=3)
-    mm._text_call, mm._fusion_call = gtext, gfusion
+    # plain attributes, NOT child modules: the branch wrappers must not show up in mm.state_dict() / named_parameters()
+    object.__setattr__(mm, "_text_call", gtext)
+    object.__setattr__(mm, "_fusion_call", gfusion)
     mm.text_stream = side
     return mm
 

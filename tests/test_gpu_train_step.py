@@ -1,7 +1,8 @@
 """GPU test of the step scheduling: the target-task step run (a) eagerly on one stream, (b) with the multimodal model
 as two HIP graphs and the text branch on a second HIP stream, (c) the same plus parallel.GradientAverager (persistent
-bucketed gradients, world size 1) must walk the same trajectory -- same losses, same updated parameters -- over three
-optimisation steps.  Dropout inside the multimodal model is off; Swin's DropPath / Gumbel noise replay from the seed."""
+bucketed gradients, world size 1) must walk the same trajectory -- same losses, same updated parameters -- over six
+optimisation steps (a ROCm 7.0 HIP-graph defect that corrupts replayed gradients from the third replay on is what this test
+first caught; facialmmt_amd/__init__.py carries the workaround).  Dropout inside the multimodal model is off; Swin's DropPath / Gumbel noise replay from the seed."""
 import types
 
 import pytest
@@ -39,15 +40,17 @@ def _build(dev, graphs, averager):
         vis, nmask = select_frames(preds, batch[5], batch[6], batch[9], cfg.FacialEmoImpor_threshold)
         sample = (batch[0], batch[1], batch[2], batch[3], batch[4], vis.detach().requires_grad_(True), nmask, batch[10])
         mm = graph_multimodal(mm, sample, None, overlap_text=True)
+        assert mm.text_stream is not None
         mm.zero_grad(set_to_none=True)
         swin.zero_grad(set_to_none=True)
-        assert mm.text_stream is not None
     if averager:
         plm = mm.roberta
         text_params = list(plm.parameters()) + list(mm.text_linear.parameters())
         ids = set(map(id, text_params))
         avg = GradientAverager(None, bucket_mb=1, groups=[[p for p in mm.parameters() if id(p) not in ids], text_params])
-    opt = torch.optim.AdamW(mm.parameters(), lr=1e-3, weight_decay=0.0)
+    # plain SGD: linear in the gradients, so run-to-run rounding noise (atomic adds in the embedding backward) stays
+    # at rounding level instead of being renormalised to +-lr by Adam on near-zero gradient entries
+    opt = torch.optim.SGD(mm.parameters(), lr=0.05)
     return TargetStep(swin, mm, opt, None, cfg, autocast_dtype=None, averager=avg), mm, batch
 
 
@@ -58,7 +61,7 @@ def test_scheduled_step_equals_eager_step(mode):
     for name, (graphs, averager) in {"eager": (False, False), mode: (True, "averager" in mode)}.items():
         step, mm, batch = _build(dev, graphs, averager)
         losses = []
-        for i in range(3):
+        for i in range(6):                                      # the ROCm graph replay defect this guards against starts at the third replay
             torch.manual_seed(1234 + i)                          # Swin's DropPath masks and Gumbel noise
             loss, _ = step(batch)
             losses.append(loss.item())
@@ -69,4 +72,4 @@ def test_scheduled_step_equals_eager_step(mode):
     for a, b in zip(l0, l1):
         assert abs(a - b) <= 2e-4 * max(1.0, abs(a)), (l0, l1)
     for k in p0:
-        assert torch.allclose(p0[k], p1[k], atol=2e-4, rtol=2e-3), k
+        assert (p0[k] - p1[k]).abs().max().item() <= 1e-4 * max(1.0, p0[k].abs().max().item()), k

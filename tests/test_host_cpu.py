@@ -150,3 +150,29 @@ def test_swin_mac_formula_matches_survey():
     from oracle.swin import swin_macs_per_frame
     m = swin_macs_per_frame()
     assert abs(m["total"] / 1e9 - 4.5128) < 2e-3 and abs(m["stage0"] / 1e6 - 811.9) < 0.2 and abs(m["head"] / 1e6 - 19.27) < 0.01
+
+
+def test_shadow_cache_is_per_parameter_object_not_per_address():
+    """ops._lp: a new parameter that lands on the memory (and version count) of a dead one must not be served the dead
+    one's cached shadow; views of one parameter (in_proj_weight[a:b]) share the parameter's cache and see its updates."""
+    import gc
+    from facialmmt_amd import ops
+    def make(val):
+        p = torch.nn.Parameter(torch.full((8, 16), val))
+        return p
+    p = make(1.0)
+    t1 = ops._lp(p, torch.float32, transpose=True)
+    assert t1.shape == (16, 8) and float(t1[0, 0]) == 1.0
+    assert ops._lp(p, torch.float32, transpose=True) is t1                       # cached
+    key = id(p)
+    assert key in ops._CAST_CACHE
+    del p, t1
+    gc.collect()
+    assert key not in ops._CAST_CACHE                                            # dropped with the parameter
+    q = make(2.0)
+    assert float(ops._lp(q, torch.float32, transpose=True)[0, 0]) == 2.0
+    v = ops._lp(q[2:6], torch.bfloat16)
+    assert v.shape == (4, 16) and v.dtype == torch.bfloat16 and ops._lp(q[2:6], torch.bfloat16) is v
+    with torch.no_grad():
+        q.mul_(3.0)                                                              # optimizer step: version bump
+    assert float(ops._lp(q[2:6], torch.bfloat16)[0, 0]) == 6.0
