@@ -43,7 +43,8 @@ def section(fn):
 
 def t_linear():
     for dt, tol in ((torch.float32, 2e-5), (torch.bfloat16, 2e-2)):
-        for (M, N, K) in [(200, 96, 96), (333, 288, 96), (128, 128, 64), (1000, 384, 96), (77, 96, 384), (50, 512, 37632 // 8), (130, 768, 3072)]:
+        for (M, N, K) in [(200, 96, 96), (333, 288, 96), (128, 128, 64), (1000, 384, 96), (77, 96, 384), (50, 512, 37632 // 8), (130, 768, 3072),
+                          (1, 96, 96), (7, 768, 768), (1, 512, 4704), (3, 8, 8)]:      # degenerate token counts / tiny channels
             x = rnd("x", (M, K), 1, dtype=dt)
             w = rnd("w", (N, K), 2, K ** -0.5, dtype=dt)
             b = rnd("b", (N,), 3, 0.1)
@@ -99,7 +100,8 @@ def t_linear_large():
 
 def t_wgrad():
     for dt, tol in ((torch.float32, 2e-5), (torch.bfloat16, 2e-2)):
-        for (M, N, K) in [(500, 96, 96), (3136, 288, 96), (777, 384, 96), (1000, 96, 384), (100, 512, 1024), (6272, 96, 48)]:
+        for (M, N, K) in [(500, 96, 96), (3136, 288, 96), (777, 384, 96), (1000, 96, 384), (100, 512, 1024), (6272, 96, 48),
+                          (1, 96, 96), (7, 768, 768), (769, 768, 768), (5000, 96, 384)]:     # single token; both sides of the 768-row direct/split boundary
             dy = rnd("dy", (M, N), 1, dtype=dt)
             x = rnd("x", (M, K), 2, dtype=dt)
             dw, db = ops.wgrad_raw(dy, x, True)
@@ -117,7 +119,7 @@ def t_wgrad():
 
 def t_layernorm():
     for dt, tol in ((torch.float32, 1e-5), (torch.bfloat16, 1.5e-2)):
-        for (M, C) in [(100, 96), (77, 192), (50, 384), (33, 768), (20, 1536), (10, 500 if dt == torch.float32 else 504)]:
+        for (M, C) in [(100, 96), (77, 192), (50, 384), (33, 768), (20, 1536), (10, 500 if dt == torch.float32 else 504), (1, 96), (1, 768)]:
             x = rnd("x", (M, C), 1, dtype=dt).requires_grad_(True)
             g = (rnd("g", (C,), 2) * 0.2 + 1).requires_grad_(True)
             b = (rnd("b", (C,), 3) * 0.1).requires_grad_(True)
@@ -168,7 +170,7 @@ def t_wattn():
     index = OS.relative_position_index(7).to(dev).int().contiguous()
     for dt, tol in ((torch.float32, 2e-5), (torch.bfloat16, 2e-2)):
         for (n_img, H, C, nh, shift) in [(2, 14, 96, 3, 0), (2, 14, 96, 3, 3), (1, 28, 192, 6, 3), (3, 7, 768, 24, 0), (5, 14, 384, 12, 3),
-                                         (1, 56, 96, 3, 3), (2, 21, 96, 3, 2)]:
+                                         (1, 56, 96, 3, 3), (2, 21, 96, 3, 2), (1, 7, 768, 24, 0), (1, 7, 96, 3, 0)]:      # incl. a single window
             for mis in ((False, True) if shift else (False,)):
                 qkv = rnd("qkv", (n_img * H * H, 3 * C), 1, dtype=dt).requires_grad_(True)
                 table = (rnd("tab", (169, nh), 2) * 0.5).requires_grad_(True)
@@ -188,7 +190,8 @@ def t_wattn():
 
 def t_mha():
     for dt, tol in ((torch.float32, 2e-5), (torch.bfloat16, 2e-2)):
-        for (Lq, Lk, B, E, nh) in [(38, 128, 2, 768, 12), (128, 38, 1, 768, 12), (166, 160, 4, 768, 12), (70, 33, 2, 256, 8)]:
+        for (Lq, Lk, B, E, nh) in [(38, 128, 2, 768, 12), (128, 38, 1, 768, 12), (166, 160, 4, 768, 12), (70, 33, 2, 256, 8),
+                                   (1, 1, 1, 768, 12), (1, 65, 2, 768, 12), (64, 1, 1, 768, 12)]:      # single query / single key
             hd = E // nh
             q = rnd("q", (Lq, B, E), 1, dtype=dt).requires_grad_(True)
             kv = rnd("kv", (Lk, B, 2 * E), 2, dtype=dt).requires_grad_(True)
@@ -203,7 +206,12 @@ def t_mha():
             dy = rnd("dy", (Lq, B, E), 3, dtype=dt)
             out.backward(dy)
             ref.backward(dy.double())
-            report(f"mha bwd dq {tag}", q.grad, q64.grad, tol * 2)
+            if Lk == 1:       # softmax over a single key is constant: dq is exactly 0 -- absolute check
+                ok = q.grad.float().abs().max().item() <= 1e-5
+                RES.append((f"mha bwd dq {tag}", ok))
+                print(f"{'OK  ' if ok else 'FAIL'} mha bwd dq {tag} (single key: |dq| <= 1e-5)", flush=True)
+            else:
+                report(f"mha bwd dq {tag}", q.grad, q64.grad, tol * 2)
             report(f"mha bwd dkv {tag}", kv.grad, kv64.grad, tol * 2)
         # additive key bias (extended attention mask of the self-attention encoders): separate k, v, self-attention
         # lengths incl. ragged tails, -10000 on padded keys plus a smooth bias to exercise the general case
