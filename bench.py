@@ -333,6 +333,7 @@ def main():
     torch.cuda.synchronize()
     timer.enabled = rank == 0
     step.host_ms = {}
+    step.gpu_events = [] if rank == 0 else None             # main-stream timeline of the phases (events are free on the GPU)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, kept = step(batch)
@@ -343,6 +344,13 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
+    gpu_phase = {}
+    if step.gpu_events:
+        evs, step.gpu_events = step.gpu_events, None
+        for (_, a), (name, b) in zip(evs, evs[1:]):
+            if name != "start":
+                gpu_phase[name] = gpu_phase.get(name, 0.0) + a.elapsed_time(b)
+    step.host_ms.pop("start", None)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -425,7 +433,8 @@ def main():
                        "model_tflops_per_s_per_gpu": round(flops_step / (ms * 1e-3) / 1e12, 1),
                        "host_enqueue_ms_per_step": round(issue_s / args.steps * 1e3, 1), "hip_graphs": bool(args.graphs), "text_encoder_on_second_stream": bool(args.graphs and args.overlap_text),
                        "second_stream_pair_over_single": round(float(getattr(mm, "text_stream_concurrency", 0.0)), 2),
-                       "host_ms_per_phase": {k: round(v / args.steps, 1) for k, v in step.host_ms.items()}},
+                       "host_ms_per_phase": {k: round(v / args.steps, 1) for k, v in step.host_ms.items()},
+                       "main_stream_gpu_ms_per_phase": {k: round(v / args.steps, 1) for k, v in gpu_phase.items()}},
             "roofline": roof,
             "cpu_baseline": None,
         }

@@ -186,9 +186,17 @@ class TargetStep:
         args = self.args
         t = [time.perf_counter()]
 
+        evs = getattr(self, "gpu_events", None)          # optional: list collecting (phase, event) on the main stream
+
         def mark(name):
             t.append(time.perf_counter())
             self.host_ms[name] = self.host_ms.get(name, 0.0) + (t[-1] - t[-2]) * 1e3
+            if evs is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                evs.append((name, e))
+        if evs is not None:
+            mark("start")
         if getattr(self.mm, "text_stream", None) is not None:
             # start the text branch on its own stream before the Swin forward is enqueued (models.launch_text)
             if self.autocast_dtype is not None:
