@@ -734,8 +734,13 @@ __device__ __forceinline__ bf16x8 lds_tr_frag(const bf16* s, int pitch, int c0, 
 
 // FEW: instantiation used for few-token problems (cross-modal encoder, embedding head) -- same code, its own
 // symbol, so that profiles keep the multi-million-token Swin launches and the tiny ones apart.
-template <typename T, int BMS, bool FEW = false>
-__global__ __launch_bounds__(256) void linear_tn_kernel(TnArgs p) {
+// PF: depth of the register prefetch (token steps in flight).  The 64-token-step instantiation is LDS-limited to two
+// workgroups per CU whatever it does with registers, and with one step in flight it sits exactly on its bytes-in-flight
+// bound (2 x 32 KB per CU / ~2 us = 8 TB/s x 64 FLOP/B = 0.52 PFLOP/s, measured 0.54): PF = 2 keeps two steps in flight.
+template <int BMS> struct TnWaves { static constexpr int value = BMS >= 64 ? 2 : 3; };   // workgroups per CU that the LDS tiles allow
+template <typename T, int BMS, bool FEW = false, int PF = 1>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TnWaves<BMS>::value)))
+void linear_tn_kernel(TnArgs p) {
     constexpr int VEC = Vec<T>::N;
     constexpr int PITCH = 128 + VEC;
     constexpr int CV = 128 / VEC;                       // vectors per tile row
@@ -764,13 +769,13 @@ __global__ __launch_bounds__(256) void linear_tn_kernel(TnArgs p) {
     const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
     const bool do_bias = (p.part_b != nullptr) && (tile_k == 0);
 
-    Vec<T> areg[NV], breg[NV];
-    float sreg[NV];
+    struct Regs { Vec<T> a[NV], b[NV]; float s[NV]; };
+    Regs R0, R1;
     float colsum[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) colsum[e] = 0.f;
 
-    auto gload = [&](int mb) {
+    auto gload = [&](Regs& R, int mb) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int v = tid + i * 256;
@@ -779,25 +784,25 @@ __global__ __launch_bounds__(256) void linear_tn_kernel(TnArgs p) {
             const bool mv = m < mend;
             // the DropPath scale is only *fetched* here and applied in lstore(), after the MFMA block: applying it
             // right away makes every tile load wait for two dependent HBM round trips (measured: 2x slower launches)
-            areg[i] = (mv && n0 + c < p.N) ? ldvec<T>(dyg + (size_t)m * p.lddy + n0 + c) : zerovec<T>();
-            if (p.rowscale) sreg[i] = mv ? p.rowscale[m / p.rows_per_scale] : 0.f;
-            breg[i] = (mv && k0 + c < p.K) ? ldvec<T>(xg + (size_t)m * p.ldx + k0 + c) : zerovec<T>();
+            R.a[i] = (mv && n0 + c < p.N) ? ldvec<T>(dyg + (size_t)m * p.lddy + n0 + c) : zerovec<T>();
+            if (p.rowscale) R.s[i] = mv ? p.rowscale[m / p.rows_per_scale] : 0.f;
+            R.b[i] = (mv && k0 + c < p.K) ? ldvec<T>(xg + (size_t)m * p.ldx + k0 + c) : zerovec<T>();
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](Regs& R, int buf) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int v = tid + i * 256;
             const int row = v / CV, c = (v % CV) * VEC;
             if (p.rowscale) {
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) areg[i].set(e, areg[i].get(e) * sreg[i]);
+                for (int e = 0; e < VEC; ++e) R.a[i].set(e, R.a[i].get(e) * R.s[i]);
             }
-            stvec<T>(As + (buf * BMS + row) * PITCH + c, areg[i]);
-            stvec<T>(Bs + (buf * BMS + row) * PITCH + c, breg[i]);
+            stvec<T>(As + (buf * BMS + row) * PITCH + c, R.a[i]);
+            stvec<T>(Bs + (buf * BMS + row) * PITCH + c, R.b[i]);
             if (do_bias) {
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) colsum[e] += areg[i].get(e);
+                for (int e = 0; e < VEC; ++e) colsum[e] += R.a[i].get(e);
             }
         }
     };
@@ -808,15 +813,7 @@ __global__ __launch_bounds__(256) void linear_tn_kernel(TnArgs p) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nsteps = (mend - mbeg + BMS - 1) / BMS;
-    if (nsteps > 0) {
-        gload(mbeg);
-        lstore(0);
-    }
-    __syncthreads();
-    for (int s = 0; s < nsteps; ++s) {
-        const int cur = s & 1;
-        if (s + 1 < nsteps) gload(mbeg + (s + 1) * BMS);
+    auto compute = [&](int cur) {
         const T* asb = As + cur * BMS * PITCH;
         const T* bsb = Bs + cur * BMS * PITCH;
 #pragma unroll
@@ -843,8 +840,38 @@ __global__ __launch_bounds__(256) void linear_tn_kernel(TnArgs p) {
                     for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], bf_[b], acc[a][b], 0, 0, 0);
             }
         }
-        if (s + 1 < nsteps) lstore(cur ^ 1);
+    };
+
+    const int nsteps = (mend - mbeg + BMS - 1) / BMS;
+    if (nsteps > 0) {
+        gload(R0, mbeg);
+        lstore(R0, 0);
+    }
+    if constexpr (PF == 2) {
+        // step k (k >= 1) travels in register set (k - 1) & 1; at iteration s the set s & 1 delivers step s + 1 to LDS and is
+        // refilled with step s + 3, so two steps are always in flight behind the one being multiplied
+        if (nsteps > 1) gload(R0, mbeg + BMS);
+        if (nsteps > 2) gload(R1, mbeg + 2 * BMS);
         __syncthreads();
+        auto iter = [&](int s, Regs& R) {
+            compute(s & 1);
+            if (s + 1 < nsteps) lstore(R, (s & 1) ^ 1);
+            if (s + 3 < nsteps) gload(R, mbeg + (s + 3) * BMS);
+            __syncthreads();
+        };
+        for (int s = 0; s < nsteps; s += 2) {
+            iter(s, R0);
+            if (s + 1 < nsteps) iter(s + 1, R1);
+        }
+    } else {
+        __syncthreads();
+        for (int s = 0; s < nsteps; ++s) {
+            const int cur = s & 1;
+            if (s + 1 < nsteps) gload(R0, mbeg + (s + 1) * BMS);
+            compute(cur);
+            if (s + 1 < nsteps) lstore(R0, cur ^ 1);
+            __syncthreads();
+        }
     }
 
     float* pw = p.part_w + (size_t)split * p.N * p.K;
@@ -874,18 +901,18 @@ __global__ __launch_bounds__(256) void linear_tn_kernel(TnArgs p) {
     }
 }
 
-template <typename T, int BMS, bool FEW = false>
+template <typename T, int BMS, bool FEW = false, int PF = 1>
 int launch_tn(const TnArgs& a, dim3 grid, hipStream_t st) {
     constexpr int VEC = Vec<T>::N;
     constexpr size_t lds = (size_t)4 * BMS * (128 + VEC) * sizeof(T) + (256 / (128 / VEC)) * 128 * sizeof(float);
     static bool attr_set = false;
     if (lds > 65536 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_tn_kernel<T, BMS, FEW>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_tn_kernel<T, BMS, FEW, PF>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((linear_tn_kernel<T, BMS, FEW>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((linear_tn_kernel<T, BMS, FEW, PF>), grid, dim3(256), lds, st, a);
     FMMT_CHECK_LAUNCH();
     return 0;
 }
@@ -1019,8 +1046,14 @@ int launch_tn_plan(int dtype, int M, int N, int K, const void* dy, int lddy, con
     // measured (tests/gpu_gemm_bench.py): 64-token steps win for the compute-heavy stage-2/3 shapes (+15-25 %),
     // 32-token steps (3 workgroups per CU) win for the HBM-bound multi-million-token stage-0/1 shapes
     const bool bms64 = tn_cfg == 2 || (tn_cfg == 0 && M <= 262144);
-    if (dtype == FMMT_BF16) return M <= 4096 ? launch_tn<bf16, 32, true>(a, grid, st)
-                                             : bms64 ? launch_tn<bf16, 64>(a, grid, st) : launch_tn<bf16, 32>(a, grid, st);
+    // two token steps in flight (register sets R0/R1): measured +3..5 % on the stage-2/3 shapes, +3..11 % on the stage-0/1
+    // ones, at unchanged occupancy (200 / 160 registers); FMMT_TN_PF=1 selects the single-step prefetch
+    static const int tn_pf = getenv("FMMT_TN_PF") ? atoi(getenv("FMMT_TN_PF")) : 3;
+    if (dtype == FMMT_BF16) {
+        if (M <= 4096) return launch_tn<bf16, 32, true>(a, grid, st);
+        if (bms64) return tn_pf >= 2 ? launch_tn<bf16, 64, false, 2>(a, grid, st) : launch_tn<bf16, 64>(a, grid, st);
+        return tn_pf >= 3 ? launch_tn<bf16, 32, false, 2>(a, grid, st) : launch_tn<bf16, 32>(a, grid, st);
+    }
     return launch_tn<float, 16>(a, grid, st);
 }
 }  // namespace
