@@ -582,8 +582,10 @@ int launch_nt(const LinArgs& a, hipStream_t st) {
 template <typename T, int BM, int BN>
 int dispatch_nt_bk(const LinArgs& a, hipStream_t st) {
     if constexpr (sizeof(T) == 2) {
-        // Swin stage 0: one K step.  (64- and 256-row tiles measured: no gain / -35 %.  These launches are bound by
-        // HBM *write* bandwidth, ~2.3 TB/s on this part: time tracks bytes written, not tile shape or store pattern.)
+        // Swin stage 0: one K step.  (64- and 256-row tiles measured: no gain / -35 %.)  These launches are HBM streams
+        // (40-70 FLOP/B); epilogue-shaped stores alone reach 5.5 TB/s on this part (profiles/r01_hbm_calibration.txt), what
+        // holds a single-step workgroup at ~3 TB/s is its load -> LDS -> MFMA -> store chain with nothing to overlap, so
+        // occupancy is what counts (NtWaves above); the fc1 + GELU + pre-activation launch is the only one still on it.
         if (!a.ksplit && a.K == 96) return launch_nt<T, BM, BN, 96, 1>(a, st);
         if (!a.ksplit && a.K <= 64) return launch_nt<T, BM, BN, 64, 1>(a, st);     // PatchEmbed (K = 48)
         // measured on MI355X (tests/gpu_gemm_bench.py, sum over the bench shapes): BK=64 5.33 ms vs BK=32 5.88 ms
