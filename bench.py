@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graphs", type=int, default=1, help="capture the multimodal model (fwd+bwd) as HIP graphs (1) or launch eagerly (0)")
     ap.add_argument("--overlap-text", type=int, default=1, help="replay the text-encoder graph on a second HIP stream, concurrently with Swin (needs --graphs 1)")
+    ap.add_argument("--parallel-fusion", type=int, default=1, help="capture independent halves of the fusion stack as parallel graph branches")
     ap.add_argument("--force-ddp", action="store_true", help="run the data-parallel gradient exchange path even with one process (exercises the N>1 code path on one GPU)")
     ap.add_argument("--shape-report", default=None, help="write a per-GEMM-shape timing table to this file (development aid)")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames in the CPU-baseline Swin sample")
@@ -303,7 +304,8 @@ def main():
             preds = swin(batch[8][:8], is_trg_task=True).float().repeat(batch[8].shape[0] // 8, 1)
         vis, nmask = select_frames(preds, batch[5], batch[6], batch[9], cfg.FacialEmoImpor_threshold)
         sample = (batch[0], batch[1], batch[2], batch[3], batch[4], vis.detach().requires_grad_(True), nmask, batch[10])
-        mm = graph_multimodal(mm, sample, torch.bfloat16 if args.dtype == "bf16" else None, overlap_text=bool(args.overlap_text))
+        mm = graph_multimodal(mm, sample, torch.bfloat16 if args.dtype == "bf16" else None, overlap_text=bool(args.overlap_text),
+                              parallel_fusion=bool(args.parallel_fusion))
         mm.zero_grad(set_to_none=True)
         swin.zero_grad(set_to_none=True)
     averager = None

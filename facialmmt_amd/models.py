@@ -147,24 +147,44 @@ class MultiModalTransformerForClassification(nn.Module):
         return slice_target_utterance(text_utt_linear, batch_text_sep_mask, batchUtt_in_dia_idx,
                                       self.get_text_utt_max_lens, self.text_pretrained_model == 'roberta')
 
+    def _pair(self, fa, fb):
+        """Run two independent sub-computations; with `self.pair_stream` set (by train_step.graph_multimodal) the first one
+        runs on that stream, forked from and joined to the current one.  Inside a HIP-graph capture this records two
+        parallel branches (and, because autograd replays a node on its forward stream, two in the backward graph as well):
+        the fusion stack's launches are 50-250 workgroups each, so two of them side by side still leave the GPU room."""
+        side = getattr(self, "pair_stream", None)
+        if side is None:
+            return fa(), fb()
+        cur = torch.cuda.current_stream()
+        side.wait_stream(cur)                                  # fork: everything fa reads is complete
+        with torch.cuda.stream(side):
+            ra = fa()
+        rb = fb()
+        cur.wait_stream(side)                                  # join before anything consumes ra
+        return ra, rb
+
     def fusion_branch(self, text_feat, text_mask, audio_inputs, audio_mask, vision_inputs, new_vision_mask):
         """self-attention encoders, four cross-modal calls, pooling, classifier (ref :152-188)"""
-        audio_ext = (1.0 - audio_mask.unsqueeze(1).unsqueeze(2)) * -10000.0
-        audio_utt = self.audio_utt_transformer(self.audio_linear(audio_inputs), audio_ext)
-        vision_ext = (1.0 - new_vision_mask.unsqueeze(1).unsqueeze(2)) * -10000.0
-        vision_utt = self.vision_utt_transformer(self.vision_linear(vision_inputs), vision_ext)
-
-        # cross-modal fusion on the HIP path, time-major, in the module's compute dtype
         cd = self.compute_dtype
         out_dtype = text_feat.dtype
-        t_tm = text_feat.transpose(0, 1).contiguous().to(cd)
-        a_tm = audio_utt.transpose(0, 1).contiguous().to(cd)
-        v_tm = vision_utt.transpose(0, 1).contiguous().to(cd)
-        text_x_audio = self.CrossModalTrans_TA(t_tm, a_tm, a_tm)
-        audio_x_text = self.CrossModalTrans_TA(a_tm, t_tm, t_tm)
+
+        def audio_side():
+            audio_ext = (1.0 - audio_mask.unsqueeze(1).unsqueeze(2)) * -10000.0
+            audio_utt = self.audio_utt_transformer(self.audio_linear(audio_inputs), audio_ext)
+            return audio_utt.transpose(0, 1).contiguous().to(cd)
+
+        def vision_side():
+            vision_ext = (1.0 - new_vision_mask.unsqueeze(1).unsqueeze(2)) * -10000.0
+            vision_utt = self.vision_utt_transformer(self.vision_linear(vision_inputs), vision_ext)
+            return vision_utt.transpose(0, 1).contiguous().to(cd), text_feat.transpose(0, 1).contiguous().to(cd)
+
+        # cross-modal fusion on the HIP path, time-major, in the module's compute dtype
+        a_tm, (v_tm, t_tm) = self._pair(audio_side, vision_side)
+        text_x_audio, audio_x_text = self._pair(lambda: self.CrossModalTrans_TA(t_tm, a_tm, a_tm),
+                                                lambda: self.CrossModalTrans_TA(a_tm, t_tm, t_tm))
         ta = torch.cat((text_x_audio, audio_x_text), dim=0)
-        vision_x_ta = self.CrossModalTrans_TA_V(v_tm, ta, ta)
-        ta_x_vision = self.CrossModalTrans_TA_V(ta, v_tm, v_tm)
+        vision_x_ta, ta_x_vision = self._pair(lambda: self.CrossModalTrans_TA_V(v_tm, ta, ta),
+                                              lambda: self.CrossModalTrans_TA_V(ta, v_tm, v_tm))
         final = torch.cat((ta_x_vision, vision_x_ta), dim=0).transpose(0, 1).to(out_dtype)
         final_mask = torch.cat((text_mask.to(audio_mask.dtype), audio_mask, new_vision_mask), dim=1)
 

@@ -107,7 +107,7 @@ class _Branch(torch.nn.Module):
         return self._fn(*args)
 
 
-def graph_multimodal(mm, sample_args, autocast_dtype=None, overlap_text=True):
+def graph_multimodal(mm, sample_args, autocast_dtype=None, overlap_text=True, parallel_fusion=True):
     """Capture forward and backward of the multimodal model as HIP graphs (torch.cuda.make_graphed_callables):
     its ~4000 small launches per step (24 PLM layers, 7 self-attention layers, 8 cross-modal layer calls) are
     host-bound when issued one by one (measured: 112 ms of host time per step against 105 ms of GPU work).
@@ -147,6 +147,9 @@ def graph_multimodal(mm, sample_args, autocast_dtype=None, overlap_text=True):
         with torch.cuda.stream(side):
             mm._text_grad_accumulators = [p.expand_as(p).grad_fn.next_functions[0][0] for p in text.parameters() if p.requires_grad]
         torch.cuda.current_stream().wait_stream(side)
+    # independent halves of the fusion stack (audio / vision encoder, the two directions of each cross-modal encoder) are
+    # captured as parallel branches of the fusion graphs: models._pair
+    mm.pair_stream = torch.cuda.Stream(device=ids.device) if parallel_fusion else None
     ctx = torch.autocast("cuda", dtype=autocast_dtype, cache_enabled=False) if autocast_dtype is not None else contextlib.nullcontext()
     with ctx:
         gtext, gfusion = torch.cuda.make_graphed_callables(
@@ -154,6 +157,7 @@ def graph_multimodal(mm, sample_args, autocast_dtype=None, overlap_text=True):
             ((ids, attn_mask, sep_mask, utt_idx), (text_feat, text_mask, audio, audio_mask, vision, vision_mask)),
             num_warmup_iters=3)
     # plain attributes, NOT child modules: the branch wrappers must not show up in mm.state_dict() / named_parameters()
+    mm.pair_stream = None                                     # eager calls of the branches stay single-stream
     object.__setattr__(mm, "_text_call", gtext)
     object.__setattr__(mm, "_fusion_call", gfusion)
     mm.text_stream = side
