@@ -176,3 +176,56 @@ def test_shadow_cache_is_per_parameter_object_not_per_address():
     with torch.no_grad():
         q.mul_(3.0)                                                              # optimizer step: version bump
     assert float(ops._lp(q[2:6], torch.bfloat16)[0, 0]) == 6.0
+
+
+def test_checkpoint_backbone_mapping_and_round_trip(tmp_path):
+    """FaceX-Zoo `backbone.` mapping (train.py:316-331) and plain state_dict files."""
+    from facialmmt_amd import checkpoint, models
+    torch.manual_seed(3)
+    m = models.SwinForAffwildClassification(default_args())
+    own = m.state_dict()
+    # a FaceX-Zoo style file: backbone.<name> for the Swin, its own head.*, and a classifier of another width
+    file_sd = {}
+    for k, v in own.items():
+        if k.startswith("swin."):
+            file_sd["backbone." + k[5:]] = torch.full_like(v, 0.5) if v.is_floating_point() else v.clone()
+    file_sd["head.weight"] = torch.zeros(93431, 512)[:4]
+    file_sd["backbone.classifier.weight"] = torch.ones_like(own["classifier.weight"])
+    path = tmp_path / "Swin_tiny_Ms-Celeb-1M.pt"
+    torch.save({"state_dict": file_sd, "epoch": 17}, path)
+    rep = checkpoint.load_pretrained_backbone(m, str(path))
+    after = m.state_dict()
+    swin_keys = [k for k in own if k.startswith("swin.")]
+    assert sorted(rep.loaded) == sorted(swin_keys) and not rep.mismatched
+    assert sorted(rep.missing) == sorted(k for k in own if not k.startswith("swin.") and not k.startswith("classifier."))
+    assert "head.weight" in rep.unused and "backbone.classifier.weight" in rep.unused
+    for k in swin_keys:
+        if own[k].is_floating_point():
+            assert bool((after[k] == 0.5).all()), k
+    for k in own:
+        if not k.startswith("swin."):
+            assert torch.equal(after[k], own[k]), k         # head keeps its initial values; classifier never loaded
+
+    # wrapped training-time module -> plain file -> fresh model, exact
+    wrapped = torch.nn.Sequential()
+    wrapped.add_module("module", m)                          # keys become "module.<name>" like DataParallel / _LiteModule
+    sd = checkpoint.extract_state_dict(wrapped)
+    assert list(sd) == list(own)
+    out = tmp_path / "best_swin.pt"
+    checkpoint.save_state(wrapped, str(out), extra={"best_f1": 0.66})
+    raw = torch.load(out, weights_only=True)
+    assert raw["best_f1"] == 0.66 and list(raw["state_dict"]) == list(own)
+    m2 = models.SwinForAffwildClassification(default_args())
+    rep2 = checkpoint.load_state(m2, str(out))
+    assert not rep2.missing and not rep2.unused and not rep2.mismatched
+    for k, v in m2.state_dict().items():
+        assert torch.equal(v, after[k]), k
+    # strict load refuses a file that does not fit
+    bad = dict(sd)
+    bad.pop("linear.weight")
+    with pytest.raises(RuntimeError, match="missing"):
+        checkpoint.load_state(m2, bad)
+    rep3 = checkpoint.load_state(m2, bad, strict=False)
+    assert rep3.missing == ["linear.weight"]
+    with pytest.raises(KeyError):
+        checkpoint.extract_state_dict({"module.a": torch.zeros(1), "a": torch.zeros(1)})
