@@ -166,6 +166,33 @@ def test_full_size_batch_independence_bf16(dev, swin):
     assert torch.equal(full[40:104], part)
 
 
+def test_full_size_backward_is_deterministic_and_linear_bf16(dev, swin):
+    """BASELINE size (640 frames = the 4-utterance step of the bench, bf16): the backward has no atomics, so two
+    runs give bit-identical gradients (a race shows up here), and it is linear in the upstream gradient: doubling it
+    (exact in bf16 / fp32) doubles every parameter gradient and the input gradient."""
+    swin.eval()                                                 # drop-path off, BatchNorm on running statistics
+    g = torch.Generator(device="cpu").manual_seed(2)
+    frames = torch.randn(640, 3, 224, 224, generator=g).bfloat16().to(dev).requires_grad_(True)
+    w = torch.randn(640, 512, generator=g).to(dev)
+    params = [p for p in swin.parameters() if p.requires_grad]
+
+    def grads(scale):
+        out = swin(frames)
+        return torch.autograd.grad((out.float() * (w * scale)).sum(), [frames] + params, allow_unused=True)
+
+    a, b, c = grads(1.0), grads(1.0), grads(2.0)
+    used = 0
+    for x, y, z in zip(a, b, c):
+        if x is None:
+            assert y is None and z is None
+            continue
+        used += 1
+        assert torch.isfinite(x).all()
+        assert torch.equal(x, y)
+        assert (z.float() - 2 * x.float()).abs().max().item() <= 1e-20
+    assert used > 150 and float(a[0].float().abs().max()) > 0
+
+
 def test_aux_task_step_learns(dev):
     """train.py:15-41 (aux task): a few AdamW steps on a fixed synthetic batch in bf16 reduce the loss and
     update every Swin parameter group (end-to-end check of forward, backward and optimizer plumbing)."""
