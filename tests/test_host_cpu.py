@@ -229,3 +229,21 @@ def test_checkpoint_backbone_mapping_and_round_trip(tmp_path):
     assert rep3.missing == ["linear.weight"]
     with pytest.raises(KeyError):
         checkpoint.extract_state_dict({"module.a": torch.zeros(1), "a": torch.zeros(1)})
+
+
+def test_bench_contract_flags_and_loud_failure_without_gpu():
+    """bench.py keeps the driver's flag contract and, like the rest of the product path, refuses to run without
+    the GPU instead of falling back to anything (the CPU baseline leg is only ever timed beside the HIP path)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+    h = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, env=env, timeout=300)
+    assert h.returncode == 0
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert flag in h.stdout
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible to this process")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "no CPU fallback" in r.stderr
+    assert not r.stdout.strip().startswith("{")            # no metric line from a run that measured nothing
