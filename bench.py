@@ -283,6 +283,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the hot path has no CPU fallback)"
+    # FMMT_BENCH_DEVICE / FMMT_BENCH_BACKEND: dry-run switches for exercising the N>1 code path on a one-GPU box (all
+    # ranks on device 0, gloo instead of RCCL, which refuses two ranks per device); never set by the driver
+    local = int(os.environ.get("FMMT_BENCH_DEVICE", local))
+    backend = os.environ.get("FMMT_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if rank != 0:                                           # only rank 0 reports; keep other ranks' C-level banners out of stdout
@@ -290,7 +294,7 @@ def main():
     if world > 1 or args.force_ddp:
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
     from facialmmt_amd.config import default_args
@@ -440,6 +444,8 @@ def main():
             "roofline": roof,
             "cpu_baseline": None,
         }
+        if "FMMT_BENCH_DEVICE" in os.environ or backend != "nccl":
+            line["config"]["dry_run"] = f"ranks share device {local}, backend {backend}: not a measurement"
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, cfg)
     if dist.is_initialized():
