@@ -135,8 +135,17 @@ class MultiModalTransformerForClassification(nn.Module):
         cls = RobertaModel if self.text_pretrained_model == 'roberta' else BertModel
         plm_config = getattr(config, "plm_config", None)
         if plm_config is not None:
-            return cls(plm_config, add_pooling_layer=False) if getattr(config, "plm_no_pooler", False) else cls(plm_config)
-        return cls.from_pretrained(config.pretrainedtextmodel_path)
+            plm = cls(plm_config, add_pooling_layer=False) if getattr(config, "plm_no_pooler", False) else cls(plm_config)
+        else:
+            plm = cls.from_pretrained(config.pretrainedtextmodel_path)
+        # forward() reads last_hidden_state only (ref :101-107): the pooler never receives a gradient.  It stays in the
+        # module (state_dict keys of the reference's checkpoints) but is frozen, so that a data-parallel gradient
+        # exchange never waits for a gradient that cannot arrive (parallel.GradientAverager raises on that, as DDP does);
+        # the optimizer skips gradient-less parameters either way, so training is unchanged.
+        if getattr(plm, "pooler", None) is not None:
+            for p in plm.pooler.parameters():
+                p.requires_grad_(False)
+        return plm
 
     # ---- the forward in two branches (the text branch does not depend on the visual path) ------------------
     def text_branch(self, batch_text_input_ids, batch_text_input_mask, batch_text_sep_mask, batchUtt_in_dia_idx):
@@ -147,20 +156,30 @@ class MultiModalTransformerForClassification(nn.Module):
         return slice_target_utterance(text_utt_linear, batch_text_sep_mask, batchUtt_in_dia_idx,
                                       self.get_text_utt_max_lens, self.text_pretrained_model == 'roberta')
 
-    def _pair(self, fa, fb):
+    def _pair(self, fa, fb, reads=()):
         """Run two independent sub-computations; with `self.pair_stream` set (by train_step.graph_multimodal) the first one
         runs on that stream, forked from and joined to the current one.  Inside a HIP-graph capture this records two
         parallel branches (and, because autograd replays a node on its forward stream, two in the backward graph as well):
-        the fusion stack's launches are 50-250 workgroups each, so two of them side by side still leave the GPU room."""
+        the fusion stack's launches are 50-250 workgroups each, so two of them side by side still leave the GPU room.
+        `reads`: the main-stream tensors fa consumes.  The caching allocator tracks a block by the stream it was allocated
+        on; both directions of the hand-over are therefore declared with record_stream (inputs read on the side stream,
+        results consumed on the main stream), so a block freed on the host is not handed out again on its home stream
+        while the other stream may still be reading it."""
         side = getattr(self, "pair_stream", None)
         if side is None:
             return fa(), fb()
         cur = torch.cuda.current_stream()
         side.wait_stream(cur)                                  # fork: everything fa reads is complete
+        for t in reads:
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(side)
         with torch.cuda.stream(side):
             ra = fa()
         rb = fb()
         cur.wait_stream(side)                                  # join before anything consumes ra
+        for t in (ra if isinstance(ra, (tuple, list)) else (ra,)):
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(cur)
         return ra, rb
 
     def fusion_branch(self, text_feat, text_mask, audio_inputs, audio_mask, vision_inputs, new_vision_mask):
@@ -179,17 +198,25 @@ class MultiModalTransformerForClassification(nn.Module):
             return vision_utt.transpose(0, 1).contiguous().to(cd), text_feat.transpose(0, 1).contiguous().to(cd)
 
         # cross-modal fusion on the HIP path, time-major, in the module's compute dtype
-        a_tm, (v_tm, t_tm) = self._pair(audio_side, vision_side)
+        a_tm, (v_tm, t_tm) = self._pair(audio_side, vision_side, reads=(audio_inputs, audio_mask))
         text_x_audio, audio_x_text = self._pair(lambda: self.CrossModalTrans_TA(t_tm, a_tm, a_tm),
-                                                lambda: self.CrossModalTrans_TA(a_tm, t_tm, t_tm))
+                                                lambda: self.CrossModalTrans_TA(a_tm, t_tm, t_tm), reads=(t_tm, a_tm))
         ta = torch.cat((text_x_audio, audio_x_text), dim=0)
         vision_x_ta, ta_x_vision = self._pair(lambda: self.CrossModalTrans_TA_V(v_tm, ta, ta),
-                                              lambda: self.CrossModalTrans_TA_V(ta, v_tm, v_tm))
+                                              lambda: self.CrossModalTrans_TA_V(ta, v_tm, v_tm), reads=(v_tm, ta))
         final = torch.cat((ta_x_vision, vision_x_ta), dim=0).transpose(0, 1).to(out_dtype)
         final_mask = torch.cat((text_mask.to(audio_mask.dtype), audio_mask, new_vision_mask), dim=1)
 
         pooled, _ = self.attention(final, final_mask)
         return self.classifier(self.dropout(pooled))
+
+    def _branch_call(self, name, eager):
+        """The HIP-graph replay of a branch (installed by train_step.graph_multimodal) or the eager branch.  The graphs
+        were captured in TRAINING mode with the training batch's static shapes (dropout active), and the graphed
+        callables are not child modules, so `mm.eval()` cannot reach them: outside training mode -- validation / test
+        after an epoch, as the reference's multimodal_evaluate does -- the eager branch runs instead."""
+        g = getattr(self, name, None)
+        return g if (g is not None and self.training) else eager
 
     def launch_text(self, batch_text_input_ids, batch_text_input_mask, batch_text_sep_mask, batchUtt_in_dia_idx):
         """Optional: issue the text branch NOW on `self.text_stream` (a second HIP stream) and let the next forward() pick
@@ -200,7 +227,7 @@ class MultiModalTransformerForClassification(nn.Module):
         side = getattr(self, "text_stream", None)
         if side is None or not batch_text_input_ids.is_cuda:
             return
-        text_call = getattr(self, "_text_call", None) or self.text_branch
+        text_call = self._branch_call("_text_call", self.text_branch)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             self._pending_text = text_call(batch_text_input_ids, batch_text_input_mask, batch_text_sep_mask,
@@ -211,7 +238,7 @@ class MultiModalTransformerForClassification(nn.Module):
         """Same signature and result as the reference's forward.  `_text_call` / `_fusion_call` are the two branches
         (replaced by their HIP-graph replays by train_step.graph_multimodal); a text branch already in flight on the
         second stream (launch_text) is joined here."""
-        fusion_call = getattr(self, "_fusion_call", None) or self.fusion_branch
+        fusion_call = self._branch_call("_fusion_call", self.fusion_branch)
         pending = getattr(self, "_pending_text", None)
         if pending is not None:
             self._pending_text = None
@@ -221,7 +248,7 @@ class MultiModalTransformerForClassification(nn.Module):
             text_feat.record_stream(main)                      # produced on the text stream, consumed here
             text_mask.record_stream(main)
         else:
-            text_call = getattr(self, "_text_call", None) or self.text_branch
+            text_call = self._branch_call("_text_call", self.text_branch)
             text_feat, text_mask = text_call(batch_text_input_ids, batch_text_input_mask, batch_text_sep_mask,
                                              torch.as_tensor(batchUtt_in_dia_idx, device=batch_text_input_ids.device))
         return fusion_call(text_feat, text_mask, audio_inputs, audio_mask, vision_inputs, new_vision_mask)

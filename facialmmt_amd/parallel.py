@@ -50,41 +50,63 @@ def accumulate(ddp_module, is_last_micro_step: bool):
 
 
 class GradientAverager:
-    """Bucketed, asynchronous gradient mean over the default process group (see the module docstring)."""
+    """Bucketed, asynchronous gradient mean over the default process group (see the module docstring).
 
-    def __init__(self, params, bucket_mb: int = BUCKET_MB, process_group=None, groups=None):
+    Ordering contract (RCCL, like NCCL, needs every rank to issue the collectives of one communicator in the same
+    order): buckets are numbered in construction order and a bucket's all-reduce is issued only after every
+    lower-numbered bucket OF ITS GROUP has been issued -- a bucket that completes early waits in `_ready`.  Each stream
+    group owns its own communicator (`dist.new_group`), because the relative order of two streams' buckets is a
+    property of each rank's timing, not of the model.
+    Completeness contract (what torch's DDP enforces with an error): when `finish()` is called with the exchange
+    enabled, every bucket must have received every one of its gradients.  A parameter that took no part in the step
+    (e.g. an unused pooler) leaves its bucket incomplete; `finish()` raises instead of letting the ranks step on
+    un-averaged gradients."""
+
+    def __init__(self, params, bucket_mb: int = BUCKET_MB, process_group=None, groups=None, comm_dtype=None):
         """`groups`: optional list of parameter lists whose gradients are produced on different HIP streams (e.g. the
         text branch on the second stream): a bucket never spans two groups, so the stream that completes a bucket
-        is the stream that produced all of it."""
-        self.group = process_group
+        is the stream that produced all of it.
+        `comm_dtype`: torch.bfloat16 halves the bytes on the wire (1.74 GB -> 0.87 GB for the multimodal model): the
+        flat fp32 bucket is rounded into a bf16 staging buffer, summed over ranks in bf16, and written back as fp32."""
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         groups = [list(params)] if groups is None else [list(g) for g in groups]
         self.params = [p for g in groups for p in g if p.requires_grad]
         if len(set(map(id, self.params))) != len(self.params):
             raise ValueError("GradientAverager: a parameter appears twice")
+        if comm_dtype not in (None, torch.float32, torch.bfloat16):
+            raise ValueError("GradientAverager: comm_dtype must be None / torch.float32 / torch.bfloat16")
+        self.comm_dtype = None if comm_dtype == torch.float32 else comm_dtype
         self.sync = True
-        self.buckets = []                                  # [flat buffer, [params], arrivals, pending work]
+        # one communicator per stream group (see the ordering contract); the first group keeps the caller's
+        self.comms = [process_group]
+        for _ in groups[1:]:
+            self.comms.append(dist.new_group() if (dist.is_initialized() and self.world > 1) else process_group)
+        self.buckets = []                                  # [flat buffer, [params], arrivals, pending work, group, staging]
+        self._next = [0] * len(groups)                     # per group: position (in its bucket list) of the next bucket to issue
+        self._order = [[] for _ in groups]                 # per group: bucket indices in issue order
+        self._ready = set()                                # complete buckets waiting for a lower-numbered one
+        self._issued = set()
         cap = bucket_mb * (1 << 20)
-        for g in groups:
+        for gi, g in enumerate(groups):
             cur, cur_bytes = [], 0
             for p in reversed([q for q in g if q.requires_grad]):
                 if p.dtype != torch.float32:
                     raise TypeError("GradientAverager: fp32 master parameters expected")
                 nbytes = p.numel() * 4
                 if cur and (cur_bytes + nbytes > cap or cur[0].device != p.device):
-                    self._close(cur)
+                    self._close(cur, gi)
                     cur, cur_bytes = [], 0
                 cur.append(p)
                 cur_bytes += nbytes
             if cur:
-                self._close(cur)
+                self._close(cur, gi)
         self._of = {}
-        for bi, (_, ps, _, _) in enumerate(self.buckets):
-            for p in ps:
+        for bi, b in enumerate(self.buckets):
+            for p in b[1]:
                 self._of[p] = bi
         self._handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
 
-    def _close(self, ps):
+    def _close(self, ps, gi):
         # 16-byte aligned slots so that every gradient view is as aligned as a stand-alone tensor
         offs, n = [], 0
         for p in ps:
@@ -93,23 +115,70 @@ class GradientAverager:
         flat = torch.zeros(n, dtype=torch.float32, device=ps[0].device)
         for p, o in zip(ps, offs):
             p.grad = flat[o:o + p.numel()].view_as(p)
-        self.buckets.append([flat, ps, 0, None])
+        stage = torch.empty(n, dtype=self.comm_dtype, device=flat.device) if self.comm_dtype is not None else None
+        self._order[gi].append(len(self.buckets))
+        self.buckets.append([flat, ps, 0, None, gi, stage])
+
+    def _issue(self, bi):
+        b = self.buckets[bi]
+        b[0].div_(self.world)
+        buf = b[0]
+        if b[5] is not None:
+            b[5].copy_(b[0])
+            buf = b[5]
+        b[3] = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.comms[b[4]], async_op=True)
+        self._issued.add(bi)
 
     def _hook(self, p):
-        b = self.buckets[self._of[p]]
+        bi = self._of[p]
+        b = self.buckets[bi]
         b[2] += 1
-        if b[2] == len(b[1]):
-            b[2] = 0
-            if self.sync and self.world > 1:
-                b[0].div_(self.world)
-                b[3] = dist.all_reduce(b[0], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if b[2] < len(b[1]):
+            return
+        b[2] = 0                                           # bucket complete
+        if not (self.sync and self.world > 1):
+            return
+        if bi in self._issued or bi in self._ready:
+            raise RuntimeError("GradientAverager: a bucket completed twice in one exchange window (call finish() once per step)")
+        self._ready.add(bi)
+        gi = b[4]
+        order = self._order[gi]
+        while self._next[gi] < len(order) and order[self._next[gi]] in self._ready:         # in-order issue, cascade
+            nxt = order[self._next[gi]]
+            self._ready.discard(nxt)
+            self._issue(nxt)
+            self._next[gi] += 1
 
     def finish(self):
-        """make the current stream wait for every outstanding exchange (call before clipping / the optimizer)"""
+        """Make the current stream wait for every outstanding exchange (call before clipping / the optimizer).
+        Raises if the exchange is enabled and some bucket is incomplete: one of its parameters received no gradient in
+        this step (freeze it or leave it out of the averager), so the ranks would otherwise diverge silently."""
+        if self.sync and self.world > 1:
+            bad = [bi for bi, b in enumerate(self.buckets) if bi not in self._issued]
+            if bad:
+                names = []
+                for bi in bad[:4]:
+                    b = self.buckets[bi]
+                    names.append(f"bucket {bi} (group {b[4]}): {b[2]}/{len(b[1])} gradients arrived")
+                self._reset_window()
+                raise RuntimeError("GradientAverager.finish(): gradient exchange incomplete -- " + "; ".join(names) +
+                                   ".  A parameter that gets no gradient (unused sub-module, e.g. a PLM pooler) must be "
+                                   "frozen (requires_grad_(False)) or excluded; nothing was stepped.")
         for b in self.buckets:
             if b[3] is not None:
                 b[3].wait()
                 b[3] = None
+                if b[5] is not None:
+                    b[0].copy_(b[5])
+        self._reset_window()
+
+    def _reset_window(self):
+        self._next = [0] * len(self._order)
+        self._ready.clear()
+        self._issued.clear()
+        for b in self.buckets:
+            b[2] = 0
+            b[3] = None
 
     def zero_grad(self):
         """zero the flat buffers in place (the .grad views must survive: never zero_grad(set_to_none=True) these)"""
@@ -119,11 +188,14 @@ class GradientAverager:
 
     @contextlib.contextmanager
     def no_sync(self):
+        """accumulate locally: arrivals of this micro-step are not counted towards the exchange window"""
         old, self.sync = self.sync, False
         try:
             yield
         finally:
             self.sync = old
+            for b in self.buckets:
+                b[2] = 0
 
     def remove(self):
         for h in self._handles:

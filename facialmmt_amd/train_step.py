@@ -184,6 +184,18 @@ class TargetStep:
         self.i_batch = 0
         self.host_ms = {}          # cumulative host-side enqueue time per phase (no device sync)
 
+    def start_epoch(self):
+        """As the reference at the top of each epoch (train.py:52,54): gradients zeroed, micro-batch count restarted, so a
+        partial accumulation window at the end of an epoch (len(loader) % trg_accumulation_steps != 0) is dropped, not
+        carried into the next epoch."""
+        self.i_batch = 0
+        averager = self.exchange if hasattr(self.exchange, "zero_grad") and not isinstance(self.exchange, torch.nn.Module) else None
+        if averager is not None:
+            averager.zero_grad()
+        else:
+            self.opt.zero_grad(set_to_none=True)
+        self.swin.zero_grad(set_to_none=True)
+
     def __call__(self, batch):
         (ids, attn_mask, sep_mask, audio, audio_mask, vision_inputs, vision_mask, labels, frames, num_imgs, utt_idx) = batch
         import time
@@ -201,6 +213,9 @@ class TargetStep:
                 evs.append((name, e))
         if evs is not None:
             mark("start")
+        from .parallel import GradientAverager, accumulate
+        self.i_batch += 1
+        last = self.i_batch % args.trg_accumulation_steps == 0
         if getattr(self.mm, "text_stream", None) is not None:
             # start the text branch on its own stream before the Swin forward is enqueued (models.launch_text)
             if self.autocast_dtype is not None:
@@ -212,17 +227,16 @@ class TargetStep:
         mark("swin_fwd")
         vis_concat, new_mask = select_frames(preds.float(), vision_inputs, vision_mask, num_imgs, args.FacialEmoImpor_threshold)
         mark("frame_filter")
-        if self.autocast_dtype is not None:
-            with torch.autocast("cuda", dtype=self.autocast_dtype):
+        # gradient exchange only on the last micro-step of the window; torch's DDP decides in its FORWARD whether the
+        # coming backward synchronises, so the no_sync context has to cover the forward as well
+        with accumulate(self.exchange, last):
+            if self.autocast_dtype is not None:
+                with torch.autocast("cuda", dtype=self.autocast_dtype):
+                    logits = self.mm_call(ids, attn_mask, sep_mask, audio, audio_mask, vis_concat, new_mask, utt_idx)
+            else:
                 logits = self.mm_call(ids, attn_mask, sep_mask, audio, audio_mask, vis_concat, new_mask, utt_idx)
-        else:
-            logits = self.mm_call(ids, attn_mask, sep_mask, audio, audio_mask, vis_concat, new_mask, utt_idx)
-        mark("multimodal_fwd")
-        loss = F.cross_entropy(logits.float(), labels) / args.trg_accumulation_steps
-        self.i_batch += 1
-        last = self.i_batch % args.trg_accumulation_steps == 0
-        from .parallel import GradientAverager, accumulate
-        with accumulate(self.exchange, last):                # gradient exchange only on the last micro-step
+            mark("multimodal_fwd")
+            loss = F.cross_entropy(logits.float(), labels) / args.trg_accumulation_steps
             loss.backward()
         mark("backward")
         if last:

@@ -1,0 +1,199 @@
+"""GPU tests of the rows either side of the hot path:
+
+* the device-side frame filter (train_step.select_frames) and target-utterance slicing (models.slice_target_utterance)
+  on DEVICE tensors against the literal loop restatements in oracle/ (train.py:75-114, src/models.py:112-150), including the
+  multi-utterance `num_imgs - 1` boundary quirk, the branch where no face passes the threshold, ragged utterances;
+* checkpoint I/O: a FaceX-Zoo style file -> checkpoint.load_pretrained_backbone -> the loaded model reproduces the
+  reference's golden features on the GPU; save_state / load_state round trip; the converted whole-module pickle;
+* eval() after HIP-graph capture runs the eager branches (the graphs hold training-mode dropout and static shapes)."""
+import os
+import sys
+import types
+
+import pytest
+import torch
+
+from facialmmt_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _filter_case(g, B, Lv, nmax, peaky, D=16):
+    num = torch.randint(max(1, nmax // 2), nmax + 1, (B,), generator=g)
+    nF = int(num.sum())
+    preds = torch.softmax(torch.randn(nF, 7, generator=g) * (3.0 if peaky else 0.3), -1)
+    vis = torch.randn(B, Lv, D, generator=g)
+    mask = (torch.arange(Lv).view(1, Lv) < num.view(B, 1)).float()
+    return preds, vis, mask, num
+
+
+def test_select_frames_on_device_matches_literal_loop(dev):
+    from facialmmt_amd.train_step import select_frames
+    from oracle.train_glue import select_frames_loop
+    g = torch.Generator().manual_seed(0)
+    branches = {"filtered": 0, "none_pass": 0, "multi_utt": 0}
+    for trial in range(80):
+        B = int(torch.randint(1, 6, (1,), generator=g))
+        preds, vis, mask, num = _filter_case(g, B, 12, 12, peaky=(trial % 3 != 0))
+        thr = [0.2, 0.5, 0.99, 0.0, 1.5][trial % 5]            # 1.5 > max sum(p^2): the no-face-passes branch
+        want, want_mask = select_frames_loop(preds, vis, mask, num.tolist(), thr)
+        got, got_mask = select_frames(preds.to(dev), vis.to(dev), mask.to(dev), num.to(dev), thr)
+        assert got.is_cuda and got_mask.is_cuda
+        assert torch.equal(got_mask.cpu(), want_mask), (trial, got_mask.cpu(), want_mask)
+        assert torch.equal(got.cpu(), want), trial               # gathers and exact copies: bit-identical
+        any_pass = bool(((preds * preds).sum(1) > thr).any())
+        branches["filtered" if any_pass else "none_pass"] += 1
+        branches["multi_utt"] += int(B > 1 and any_pass)
+    assert all(v >= 10 for v in branches.values()), branches
+
+
+def test_select_frames_full_size_properties(dev):
+    """bench size (4 utterances x 160 frames, 512-d features): threshold 0 keeps every face -- for one utterance the
+    result is the input with the emotion features appended; the packed prefix property holds at any threshold."""
+    from facialmmt_amd.train_step import select_frames
+    g = torch.Generator().manual_seed(3)
+    preds, vis, mask, num = _filter_case(g, 1, 160, 160, peaky=True, D=512)
+    out, m = select_frames(preds.to(dev), vis.to(dev), mask.to(dev), num.to(dev), 0.0)
+    n = int(num[0])
+    assert torch.equal(m.cpu(), mask)
+    assert torch.equal(out[0, :n, :512].cpu(), vis[0, :n]) and torch.equal(out[0, :n, 512:].cpu(), preds[:n])
+    preds, vis, mask, num = _filter_case(g, 4, 160, 160, peaky=True, D=512)
+    out, m = select_frames(preds.to(dev), vis.to(dev), mask.to(dev), num.to(dev), 0.2)
+    m = m.cpu()
+    assert torch.equal(m, (torch.cumsum(m, 1) == torch.arange(1, 161).view(1, -1)).float() * m)     # ones form a prefix
+    assert bool((out.cpu()[m == 0] == 0).all())                                                    # nothing behind the prefix
+
+
+def test_slice_target_utterance_on_device_matches_literal_loop(dev):
+    from facialmmt_amd.models import slice_target_utterance
+    from oracle.multimodal import slice_target_utterance_loop
+    g = torch.Generator().manual_seed(0)
+    for trial in range(20):
+        B, T, H = 5, 60, 8
+        feats = torch.randn(B, T, H, generator=g)
+        sep = torch.zeros(B, T)
+        for i in range(B):
+            pos = 1
+            while True:
+                pos += int(torch.randint(3, 14, (1,), generator=g))
+                if pos >= T:
+                    break
+                sep[i, pos] = 1
+        utt = torch.randint(0, 5, (B,), generator=g)
+        for roberta in (True, False):
+            a, am = slice_target_utterance(feats.to(dev), sep.to(dev), utt.to(dev), 7, roberta)
+            b, bm = slice_target_utterance_loop(feats, sep, utt, 7, roberta)
+            assert a.is_cuda and torch.equal(a.cpu(), b) and torch.equal(am.cpu(), bm)
+    # bench geometry: 512 tokens, 1024-wide features, separators every 20 tokens, utterance index up to 7, 38 kept
+    feats = torch.randn(4, 512, 64, generator=g)
+    sep = torch.zeros(4, 512)
+    sep[:, 20:400:20] = 1
+    utt = torch.tensor([0, 1, 5, 7])
+    for roberta in (True, False):
+        a, am = slice_target_utterance(feats.to(dev), sep.to(dev), utt.to(dev), 38, roberta)
+        b, bm = slice_target_utterance_loop(feats, sep, utt, 38, roberta)
+        assert torch.equal(a.cpu(), b) and torch.equal(am.cpu(), bm)
+
+
+def _facex_zoo_file(path, seed=100):
+    """A FaceX-Zoo style checkpoint ({'state_dict': {'backbone.<name>': tensor}}, train.py:316-331) holding the weights
+    the golden fixtures were generated with; the head (`linear`, `classifier`) is absent, as in the published file."""
+    from facialmmt_amd import models
+    from facialmmt_amd.config import default_args
+    donor = models.SwinForAffwildClassification(default_args())
+    synth.fill_state_dict(donor, seed=seed)
+    sd = {"backbone." + k[5:]: v.clone() for k, v in donor.state_dict().items() if k.startswith("swin.")}
+    sd["head.weight"] = torch.zeros(10, 512)                                  # something nothing asks for
+    torch.save({"state_dict": sd, "epoch": 17}, path)
+    return donor
+
+
+def test_loaded_backbone_reproduces_reference_features(golden, dev, tmp_path):
+    from facialmmt_amd import checkpoint, models
+    from facialmmt_amd.config import default_args
+    path = str(tmp_path / "Swin_tiny_Ms-Celeb-1M.pt")
+    _facex_zoo_file(path)
+    torch.manual_seed(7)
+    aff = models.SwinForAffwildClassification(default_args())               # random init, different from the file
+    rep = checkpoint.load_pretrained_backbone(aff, path)
+    assert len(rep.loaded) == 195 and rep.unused == ["head.weight"] and not rep.mismatched
+    assert sorted(rep.missing) == ["linear.bias", "linear.weight"]
+    aff.to(dev).eval()
+    frames = synth.tensor("frames", (8, 3, 224, 224), seed=1).to(dev)
+    with torch.no_grad():
+        golden.check("swin_full", "swin_eval_n8", aff.swin(frames), atol=1e-3, rtol=1e-3)
+    # save_state -> load_state round trip into a third model: same features, bit for bit
+    out = str(tmp_path / "best_swin.state.pt")
+    checkpoint.save_state(aff, out, extra={"val_f1": 0.5})
+    other = models.SwinForAffwildClassification(default_args())
+    checkpoint.load_state(other, out)
+    other.to(dev).eval()
+    with torch.no_grad():
+        assert torch.equal(other.swin(frames), aff.swin(frames))
+
+
+def test_converted_whole_module_pickle_loads_and_matches(golden, dev, tmp_path):
+    """tools/convert_checkpoint.py on a whole-module pickle of the kind utils/util.py:121-133 writes (here: this package's
+    own model class wrapped like LightningLite's _LiteModule) -> plain file -> load_state -> golden features."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import convert_checkpoint
+    from facialmmt_amd import checkpoint, models
+    from facialmmt_amd.config import default_args
+    from tests.pickle_fixture import _LiteModule
+    donor = models.SwinForAffwildClassification(default_args())
+    synth.fill_state_dict(donor, seed=100)
+    src = str(tmp_path / "best_swin_09-28.pt")
+    torch.save(_LiteModule(donor), src, pickle_protocol=4)
+    out = str(tmp_path / "best_swin.state.pt")
+    rep = convert_checkpoint.convert(src, out, reference_root=None, expect_class="SwinForAffwildClassification")
+    assert rep["wrappers"] == ["_LiteModule"] and rep["n_tensors"] == len(donor.state_dict())
+    m = models.SwinForAffwildClassification(default_args())
+    checkpoint.load_state(m, out)
+    m.to(dev).eval()
+    frames = synth.tensor("frames", (8, 3, 224, 224), seed=1).to(dev)
+    with torch.no_grad():
+        golden.check("swin_full", "swin_eval_n8", m.swin(frames), atol=1e-3, rtol=1e-3)
+
+
+def test_eval_after_graph_capture_runs_eager_branches(dev):
+    """after graph_multimodal, mm.eval() must not replay the training-mode graphs (dropout, static shapes)."""
+    import bench
+    from facialmmt_amd import models
+    from facialmmt_amd.config import default_args
+    from facialmmt_amd.train_step import graph_multimodal
+    B, Lv = 2, 6
+    cfg = default_args(get_vision_utt_max_lens=Lv, get_audio_utt_max_lens=24, plm_module=synth.make_standin_plm())
+    cfg.compute_dtype = torch.float32
+    mm = models.MultiModalTransformerForClassification(cfg)
+    synth.fill_state_dict(mm, seed=200)
+    mm.to(dev)
+    args = types.SimpleNamespace(utts=B, frames=Lv, dtype="fp32")
+    batch = list(bench.synth_batch(args, dev, 0, cfg))
+    batch[0] = batch[0] % 1000
+    vis = torch.cat((batch[5], torch.softmax(torch.randn(B, Lv, 7, device=dev), -1)), -1)
+    call = (batch[0], batch[1], batch[2], batch[3], batch[4], vis, batch[6], batch[10])
+    mm.eval()
+    with torch.no_grad():
+        want = mm(*call).clone()
+        want3 = mm(*(t[:1] if torch.is_tensor(t) else t for t in call)).clone()      # a batch of another size
+    mm.train()
+    sample = tuple(t.detach().clone().requires_grad_(True) if i == 5 else t for i, t in enumerate(call))
+    mm = graph_multimodal(mm, sample, None, overlap_text=True)
+    with torch.no_grad():
+        noisy = mm(*call)                                        # training mode: dropout (p = 0.1) is active in the replay
+    mm.eval()
+    with torch.no_grad():
+        got = mm(*call)
+        got3 = mm(*(t[:1] if torch.is_tensor(t) else t for t in call))
+    assert torch.equal(got, want) and torch.equal(got3, want3)
+    assert not torch.equal(noisy, want)
+    mm.train()
+    with torch.no_grad():
+        assert mm(*call).shape == want.shape                     # and the graphs are used again in training mode

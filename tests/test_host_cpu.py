@@ -231,6 +231,45 @@ def test_checkpoint_backbone_mapping_and_round_trip(tmp_path):
         checkpoint.extract_state_dict({"module.a": torch.zeros(1), "a": torch.zeros(1)})
 
 
+def test_convert_checkpoint_unwraps_whole_module_pickles(tmp_path):
+    """tools/convert_checkpoint.py: a whole-module pickle (utils/util.py:121-133) wrapped as LightningLite / DataParallel
+    wrap it -> a plain file that torch.load(weights_only=True) reads, with the wrapper prefixes gone."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import convert_checkpoint
+    from facialmmt_amd import checkpoint
+    from tests.pickle_fixture import TinyHead, _LiteModule
+    torch.manual_seed(0)
+    inner = TinyHead()
+    src, out = str(tmp_path / "multimodal_model_T+A+V_x.pt"), str(tmp_path / "plain.pt")
+    torch.save(_LiteModule(torch.nn.DataParallel(inner)), src, pickle_protocol=4)
+    rep = convert_checkpoint.convert(src, out, reference_root=str(tmp_path), expect_class="TinyHead")
+    assert rep["wrappers"] == ["_LiteModule", "DataParallel"] and rep["n_tensors"] == len(inner.state_dict())
+    payload = torch.load(out, weights_only=True)
+    assert list(payload["state_dict"]) == list(inner.state_dict()) and payload["class"] == "TinyHead"
+    fresh = TinyHead()
+    checkpoint.load_state(fresh, out)
+    for k, v in inner.state_dict().items():
+        assert torch.equal(fresh.state_dict()[k], v), k
+    with pytest.raises(TypeError, match="expected"):
+        convert_checkpoint.convert(src, out, expect_class="SwinForAffwildClassification")
+    assert convert_checkpoint.main(["--in", src, "--out", out]) == 0
+
+
+def test_plm_pooler_is_kept_but_frozen():
+    """the PLM pooler never receives a gradient (forward reads last_hidden_state only); it keeps its
+    state_dict keys but must not be a trainable parameter a data-parallel exchange would wait for."""
+    from transformers import RobertaConfig
+    from facialmmt_amd import models
+    cfg = default_args()
+    cfg.plm_config = RobertaConfig(vocab_size=100, hidden_size=32, num_hidden_layers=1, num_attention_heads=2, intermediate_size=64,
+                                   max_position_embeddings=40, type_vocab_size=1, pad_token_id=1)
+    mm = models.MultiModalTransformerForClassification(cfg)
+    assert "roberta.pooler.dense.weight" in mm.state_dict()
+    assert all(not p.requires_grad for p in mm.roberta.pooler.parameters())
+    assert all(p.requires_grad for n, p in mm.named_parameters() if ".pooler." not in n)
+
+
 def test_bench_contract_flags_and_loud_failure_without_gpu():
     """bench.py keeps the driver's flag contract and, like the rest of the product path, refuses to run without
     the GPU instead of falling back to anything (the CPU baseline leg is only ever timed beside the HIP path)."""

@@ -124,6 +124,73 @@ def test_gradient_averager_equals_single_process():
                 assert torch.allclose(ret[r][step][k], p.grad, atol=1e-5, rtol=1e-4), (k, r, step)
 
 
+def _worker_contracts(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from facialmmt_amd.parallel import GradientAverager, shard_utterances
+    x, mask, y = _data()
+    sl = list(shard_utterances(8, rank, world))
+    out = {}
+    # (1) a parameter that takes no part in the step: finish() must raise instead of stepping on un-averaged gradients
+    m = _model()
+    m.unused = torch.nn.Linear(4, 4)                          # last registered -> first bucket, together with `cls`
+    avg = GradientAverager(m.parameters(), bucket_mb=64)
+    (torch.nn.functional.cross_entropy(m(x[sl], mask[sl]), y[sl], reduction="sum") / 4.0).backward()
+    try:
+        avg.finish()
+        out["unused"] = "no error"
+    except RuntimeError as e:
+        out["unused"] = str(e)
+    avg.remove()
+    # the same with the parameter frozen: fine
+    m = _model()
+    m.unused = torch.nn.Linear(4, 4).requires_grad_(False)
+    avg = GradientAverager(m.parameters(), bucket_mb=64)
+    (torch.nn.functional.cross_entropy(m(x[sl], mask[sl]), y[sl], reduction="sum") / 4.0).backward()
+    avg.finish()
+    out["frozen"] = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    avg.remove()
+    # (2) buckets completing out of construction order are issued in order: hand the averager the layers in FORWARD
+    # order reversed, so bucket 0 holds `inp` (whose gradients arrive last) and bucket 2 `cls` (first)
+    m = _model()
+    avg = GradientAverager(list(m.cls.parameters()) + list(m.mid.parameters()) + list(m.inp.parameters()), bucket_mb=0)
+    issued = []
+    raw_issue = avg._issue
+    avg._issue = lambda bi: (issued.append(bi), raw_issue(bi))[1]
+    (torch.nn.functional.cross_entropy(m(x[sl], mask[sl]), y[sl], reduction="sum") / 4.0).backward()
+    avg.finish()
+    out["order"] = issued
+    out["ordered"] = {k: p.grad.clone() for k, p in m.named_parameters()}
+    avg.remove()
+    # (3) bf16 on the wire
+    m = _model()
+    avg = GradientAverager(m.parameters(), bucket_mb=0, comm_dtype=torch.bfloat16)
+    (torch.nn.functional.cross_entropy(m(x[sl], mask[sl]), y[sl], reduction="sum") / 4.0).backward()
+    avg.finish()
+    out["bf16"] = {k: p.grad.clone() for k, p in m.named_parameters()}
+    ret[rank] = out
+    dist.destroy_process_group()
+
+
+def test_gradient_averager_contracts():
+    """unused parameter -> error (as torch DDP); out-of-order bucket completion -> in-order issue; bf16 buckets"""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_contracts, args=(world, _free_port(), ret), nprocs=world, join=True)
+    m = _model()
+    x, mask, y = _data()
+    (torch.nn.functional.cross_entropy(m(x, mask), y, reduction="sum") / 8.0).backward()
+    for r in range(world):
+        assert "gradient exchange incomplete" in ret[r]["unused"] and "frozen" in ret[r]["unused"], ret[r]["unused"]
+        assert ret[r]["order"] == sorted(ret[r]["order"]) and len(ret[r]["order"]) >= 3, ret[r]["order"]
+        for k, p in m.named_parameters():
+            assert torch.allclose(ret[r]["frozen"][k], p.grad, atol=1e-5, rtol=1e-4), k
+            assert torch.allclose(ret[r]["ordered"][k], p.grad, atol=1e-5, rtol=1e-4), k
+            assert torch.allclose(ret[r]["bf16"][k], p.grad, atol=2e-2 * float(p.grad.abs().max()), rtol=2e-2), k
+            assert torch.equal(ret[0]["bf16"][k], ret[1]["bf16"][k]), k          # every rank holds the same averaged gradient
+
+
 def test_shard_utterances_partitions():
     from facialmmt_amd.parallel import shard_utterances
     for n, w in [(32, 8), (16, 4), (8, 8), (7, 4), (1, 2)]:
