@@ -13,10 +13,11 @@ LIB_PATH = os.path.join(_HERE, "libfmmt_hip.so")
 
 F32, BF16 = 0, 1
 EPI_NONE, EPI_GELU, EPI_GELU_BWD = 0, 1, 2
+RESIZE_PIL, RESIZE_CV2 = 0, 1
 
 _p, _i, _f, _sz, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_uint64
 
-# name -> (restype, argtypes); mirrors include/fmmt.h one to one (tests/test_abi.py checks both ways)
+# name -> (restype, argtypes); mirrors include/fmmt.h one to one (tests/test_host_cpu.py::test_header_and_ctypes_signatures_agree checks both ways)
 SIGNATURES = {
     "fmmt_version": (_i, []),
     "fmmt_linear_fwd": (_i, [_i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p]),
@@ -40,6 +41,9 @@ SIGNATURES = {
     "fmmt_batchnorm1d_bwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p]),
     "fmmt_posemb_scale_fwd": (_i, [_i, _i, _i, _i, _p, _p, _f, _p, _p]),
     "fmmt_scale": (_i, [_i, _sz, _p, _f, _p, _p]),
+    "fmmt_resize_table": (_i, [_i, _i, _i, _p, _p]),
+    "fmmt_resize_band_rows": (_i, [_p, _i]),
+    "fmmt_patch_embed_u8": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p]),
 }
 
 _ERR = {-1: "FMMT_EINVAL (bad shape / unsupported size)", -2: "FMMT_EALIGN (pointer or leading dimension not 16-byte aligned)",

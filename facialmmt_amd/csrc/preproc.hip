@@ -1,0 +1,194 @@
+// Input pre-step fused into PatchEmbed's gather: uint8 face crops go straight to the
+// (patches x 48) operand of the patch-embedding GEMM -- bicubic resize to 224x224 (uint8, integer arithmetic, bit-exact
+// with the library the reference calls), ToTensor (/255), Normalize(.5,.5), 4x4 patch gather -- without ever
+// materialising the 224x224 float tensor the reference caches per frame (utils/dataset.py:47-69,275; utils/util.py:43-52).
+//
+// Two resize flavours (oracle/preproc.py restates both on the CPU and says which one is pinned):
+//   FMMT_RESIZE_PIL  Pillow Image.resize(BICUBIC) -- the Aff-Wild2 path (transforms.Resize on a PIL image, util.py:45):
+//                    a = -0.5, truncated + renormalised window at the border, 22-bit coefficients, uint8 after EACH pass;
+//   FMMT_RESIZE_CV2  cv2.resize(INTER_CUBIC) on uint8 -- the MELD path (dataset.py:57): a = -0.75 in float, replicate
+//                    border, 11-bit coefficients, un-rounded int32 row sums, one 22-bit rounding after the vertical pass.
+// Both reduce to: per output coordinate four source indices and four integer weights (one table, used for x and for y --
+// the crops are square), built on the HOST by fmmt_resize_table() so that the double / float coefficient arithmetic is
+// the library's own, and uploaded once per (flavour, size) by the caller.
+#include "fmmt_common.h"
+#include "../../include/fmmt.h"
+#include <math.h>
+
+namespace {
+
+constexpr int OUT = 224, GRID = 56, KPATCH = 48;
+constexpr int RMAX = 8;              // source rows a band of 4 output rows may touch (checked on the host for the table)
+constexpr int SMAX = 224;            // largest source edge (up-scaling only)
+
+double pil_cubic(double x) {
+    const double a = -0.5;
+    if (x < 0.0) x = -x;
+    if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+    if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+    return 0.0;
+}
+
+// block = (patch row p, image n); 256 threads.
+//   1. stage the source rows [ymin, ymax] of the band as bytes            (coalesced 4-byte loads)
+//   2. horizontal pass into LDS: H[r][x*3+c]  (PIL: uint8-rounded; cv2: raw int32 sums)
+//   3. vertical pass, rounding, byte -> float through the ToTensor/Normalize table, store in patch-column order
+template <typename T, bool PIL>
+__global__ __launch_bounds__(256) void patch_embed_u8_kernel(const uint8_t* __restrict__ img, int S, const int32_t* __restrict__ tab,
+                                                            const float* __restrict__ lut, T* __restrict__ cols) {
+    __shared__ __attribute__((aligned(16))) uint8_t src[RMAX * SMAX * 3];
+    __shared__ int32_t H[RMAX][OUT * 3];
+    __shared__ int32_t tx[OUT * 8];
+    __shared__ int32_t ty[4][8];
+    __shared__ float slut[256];
+    const int p = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+    if (tid < 32) ty[tid >> 3][tid & 7] = tab[(4 * p + (tid >> 3)) * 8 + (tid & 7)];
+    slut[tid] = lut[tid];
+    for (int i = tid; i < OUT * 8; i += 256) tx[i] = tab[i];
+    __syncthreads();
+    int ymin = S, ymax = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            ymin = min(ymin, ty[j][k]);
+            ymax = max(ymax, ty[j][k]);
+        }
+    const int nr = ymax - ymin + 1;                          // <= RMAX (host-checked)
+    const int rowb = S * 3;
+    const uint8_t* base = img + ((size_t)n * S + ymin) * rowb;
+    const int nbytes = nr * rowb;                            // the rows are contiguous in the image
+    // (n * S + ymin) * S * 3 is a multiple of 4 only for some rows: stage bytes with a 4-byte main loop on the aligned part
+    const int mis = (int)((uintptr_t)base & 3);
+    const int head = mis ? min(4 - mis, nbytes) : 0;
+    if (tid < head) src[tid] = base[tid];
+    const int words = (nbytes - head) >> 2;
+    const uint32_t* b4 = reinterpret_cast<const uint32_t*>(base + head);
+    for (int i = tid; i < words; i += 256) {
+        const uint32_t v = b4[i];
+        const int o = head + 4 * i;
+        src[o] = (uint8_t)v;
+        src[o + 1] = (uint8_t)(v >> 8);
+        src[o + 2] = (uint8_t)(v >> 16);
+        src[o + 3] = (uint8_t)(v >> 24);
+    }
+    for (int i = head + 4 * words + tid; i < nbytes; i += 256) src[i] = base[i];
+    __syncthreads();
+    for (int e = tid; e < nr * OUT * 3; e += 256) {
+        const int r = e / (OUT * 3), rem = e - r * (OUT * 3);
+        const int x = rem / 3, c = rem - 3 * x;
+        const int32_t* t = tx + x * 8;
+        const uint8_t* s = src + r * rowb + c;
+        int32_t acc = PIL ? (1 << 21) : 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc += (int32_t)s[t[k] * 3] * t[4 + k];
+        H[r][rem] = PIL ? min(max(acc >> 22, 0), 255) : acc;
+    }
+    __syncthreads();
+    T* out = cols + ((size_t)n * GRID + p) * GRID * KPATCH;
+    for (int e = tid; e < GRID * KPATCH; e += 256) {
+        const int patch = e / KPATCH, kk = e - patch * KPATCH;
+        const int c = kk >> 4, dy = (kk >> 2) & 3, dx = kk & 3;
+        const int col = (patch * 4 + dx) * 3 + c;
+        int32_t acc = 1 << 21;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc += H[ty[dy][k] - ymin][col] * ty[dy][4 + k];
+        const int v = min(max(acc >> 22, 0), 255);
+        out[e] = from_f32<T>(slut[v]);
+    }
+}
+
+}  // namespace
+
+extern "C" int fmmt_resize_table(int mode, int in_size, int out_size, int32_t* table, float* lut) {
+    if ((mode != FMMT_RESIZE_PIL && mode != FMMT_RESIZE_CV2) || in_size < 4 || out_size < in_size || !table) return FMMT_EINVAL;
+    if (mode == FMMT_RESIZE_PIL) {
+        // Pillow src/libImaging/Resample.c precompute_coeffs / normalize_coeffs_8bpc, bicubic filter (support 2)
+        const double scale = (double)in_size / out_size;
+        const double fscale = scale < 1.0 ? 1.0 : scale, support = 2.0 * fscale;
+        for (int xx = 0; xx < out_size; ++xx) {
+            const double center = (xx + 0.5) * scale;
+            int xmin = (int)(center - support + 0.5);
+            if (xmin < 0) xmin = 0;
+            int xmax = (int)(center + support + 0.5);
+            if (xmax > in_size) xmax = in_size;
+            const int n = xmax - xmin;
+            if (n < 1 || n > 4) return FMMT_EINVAL;
+            double k[4], ww = 0.0;
+            for (int x = 0; x < n; ++x) {
+                k[x] = pil_cubic((x + xmin - center + 0.5) * (1.0 / fscale));
+                ww += k[x];
+            }
+            for (int x = 0; x < 4; ++x) {
+                table[xx * 8 + x] = xmin + (x < n ? x : n - 1);
+                int32_t w = 0;
+                if (x < n) {
+                    const double v = k[x] / ww;                 // Pillow: k[x] /= ww (ww != 0 always holds for the cubic window)
+                    w = v < 0 ? (int32_t)(-0.5 + v * (1 << 22)) : (int32_t)(0.5 + v * (1 << 22));
+                }
+                table[xx * 8 + 4 + x] = w;
+            }
+        }
+    } else {
+        // OpenCV modules/imgproc/src/resize.cpp (8U, INTER_CUBIC): float coordinate and interpolateCubic, A = -0.75
+        const double scale = 1.0 / ((double)out_size / in_size);
+        const float A = -0.75f;
+        for (int dx = 0; dx < out_size; ++dx) {
+            float fx = (float)((dx + 0.5) * scale - 0.5);
+            const int sx = (int)floorf(fx);
+            fx -= sx;
+            float c[4];
+            c[0] = ((A * (fx + 1) - 5 * A) * (fx + 1) + 8 * A) * (fx + 1) - 4 * A;
+            c[1] = ((A + 2) * fx - (A + 3)) * fx * fx + 1;
+            c[2] = ((A + 2) * (1 - fx) - (A + 3)) * (1 - fx) * (1 - fx) + 1;
+            c[3] = 1.f - c[0] - c[1] - c[2];
+            for (int k = 0; k < 4; ++k) {
+                int s = sx - 1 + k;
+                s = s < 0 ? 0 : (s > in_size - 1 ? in_size - 1 : s);
+                table[dx * 8 + k] = s;
+                long r = lrintf(c[k] * 2048.f);                  // cvRound: to nearest even (default rounding mode)
+                r = r < -32768 ? -32768 : (r > 32767 ? 32767 : r);
+                table[dx * 8 + 4 + k] = (int32_t)r;
+            }
+        }
+    }
+    if (lut)
+        for (int v = 0; v < 256; ++v) lut[v] = ((float)v / 255.0f - 0.5f) / 0.5f;     // ToTensor, then Normalize(.5, .5), in float32
+    return 0;
+}
+
+extern "C" int fmmt_resize_band_rows(const int32_t* table, int out_size) {
+    // largest number of distinct source rows that four consecutive output rows (one patch row) touch
+    if (!table || out_size < 4 || out_size % 4) return FMMT_EINVAL;
+    int worst = 0;
+    for (int p = 0; p < out_size / 4; ++p) {
+        int lo = 1 << 30, hi = -1;
+        for (int j = 0; j < 4; ++j)
+            for (int k = 0; k < 4; ++k) {
+                const int v = table[(4 * p + j) * 8 + k];
+                lo = v < lo ? v : lo;
+                hi = v > hi ? v : hi;
+            }
+        worst = hi - lo + 1 > worst ? hi - lo + 1 : worst;
+    }
+    return worst;
+}
+
+extern "C" int fmmt_patch_embed_u8(int dtype, int mode, int n_img, int in_size, const void* img_u8, const int32_t* table_dev,
+                                   const float* lut_dev, void* cols, void* stream) {
+    if ((dtype != FMMT_BF16 && dtype != FMMT_F32) || (mode != FMMT_RESIZE_PIL && mode != FMMT_RESIZE_CV2)) return FMMT_EINVAL;
+    if (n_img <= 0 || n_img > 65535 || in_size < 4 || in_size > SMAX || !img_u8 || !table_dev || !lut_dev || !cols) return FMMT_EINVAL;
+    // a band of four output rows of an up-scaling (in_size <= 224) table touches at most 4 + 3 + 1 = 8 source rows
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid(GRID, n_img);
+    const uint8_t* img = reinterpret_cast<const uint8_t*>(img_u8);
+    if (dtype == FMMT_BF16) {
+        if (mode == FMMT_RESIZE_PIL) hipLaunchKernelGGL((patch_embed_u8_kernel<bf16, true>), grid, dim3(256), 0, st, img, in_size, table_dev, lut_dev, (bf16*)cols);
+        else hipLaunchKernelGGL((patch_embed_u8_kernel<bf16, false>), grid, dim3(256), 0, st, img, in_size, table_dev, lut_dev, (bf16*)cols);
+    } else {
+        if (mode == FMMT_RESIZE_PIL) hipLaunchKernelGGL((patch_embed_u8_kernel<float, true>), grid, dim3(256), 0, st, img, in_size, table_dev, lut_dev, (float*)cols);
+        else hipLaunchKernelGGL((patch_embed_u8_kernel<float, false>), grid, dim3(256), 0, st, img, in_size, table_dev, lut_dev, (float*)cols);
+    }
+    FMMT_CHECK_LAUNCH();
+    return 0;
+}

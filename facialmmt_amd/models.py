@@ -10,7 +10,8 @@ Differences from the reference, on purpose:
   * no hard-coded .cuda() (ref src/models.py:114-115): buffers are created on the input's device;
   * the per-utterance token slicing (ref :112-150), a Python double loop with one host sync per token,
     is restated as cumsum + gather on the device with no host synchronisation (same result; pinned by
-    tests/test_models_cpu.py against a literal loop);
+    tests/test_host_cpu.py::test_slice_target_utterance_matches_literal_loop and, on device tensors,
+    tests/test_gpu_glue.py against a literal loop);
   * the activations handed to the HIP encoders are cast to the compute dtype of the module
     (`compute_dtype`, bf16 for throughput / fp32 for parity) and back."""
 from __future__ import annotations

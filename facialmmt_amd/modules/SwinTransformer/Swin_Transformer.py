@@ -308,6 +308,19 @@ class PatchEmbed(nn.Module):
         self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
         self.norm = norm_layer(embed_dim) if norm_layer is not None else None
 
+    def forward_u8(self, x, resize="pil", dtype=None):
+        """x: (B, S, S, 3) uint8 face crops in image layout.  The reference's host-side pre-step -- bicubic resize to
+        224x224, ToTensor, Normalize(.5,.5) (utils/util.py:43-52 'pil' / utils/dataset.py:47-69 'cv2') -- is fused into the
+        patch gather (ops.patch_embed_u8): same result as forward(Normalize(ToTensor(resize(x)))), without the float image."""
+        _require(tuple(self.img_size) == (224, 224) and tuple(self.patch_size) == (4, 4) and self.in_chans == 3,
+                 "PatchEmbed kernel is built for 3x224x224 images and 4x4 patches")
+        B = x.shape[0]
+        cols = ops.patch_embed_u8(x, resize, dtype or self.proj.weight.dtype)
+        y = ops.linear(cols, self.proj.weight.view(self.embed_dim, -1), self.proj.bias).view(B, self.num_patches, self.embed_dim)
+        if self.norm is not None:
+            y = ops.layer_norm(y, self.norm.weight, self.norm.bias, self.norm.eps)
+        return y
+
     def forward(self, x):
         B, C, H, W = x.shape
         assert H == self.img_size[0] and W == self.img_size[1], \
@@ -384,9 +397,17 @@ class SwinTransformer(nn.Module):
             bn.num_batches_tracked += 1
         return ops.batch_norm_1d(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, use_batch)
 
+    # uint8 input (B, S, S, 3): which library's bicubic the fused pre-step reproduces ('pil': Aff-Wild2 path, pinned
+    # bit-exactly; 'cv2': MELD path, unpinned) and the activation dtype it produces (None: the parameters' dtype)
+    input_resize = "pil"
+    input_dtype = None
+
     def forward_features(self, x):
         _require(self.pos_drop.p == 0.0 or not self.training, "pos_drop p > 0 in training")
-        x = self.patch_embed(x)
+        if x.dtype == torch.uint8:
+            x = self.patch_embed.forward_u8(x, self.input_resize, self.input_dtype)
+        else:
+            x = self.patch_embed(x)
         for layer in self.layers:
             x = layer(x)
         return self._head(x)

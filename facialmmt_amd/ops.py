@@ -421,6 +421,48 @@ def patch_im2col(img):
     return PatchIm2colFn.apply(img)
 
 
+_RESIZE_TABLES: dict = {}        # (mode, in_size, device) -> (int32 table [224,8], float32 lut [256]) on the device
+
+
+def resize_tables(mode: str, in_size: int, device):
+    """Device copies of the host-built coefficient / normalisation tables of fmmt_patch_embed_u8 (built once per flavour,
+    source size and device by the library's own host function -- never by the oracle)."""
+    import ctypes
+    key = (mode, int(in_size), str(device))
+    hit = _RESIZE_TABLES.get(key)
+    if hit is not None:
+        return hit
+    lib = _lib.load()
+    code = {"pil": _lib.RESIZE_PIL, "cv2": _lib.RESIZE_CV2}.get(mode)
+    if code is None:
+        raise ValueError(f"resize flavour {mode!r}: 'pil' (utils/util.py:45, pinned) or 'cv2' (utils/dataset.py:57, unpinned)")
+    tab = (ctypes.c_int32 * (224 * 8))()
+    lut = (ctypes.c_float * 256)()
+    check(lib.fmmt_resize_table(code, int(in_size), 224, ctypes.addressof(tab), ctypes.addressof(lut)), f"fmmt_resize_table({mode},{in_size})")
+    rows = lib.fmmt_resize_band_rows(ctypes.addressof(tab), 224)
+    if not 0 < rows <= 8:
+        raise _lib.FmmtError(f"fmmt_patch_embed_u8: a band of 4 output rows touches {rows} source rows at size {in_size} (kernel limit 8)")
+    t = torch.tensor(list(tab), dtype=torch.int32).view(224, 8).to(device)
+    l = torch.tensor(list(lut), dtype=torch.float32).to(device)
+    _RESIZE_TABLES[key] = (code, t, l)
+    return _RESIZE_TABLES[key]
+
+
+def patch_embed_u8(img_u8: torch.Tensor, mode: str, dtype) -> torch.Tensor:
+    """(n, S, S, 3) uint8 crops (image layout) -> (n*3136, 48) patch matrix of Normalize(ToTensor(resize_224(img))):
+    the input pre-step fused into PatchEmbed's gather (no gradient: the input is integer data)."""
+    _need_cuda(img_u8, "patch_embed_u8")
+    if img_u8.dtype != torch.uint8 or img_u8.dim() != 4 or img_u8.shape[1] != img_u8.shape[2] or img_u8.shape[3] != 3:
+        raise ValueError(f"patch_embed_u8 expects (n, S, S, 3) uint8 crops, got {tuple(img_u8.shape)} {img_u8.dtype}")
+    img_u8 = img_u8.contiguous()
+    n, S = img_u8.shape[0], img_u8.shape[1]
+    code, tab, lut = resize_tables(mode, S, img_u8.device)
+    cols = torch.empty((n * 3136, 48), dtype=dtype, device=img_u8.device)
+    rc = _lib.load().fmmt_patch_embed_u8(dtype_code(dtype), code, n, S, _p(img_u8), _p(tab), _p(lut), _p(cols), _st())
+    check(rc, f"fmmt_patch_embed_u8(n={n},S={S},{mode})")
+    return cols
+
+
 class BatchNorm1dFn(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, training):

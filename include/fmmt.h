@@ -200,6 +200,31 @@ int fmmt_posemb_scale_fwd(int dtype, int L, int B, int E, const void* x, const f
 /* y = alpha * x elementwise (backward of the embedding scale); n elements, n % 8 == 0. */
 int fmmt_scale(int dtype, size_t n, const void* x, float alpha, void* y, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Input pre-step fused into PatchEmbed's gather.  Replaces, for one batch of square uint8 face
+ * crops (n, S, S, 3) in image (HWC) layout, the chain the reference runs per frame on the host and caches as a
+ * 224x224 float tensor:
+ *   Aff-Wild2: transforms.Resize(224, BICUBIC) on the PIL image -> ToTensor -> Normalize(.5,.5)   utils/util.py:43-52
+ *   MELD:      cv2.resize(im, (224,224), INTER_CUBIC) on the uint8 array -> ToTensor -> Normalize  utils/dataset.py:47-69
+ * followed by PatchEmbed's 4x4 / stride-4 patch gather (Swin_Transformer.py:407,419): the output IS the
+ * (n*3136, 48) operand of the patch-embedding GEMM (same layout as fmmt_patch_im2col), element type `dtype`.
+ * Augmentations (ColorJitter, RandomErasing, ...) are host-side data pipeline and not part of this entry point.
+ *
+ * fmmt_resize_table   HOST function: fills table[out_size][8] = {4 source indices, 4 integer weights} per output
+ *                     coordinate (the same table serves x and y) and lut[256] = float32 Normalize(ToTensor(byte)), with the
+ *                     coefficient arithmetic of the library the reference calls (FMMT_RESIZE_PIL: Pillow, 22-bit, bit-exact,
+ *                     pinned by tests/golden/preproc.npz; FMMT_RESIZE_CV2: OpenCV 8U INTER_CUBIC, 11-bit, restated from the
+ *                     published algorithm, parity unpinned).  Up-scaling only (in_size <= out_size).
+ * fmmt_resize_band_rows  HOST: the largest number of source rows one band of 4 output rows touches (must be <= 8).
+ * fmmt_patch_embed_u8 device launch; table_dev / lut_dev are the two host tables copied to the device by the caller.
+ */
+#define FMMT_RESIZE_PIL 0
+#define FMMT_RESIZE_CV2 1
+int fmmt_resize_table(int mode, int in_size, int out_size, int32_t* table, float* lut);
+int fmmt_resize_band_rows(const int32_t* table, int out_size);
+int fmmt_patch_embed_u8(int dtype, int mode, int n_img, int in_size, const void* img_u8, const int32_t* table_dev,
+                        const float* lut_dev, void* cols, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

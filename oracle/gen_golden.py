@@ -286,9 +286,79 @@ def main():
 
     with open(os.path.join(OUT, "state_dict_keys.json"), "w") as f:
         json.dump(keys, f)
+    main_round2(synth, RM, CrossModalTransformerEncoder, seq)
     for fn in sorted(os.listdir(OUT)):
         print(fn, os.path.getsize(os.path.join(OUT, fn)))
 
 
+def _seq(synth):
+    def seq(name, L, B, n_zero_rows, seed):
+        t = synth.tensor(name, (L, B, 768), seed=seed)
+        if n_zero_rows:
+            t[L - n_zero_rows:] = 0.0
+        t[1, 0, 0] = 0.0
+        return t
+    return seq
+
+
+def only_round2():
+    """`python -m oracle.gen_golden --round2`: the round-2 files alone (minutes instead of the full regeneration)"""
+    _install_shims()
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from facialmmt_amd import synth
+    from modules.CrossmodalTransformer import CrossModalTransformerEncoder
+    import src.models as RM
+    torch.manual_seed(0)
+    torch.set_grad_enabled(False)
+    main_round2(synth, RM, CrossModalTransformerEncoder, _seq(synth))
+    for fn in sorted(os.listdir(OUT)):
+        print(fn, os.path.getsize(os.path.join(OUT, fn)))
+
+
+def main_round2(synth, RM, CrossModalTransformerEncoder, seq):
+    """Round-2 fixtures, written to NEW files (the four round-1 files above stay byte-identical):
+
+    lv320.npz    BASELINE.json configs[4] (320-frame face sequence): the cross-modal encoder at (320;166) and (166;320), the
+                 vision self-attention encoder + pooling at L = 320 (meld_utt_transformer), and the whole multimodal model
+                 with L_v = 320 -- all produced by the REFERENCE's classes, same hash-generated weights as round 1.
+    preproc.npz  the input pre-step: Pillow's own Image.resize(BICUBIC) (what transforms.Resize does to a PIL image,
+                 utils/util.py:45) on hash-generated 112x112 and 160x160 uint8 crops, and the float tensor
+                 ToTensor + Normalize(.5,.5) make of it (computed with torch as torchvision does: /255, (t-.5)/.5)."""
+    from facialmmt_amd.config import default_args
+    g = {}
+    enc = CrossModalTransformerEncoder(768, 12, 2, 0.1).eval()
+    synth.fill_state_dict(enc, seed=50, prefix="enc.")
+    for (Lq, Lk) in [(320, 166), (166, 320)]:
+        xq = seq(f"x{Lq}", Lq, 1, 0, seed=60)
+        xk = seq(f"x{Lk}", Lk, 1, 0, seed=60)
+        flatten(f"enc/{Lq}_{Lk}_b1", pack(enc(xq, xk, xk)), g)
+    cfg = default_args(get_vision_utt_max_lens=320)
+    vm = RM.meld_utt_transformer(cfg).eval()
+    synth.fill_state_dict(vm, seed=201)
+    vin = synth.tensor("vfeat320", (2, 320, 512), seed=12)
+    vmask = torch.ones(2, 320); vmask[1, 250:] = 0
+    flatten("meld_utt_320", pack(vm(vin, vmask)), g)
+    cfg = default_args(get_audio_utt_max_lens=24, get_vision_utt_max_lens=320, pretrainedtextmodel_path="pretrained_model/roberta-large")
+    standin = synth.make_standin_plm()
+    RM.RobertaModel.from_pretrained = staticmethod(lambda path: standin)
+    mm = RM.MultiModalTransformerForClassification(cfg).eval()
+    synth.fill_state_dict(mm, seed=200)
+    standin.emb.weight.copy_(synth.make_standin_plm().emb.weight)
+    inp = synth_multimodal_inputs(synth, B=3, T=64, La=24, Lv=320)
+    flatten("mm/roberta_lv320", pack(mm(*inp)), g)
+    np.savez_compressed(os.path.join(OUT, "lv320.npz"), **g)
+
+    from PIL import Image
+    g = {"pillow_version": np.array(Image.__version__ if hasattr(Image, "__version__") else __import__("PIL").__version__)}
+    for S in (112, 160):
+        crops = synth.randint("crop", (2, S, S, 3), 0, 256, seed=7).astype(np.uint8)
+        res = np.stack([np.asarray(Image.fromarray(c, "RGB").resize((224, 224), Image.BICUBIC)) for c in crops])
+        g[f"pil_resize_{S}"] = res
+        if S == 112:
+            t = torch.from_numpy(res[:1]).permute(0, 3, 1, 2).to(torch.float32).div(255)  # ToTensor
+            g["pil_frames_112"] = t.sub(0.5).div(0.5).numpy()                               # Normalize(.5, .5)
+    np.savez_compressed(os.path.join(OUT, "preproc.npz"), **g)
+
+
 if __name__ == "__main__":
-    main()
+    only_round2() if "--round2" in sys.argv else main()

@@ -190,7 +190,7 @@ def t_wattn():
 
 def t_mha():
     for dt, tol in ((torch.float32, 2e-5), (torch.bfloat16, 2e-2)):
-        for (Lq, Lk, B, E, nh) in [(38, 128, 2, 768, 12), (128, 38, 1, 768, 12), (166, 160, 4, 768, 12), (70, 33, 2, 256, 8),
+        for (Lq, Lk, B, E, nh) in [(38, 128, 2, 768, 12), (128, 38, 1, 768, 12), (166, 160, 4, 768, 12), (320, 166, 1, 768, 12), (166, 320, 2, 768, 12), (70, 33, 2, 256, 8),
                                    (1, 1, 1, 768, 12), (1, 65, 2, 768, 12), (64, 1, 1, 768, 12)]:      # single query / single key
             hd = E // nh
             q = rnd("q", (Lq, B, E), 1, dtype=dt).requires_grad_(True)
@@ -215,7 +215,7 @@ def t_mha():
             report(f"mha bwd dkv {tag}", kv.grad, kv64.grad, tol * 2)
         # additive key bias (extended attention mask of the self-attention encoders): separate k, v, self-attention
         # lengths incl. ragged tails, -10000 on padded keys plus a smooth bias to exercise the general case
-        for (L, B, E, nh) in [(128, 4, 768, 12), (37, 3, 768, 12), (160, 2, 768, 12), (70, 2, 256, 8)]:
+        for (L, B, E, nh) in [(128, 4, 768, 12), (37, 3, 768, 12), (160, 2, 768, 12), (320, 2, 768, 12), (70, 2, 256, 8)]:
             hd = E // nh
             q = rnd("q", (L, B, E), 1, dtype=dt).requires_grad_(True)
             k = rnd("k", (L, B, E), 2, dtype=dt).requires_grad_(True)

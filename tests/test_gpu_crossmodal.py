@@ -282,3 +282,46 @@ def test_meld_encoder_rejects_cpu():
     enc = MELDTransEncoder(default_args(), 1, 8, 768)
     with pytest.raises(FmmtError):
         enc(torch.zeros(1, 8, 768), torch.zeros(1, 1, 1, 8))
+
+
+# ------------------------------------------------------------------------------------------------
+# round 2: BASELINE.json configs[4] -- 320-frame face sequences (tests/golden/lv320.npz, produced by the reference)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("Lq,Lk", [(320, 166), (166, 320)])
+def test_encoder_lv320(golden, dev, enc, Lq, Lk):
+    xq, xk = _seq(dev, f"x{Lq}", Lq, 1, 0), _seq(dev, f"x{Lk}", Lk, 1, 0)
+    with torch.no_grad():
+        golden.check("lv320", f"enc/{Lq}_{Lk}_b1", enc(xq, xk, xk), **TOL)
+        o32 = enc(xq, xk, xk)
+        o16 = enc(xq.bfloat16(), xk.bfloat16(), xk.bfloat16()).float()              # the MFMA attention kernels at Lk = 320 / 166
+    assert (o16 - o32).abs().max().item() <= 4e-2 * o32.abs().max().item()
+
+
+def test_meld_utt_and_multimodal_lv320(golden, dev):
+    from facialmmt_amd import models
+    from facialmmt_amd.config import default_args
+    from oracle.gen_golden import synth_multimodal_inputs
+    x = synth.tensor("vfeat320", (2, 320, 512), seed=12).to(dev)
+    vmask = torch.ones(2, 320, device=dev)
+    vmask[1, 250:] = 0
+    m = models.meld_utt_transformer(default_args(get_vision_utt_max_lens=320)).eval()
+    synth.fill_state_dict(m, seed=201)
+    m.to(dev)
+    with torch.no_grad():
+        out = m(x, vmask)
+    golden.check("lv320", "meld_utt_320", out, **TOL)
+    m16 = models.meld_utt_transformer(default_args(get_vision_utt_max_lens=320, compute_dtype=torch.bfloat16)).eval()
+    synth.fill_state_dict(m16, seed=201)
+    m16.to(dev)
+    with torch.no_grad():
+        out16 = m16(x, vmask)
+    assert (out16.float() - out).abs().max().item() <= 5e-2 * max(1.0, out.abs().max().item())
+    cfg = default_args(get_audio_utt_max_lens=24, get_vision_utt_max_lens=320, plm_module=synth.make_standin_plm())
+    mm = models.MultiModalTransformerForClassification(cfg).eval()
+    synth.fill_state_dict(mm, seed=200)
+    with torch.no_grad():
+        mm.roberta.emb.weight.copy_(synth.make_standin_plm().emb.weight)
+    mm.to(dev)
+    inp = [t.to(dev) for t in synth_multimodal_inputs(synth, B=3, T=64, La=24, Lv=320)]
+    with torch.no_grad():
+        golden.check("lv320", "mm/roberta_lv320", mm(*inp), **TOL)

@@ -183,6 +183,41 @@ def test_meld_utt_logits(golden):
     golden.check("multimodal", "meld_utt", out, atol=1e-4, rtol=1e-4)
 
 
+# ---------------------------------------------------------------------------------------------
+# round 2: BASELINE.json configs[4] (320-frame face sequence) -- tests/golden/lv320.npz
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("Lq,Lk", [(320, 166), (166, 320)])
+def test_crossmodal_encoder_lv320(golden, Lq, Lk):
+    sd = synth.state_dict_from_keys(golden.keys["crossmodal"], seed=50, prefix="enc.")
+    xq, xk = _seq(f"x{Lq}", Lq, 1, 0), _seq(f"x{Lk}", Lk, 1, 0)
+    with torch.no_grad():
+        golden.check("lv320", f"enc/{Lq}_{Lk}_b1", OC.crossmodal_encoder(sd, xq, xk, xk), **TOL)
+
+
+def _keys_with_pos(keys, name, L):
+    """the committed key lists were dumped for 20/24-step sequences: same keys, position table resized to L rows"""
+    return [[k, ([L, shp[1]] if k == name else shp), dt] for k, shp, dt in keys]
+
+
+def test_meld_utt_and_multimodal_lv320(golden):
+    from facialmmt_amd.config import default_args
+    from oracle import multimodal as OM
+    from oracle.gen_golden import synth_multimodal_inputs
+    cfg = default_args(get_vision_utt_max_lens=320)
+    sd = synth.state_dict_from_keys(_keys_with_pos(golden.keys["meld_utt"], "utt_transformer.position_embeddings.weight", 320), seed=201)
+    vmask = torch.ones(2, 320)
+    vmask[1, 250:] = 0
+    with torch.no_grad():
+        out = OM.meld_utt_logits(sd, cfg, synth.tensor("vfeat320", (2, 320, 512), seed=12), vmask)
+    golden.check("lv320", "meld_utt_320", out, atol=1e-4, rtol=1e-4)
+    cfg = default_args(get_audio_utt_max_lens=24, get_vision_utt_max_lens=320)
+    sd = synth.state_dict_from_keys(_keys_with_pos(golden.keys["multimodal_roberta"], "vision_utt_transformer.position_embeddings.weight", 320), seed=200)
+    inp = synth_multimodal_inputs(synth, B=3, T=64, La=24, Lv=320)
+    with torch.no_grad():
+        out = OM.multimodal_logits(sd, synth.make_standin_plm(), cfg, *inp, roberta=True)
+    golden.check("lv320", "mm/roberta_lv320", out, atol=1e-4, rtol=1e-4)
+
+
 def test_bn_running_stats(golden, swin_sd):
     """running_mean/var after one training step = 0.9*old + 0.1*batch (unbiased var) -- Swin_Transformer.py:494."""
     frames = synth.tensor("frames", (8, 3, 224, 224), seed=1)
