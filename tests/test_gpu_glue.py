@@ -105,11 +105,12 @@ def test_slice_target_utterance_on_device_matches_literal_loop(dev):
 def _facex_zoo_file(path, seed=100):
     """A FaceX-Zoo style checkpoint ({'state_dict': {'backbone.<name>': tensor}}, train.py:316-331) holding the weights
     the golden fixtures were generated with; the head (`linear`, `classifier`) is absent, as in the published file."""
-    from facialmmt_amd import models
     from facialmmt_amd.config import default_args
-    donor = models.SwinForAffwildClassification(default_args())
-    synth.fill_state_dict(donor, seed=seed)
-    sd = {"backbone." + k[5:]: v.clone() for k, v in donor.state_dict().items() if k.startswith("swin.")}
+    from facialmmt_amd.modules.SwinTransformer.backbone_def import BackboneFactory
+    a = default_args()
+    donor = BackboneFactory(a.backbone_type, a.backbone_conf_file).get_backbone()
+    synth.fill_state_dict(donor, seed=seed)            # the bare backbone: the weights `swin_eval_n8` was generated with
+    sd = {"backbone." + k: v.clone() for k, v in donor.state_dict().items()}
     sd["head.weight"] = torch.zeros(10, 512)                                  # something nothing asks for
     torch.save({"state_dict": sd, "epoch": 17}, path)
     return donor
@@ -148,7 +149,7 @@ def test_converted_whole_module_pickle_loads_and_matches(golden, dev, tmp_path):
     from facialmmt_amd.config import default_args
     from tests.pickle_fixture import _LiteModule
     donor = models.SwinForAffwildClassification(default_args())
-    synth.fill_state_dict(donor, seed=100)
+    synth.fill_state_dict(donor.swin, seed=100)        # the bare backbone's names: the weights `swin_eval_n8` was generated with
     src = str(tmp_path / "best_swin_09-28.pt")
     torch.save(_LiteModule(donor), src, pickle_protocol=4)
     out = str(tmp_path / "best_swin.state.pt")
