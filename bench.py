@@ -4,20 +4,26 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One step = one target-task training step (train.py:54-143) on a synthetic MELD-shaped batch of
-`--utts` utterances per GPU (BASELINE.json configs[1]: T+A+V, RoBERTa-large, 160-frame face sequence,
-batch 4, bf16): Swin-tiny forward+backward over utts*160 frames of 3x224x224 on the HIP path, frame
-filter, RoBERTa-large (PyTorch-ROCm, bf16 autocast, random init), audio/vision self-attention encoders,
-the four cross-modal encoder calls on the HIP path, cross-entropy, backward through everything, gradient
-clip + AdamW step on the multimodal model EVERY step (the reference steps every 4th micro-batch; stepping
-every time only adds work).  Inputs are resident in HBM before the timed region.
+One step = one target-task training step (train.py:54-143) on a synthetic MELD-shaped batch of `--utts` utterances per GPU
+(default BASELINE.json configs[1]: T+A+V, RoBERTa-large, 160-frame face sequence, batch 4, bf16): the uint8 112x112 face crops
+go through the fused pre-step (bicubic x2 + ToTensor + Normalize inside PatchEmbed's gather), Swin-tiny forward+backward over
+utts*frames frames on the HIP path, frame filter, the text encoder (PyTorch-ROCm, bf16 autocast, random init), audio/vision
+self-attention encoders, the four cross-modal encoder calls on the HIP path, cross-entropy, backward through everything,
+gradient clip + AdamW step on the multimodal model EVERY step (the reference steps every 4th micro-batch; stepping every time
+only adds work).  Inputs are resident in HBM before the timed region.  With `--aux-images A` every step is preceded by one
+auxiliary-task step (train.py:15-41) on A Aff-Wild2-shaped crops: Swin fwd+bwd, clip, AdamW on the Swin model.
+
+Other BASELINE.json configs (each run prints its own line naming its configs[i]):
+    --config 3    BERT-large text encoder (src/models.py:75-77), 4 utterances/GPU                 (configs[3], per-GPU leg)
+    --config 4    320-frame face sequence, 1 utterance/GPU, 150 auxiliary images per step          (configs[4], per-GPU leg)
 
 Rank 0 prints ONE JSON line: metric utterances/s (whole job), plus
-  roofline     -- the dominant kernel (the instantiation of linear_nt_kernel, the MFMA GEMM of every Linear
-                  layer, with the largest total time) timed live with HIP events on the launch stream during the timed steps:
-                  achieved = sum(2*M*N*K) / sum(duration) against the 2.5 PFLOP/s dense bf16 MFMA peak;
-  cpu_baseline -- the oracle (CPU restatement, fp32) timed on the host cores of this box on a bounded
-                  sample of the same workload (N=1 only)."""
+  roofline     -- the dominant kernel family of the Linear layers (largest total time), timed with HIP events on the launch
+                  stream in eager steps issued right after the timed region (the timed steps themselves are two HIP-graph
+                  replays each, inside which nothing can be bracketed): achieved = sum(2*M*N*K) / sum(duration) against the
+                  2.5 PFLOP/s dense bf16 MFMA peak; `traffic` from the committed PMC pass (profiles/traffic.json);
+  cpu_baseline -- the oracle (CPU restatement, fp32) timed on the host cores of this box on a bounded sample of the same
+                  workload (N=1 only): forward+backward (value) and forward-only, with a thread sweep."""
 from __future__ import annotations
 
 import argparse
@@ -48,13 +54,28 @@ def parse():
     ap.add_argument("--frames", type=int, default=160, help="face frames per utterance (vision_max_utt_len)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graphs", type=int, default=1, help="capture the multimodal model (fwd+bwd) as HIP graphs (1) or launch eagerly (0)")
-    ap.add_argument("--overlap-text", type=int, default=1, help="replay the text-encoder graph on a second HIP stream, concurrently with Swin (needs --graphs 1)")
+    ap.add_argument("--config", type=int, default=1, choices=[1, 3, 4], help="BASELINE.json configs[i] per-GPU leg: 1 (default), 3 = BERT-large, 4 = 320 frames + auxiliary task")
+    ap.add_argument("--plm", default=None, choices=["roberta-large", "bert-large"], help="text encoder architecture (random init)")
+    ap.add_argument("--aux-images", type=int, default=None, help="auxiliary-task images per GPU per step (0 = no auxiliary step)")
+    ap.add_argument("--input", default="u8", choices=["u8", "float"], help="u8: 112x112 uint8 crops through the fused pre-step; float: pre-resized 224x224 frames")
+    ap.add_argument("--resize", default="pil", choices=["pil", "cv2"], help="bicubic flavour of the fused pre-step (pil: pinned bit-exactly; cv2: unpinned)")
+    ap.add_argument("--graphs", type=int, default=2, help="2: the whole step as two HIP graphs; 1: only the multimodal model graphed, Swin eager; 0: eager")
+    ap.add_argument("--overlap-text", type=int, default=1, help="text encoder on a second HIP stream / graph branch, concurrently with Swin")
+    ap.add_argument("--plm-dtype", default="bf16", choices=["bf16", "fp32"], help="parameter dtype of the text encoder in --graphs 2: bf16 with fp32 master weights in the optimizer, or fp32 under autocast")
+    ap.add_argument("--grad-comm", default="fp32", choices=["fp32", "bf16"], help="element type of the gradient all-reduce (N > 1)")
     ap.add_argument("--parallel-fusion", type=int, default=1, help="capture independent halves of the fusion stack as parallel graph branches")
     ap.add_argument("--force-ddp", action="store_true", help="run the data-parallel gradient exchange path even with one process (exercises the N>1 code path on one GPU)")
     ap.add_argument("--shape-report", default=None, help="write a per-GEMM-shape timing table to this file (development aid)")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames in the CPU-baseline Swin sample")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.config == 3:
+        a.plm = a.plm or "bert-large"
+    if a.config == 4:
+        a.frames, a.utts = (320 if a.frames == 160 else a.frames), (1 if a.utts == 4 else a.utts)
+        a.aux_images = 150 if a.aux_images is None else a.aux_images
+    a.plm = a.plm or "roberta-large"
+    a.aux_images = a.aux_images or 0
+    return a
 
 
 def synth_batch(args, dev, rank, cfg):
@@ -62,13 +83,18 @@ def synth_batch(args, dev, rank, cfg):
     g = torch.Generator(device=dev).manual_seed(1111 + rank)
     B, Lv, La, T = args.utts, args.frames, cfg.get_audio_utt_max_lens, 512
     act = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    # raw 112x112 uint8 crops -> [0,1] -> Normalize(.5,.5) -> bicubic x2 (utils/dataset.py:18-20,41-57)
-    raw = torch.randint(0, 256, (B * Lv, 3, 112, 112), generator=g, device=dev, dtype=torch.uint8)
-    frames = torch.nn.functional.interpolate((raw.float() / 255.0 - 0.5) / 0.5, size=(224, 224), mode="bicubic", align_corners=False)
-    frames = frames.to(act).contiguous()
-    del raw
-    ids = torch.randint(3, 50265, (B, T), generator=g, device=dev)
-    ids[:, 0] = 0
+    bert = getattr(args, "plm", "roberta-large") == "bert-large"
+    # raw 112x112 uint8 crops in image layout (utils/dataset.py:47-57).  --input u8: they ARE the model input (resize,
+    # ToTensor, Normalize fused into PatchEmbed's gather); --input float: the 224x224 float frames the reference caches
+    raw = torch.randint(0, 256, (B * Lv, 112, 112, 3), generator=g, device=dev, dtype=torch.uint8)
+    if getattr(args, "input", "u8") == "u8":
+        frames = raw
+    else:
+        frames = torch.nn.functional.interpolate((raw.permute(0, 3, 1, 2).float() / 255.0 - 0.5) / 0.5, size=(224, 224), mode="bicubic", align_corners=False)
+        frames = frames.to(act).contiguous()
+        del raw
+    ids = torch.randint(3, 30522 if bert else 50265, (B, T), generator=g, device=dev)
+    ids[:, 0] = 101 if bert else 0
     attn = torch.zeros(B, T, device=dev)
     attn[:, :400] = 1
     sep = torch.zeros(B, T, device=dev)
@@ -84,16 +110,37 @@ def synth_batch(args, dev, rank, cfg):
     return (ids, attn, sep, audio, amask, vision, vmask, labels, frames, num_imgs, utt_idx)
 
 
+def synth_aux_batch(args, dev, rank):
+    """Aff-Wild2-shaped auxiliary batch: uint8 112x112 crops + expression labels (utils/dataset.py AffwildDataset)"""
+    g = torch.Generator(device=dev).manual_seed(2222 + rank)
+    imgs = torch.randint(0, 256, (args.aux_images, 112, 112, 3), generator=g, device=dev, dtype=torch.uint8)
+    if getattr(args, "input", "u8") != "u8":
+        act = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+        imgs = torch.nn.functional.interpolate((imgs.permute(0, 3, 1, 2).float() / 255.0 - 0.5) / 0.5, size=(224, 224), mode="bicubic", align_corners=False).to(act).contiguous()
+    return imgs, torch.randint(0, 7, (args.aux_images,), generator=g, device=dev)
+
+
+def plm_config(name):
+    """architecture of the text encoder (random init: no checkpoints on the benchmark box); src/models.py:72-77"""
+    from transformers import BertConfig, RobertaConfig
+    if name == "bert-large":
+        return BertConfig(vocab_size=30522, hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096,
+                          max_position_embeddings=512, type_vocab_size=2, pad_token_id=0)
+    return RobertaConfig(vocab_size=50265, hidden_size=1024, num_hidden_layers=24, num_attention_heads=16,
+                         intermediate_size=4096, max_position_embeddings=514, type_vocab_size=1, pad_token_id=1)
+
+
 def build_models(args, dev, cfg):
-    from transformers import RobertaConfig
     from facialmmt_amd import models
     act = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     cfg.compute_dtype = act
-    cfg.plm_config = RobertaConfig(vocab_size=50265, hidden_size=1024, num_hidden_layers=24, num_attention_heads=16,
-                                   intermediate_size=4096, max_position_embeddings=514, type_vocab_size=1, pad_token_id=1)
+    cfg.pretrainedtextmodel_path = "pretrained_model/" + args.plm        # selects the RoBERTa / BERT slicing offsets (src/models.py:118-146)
+    cfg.plm_config = plm_config(args.plm)
     cfg.plm_no_pooler = True
     torch.manual_seed(cfg.seed)
     swin = models.SwinForAffwildClassification(cfg).to(dev).train()
+    swin.swin.input_resize = args.resize
+    swin.swin.input_dtype = act
     mm = models.MultiModalTransformerForClassification(cfg).to(dev).train()
     return swin, mm
 
@@ -179,17 +226,20 @@ class KernelTimer:
 
 
 def cpu_baseline(args, cfg):
-    """The oracle (oracle/*.py, fp32 CPU restatement) timed on this box's host cores on a bounded sample:
-    Swin forward+backward on `cpu_frames` frames (scaled to `frames` per utterance) + the fusion stack
-    forward+backward for one utterance (PLM excluded: it is the same third-party library on both sides).
-    Reported as utterances/s of the section-8 hot path."""
+    """The oracle (oracle/*.py, fp32 CPU restatement) timed on this box's host cores on a bounded sample of the same
+    workload: Swin forward(+backward) on `cpu_frames` frames (scaled to `frames` per utterance), the fusion stack, the two
+    self-attention encoders and the text encoder for one utterance.  `value` = forward+backward utterances/s (what the GPU
+    line measures, optimizer excluded); `forward_only` next to it (north_star asks for the CPU forward); `thread_sweep` =
+    Swin forward on 16 / 32 / 64 threads (more threads are slower on this box: 256 hardware threads, see below)."""
     import numpy as np
     from facialmmt_amd import synth
     from oracle import crossmodal as OC
+    from oracle import multimodal as OM
     from oracle import swin as OS
     # 256 hardware threads on the GPU box make torch's CPU ops slower, not faster (measured: 234 s for the
     # 8-frame step with 256 threads vs ~2 s with 8-16); use 16 threads and say so.
-    cores = min(os.cpu_count() or 1, 16)
+    ncpu = os.cpu_count() or 1
+    cores = min(ncpu, 16)
     torch.set_num_threads(cores)
     with open(os.path.join(ROOT, "tests", "golden", "state_dict_keys.json")) as f:
         keys = json.load(f)
@@ -199,39 +249,52 @@ def cpu_baseline(args, cfg):
     nF = args.cpu_frames
     x = synth.tensor("frames", (nF, 3, 224, 224), seed=1)
 
+    def timed(fn, reps=3, bound=10.0):
+        t0 = time.perf_counter()
+        fn()
+        ts = [time.perf_counter() - t0]
+        if ts[0] < bound:                                   # bounded: skip the repeats if one call is already slow
+            ts = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                fn()
+                ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)), len(ts)
+
     def swin_step():
         for v in sd.values():
             v.grad = None
         OS.swin_affwild_logits(sd, x, training=True).square().sum().backward()
-    t0 = time.perf_counter()
-    swin_step()
-    ts = [time.perf_counter() - t0]
-    if ts[0] < 10.0:                                   # bounded: skip the repeats if one step is already slow
-        ts = []
-        for _ in range(3):
-            t0 = time.perf_counter()
-            swin_step()
-            ts.append(time.perf_counter() - t0)
-    t_swin = float(np.median(ts)) / nF * args.frames
+
+    def swin_fwd():
+        with torch.no_grad():
+            OS.swin_affwild_logits(sd, x, training=False)
+    t8, nrep = timed(swin_step)
+    t_swin = t8 / nF * args.frames
+    f8, _ = timed(swin_fwd)
+    f_swin = f8 / nF * args.frames
+    sweep = {str(cores): round(nF / f8, 2)}
+    for th in (32, 64):
+        if th <= ncpu:
+            torch.set_num_threads(th)
+            ft, _ = timed(swin_fwd, reps=2, bound=5.0)
+            sweep[str(th)] = round(nF / ft, 2)
+    torch.set_num_threads(cores)
     esd = synth.state_dict_from_keys(keys["crossmodal"], seed=50, prefix="enc.")
     for v in esd.values():
         v.requires_grad_(True)
     La, Lv, Lt = cfg.get_audio_utt_max_lens, args.frames, cfg.get_text_utt_max_lens
     t_, a_, v_ = (synth.tensor(n, (L, 1, 768), seed=60) for n, L in (("t", Lt), ("a", La), ("v", Lv)))
 
-    def fusion_step():
+    def fusion(backward):
         ta = torch.cat((OC.crossmodal_encoder(esd, t_, a_, a_), OC.crossmodal_encoder(esd, a_, t_, t_)), 0)
         out = torch.cat((OC.crossmodal_encoder(esd, ta, v_, v_), OC.crossmodal_encoder(esd, v_, ta, ta)), 0)
-        out.square().mean().backward()
-    t0 = time.perf_counter()
-    fusion_step()
-    t_fus = time.perf_counter() - t0
-    if t_fus < 10.0:
-        t0 = time.perf_counter()
-        fusion_step()
-        t_fus = time.perf_counter() - t0
+        if backward:
+            out.square().mean().backward()
+    t_fus, _ = timed(lambda: fusion(True), reps=1)
+    with torch.no_grad():
+        f_fus, _ = timed(lambda: fusion(False), reps=1)
     # the two self-attention encoders in front of the fusion (oracle restatement) ...
-    from oracle import multimodal as OM
     msd = {k: v for k, v in synth.state_dict_from_keys(keys["multimodal_roberta"], seed=200).items()
            if k.startswith(("audio_utt_transformer.", "vision_utt_transformer."))}
     # the fixture keys were dumped for 24/20-step sequences: rebuild the position tables for the bench lengths
@@ -241,40 +304,50 @@ def cpu_baseline(args, cfg):
         v.requires_grad_(True)
     a_in, v_in = synth.tensor("a_in", (1, La, 768), seed=61), synth.tensor("v_in", (1, Lv, 768), seed=62)
 
-    def meld_step():
+    def meld(backward):
         za = torch.zeros(1, 1, 1, La)
         zv = torch.zeros(1, 1, 1, Lv)
         out = OM.meld_encoder(msd, "audio_utt_transformer.", a_in, za, cfg.audio_utt_Transformernum).square().mean() \
             + OM.meld_encoder(msd, "vision_utt_transformer.", v_in, zv, cfg.vision_utt_Transformernum).square().mean()
-        out.backward()
-    meld_step()
-    t0 = time.perf_counter()
-    meld_step()
-    t_meld = time.perf_counter() - t0
-    # ... and the text encoder: the same third-party RoBERTa-large (random init), one 512-token dialogue, fp32
-    t_plm = None
+        if backward:
+            out.backward()
+    t_meld, _ = timed(lambda: meld(True), reps=1)
+    with torch.no_grad():
+        f_meld, _ = timed(lambda: meld(False), reps=1)
+    # ... and the text encoder: the same third-party model (random init), one 512-token dialogue, fp32
+    t_plm = f_plm = None
     try:
-        from transformers import RobertaConfig, RobertaModel
-        plm = RobertaModel(RobertaConfig(vocab_size=50265, hidden_size=1024, num_hidden_layers=24, num_attention_heads=16,
-                                         intermediate_size=4096, max_position_embeddings=514, type_vocab_size=1, pad_token_id=1),
-                           add_pooling_layer=False)
-        ids = torch.from_numpy(synth.randint("cpu_ids", (1, 512), 3, 50265, seed=2))
+        from transformers import BertModel, RobertaModel
+        conf = plm_config(args.plm)
+        plm = (BertModel if args.plm == "bert-large" else RobertaModel)(conf, add_pooling_layer=False)
+        ids = torch.from_numpy(synth.randint("cpu_ids", (1, 512), 3, conf.vocab_size, seed=2))
         am = torch.ones(1, 512)
 
         def plm_step():
             plm.zero_grad(set_to_none=True)
             plm(ids, am)[0].square().mean().backward()
-        plm_step()
-        t0 = time.perf_counter()
-        plm_step()
-        t_plm = time.perf_counter() - t0
+
+        def plm_fwd():
+            with torch.no_grad():
+                plm(ids, am)
+        t_plm, _ = timed(plm_step, reps=1)
+        f_plm, _ = timed(plm_fwd, reps=1)
     except Exception as e:                               # the CPU leg must never take the bench down
         print(f"cpu_baseline: text-encoder leg skipped ({e})", file=sys.stderr)
     total = t_swin + t_fus + t_meld + (t_plm or 0.0)
+    total_f = f_swin + f_fus + f_meld + (f_plm or 0.0)
+    cpu_name = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_name = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "")
+    except OSError:
+        pass
     return {"value": round(1.0 / total, 5), "unit": "utterances/s", "cores": cores, "kind": "port",
-            "sample": f"oracle fp32 fwd+bwd for ONE utterance on {cores} threads: Swin+head on {nF} frames (median of {len(ts)}, scaled x{args.frames / nF:g} to "
-                      f"{args.frames} frames: {t_swin:.2f} s) + 4 cross-modal encoder calls ({t_fus:.2f} s) + audio/vision self-attention encoders "
-                      f"({t_meld:.2f} s) + RoBERTa-large 512 tokens (HF, {'%.2f s' % t_plm if t_plm else 'skipped'}); optimizer excluded"}
+            "forward_only": {"value": round(1.0 / total_f, 5), "unit": "utterances/s", "swin_frames_per_s": round(nF / f8, 2)},
+            "swin_forward_frames_per_s_by_threads": sweep, "host": f"{cpu_name} ({ncpu} hardware threads)",
+            "sample": f"oracle fp32 for ONE utterance on {cores} threads, fwd+bwd [fwd only]: Swin+head on {nF} frames (median of {nrep}, scaled x{args.frames / nF:g} to "
+                      f"{args.frames} frames: {t_swin:.2f} s [{f_swin:.2f} s]) + 4 cross-modal encoder calls ({t_fus:.2f} s [{f_fus:.2f} s]) + audio/vision self-attention "
+                      f"encoders ({t_meld:.2f} s [{f_meld:.2f} s]) + {args.plm} 512 tokens (HF, {'%.2f s [%.2f s]' % (t_plm, f_plm) if t_plm else 'skipped'}); optimizer excluded"}
 
 
 def main():
@@ -298,51 +371,83 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
     from facialmmt_amd.config import default_args
-    from facialmmt_amd.train_step import TargetStep
+    from facialmmt_amd.parallel import GradientAverager, broadcast_parameters
+    from facialmmt_amd.train_step import AuxStep, GraphedAuxStep, GraphedTargetStep, TargetStep
     cfg = default_args(get_vision_utt_max_lens=args.frames, trg_accumulation_steps=1)
+    act = torch.bfloat16 if args.dtype == "bf16" else None
     swin, mm = build_models(args, dev, cfg)
     batch = synth_batch(args, dev, rank, cfg)
-    if args.graphs:
-        from facialmmt_amd.train_step import graph_multimodal, select_frames
-        with torch.no_grad():
-            preds = swin(batch[8][:8], is_trg_task=True).float().repeat(batch[8].shape[0] // 8, 1)
-        vis, nmask = select_frames(preds, batch[5], batch[6], batch[9], cfg.FacialEmoImpor_threshold)
-        sample = (batch[0], batch[1], batch[2], batch[3], batch[4], vis.detach().requires_grad_(True), nmask, batch[10])
-        mm = graph_multimodal(mm, sample, torch.bfloat16 if args.dtype == "bf16" else None, overlap_text=bool(args.overlap_text),
-                              parallel_fusion=bool(args.parallel_fusion))
-        mm.zero_grad(set_to_none=True)
-        swin.zero_grad(set_to_none=True)
-    averager = None
-    if world > 1 or args.force_ddp:
-        # gradient mean over ranks for the parameters this step's optimizer updates (parallel.GradientAverager); two
-        # stream groups: the text branch's gradients are produced on the second HIP stream
-        from facialmmt_amd.parallel import GradientAverager, broadcast_parameters
+    aux_batch = synth_aux_batch(args, dev, rank) if args.aux_images else None
+    ddp = world > 1 or args.force_ddp
+    comm = torch.bfloat16 if args.grad_comm == "bf16" else None
+    if ddp:
         broadcast_parameters(mm)
-        plm = mm.roberta if mm.text_pretrained_model == "roberta" else mm.bert
-        text_params = list(plm.parameters()) + list(mm.text_linear.parameters())
-        text_ids = set(map(id, text_params))
-        averager = GradientAverager(None, groups=[[p for p in mm.parameters() if id(p) not in text_ids], text_params])
-    # (bf16 text-encoder parameters with fp32 masters in the optimizer were measured: 113.4 vs 110.4 ms -- no gain)
-    opt = torch.optim.AdamW(mm.parameters(), lr=cfg.trg_lr, weight_decay=cfg.weight_decay, fused=True)
-    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: min(1.0, (s + 1) / 100.0))
-    step = TargetStep(swin, mm, opt, sched, cfg, autocast_dtype=torch.bfloat16 if args.dtype == "bf16" else None, averager=averager)
+        broadcast_parameters(swin)
+    lr_of = lambda s: min(1.0, (s + 1) / 100.0)            # linear warm-up (transformers.get_linear_schedule_with_warmup, train.py:333-339)
+    aux_step = None
+    if args.graphs == 2:
+        # the whole step as two HIP graphs (train_step.GraphedTargetStep): gradients in static flat buffers, the only
+        # collective -- one all-reduce per flat bucket -- issued between the graphs when N > 1
+        from facialmmt_amd.train_step import MasterWeights, step_parameters
+        masters = None
+        if args.plm_dtype == "bf16" and args.dtype == "bf16":
+            masters = MasterWeights(mm.roberta if mm.text_pretrained_model == "roberta" else mm.bert, torch.bfloat16)
+        params = step_parameters(mm, masters)
+        flat = GradientAverager(params, hooks=False, comm_dtype=comm)
+        opt = torch.optim.AdamW(params, lr=torch.tensor(cfg.trg_lr, device=dev), weight_decay=cfg.weight_decay, fused=True, capturable=True)
+        sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_of)
+        if args.aux_images:
+            aflat = GradientAverager(swin.parameters(), hooks=False, comm_dtype=comm)
+            aopt = torch.optim.AdamW(swin.parameters(), lr=torch.tensor(cfg.aux_lr, device=dev), fused=True, capturable=True)
+            aux_step = GraphedAuxStep(swin, aopt, torch.optim.lr_scheduler.LambdaLR(aopt, lr_of), cfg, *aux_batch, averager=aflat)
+        step = GraphedTargetStep(swin, mm, opt, sched, cfg, batch, autocast_dtype=act, overlap_text=bool(args.overlap_text),
+                                 parallel_fusion=bool(args.parallel_fusion), averager=flat, masters=masters)
+    else:
+        if args.graphs == 1:
+            from facialmmt_amd.train_step import graph_multimodal, select_frames
+            with torch.no_grad():
+                preds = swin(batch[8][:8], is_trg_task=True).float().repeat(batch[8].shape[0] // 8, 1)
+            vis, nmask = select_frames(preds, batch[5], batch[6], batch[9], cfg.FacialEmoImpor_threshold)
+            sample = (batch[0], batch[1], batch[2], batch[3], batch[4], vis.detach().requires_grad_(True), nmask, batch[10])
+            mm = graph_multimodal(mm, sample, act, overlap_text=bool(args.overlap_text), parallel_fusion=bool(args.parallel_fusion))
+            mm.zero_grad(set_to_none=True)
+            swin.zero_grad(set_to_none=True)
+        averager = None
+        if ddp:
+            # hook-driven exchange overlapped with the backward; two stream groups: the text branch's gradients are
+            # produced on the second HIP stream
+            plm = mm.roberta if mm.text_pretrained_model == "roberta" else mm.bert
+            text_params = list(plm.parameters()) + list(mm.text_linear.parameters())
+            text_ids = set(map(id, text_params))
+            averager = GradientAverager(None, groups=[[p for p in mm.parameters() if id(p) not in text_ids], text_params], comm_dtype=comm)
+        opt = torch.optim.AdamW(mm.parameters(), lr=cfg.trg_lr, weight_decay=cfg.weight_decay, fused=True)
+        sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_of)
+        step = TargetStep(swin, mm, opt, sched, cfg, autocast_dtype=act, averager=averager)
+        if args.aux_images:
+            aopt = torch.optim.AdamW(swin.parameters(), lr=cfg.aux_lr, fused=True)
+            eager_aux = AuxStep(swin, aopt, torch.optim.lr_scheduler.LambdaLR(aopt, lr_of), cfg)
+            aux_step = lambda imgs, labels: eager_aux(imgs, labels)
     timer = KernelTimer()
     timer.install()
 
+    def one_step():
+        if aux_step is not None:
+            aux_step(*aux_batch)
+        return step(batch)
+
     kept = None
     for _ in range(args.warmup):
-        _, m = step(batch)
-        kept = m
+        _, kept = one_step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    timer.enabled = rank == 0
+    timer.enabled = rank == 0 and args.graphs != 2
     step.host_ms = {}
-    step.gpu_events = [] if rank == 0 else None             # main-stream timeline of the phases (events are free on the GPU)
+    step.gpu_events = [] if (rank == 0 and args.graphs != 2) else None      # main-stream timeline of the phases (eager Swin only)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss, kept = step(batch)
+        loss, kept = one_step()
     issue_s = time.perf_counter() - t0                      # host time to enqueue the steps (GPU still running)
     torch.cuda.synchronize()
     if world > 1:
@@ -351,7 +456,7 @@ def main():
     elapsed = time.perf_counter() - t0
     timer.enabled = False
     gpu_phase = {}
-    if step.gpu_events:
+    if getattr(step, "gpu_events", None):
         evs, step.gpu_events = step.gpu_events, None
         for (_, a), (name, b) in zip(evs, evs[1:]):
             if name != "start":
@@ -362,88 +467,106 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # After the timed region (not part of `value`): the same kernels with the text encoder back on the main stream.
-    # During the timed steps the text-encoder graph shares the CUs with Swin's launches, which stretches every Swin
-    # kernel; two extra steps without that overlap give the kernel's own rate next to the live one.
+    # host cost of issuing one step into an IDLE queue (during the timed loop the host mostly waits for the previous replay
+    # of the same graph to drain, so the enqueue time above is back-pressure, not cost)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    one_step()
+    idle_issue_ms = (time.perf_counter() - t1) * 1e3
+    torch.cuda.synchronize()
+
+    # After the timed region (not part of `value`): the kernels of the Linear layers bracketed with HIP events in EAGER
+    # forward+backward passes on the main stream (inside a graph replay nothing can be bracketed; with --graphs 1 the timed
+    # steps themselves are bracketed too, but there the text-encoder graph shares the CUs and stretches every Swin kernel).
+    timed_events, timer.events = timer.events, []
     iso = None
-    if args.graphs and args.overlap_text and getattr(mm, "text_stream", None) is not None:
-        timed_events, timer.events = timer.events, []
-        side, mm.text_stream = mm.text_stream, None
-        step(batch)
-        timer.enabled = rank == 0
+    if rank == 0:
+        probe_cfg = default_args(get_vision_utt_max_lens=args.frames, trg_accumulation_steps=1 << 30)     # never reaches clip / optimizer
+        side, mm.text_stream = getattr(mm, "text_stream", None), None
+        probe = TargetStep(swin, mm, None, None, probe_cfg, autocast_dtype=act)
+        was_training = mm.training
+        if args.graphs == 1:
+            mm.eval()                                        # eager branches (models._branch_call); dropout off does not change the GEMM shapes
+        probe(batch)
+        timer.enabled = True
         for _ in range(2):
-            step(batch)
+            probe(batch)
         torch.cuda.synchronize()
         timer.enabled = False
+        mm.train(was_training)
         mm.text_stream = side
         iso, timer.events = timer.summary(), timed_events
-        if world > 1:
-            dist.barrier()
+    if world > 1:
+        dist.barrier()
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = args.utts * world * args.steps / elapsed
-        fams = timer.summary()
+        fams = iso or timer.summary()
         if args.shape_report:
             with open(args.shape_report, "w") as f:
                 f.write(timer.shape_report(args.steps) + "\n")
         roof = None
         if fams:
             bn, (cnt, fl, by, sec) = max(fams.items(), key=lambda kv: kv[1][3])
-            achieved = fl / sec / 1e12
-            if bn.startswith("linear_tn"):
-                kname = bn
-            elif bn.startswith("deep256") and bn != "deep256x128x64":         # deep256x{128,96}x32[,nkN]
-                width = "128" if bn.startswith("deep256x128") else "96"
-                kname = f"linear_nt_deep32_kernel<{bn[-1] if ',nk' in bn else '0'},{width}>"
-            elif bn.startswith("deep"):
-                kname = "linear_nt_deep_kernel"
-            else:
-                kname = f"linear_nt_kernel<bf16,{bn}>"
-            traffic = None                       # PMC counters cannot be read in-process: taken from the committed PMC summary
+            kname = kernel_symbol(bn)
+            traffic, traffic_src = None, None                # PMC counters cannot be read in-process: taken from the committed PMC summary
             try:
                 with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-                    t = json.load(f).get(kname)
+                    tj = json.load(f)
+                t = tj.get(kname)
                 if t:
                     traffic = (2 * t["fetch_size_kb"] + t["write_size_kb"]) * 1024
+                    traffic_src = f"profiles/traffic.json ({tj.get('_source', 'committed rocprofv3 --pmc pass')}): 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE per launch; not measured in this run"
             except OSError:
                 pass
+
             def rate(c, f, b, t):
                 return {"achieved": round(f / t / 1e12, 1), "frac": round(f / t / 1e12 / PEAK_BF16_TFLOPS, 4),
                         "avg_launch_us": round(t / c * 1e6, 1), "algorithmic_GB_per_s": round(b / t / 1e9, 0)}
-            live = rate(cnt, fl, by, sec)
-            roof = {"bound": "mfma", "kernel": kname, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "traffic": traffic,
-                    "algorithmic_bytes_per_launch": round(by / cnt), "launches_per_step": cnt // args.steps,
-                    "share_of_step": round(sec / elapsed, 3)}
-            if iso and bn in iso:
-                # During the timed steps this kernel is time-sliced with the text-encoder graph on the second stream, so
-                # event durations there are not the kernel's own.  Headline = the two steps issued right after the timed
-                # region with that graph back on the main stream (also what rocprofv3 reports: its tracing serialises
-                # the two streams); the in-region timing is kept next to it.
-                roof.update(rate(*iso[bn]))
-                roof["measured"] = "HIP events, 2 steps after the timed region, text encoder on the main stream"
-                roof["in_timed_region_with_text_stream"] = live
-            else:
-                roof.update(live)
-                roof["measured"] = "HIP events over the timed region"
-        flops_step = args.utts * (args.frames * SWIN_FWD_GFLOP_PER_FRAME * 3 + (335 + 29.7) * 3) * 1e9
+            roof = {"bound": "mfma", "kernel": kname, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s"}
+            roof.update(rate(cnt, fl, by, sec))
+            roof.update({"traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": round(by / cnt), "launches_per_step": cnt // 2,
+                         "share_of_step": round(sec / 2 / (ms * 1e-3), 3),
+                         "measured": "HIP events on the launch stream, 2 eager forward+backward passes right after the timed region (text encoder on the main stream)"})
+            live = timer.summary().get(bn) if timed_events else None
+            if live:
+                roof["in_timed_region_with_text_stream"] = rate(*live)
+                roof["frac_in_timed_region"] = roof["in_timed_region_with_text_stream"]["frac"]
+            roof["families"] = {kernel_symbol(k): {"ms_per_step": round(v[3] / 2 * 1e3, 3), "TFLOP_per_s": round(v[1] / v[3] / 1e12, 1)}
+                                for k, v in sorted(fams.items(), key=lambda kv: -kv[1][3])[:8]}
+        aux_flops = args.aux_images * SWIN_FWD_GFLOP_PER_FRAME * 3 * 1e9
+        flops_step = args.utts * (args.frames * SWIN_FWD_GFLOP_PER_FRAME * 3 + (335 + 29.7) * 3) * 1e9 + aux_flops
+        which = {1: "configs[1]", 3: "configs[3] (per-GPU leg of batch 16 on 4 GPUs)", 4: "configs[4] (per-GPU leg of batch 8 on 8 GPUs)"}[args.config]
+        if args.config == 1 and world == 8:
+            which = "configs[2]"
+        plm_name = "RoBERTa-large" if args.plm == "roberta-large" else "BERT-large"
         line = {
             "metric": "utterances/sec T+A+V forward+bwd, 160-frame face seq, 1/2/4/8 GPU",
             "value": round(value, 3), "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"configs[1]: T+A+V, RoBERTa-large (random init), {args.frames}-frame face seq 3x224x224, "
-                                   f"batch {args.utts} utterances/GPU, {args.dtype}, fwd+bwd+AdamW every step",
-                       "global_batch": args.utts * world, "frames_per_step_per_gpu": args.utts * args.frames,
+            "config": {"workload": f"{which}: T+A+V, {plm_name} (random init), {args.frames}-frame face seq "
+                                   f"({'uint8 112x112 crops, fused ' + args.resize + '-bicubic x2 + normalise' if args.input == 'u8' else 'pre-resized 3x224x224 frames'}), "
+                                   f"batch {args.utts} utterances/GPU, {args.dtype}, fwd+bwd+clip+AdamW every step"
+                                   + (f", preceded by one auxiliary-task step on {args.aux_images} Aff-Wild2-shaped crops (Swin fwd+bwd+clip+AdamW)" if args.aux_images else ""),
+                       "global_batch": args.utts * world, "frames_per_step_per_gpu": args.utts * args.frames, "aux_images_per_step_per_gpu": args.aux_images,
                        "parallelism": f"dp{world}", "kept_frame_fraction": round(float(kept.mean().item()), 3),
                        "model_tflops_per_s_per_gpu": round(flops_step / (ms * 1e-3) / 1e12, 1),
-                       "host_enqueue_ms_per_step": round(issue_s / args.steps * 1e3, 1), "hip_graphs": bool(args.graphs), "text_encoder_on_second_stream": bool(args.graphs and args.overlap_text),
-                       "second_stream_pair_over_single": round(float(getattr(mm, "text_stream_concurrency", 0.0)), 2),
-                       "host_ms_per_phase": {k: round(v / args.steps, 1) for k, v in step.host_ms.items()},
-                       "main_stream_gpu_ms_per_phase": {k: round(v / args.steps, 1) for k, v in gpu_phase.items()}},
+                       "host_enqueue_ms_per_step": round(issue_s / args.steps * 1e3, 1), "host_issue_ms_into_idle_queue": round(idle_issue_ms, 1),
+                       "hip_graphs": {2: "whole step: 2 graphs (fwd+bwd | clip+optimizer)", 1: "multimodal model only (Swin eager)", 0: "none"}[args.graphs],
+                       "text_encoder_concurrent_with_swin": bool(args.graphs and args.overlap_text),
+                       "text_encoder_parameters": "bf16 with fp32 master weights in the optimizer" if (args.graphs == 2 and args.plm_dtype == "bf16" and args.dtype == "bf16") else "fp32 under bf16 autocast",
+                       "gradient_allreduce": None if not ddp else f"{args.grad_comm}, {'between the two graphs' if args.graphs == 2 else 'hook-driven, overlapped with backward'}"},
             "roofline": roof,
             "cpu_baseline": None,
         }
+        if args.graphs == 1:
+            line["config"]["second_stream_pair_over_single"] = round(float(getattr(mm, "text_stream_concurrency", 0.0)), 2)
+        if step.host_ms:
+            line["config"]["host_ms_per_phase"] = {k: round(v / args.steps, 1) for k, v in step.host_ms.items()}
+            line["config"]["main_stream_gpu_ms_per_phase"] = {k: round(v / args.steps, 1) for k, v in gpu_phase.items()}
         if "FMMT_BENCH_DEVICE" in os.environ or backend != "nccl":
             line["config"]["dry_run"] = f"ranks share device {local}, backend {backend}: not a measurement"
         if world == 1 and not args.no_cpu_baseline:
@@ -459,6 +582,18 @@ def main():
         except OSError:
             pass
         print(json.dumps(line), flush=True)
+
+
+def kernel_symbol(bn):
+    """KernelTimer family tag -> name of the kernel template instantiation as rocprofv3 prints it"""
+    if bn.startswith("linear_tn"):
+        return bn
+    if bn.startswith("deep256") and bn != "deep256x128x64":         # deep256x{128,96}x32[,nkN]
+        width = "128" if bn.startswith("deep256x128") else "96"
+        return f"linear_nt_deep32_kernel<{bn[-1] if ',nk' in bn else '0'},{width}>"
+    if bn.startswith("deep"):
+        return "linear_nt_deep_kernel"
+    return f"linear_nt_kernel<bf16,{bn}>"
 
 
 if __name__ == "__main__":

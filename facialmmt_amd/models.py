@@ -152,7 +152,13 @@ class MultiModalTransformerForClassification(nn.Module):
     def text_branch(self, batch_text_input_ids, batch_text_input_mask, batch_text_sep_mask, batchUtt_in_dia_idx):
         """PLM -> text_linear -> tokens of the target utterance (ref :95-150): (B, L_t, H), mask (B, L_t)"""
         plm = self.roberta if self.text_pretrained_model == 'roberta' else self.bert
-        text_out = plm(batch_text_input_ids, batch_text_input_mask)[0]                   # (B, T, plm_hidden)
+        if next(plm.parameters()).dtype in (torch.bfloat16, torch.float16) and batch_text_input_ids.is_cuda:
+            # a text encoder whose parameters already are low precision (train_step.MasterWeights) runs as it is: autocast
+            # would still force its LayerNorms / softmax through fp32 tensors and casts
+            with torch.autocast("cuda", enabled=False):
+                text_out = plm(batch_text_input_ids, batch_text_input_mask)[0]
+        else:
+            text_out = plm(batch_text_input_ids, batch_text_input_mask)[0]               # (B, T, plm_hidden)
         text_utt_linear = self.text_linear(text_out.to(self.text_linear.weight.dtype))
         return slice_target_utterance(text_utt_linear, batch_text_sep_mask, batchUtt_in_dia_idx,
                                       self.get_text_utt_max_lens, self.text_pretrained_model == 'roberta')

@@ -62,7 +62,7 @@ class GradientAverager:
     (e.g. an unused pooler) leaves its bucket incomplete; `finish()` raises instead of letting the ranks step on
     un-averaged gradients."""
 
-    def __init__(self, params, bucket_mb: int = BUCKET_MB, process_group=None, groups=None, comm_dtype=None):
+    def __init__(self, params, bucket_mb: int = BUCKET_MB, process_group=None, groups=None, comm_dtype=None, hooks: bool = True):
         """`groups`: optional list of parameter lists whose gradients are produced on different HIP streams (e.g. the
         text branch on the second stream): a bucket never spans two groups, so the stream that completes a bucket
         is the stream that produced all of it.
@@ -104,7 +104,7 @@ class GradientAverager:
         for bi, b in enumerate(self.buckets):
             for p in b[1]:
                 self._of[p] = bi
-        self._handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
+        self._handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params] if hooks else []
 
     def _close(self, ps, gi):
         # 16-byte aligned slots so that every gradient view is as aligned as a stand-alone tensor
@@ -170,6 +170,20 @@ class GradientAverager:
                 b[3] = None
                 if b[5] is not None:
                     b[0].copy_(b[5])
+        self._reset_window()
+
+    def exchange_all(self):
+        """Average every bucket over the ranks now, in bucket order, on the current stream (blocking semantics of the
+        stream: later work on it sees the averaged gradients).  For owners without hooks; no-op at world size 1."""
+        if not (self.sync and self.world > 1):
+            return
+        for bi in range(len(self.buckets)):
+            self._issue(bi)
+        for b in self.buckets:
+            b[3].wait()
+            b[3] = None
+            if b[5] is not None:
+                b[0].copy_(b[5])
         self._reset_window()
 
     def _reset_window(self):

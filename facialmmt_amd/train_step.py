@@ -257,6 +257,314 @@ class TargetStep:
         return loss.detach(), new_mask
 
 
+class MasterWeights:
+    """fp32 master copies of a sub-module that runs in a low-precision parameter dtype (the text encoder in bf16).
+
+    Under autocast an fp32 text encoder re-casts every weight to bf16 in every step and casts every weight gradient
+    back (about 1050 small launches and 2.5 GB of traffic per step for RoBERTa-large: measured 650 fp32->bf16 and 403
+    bf16->fp32 copy kernels per step), and its LayerNorms run with fp32 I/O.  With bf16 parameters the module needs no
+    autocast; the optimizer steps fp32 masters (`self.masters`, nn.Parameters that are views of one flat buffer) and
+    `sync_low()` rounds them back into the module with one multi-tensor copy.  The masters start as exact copies of the
+    fp32 parameters, so the trajectory is that of mixed-precision training with fp32 master weights."""
+
+    def __init__(self, module: torch.nn.Module, dtype=torch.bfloat16):
+        low = [p for p in module.parameters() if p.requires_grad]
+        if any(p.dtype != torch.float32 for p in low):
+            raise TypeError("MasterWeights: the module must still be in fp32 when the masters are taken")
+        offs, n = [], 0
+        for p in low:
+            offs.append(n)
+            n += (p.numel() + 3) // 4 * 4
+        flat = torch.empty(n, dtype=torch.float32, device=low[0].device)
+        self.masters = []
+        for p, o in zip(low, offs):
+            v = flat[o:o + p.numel()].view_as(p)
+            v.copy_(p.detach())
+            self.masters.append(torch.nn.Parameter(v))
+        module.to(dtype)                                    # in place: the Parameter objects survive, their data becomes bf16
+        self.low = low
+        self.flat = flat
+        self.module = module
+
+    def pairs(self):
+        return list(zip(self.low, self.masters))
+
+    @torch.no_grad()
+    def sync_low(self):
+        torch._foreach_copy_(self.low, self.masters)
+
+    def state_dict_fp32(self):
+        """the module's state_dict with the master values in place of the rounded ones (what a checkpoint should hold)"""
+        sd = {k: v.detach().clone() for k, v in self.module.state_dict().items()}
+        by_id = {id(p): m for p, m in zip(self.low, self.masters)}
+        for k, p in self.module.named_parameters():
+            if id(p) in by_id:
+                sd[k] = by_id[id(p)].detach().clone()
+        return sd
+
+
+def _hand_over_gradients(pairs, flat_view_of, accumulate: bool):
+    """After a backward: move the fresh gradients (p.grad of the model parameters) into the static flat fp32 buffers the
+    optimizer and the all-reduce work on, with a handful of multi-tensor launches instead of one AccumulateGrad add per
+    parameter (measured: 768 elementwise adds per step).  `accumulate=False` overwrites (one micro-step per update: no
+    zeroing needed), True adds (gradient accumulation).  Leaves p.grad = None on the model parameters."""
+    same_src, same_dst, cast_src, cast_dst = [], [], [], []
+    for p, master in pairs:
+        g = p.grad
+        if g is None:
+            continue
+        p.grad = None
+        dst = flat_view_of[master]
+        if g.dtype == dst.dtype:
+            same_src.append(g)
+            same_dst.append(dst)
+        else:
+            cast_src.append(g)
+            cast_dst.append(dst)
+    with torch.no_grad():
+        if accumulate:
+            if same_src:
+                torch._foreach_add_(same_dst, same_src)
+            if cast_src:                                     # bf16 gradients into fp32 buffers: multi-tensor cast, then add
+                tmp = [torch.empty_like(d) for d in cast_dst]
+                torch._foreach_copy_(tmp, cast_src)
+                torch._foreach_add_(cast_dst, tmp)
+        else:
+            if same_src:
+                torch._foreach_copy_(same_dst, same_src)
+            if cast_src:
+                torch._foreach_copy_(cast_dst, cast_src)
+
+
+def _restore(snap):
+    """copy the snapshot back, touching only what changed: an untouched buffer keeps its version counter, so host-side
+    caches keyed on it (SwinTransformerBlock._mask_is_standard) stay valid and nothing synchronises inside the capture"""
+    with torch.no_grad():
+        for t, v in snap:
+            if not torch.equal(t, v):
+                t.copy_(v)
+
+
+def step_parameters(mm, masters=None):
+    """the parameters the target step's optimizer updates: the multimodal model's, with the text encoder's replaced by
+    their fp32 masters when it runs in bf16 (MasterWeights)"""
+    if masters is None:
+        return [p for p in mm.parameters() if p.requires_grad]
+    master_of = {id(l): m for l, m in masters.pairs()}
+    return [master_of.get(id(p), p) for p in mm.parameters() if p.requires_grad]
+
+
+def _reset_optimizer_state(opt):
+    """zero every tensor of the optimizer state in place (moments, step counters): undoes the warm-up steps that precede
+    a graph capture without re-allocating the state the captured graph will address"""
+    for st in opt.state.values():
+        for v in st.values():
+            if torch.is_tensor(v):
+                v.zero_()
+
+
+class GraphedTargetStep:
+    """The whole target-task step as TWO HIP graphs, replayed per step with one host call each:
+
+      A  text encoder (forked onto a second stream) || Swin forward -> frame filter -> fusion stack -> cross-entropy ->
+         backward through everything; the multimodal gradients accumulate IN PLACE into static flat fp32 buffers
+         (parallel.GradientAverager's buckets, hooks off), Swin's gradients land in static buffers nobody reads
+         (they are discarded in the target step, train.py:20,141);
+      -- N > 1: one eager all-reduce per flat bucket between the two graphs (the only collective of the step) --
+      B  clip_grad_norm_ + optimizer.step() (capturable) + zeroing of the flat buffers.
+
+    Why: issued launch by launch the step costs ~75 ms of host time (Swin's ~600 launches through Python autograd and
+    ctypes, ~800 AccumulateGrad nodes, clip_grad_norm_ over ~800 tensors, the optimizer) against ~80 ms of GPU time, so
+    any kernel speed-up would disappear behind the host; two graph launches cost a few milliseconds.  Everything inside is
+    capture-safe: no host synchronisation, DropPath / Gumbel / dropout noise from device-side generators, bf16 weight
+    shadows re-cast inside the graph.  Shapes are static: __call__ copies the batch into the captured input buffers.
+    `accumulation_steps` > 1 replays A that many times per B (gradients accumulate in the flat buffers).
+    Parity: tests/test_gpu_train_step.py walks this against the eager TargetStep (same losses, same parameters)."""
+
+    def __init__(self, swin_model, multimodal_model, optimizer, scheduler, args, batch, autocast_dtype=None,
+                 overlap_text=True, parallel_fusion=True, averager=None, warmup_iters=2, masters=None):
+        """`averager`: GradientAverager(hooks=False) over the parameters the optimizer steps (default: the multimodal
+        model's); `masters`: optional MasterWeights of the text encoder -- then `averager` and the optimizer must have been
+        built over `step_parameters(multimodal_model, masters)`."""
+        import os
+        from .parallel import GradientAverager
+        if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "") != "0":
+            raise RuntimeError("GraphedTargetStep: DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 must be in the environment before the HIP "
+                               "runtime initialises (see facialmmt_amd/__init__.py)")
+        self.swin, self.mm, self.opt, self.sched, self.args = swin_model, multimodal_model, optimizer, scheduler, args
+        self.autocast_dtype = autocast_dtype
+        self.i_batch = 0
+        dev = batch[0].device
+        self.static = [t.clone() if torch.is_tensor(t) else t for t in batch]
+        # static flat gradient buffers for the multimodal parameters (hooks off: inside a replay no autograd hook fires)
+        self.masters = masters
+        self.flat = averager if averager is not None else GradientAverager(step_parameters(self.mm, masters), hooks=False)
+        if self.flat._handles:
+            raise ValueError("GraphedTargetStep needs GradientAverager(..., hooks=False): the exchange runs between the graphs")
+        self.flat_view_of = {p: p.grad for p in self.flat.params}          # the averager made every .grad a view of its bucket
+        low_of = {id(m): l for l, m in (masters.pairs() if masters is not None else [])}
+        self.pairs = [(low_of.get(id(p), p), p) for p in self.flat.params]     # (parameter the model differentiates, parameter the optimizer steps)
+        for l, m in self.pairs:
+            l.grad = None
+        self.accumulate = args.trg_accumulation_steps > 1
+        self.mm.text_stream = None
+        # inside ONE graph the fork / join below become parallel branches; which hardware queue the branches replay on is the
+        # runtime's choice at replay time, not a property of the stream object used during capture
+        self.text_stream = torch.cuda.Stream(device=dev) if overlap_text else None
+        self.mm.pair_stream = torch.cuda.Stream(device=dev) if parallel_fusion else None
+        # -- warm-up on a side stream (lazy initialisations: kernel attributes, shadow caches, optimizer state), undone below
+        snap = [(t, t.detach().clone()) for m in (self.swin, self.mm) for t in list(m.parameters()) + list(m.buffers())]
+        if masters is not None:
+            snap += [(t, t.detach().clone()) for t in masters.masters]
+        rng = torch.cuda.get_rng_state(dev)
+        cap = torch.cuda.Stream(device=dev)
+        cap.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cap):
+            for _ in range(warmup_iters):
+                self._fwd_bwd()
+                self._update()
+            self.swin.zero_grad(set_to_none=True)
+        torch.cuda.current_stream().wait_stream(cap)
+        torch.cuda.synchronize(dev)
+        _restore(snap)
+        del snap
+        _reset_optimizer_state(self.opt)
+        self.flat.zero_grad()
+        torch.cuda.set_rng_state(rng, dev)
+        # -- capture
+        self.graph_a, self.graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_a):
+            self.loss, self.new_mask = self._fwd_bwd()
+        with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
+            self._update()
+        self.swin.zero_grad(set_to_none=True)              # drop the references; the graph's pool keeps the buffers
+        self.mm.pair_stream = None
+        self.flat.zero_grad()                              # the capture itself executes nothing
+
+    # one micro-step: forward + backward (runs eagerly during warm-up, once more under capture)
+    def _fwd_bwd(self):
+        (ids, attn_mask, sep_mask, audio, audio_mask, vision_inputs, vision_mask, labels, frames, num_imgs, utt_idx) = self.static
+        mm, args = self.mm, self.args
+        ctx = (lambda: torch.autocast("cuda", dtype=self.autocast_dtype)) if self.autocast_dtype is not None else None
+        import contextlib
+        ac = ctx if ctx is not None else contextlib.nullcontext
+        main = torch.cuda.current_stream()
+        pending = None
+        if self.text_stream is not None:
+            self.text_stream.wait_stream(main)             # fork: the text branch does not depend on the visual path
+            with torch.cuda.stream(self.text_stream), ac():
+                pending = mm.text_branch(ids, attn_mask, sep_mask, torch.as_tensor(utt_idx, device=ids.device))
+        preds = self.swin(frames, is_trg_task=True)
+        vis_concat, new_mask = select_frames(preds.float(), vision_inputs, vision_mask, num_imgs, args.FacialEmoImpor_threshold)
+        with ac():
+            if pending is None:
+                pending = mm.text_branch(ids, attn_mask, sep_mask, torch.as_tensor(utt_idx, device=ids.device))
+            else:
+                main.wait_stream(self.text_stream)         # join
+                for t in pending:
+                    t.record_stream(main)
+            logits = mm.fusion_branch(pending[0], pending[1], audio, audio_mask, vis_concat, new_mask)
+        loss = F.cross_entropy(logits.float(), labels) / args.trg_accumulation_steps
+        loss.backward()
+        _hand_over_gradients(self.pairs, self.flat_view_of, self.accumulate)
+        return loss.detach(), new_mask
+
+    def _update(self):
+        for p in self.flat.params:                           # the optimizer reads the static flat buffers
+            p.grad = self.flat_view_of[p]
+        torch.nn.utils.clip_grad_norm_(self.flat.params, self.args.clip)
+        self.opt.step()
+        if self.masters is not None:
+            self.masters.sync_low()
+        if self.accumulate:
+            self.flat.zero_grad()
+        for l, _ in self.pairs:                              # the next backward must produce fresh gradient tensors
+            l.grad = None
+
+    def __call__(self, batch):
+        with torch.no_grad():
+            for dst, src in zip(self.static, batch):
+                if torch.is_tensor(dst) and dst is not src:
+                    dst.copy_(src, non_blocking=True)
+        self.graph_a.replay()
+        self.i_batch += 1
+        if self.i_batch % self.args.trg_accumulation_steps == 0:
+            self.flat.exchange_all()                       # no-op at world size 1
+            self.graph_b.replay()
+            if self.sched is not None:
+                self.sched.step()
+        return self.loss, self.new_mask
+
+
+class GraphedAuxStep:
+    """The auxiliary-task step (train.py:15-41: Swin -> logits -> cross-entropy -> backward -> clip -> AdamW on the Swin
+    model) as two HIP graphs, same construction as GraphedTargetStep; the Swin gradients are the exchanged ones here."""
+
+    def __init__(self, swin_model, optimizer, scheduler, args, images, labels, averager=None, warmup_iters=2):
+        from .parallel import GradientAverager
+        self.swin, self.opt, self.sched, self.args = swin_model, optimizer, scheduler, args
+        self.images, self.labels = images.clone(), labels.clone()
+        self.i_batch = 0
+        dev = images.device
+        self.flat = averager if averager is not None else GradientAverager(self.swin.parameters(), hooks=False)
+        self.flat_view_of = {p: p.grad for p in self.flat.params}
+        self.pairs = [(p, p) for p in self.flat.params]
+        for p in self.flat.params:
+            p.grad = None
+        self.accumulate = args.aux_accumulation_steps > 1
+        snap = [(t, t.detach().clone()) for t in list(self.swin.parameters()) + list(self.swin.buffers())]
+        rng = torch.cuda.get_rng_state(dev)
+        cap = torch.cuda.Stream(device=dev)
+        cap.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cap):
+            for _ in range(warmup_iters):
+                self._fwd_bwd()
+                self._update()
+        torch.cuda.current_stream().wait_stream(cap)
+        torch.cuda.synchronize(dev)
+        _restore(snap)
+        del snap
+        _reset_optimizer_state(self.opt)
+        self.flat.zero_grad()
+        torch.cuda.set_rng_state(rng, dev)
+        self.graph_a, self.graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_a):
+            self.loss = self._fwd_bwd()
+        with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
+            self._update()
+        self.flat.zero_grad()
+
+    def _fwd_bwd(self):
+        loss = self.swin(self.images, False, self.labels, F.cross_entropy) / self.args.aux_accumulation_steps
+        loss.backward()
+        _hand_over_gradients(self.pairs, self.flat_view_of, self.accumulate)
+        return loss.detach()
+
+    def _update(self):
+        for p in self.flat.params:
+            p.grad = self.flat_view_of[p]
+        torch.nn.utils.clip_grad_norm_(self.flat.params, self.args.clip)
+        self.opt.step()
+        if self.accumulate:
+            self.flat.zero_grad()
+        for p in self.flat.params:                           # the next backward must produce fresh gradient tensors
+            p.grad = None
+
+    def __call__(self, images, labels):
+        with torch.no_grad():
+            if images is not self.images:
+                self.images.copy_(images, non_blocking=True)
+                self.labels.copy_(labels, non_blocking=True)
+        self.graph_a.replay()
+        self.i_batch += 1
+        if self.i_batch % self.args.aux_accumulation_steps == 0:
+            self.flat.exchange_all()
+            self.graph_b.replay()
+            if self.sched is not None:
+                self.sched.step()
+        return self.loss
+
+
 class AuxStep:
     """One auxiliary-task (Aff-Wild2 frame classification) step, train.py:15-41: Swin -> logits (no Gumbel)
     -> cross-entropy -> backward -> clip (0.8) -> AdamW on the Swin model (aux_lr 5e-5) every

@@ -73,3 +73,83 @@ def test_scheduled_step_equals_eager_step(mode):
         assert abs(a - b) <= 2e-4 * max(1.0, abs(a)), (l0, l1)
     for k in p0:
         assert (p0[k] - p1[k]).abs().max().item() <= 1e-4 * max(1.0, p0[k].abs().max().item()), k
+
+
+def _run_six(dev, graphed, accumulation, bf16_plm=False):
+    from facialmmt_amd import models
+    from facialmmt_amd.config import default_args
+    from facialmmt_amd.train_step import GraphedTargetStep, TargetStep
+    import bench
+    B, Lv = 2, 6
+    # noise-free configuration: dropout and DropPath off; Gumbel-softmax at a huge temperature (the noise enters as g / tau)
+    # with the importance threshold below 1/7 so that the filter branch (not the keep-everything fallback) runs
+    cfg = default_args(get_vision_utt_max_lens=Lv, get_audio_utt_max_lens=24, trg_accumulation_steps=accumulation, plm_module=synth.make_standin_plm(),
+                       hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, crossmodal_attn_dropout_TA=0.0, crossmodal_attn_dropout_TA_V=0.0,
+                       tau=1e5, FacialEmoImpor_threshold=0.1)
+    cfg.compute_dtype = torch.float32
+    swin = models.SwinForAffwildClassification(cfg)
+    mm = models.MultiModalTransformerForClassification(cfg)
+    synth.fill_state_dict(swin, seed=100)
+    synth.fill_state_dict(mm, seed=200)
+    for m in swin.modules():
+        if hasattr(m, "drop_prob"):
+            m.drop_prob = 0.0
+    swin.to(dev).train()
+    mm.to(dev).train()
+    args = types.SimpleNamespace(utts=B, frames=Lv, dtype="fp32", plm="roberta-large", input="float", resize="pil")
+    batch = list(bench.synth_batch(args, dev, 0, cfg))
+    batch[0] = batch[0] % 1000
+    batch = tuple(batch)
+    masters = None
+    if bf16_plm:
+        from facialmmt_amd.train_step import MasterWeights, step_parameters
+        masters = MasterWeights(mm.roberta, torch.bfloat16)
+        opt = torch.optim.SGD(step_parameters(mm, masters), lr=0.05)
+    else:
+        opt = torch.optim.SGD(mm.parameters(), lr=0.05)
+    if graphed:
+        step = GraphedTargetStep(swin, mm, opt, None, cfg, batch, autocast_dtype=None, masters=masters)
+        assert step.text_stream is not None
+    else:
+        step = TargetStep(swin, mm, opt, None, cfg, autocast_dtype=None)
+    losses = []
+    for _ in range(6):
+        loss, kept = step(batch)
+        losses.append(float(loss))
+    torch.cuda.synchronize()
+    if masters is not None:
+        for low, m in masters.pairs():                           # the module holds the rounded masters, the masters moved
+            assert low.dtype == torch.bfloat16 and torch.equal(low, m.to(torch.bfloat16))
+    bn = swin.swin.output_layer[3]
+    return losses, {k: v.detach().clone() for k, v in mm.named_parameters()}, bn.running_mean.clone(), int(bn.num_batches_tracked), kept.clone()
+
+
+@pytest.mark.parametrize("accumulation", [1, 2])
+def test_whole_step_graphs_equal_eager_step(accumulation):
+    """GraphedTargetStep (graph A: text branch forked onto a second stream || Swin, fusion, loss, backward into static flat
+    gradient buffers; graph B: clip + optimizer + zero) against the eager single-stream TargetStep over six micro-steps:
+    same losses, same updated parameters, same BatchNorm running statistics and step counter, same kept-frame mask --
+    including the warm-up being undone exactly (parameters, buffers, optimizer state) before the capture."""
+    dev = torch.device("cuda:0")
+    l0, p0, rm0, nb0, k0 = _run_six(dev, False, accumulation)
+    l1, p1, rm1, nb1, k1 = _run_six(dev, True, accumulation)
+    assert l0[0] != l0[-1]                                       # the optimiser moved something
+    for a, b in zip(l0, l1):
+        assert abs(a - b) <= 2e-4 * max(1.0, abs(a)), (l0, l1)
+    assert nb0 == nb1 == 6 and torch.equal(k0, k1) and float(k0.sum()) > 0
+    assert (rm0 - rm1).abs().max().item() <= 1e-4 * max(1.0, rm0.abs().max().item())
+    for k in p0:
+        assert (p0[k] - p1[k]).abs().max().item() <= 1e-4 * max(1.0, p0[k].abs().max().item()), k
+
+
+def test_bf16_text_encoder_with_fp32_masters_tracks_fp32_run():
+    """MasterWeights: text encoder in bf16 (no autocast, no per-step weight casts), optimizer on fp32 masters.  Against the
+    all-fp32 graphed run: same kept frames, losses within bf16 tolerance; the module always holds bf16(master)."""
+    dev = torch.device("cuda:0")
+    l0, p0, _, _, k0 = _run_six(dev, True, 1)
+    l1, p1, _, _, k1 = _run_six(dev, True, 1, bf16_plm=True)
+    assert torch.equal(k0, k1)
+    for a, b in zip(l0, l1):
+        assert abs(a - b) <= 3e-2 * max(1.0, abs(a)), (l0, l1)
+    moved = [k for k in p0 if not k.startswith("roberta.") and (p0[k] - p1[k]).abs().max().item() > 5e-2 * max(1.0, p0[k].abs().max().item())]
+    assert not moved, moved[:5]
