@@ -145,6 +145,23 @@ def build_models(args, dev, cfg):
     return swin, mm
 
 
+def p256_tile(M, N, K, kw):
+    """mirror of csrc/gemm.hip::p256_plan (persistent 256-row-tile kernel): channel-tile width, or 0"""
+    if M < 16384 or M % 16 or K % 64 or K < 192 or kw.get("res") is not None or kw.get("aux") is not None or kw.get("rowscale") is not None:
+        return 0
+    tm, best, cost = (M + 255) // 256, 0, 0.0
+    for bn, pen in ((256, 1.0), (192, 1.04), (128, 1.10)):
+        if N % bn:
+            continue
+        tiles = tm * (N // bn)
+        if tiles < 256:
+            continue
+        c = ((tiles + 255) // 256) * bn * pen
+        if not best or c < cost:
+            best, cost = bn, c
+    return best
+
+
 class KernelTimer:
     """HIP-event timing of one kernel family on the launch stream, live inside the timed region."""
 
@@ -163,6 +180,7 @@ class KernelTimer:
             M, K = x2.shape
             N = w.shape[0]
             # same dispatch as csrc/gemm.hip::dispatch_nt: <BN, BK, LDS buffers>
+            p256 = p256_tile(M, N, K, kw)
             bn = 96 if (N % 96 == 0 and N % 128 != 0) else 128
             bn = f"{bn},96,1" if K == 96 else f"{bn},64,1" if K <= 64 else f"{bn},64,2" if K % 64 == 0 else f"{bn},32,2"
             bn = f"{64 if M <= 4096 else 128},{bn}" + (",glds" if (K % 64 == 0 and K > 64) else "")
@@ -172,6 +190,8 @@ class KernelTimer:
                     bn = "deep256x128x32" + nk if (nk or kw.get("epi", 0) != 0 or K <= 512 or K % 64) else "deep256x128x64"
                 else:
                     bn = "deep256x96x32" + nk
+            if p256:
+                bn = f"p256x{p256}"
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             y = raw(x2, w, bias, **kw)
@@ -588,6 +608,9 @@ def kernel_symbol(bn):
     """KernelTimer family tag -> name of the kernel template instantiation as rocprofv3 prints it"""
     if bn.startswith("linear_tn"):
         return bn
+    if bn.startswith("p256x"):
+        w = bn[5:]
+        return f"linear_nt_p256_kernel<{w},64,{3 if w == '128' else 2}>"
     if bn.startswith("deep256") and bn != "deep256x128x64":         # deep256x{128,96}x32[,nkN]
         width = "128" if bn.startswith("deep256x128") else "96"
         return f"linear_nt_deep32_kernel<{bn[-1] if ',nk' in bn else '0'},{width}>"

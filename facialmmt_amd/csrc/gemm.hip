@@ -69,7 +69,7 @@ __device__ __forceinline__ int chan_of(int nt, int g, int r) {
 
 // Epilogue of one wave tile (MT x NT MFMA tiles at rows mbase.., channels nbase..): bias, GELU / GELU',
 // DropPath row scale, residual, 16-byte stores; or raw fp32 partials for the split-K path.
-template <typename T, int MT, int NT>
+template <typename T, int MT, int NT, bool BIAS_DONE = false>
 __device__ __forceinline__ void nt_epilogue(const LinArgs& p, f32x4 (&acc)[MT][NT], int mbase, int nbase, int li, int lg) {
     constexpr int VEC = Vec<T>::N;
     T* __restrict__ yg = reinterpret_cast<T*>(p.y);
@@ -106,7 +106,7 @@ __device__ __forceinline__ void nt_epilogue(const LinArgs& p, f32x4 (&acc)[MT][N
                 float v[VEC];
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) v[e] = (e < w) ? acc[a][b0 + (e >> 2)][e & 3] : 0.f;
-                if (p.bias) {
+                if (!BIAS_DONE && p.bias) {
 #pragma unroll
                     for (int e4 = 0; e4 < VEC; e4 += 4)
                         if (e4 < w) {
@@ -558,6 +558,225 @@ void linear_nt_deep32_kernel(LinArgs p) {
 //  that caps the kernel near 1.1 PFLOP/s, and the measured 0.8 PFLOP/s on K = 1536 is 72 % of that cap.  The next
 //  step up is a 256 x 256 tile (128 FLOP/B) with persistent scheduling for the tile-count quantisation.)
 
+// ---------------------------------------------------------------------------------------------
+// Persistent NT kernel for the compute-heavy shapes (bf16; M % 8 == 0; N % BN == 0; K % BK == 0, K >= 192):
+// one workgroup of 8 waves per CU walks 256-token x BN-channel output tiles (BN = 256 / 192 / 128: 128 / 110 / 85 FLOP
+// per loaded byte against 85 for the 256 x 128 kernels above).  Waves: 2 along tokens x 4 along channels, wave tile
+// 128 x BN/4, i.e. 0.375 KB of LDS fragment reads per MFMA (0.5 KB with 64 x 64 wave tiles).
+//  * ONE flat pipeline over (tile, K step) pairs: a ring of NBUF LDS stages filled by direct global->LDS DMA, NBUF - 1
+//    stages in flight, counted s_waitcnt vmcnt + one raw s_barrier per K step.  The ring does not drain at a tile
+//    boundary: while a tile's accumulators are converted and stored, the first stages of the workgroup's next tile are
+//    already landing (a one-tile-per-workgroup kernel pays the DMA latency and an idle epilogue once per tile -- at
+//    K = 384 that is a third of the tile's life -- and two co-resident workgroups do not fit: 128 accumulator
+//    registers per lane).
+//  * the bias slab travels through the ring as well (one extra 1 KB DMA per stage by wave 7, two slots by tile parity):
+//    an ordinary global load in the epilogue would make the in-order vmcnt wait for every DMA issued before it.
+//    Residual / GELU' operand / DropPath scale are M x N data and do load in the epilogue (one partial drain per tile).
+//  * tile order: channel tiles fastest within a token panel; workgroup b (observed on XCD b % 8) takes, in round i,
+//    tile i * 256 + (b % 8) * 32 + b / 8 -- each XCD works on a contiguous run of 32 tiles, so a token panel is fetched
+//    into one XCD's L2 once per round.
+// ---------------------------------------------------------------------------------------------
+template <int BN, int BK, int NBUF>
+__global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
+    using T = bf16;
+    constexpr int BM = 256, PITCH = BK, MT = 8, NT = BN / 64, WN = BN / 4, CW = 4 * NT;
+    constexpr int RPI = BK == 64 ? 8 : 16;                 // tile rows per DMA instruction (64 lanes x 16 B = 1 KB)
+    constexpr int STAGE = (BN + BM) * PITCH;               // elements per ring stage: BN weight rows, then 256 token rows
+    constexpr int NI = (BN + BM) / RPI;                    // DMA instructions per stage, dealt round-robin to the 8 waves
+    constexpr int CNT_LO = NI / 8;
+    static_assert(BK == 32 || BK == 64, "K step");
+    static_assert(BN % 64 == 0 && (NBUF - 2) * (CNT_LO + 2) <= 63, "tile / vmcnt immediate");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* S = reinterpret_cast<T*>(smem);                                              // [NBUF][BN + 256][BK]
+    float* bias_s = reinterpret_cast<float*>(smem + (size_t)NBUF * STAGE * sizeof(T));   // [2][256]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int li = lane & 15, lg = lane >> 4;
+    const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
+    const T* __restrict__ wg = reinterpret_cast<const T*>(p.w);
+    const int nk = p.K / BK;
+
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    auto key = [](int row) { return BK == 64 ? ((row >> 1) & 7) : (((row >> 3) ^ (row >> 2)) & 3); };   // 16-byte chunk swizzle
+    const int rl = BK == 64 ? (lane >> 3) : (lane >> 2), cl = BK == 64 ? (lane & 7) : (lane & 3);
+
+    // DMA instructions this wave issues per stage (wave 7 carries the bias slab on top)
+    const int my_cnt = (NI - wave + 7) / 8 + (wave == 7 ? 1 : 0);
+    const bool cnt_hi = my_cnt > CNT_LO;                                            // CNT_LO or CNT_LO + 1 (+ 2 never: see below)
+    auto issue = [&](int slot, int m0, int n0, int k0, int par) {
+        T* base = S + slot * STAGE;
+#pragma unroll
+        for (int i = 0; i < (NI + 7) / 8; ++i) {
+            const int j = i * 8 + wave;                                             // wave-uniform
+            if (j < NI) {
+                const int row0 = j * RPI;
+                const T* src;
+                if (row0 < BN) {
+                    const int r = row0 + rl;
+                    src = wg + (size_t)(n0 + r) * p.ldw + k0 + ((cl ^ key(r)) << 3);
+                } else {
+                    const int rx = row0 - BN;
+                    const int rb = min(m0 + rx, p.M - RPI);                         // ragged last panel: re-read valid rows (never stored)
+                    src = xg + (size_t)(rb + rl) * p.ldx + k0 + ((cl ^ key(rx + rl)) << 3);
+                }
+                __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(base + row0 * PITCH), 16, 0, 0);
+            }
+        }
+        if (wave == 7) {
+            const float* bsrc = p.bias ? p.bias + n0 + min(lane * 4, BN - 4) : reinterpret_cast<const float*>(wg) + lane * 4;
+            __builtin_amdgcn_global_load_lds((gptr_t*)bsrc, (lptr_t*)(bias_s + par * 256), 16, 0, 0);
+        }
+    };
+    auto wait_landed = [&](int ahead) {                    // the oldest stage in flight has landed; `ahead` younger ones may fly
+        if (ahead <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (ahead == 1) {
+            if (cnt_hi) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT_LO + 1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT_LO) : "memory");
+        } else {
+            if (cnt_hi) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (CNT_LO + 1)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CNT_LO) : "memory");
+        }
+    };
+    static_assert(NBUF >= 2 && NBUF <= 4, "ring depth");
+    static_assert(NI % 8 == 0 || NI % 8 <= 7, "wave 7 never owns a high count plus the bias slab");
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int woff[NT], xoff[MT];                                // element offsets of this lane's fragments inside a stage (K chunk lg)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+        const int r = wn * WN + chan_of<CW>(b, li >> 2, li & 3);
+        woff[b] = r * PITCH + ((lg ^ key(r)) << 3);
+    }
+#pragma unroll
+    for (int a = 0; a < MT; ++a) {
+        const int r = wm * 128 + a * 16 + li;
+        xoff[a] = (BN + r) * PITCH + ((lg ^ key(r)) << 3);
+    }
+    auto compute = [&](int slot) {
+        const T* sb = S + slot * STAGE;
+#pragma unroll
+        for (int kk = 0; kk < BK / 32; ++kk) {
+            // second half of a 64-wide K step: chunk index + 4 -> the swizzled chunk offset flips bit 2 (32 elements)
+            bf16x8 wf[NT], xf[MT];
+#pragma unroll
+            for (int b = 0; b < NT; ++b) wf[b] = *reinterpret_cast<const bf16x8*>(sb + (kk ? (woff[b] ^ 32) : woff[b]));
+#pragma unroll
+            for (int a = 0; a < MT; ++a) xf[a] = *reinterpret_cast<const bf16x8*>(sb + (kk ? (xoff[a] ^ 32) : xoff[a]));
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b], xf[a], acc[a][b], 0, 0, 0);
+        }
+    };
+
+    const int G = gridDim.x;                               // multiple of 8
+    const int first = ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3);
+    const int total = p.tiles_m * p.tiles_n;
+    const int ntile = first < total ? (total - first + G - 1) / G : 0;
+    const int nsteps = ntile * nk;
+    // issue-side cursor
+    int it = first, ik = 0, im0 = (first / p.tiles_n) * BM, in0 = (first % p.tiles_n) * BN, ipar = 0, islot = 0;
+    auto issue_next = [&]() {
+        issue(islot, im0, in0, ik * BK, ipar);
+        islot = islot + 1 == NBUF ? 0 : islot + 1;
+        if (++ik == nk) {
+            ik = 0;
+            it += G;
+            im0 = (it / p.tiles_n) * BM;
+            in0 = (it % p.tiles_n) * BN;
+            ipar ^= 1;
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < NBUF - 1; ++s)
+        if (s < nsteps) issue_next();
+    // compute-side cursor
+    int ct = first, ck = 0, cpar = 0, cslot = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        wait_landed(min(nsteps - 1 - s, NBUF - 2));
+        __builtin_amdgcn_s_barrier();                      // every wave's part of stage s is in LDS; stage s - 1 is free
+        if (s + NBUF - 1 < nsteps) issue_next();
+        compute(cslot);
+        cslot = cslot + 1 == NBUF ? 0 : cslot + 1;
+        if (++ck == nk) {
+            const int m0 = (ct / p.tiles_n) * BM, n0 = (ct % p.tiles_n) * BN;
+            if (p.bias) {
+#pragma unroll
+                for (int b = 0; b < NT; ++b) {
+                    const f32x4 bb = *reinterpret_cast<const f32x4*>(bias_s + cpar * 256 + wn * WN + chan_of<CW>(b, lg, 0));
+#pragma unroll
+                    for (int a = 0; a < MT; ++a) acc[a][b] += bb;
+                }
+            }
+            nt_epilogue<T, MT, NT, true>(p, acc, m0 + wm * 128, n0 + wn * WN, li, lg);
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            ck = 0;
+            ct += G;
+            cpar ^= 1;
+        }
+    }
+}
+
+template <int BN, int BK, int NBUF>
+int launch_p256(const LinArgs& a, hipStream_t st) {
+    constexpr size_t lds = (size_t)NBUF * (BN + 256) * BK * 2 + 2 * 256 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_nt_p256_kernel<BN, BK, NBUF>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    LinArgs p = a;
+    p.tiles_m = (a.M + 255) / 256;
+    p.tiles_n = a.N / BN;
+    hipLaunchKernelGGL((linear_nt_p256_kernel<BN, BK, NBUF>), dim3(256), dim3(512), lds, st, p);
+    FMMT_CHECK_LAUNCH();
+    return 0;
+}
+
+// Tile choice for the persistent kernel: the widest channel tile that divides N, unless a narrower one fills the last
+// round of 256 workgroups better (31360 tokens x 768 channels: 369 tiles of 256 x 256 = 2 rounds at 72 %, 492 tiles of
+// 256 x 192 = 2 rounds at 96 %).  Returns 0 if the shape is not for this kernel.
+int p256_plan(const LinArgs& a) {
+    static const int mode = getenv("FMMT_NT_P256") ? atoi(getenv("FMMT_NT_P256")) : 1;       // 0: off; 2: every epilogue; 256 / 192 / 128: force that tile
+    if (!mode || a.ksplit || a.M < 16384 || a.M % 16 || a.K % 64 || a.K < 192 || a.ldx % 8 || a.ldw % 8) return 0;
+    // One workgroup per CU has nothing to hide an epilogue's own M x N loads behind (residual, GELU' operand, DropPath
+    // scale: the in-order vmcnt also makes them wait for the DMA stages in flight).  Measured on MI355X
+    // (profiles/r02_gemm_shapes.txt): plain / bias / GELU + pre-activation launches gain 5-50 % over the two-workgroup
+    // 256 x 128 kernels (125440 x 1536 x 384 GELU: 0.439 -> 0.295 ms), launches with such loads lose 0-25 %: those stay
+    // on the older kernels.  FMMT_NT_P256=2 sends them here as well (A/B switch).
+    if (mode == 1 && (a.res || a.aux || a.rowscale)) return 0;
+    const int tm = (a.M + 255) / 256;
+    int best = 0;
+    double best_cost = 0;
+    const int cand[3] = {256, 192, 128};
+    const double pen[3] = {1.0, 1.04, 1.10};
+    for (int i = 0; i < 3; ++i) {
+        const int bn = cand[i];
+        if (a.N % bn) continue;
+        if (mode > 2 && mode != bn) continue;
+        const int tiles = tm * (a.N / bn);
+        if (tiles < 256) continue;
+        const double cost = (double)((tiles + 255) / 256) * bn * pen[i];
+        if (!best || cost < best_cost) {
+            best = bn;
+            best_cost = cost;
+        }
+    }
+    return best;
+}
+
 template <typename T, int BM, int BN, int BK, int NBUF, bool GLDS = false>
 int launch_nt(const LinArgs& a, hipStream_t st) {
     constexpr int VEC = Vec<T>::N;
@@ -617,6 +836,13 @@ int dispatch_nt(const LinArgs& a, hipStream_t st) {
     // that twice as many workgroups share the work; the multi-million-token Swin GEMMs use 128-row tiles
     if (a.M <= 4096) return n96 ? dispatch_nt_bk<T, 64, 96>(a, st) : dispatch_nt_bk<T, 64, 128>(a, st);
     if constexpr (sizeof(T) == 2) {
+        if (const int bn = p256_plan(a)) {
+            // FMMT_NT_P256_RING: 1 (default) = K step 64, ring of 2 (3 for 128-wide tiles); 0 = K step 32, ring of 4.
+            // Measured (profiles/r02_gemm_shapes.txt): the K-step-64 form wins on every shape by 3-17 % (half the barriers)
+            static const int ring = getenv("FMMT_NT_P256_RING") ? atoi(getenv("FMMT_NT_P256_RING")) : 1;
+            if (ring == 0) return bn == 256 ? launch_p256<256, 32, 4>(a, st) : bn == 192 ? launch_p256<192, 32, 4>(a, st) : launch_p256<128, 32, 4>(a, st);
+            return bn == 256 ? launch_p256<256, 64, 2>(a, st) : bn == 192 ? launch_p256<192, 64, 2>(a, st) : launch_p256<128, 64, 3>(a, st);
+        }
         // measured (tests/gpu_gemm_bench.py): +8 % on the 125440-token stage-2 shapes (K = 384: 496 -> 540 TF/s),
         // -4 % on the 31360-token stage-3 shapes (tile quantisation at one workgroup per CU) -> only for M >= 65536
         static const int deep = getenv("FMMT_NT_DEEP") ? atoi(getenv("FMMT_NT_DEEP")) : 1;
