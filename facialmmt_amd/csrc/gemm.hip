@@ -750,7 +750,10 @@ int launch_p256(const LinArgs& a, hipStream_t st) {
 // 256 x 192 = 2 rounds at 96 %).  Returns 0 if the shape is not for this kernel.
 int p256_plan(const LinArgs& a) {
     static const int mode = getenv("FMMT_NT_P256") ? atoi(getenv("FMMT_NT_P256")) : 1;       // 0: off; 2: every epilogue; 256 / 192 / 128: force that tile
-    if (!mode || a.ksplit || a.M < 16384 || a.M % 16 || a.K % 64 || a.K < 192 || a.ldx % 8 || a.ldw % 8) return 0;
+    // K % 64 != 0 (Swin stage 0: K = 96, three K steps of 32): only with FMMT_NT_P256_K32=1 (A/B switch)
+    static const int k32 = getenv("FMMT_NT_P256_K32") ? atoi(getenv("FMMT_NT_P256_K32")) : 0;
+    if (!mode || a.ksplit || a.M < 16384 || a.M % 16 || a.K % 32 || a.K < 96 || a.ldx % 8 || a.ldw % 8) return 0;
+    if (a.K % 64 && !k32) return 0;
     // One workgroup per CU has nothing to hide an epilogue's own M x N loads behind (residual, GELU' operand, DropPath
     // scale: the in-order vmcnt also makes them wait for the DMA stages in flight).  Measured on MI355X
     // (profiles/r02_gemm_shapes.txt): plain / bias / GELU + pre-activation launches gain 5-50 % over the two-workgroup
@@ -840,7 +843,7 @@ int dispatch_nt(const LinArgs& a, hipStream_t st) {
             // FMMT_NT_P256_RING: 1 (default) = K step 64, ring of 2 (3 for 128-wide tiles); 0 = K step 32, ring of 4.
             // Measured (profiles/r02_gemm_shapes.txt): the K-step-64 form wins on every shape by 3-17 % (half the barriers)
             static const int ring = getenv("FMMT_NT_P256_RING") ? atoi(getenv("FMMT_NT_P256_RING")) : 1;
-            if (ring == 0) return bn == 256 ? launch_p256<256, 32, 4>(a, st) : bn == 192 ? launch_p256<192, 32, 4>(a, st) : launch_p256<128, 32, 4>(a, st);
+            if (ring == 0 || a.K % 64) return bn == 256 ? launch_p256<256, 32, 4>(a, st) : bn == 192 ? launch_p256<192, 32, 4>(a, st) : launch_p256<128, 32, 4>(a, st);
             return bn == 256 ? launch_p256<256, 64, 2>(a, st) : bn == 192 ? launch_p256<192, 64, 2>(a, st) : launch_p256<128, 64, 3>(a, st);
         }
         // measured (tests/gpu_gemm_bench.py): +8 % on the 125440-token stage-2 shapes (K = 384: 496 -> 540 TF/s),
@@ -960,6 +963,25 @@ __device__ __forceinline__ bf16x8 lds_tr_frag(const bf16* s, int pitch, int c0, 
     return u.v;
 }
 
+// bf16 tiles of the TN kernel: unpadded 256-byte rows (128 channels) whose eight 32-byte column blocks are XOR-permuted by
+// g(row) = (row & 3) | ((row >> 3) & 1) << 2.  A ds_read_b64_tr_b16 serves lanes 0-31 in one LDS cycle: two 16-lane groups,
+// i.e. token rows {0..3, 8..11} (or {4..7, 12..15}) x one 32-byte column block each -- with 256-byte rows every row starts on
+// bank 0, and g() sends the eight rows of a cycle to eight different 8-bank slots: conflict-free, where the padded
+// layout (272-byte pitch) was 2-way on every fragment read.  It is also 6 % smaller.
+__device__ __forceinline__ int tn_swz(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+__device__ __forceinline__ bf16x8 lds_tr_frag_swz(const bf16* s, int row0, int c0, int li, int lg) {
+    // rows row0 + lg*8 + (li>>2) and + 4; column block c0 / 16, this lane's 8 bytes at (li & 3) * 4 elements inside it
+    const int r = row0 + lg * 8 + (li >> 2);
+    const bf16* a0 = s + r * 128 + (((c0 >> 4) ^ tn_swz(r)) << 4) + (li & 3) * 4;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * 128));        // row + 4: same g()
+    union { struct { s16x4 lo, hi; } s; bf16x8 v; } u;
+    u.s.lo = lo;
+    u.s.hi = hi;
+    return u.v;
+}
+
 // FEW: instantiation used for few-token problems (cross-modal encoder, embedding head) -- same code, its own
 // symbol, so that profiles keep the multi-million-token Swin launches and the tiny ones apart.
 // PF: depth of the register prefetch (token steps in flight).  The 64-token-step instantiation is LDS-limited to two
@@ -970,7 +992,8 @@ template <typename T, int BMS, bool FEW = false, int PF = 1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TnWaves<BMS>::value)))
 void linear_tn_kernel(TnArgs p) {
     constexpr int VEC = Vec<T>::N;
-    constexpr int PITCH = 128 + VEC;
+    constexpr bool SWZ = sizeof(T) == 2;                // bf16: unpadded, XOR-swizzled rows (see tn_swz)
+    constexpr int PITCH = SWZ ? 128 : 128 + VEC;
     constexpr int CV = 128 / VEC;                       // vectors per tile row
     constexpr int NV = BMS * CV / 256;                  // vectors per thread per operand
     constexpr int KM = sizeof(T) == 2 ? 32 : 4;         // token rows consumed per MFMA
@@ -1026,8 +1049,9 @@ void linear_tn_kernel(TnArgs p) {
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) R.a[i].set(e, R.a[i].get(e) * R.s[i]);
             }
-            stvec<T>(As + (buf * BMS + row) * PITCH + c, R.a[i]);
-            stvec<T>(Bs + (buf * BMS + row) * PITCH + c, R.b[i]);
+            const int cs = SWZ ? ((((c >> 4) ^ tn_swz(row)) << 4) | (c & 8)) : c;          // 16-byte vector inside its permuted 32-byte block
+            stvec<T>(As + (buf * BMS + row) * PITCH + cs, R.a[i]);
+            stvec<T>(Bs + (buf * BMS + row) * PITCH + cs, R.b[i]);
             if (do_bias) {
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) colsum[e] += R.a[i].get(e);
@@ -1049,9 +1073,9 @@ void linear_tn_kernel(TnArgs p) {
             if constexpr (sizeof(T) == 2) {
                 bf16x8 af[4], bf_[4];
 #pragma unroll
-                for (int a = 0; a < 4; ++a) af[a] = lds_tr_frag(reinterpret_cast<const bf16*>(asb) + kk * 32 * PITCH, PITCH, wn * 64 + a * 16, li, lg);
+                for (int a = 0; a < 4; ++a) af[a] = lds_tr_frag_swz(reinterpret_cast<const bf16*>(asb), kk * 32, wn * 64 + a * 16, li, lg);
 #pragma unroll
-                for (int b = 0; b < 4; ++b) bf_[b] = lds_tr_frag(reinterpret_cast<const bf16*>(bsb) + kk * 32 * PITCH, PITCH, wk * 64 + b * 16, li, lg);
+                for (int b = 0; b < 4; ++b) bf_[b] = lds_tr_frag_swz(reinterpret_cast<const bf16*>(bsb), kk * 32, wk * 64 + b * 16, li, lg);
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -1132,7 +1156,7 @@ void linear_tn_kernel(TnArgs p) {
 template <typename T, int BMS, bool FEW = false, int PF = 1>
 int launch_tn(const TnArgs& a, dim3 grid, hipStream_t st) {
     constexpr int VEC = Vec<T>::N;
-    constexpr size_t lds = (size_t)4 * BMS * (128 + VEC) * sizeof(T) + (256 / (128 / VEC)) * 128 * sizeof(float);
+    constexpr size_t lds = (size_t)4 * BMS * (sizeof(T) == 2 ? 128 : 128 + VEC) * sizeof(T) + (256 / (128 / VEC)) * 128 * sizeof(float);
     static bool attr_set = false;
     if (lds > 65536 && !attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_tn_kernel<T, BMS, FEW, PF>),
@@ -1141,6 +1165,205 @@ int launch_tn(const TnArgs& a, dim3 grid, hipStream_t st) {
         attr_set = true;
     }
     hipLaunchKernelGGL((linear_tn_kernel<T, BMS, FEW, PF>), grid, dim3(256), lds, st, a);
+    FMMT_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// XCD-local TN kernel (bf16 weight gradients of the many-token Swin launches whose output fits 64 tiles).
+// Same arithmetic as linear_tn_kernel<bf16,64,false,2>, different decomposition:
+//  * the output tile shape is a template parameter (192 x 96, 96 x 192, 128 x 128: all 64 FLOP per loaded byte), chosen per
+//    (N, K) so that `tiles` divides the 64 workgroup slots of an XCD as evenly as possible (1536 x 384 -> 32 tiles of
+//    192 x 96: two splits per XCD, every slot used; 128 x 128 would be 36 tiles: one split and 28 idle slots, or two
+//    straddling splits);
+//  * workgroup b (observed on XCD b % 8, slot b / 8) takes split (b % 8) * spx + slot / tiles, tile slot % tiles: ALL output
+//    tiles of a split run on ONE XCD at the same time, so every token slab of dy and x is fetched into exactly one L2.  With
+//    the split-major chunked order of linear_tn_kernel 1.75 splits shared an XCD and most slabs crossed the fabric twice
+//    (PMC, stage-2 launches: 2 x FETCH_SIZE + WRITE_SIZE = 1.8 x the algorithmic bytes).  A different placement is slower,
+//    never wrong.
+//  * operand A (dy) is staged with a fixed column chunk per thread (row = tid / CV + i * (256 / CV)), so the bias gradient
+//    is still a per-thread column sum although 192 / 8 = 24 does not divide 256.
+// ---------------------------------------------------------------------------------------------
+template <int TNn, int TKk>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+void linear_tn_x_kernel(TnArgs p) {
+    using T = bf16;
+    constexpr int BMS = 64, VEC = 8;
+    constexpr int PA = TNn == 128 ? 128 : (TNn == 192 ? 208 : 96);      // LDS row pitch in elements (128: XOR-swizzled; 192: padded; 96: as is)
+    constexpr int PB = TKk == 128 ? 128 : (TKk == 192 ? 208 : 96);
+    constexpr int CVA = TNn / VEC, CVB = TKk / VEC;                     // 16-byte vectors per row
+    constexpr int TPRA = 256 / CVA, NVA = (BMS + TPRA - 1) / TPRA;      // A: fixed column chunk per thread, rows tid / CVA + i * TPRA
+    constexpr int NVB = BMS * CVB / 256;                                // B: v = tid + i * 256
+    static_assert(BMS * CVB % 256 == 0, "B operand staging");
+    constexpr int FA = TNn / 32, FB = TKk / 32;                         // 16-wide fragments per wave (2 x 2 waves)
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* As = reinterpret_cast<T*>(smem);                                 // [2][BMS][PA]
+    T* Bs = As + 2 * BMS * PA;                                          // [2][BMS][PB]
+    float* bsum = reinterpret_cast<float*>(smem);                       // [TPRA][TNn], aliases As after the token loop
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wk = wave & 1;
+    const int li = lane & 15, lg = lane >> 4;
+    const int tiles = p.tiles_n * p.tiles_k;
+    const int spx = 64 / tiles;                                         // splits per XCD
+    const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+    if (slot >= spx * tiles) return;
+    const int split = xcd * spx + slot / tiles, tile = slot % tiles;
+    const int tile_n = tile / p.tiles_k, tile_k = tile % p.tiles_k;
+    const int n0 = tile_n * TNn, k0 = tile_k * TKk;
+    const int mbeg = split * p.chunk, mend = min(p.M, mbeg + p.chunk);
+
+    const T* __restrict__ dyg = reinterpret_cast<const T*>(p.dy);
+    const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
+    const bool do_bias = (p.part_b != nullptr) && (tile_k == 0);
+    const bool a_thread = tid < TPRA * CVA;
+    const int a_row0 = tid / CVA, a_c = (tid % CVA) * VEC;
+
+    struct Regs { Vec<T> a[NVA], b[NVB]; float s[NVA]; };
+    Regs R0, R1;
+    float colsum[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) colsum[e] = 0.f;
+
+    auto a_off = [&](int row, int c) {                                  // element offset of the 16-byte vector (row, c) in an A buffer
+        if constexpr (TNn == 128) return row * PA + ((((c >> 4) ^ tn_swz(row)) << 4) | (c & 8));
+        else return row * PA + c;
+    };
+    auto b_off = [&](int row, int c) {
+        if constexpr (TKk == 128) return row * PB + ((((c >> 4) ^ tn_swz(row)) << 4) | (c & 8));
+        else return row * PB + c;
+    };
+    auto gload = [&](Regs& R, int mb) {
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) {
+            const int row = a_row0 + i * TPRA;
+            const int m = mb + row;
+            const bool mv = a_thread && row < BMS && m < mend;
+            R.a[i] = mv ? ldvec<T>(dyg + (size_t)m * p.lddy + n0 + a_c) : zerovec<T>();
+            if (p.rowscale) R.s[i] = mv ? p.rowscale[m / p.rows_per_scale] : 0.f;      // applied in lstore (see linear_tn_kernel)
+        }
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) {
+            const int v = tid + i * 256;
+            const int row = v / CVB, c = (v % CVB) * VEC;
+            const int m = mb + row;
+            R.b[i] = m < mend ? ldvec<T>(xg + (size_t)m * p.ldx + k0 + c) : zerovec<T>();
+        }
+    };
+    auto lstore = [&](Regs& R, int buf) {
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) {
+            const int row = a_row0 + i * TPRA;
+            if (p.rowscale) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) R.a[i].set(e, R.a[i].get(e) * R.s[i]);
+            }
+            if (a_thread && row < BMS) stvec<T>(As + buf * BMS * PA + a_off(row, a_c), R.a[i]);
+            if (do_bias) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) colsum[e] += R.a[i].get(e);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) {
+            const int v = tid + i * 256;
+            stvec<T>(Bs + buf * BMS * PB + b_off(v / CVB, (v % CVB) * VEC), R.b[i]);
+        }
+    };
+    auto frag = [&](const T* base, int pitch, bool swz, int row0, int c0) {
+        // ds_read_b64_tr_b16 pair: token rows row0 + lg*8 + (li>>2) and + 4, channels c0 .. c0 + 15 (see lds_tr_frag_swz)
+        const int r = row0 + lg * 8 + (li >> 2);
+        const T* a0 = swz ? base + r * pitch + (((c0 >> 4) ^ tn_swz(r)) << 4) + (li & 3) * 4 : base + r * pitch + c0 + (li & 3) * 4;
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * pitch));
+        union { struct { s16x4 lo, hi; } s; bf16x8 v; } u;
+        u.s.lo = lo;
+        u.s.hi = hi;
+        return u.v;
+    };
+
+    f32x4 acc[FA][FB];
+#pragma unroll
+    for (int a = 0; a < FA; ++a)
+#pragma unroll
+        for (int b = 0; b < FB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](int cur) {
+        const T* asb = As + cur * BMS * PA;
+        const T* bsb = Bs + cur * BMS * PB;
+#pragma unroll
+        for (int kk = 0; kk < BMS / 32; ++kk) {
+            bf16x8 af[FA], bf_[FB];
+#pragma unroll
+            for (int a = 0; a < FA; ++a) af[a] = frag(asb, PA, TNn == 128, kk * 32, wn * (TNn / 2) + a * 16);
+#pragma unroll
+            for (int b = 0; b < FB; ++b) bf_[b] = frag(bsb, PB, TKk == 128, kk * 32, wk * (TKk / 2) + b * 16);
+#pragma unroll
+            for (int a = 0; a < FA; ++a)
+#pragma unroll
+                for (int b = 0; b < FB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf_[b], acc[a][b], 0, 0, 0);
+        }
+    };
+
+    const int nsteps = (mend - mbeg + BMS - 1) / BMS;
+    if (nsteps > 0) {
+        gload(R0, mbeg);
+        lstore(R0, 0);
+    }
+    // two token steps in flight behind the one being multiplied (register sets R0 / R1), as linear_tn_kernel with PF = 2
+    if (nsteps > 1) gload(R0, mbeg + BMS);
+    if (nsteps > 2) gload(R1, mbeg + 2 * BMS);
+    __syncthreads();
+    auto iter = [&](int st, Regs& R) {
+        compute(st & 1);
+        if (st + 1 < nsteps) lstore(R, (st & 1) ^ 1);
+        if (st + 3 < nsteps) gload(R, mbeg + (st + 3) * BMS);
+        __syncthreads();
+    };
+    for (int st = 0; st < nsteps; st += 2) {
+        iter(st, R0);
+        if (st + 1 < nsteps) iter(st + 1, R1);
+    }
+
+    float* pw = p.part_w + (size_t)split * p.N * p.K;
+#pragma unroll
+    for (int a = 0; a < FA; ++a)
+#pragma unroll
+        for (int b = 0; b < FB; ++b) {
+            const int k = k0 + wk * (TKk / 2) + b * 16 + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * (TNn / 2) + a * 16 + lg * 4 + r;
+                pw[(size_t)n * p.K + k] = acc[a][b][r];
+            }
+        }
+    if (do_bias) {                                                       // uniform per workgroup; the token loop ended with a barrier
+        if (a_thread) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) bsum[a_row0 * TNn + a_c + e] = colsum[e];
+        }
+        __syncthreads();
+        if (tid < TNn) {
+            float t = 0.f;
+            for (int g = 0; g < TPRA; ++g) t += bsum[g * TNn + tid];
+            p.part_b[(size_t)split * p.N + n0 + tid] = t;
+        }
+    }
+}
+
+template <int TNn, int TKk>
+int launch_tn_x(const TnArgs& a, hipStream_t st) {
+    constexpr int PA = TNn == 128 ? 128 : (TNn == 192 ? 208 : 96), PB = TKk == 128 ? 128 : (TKk == 192 ? 208 : 96);
+    constexpr size_t lds = (size_t)2 * 64 * (PA + PB) * 2;
+    static_assert(lds >= (size_t)(256 / (TNn / 8)) * TNn * 4, "column-sum scratch aliases the A buffers");
+    static bool attr_set = false;
+    if (lds > 65536 && !attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_tn_x_kernel<TNn, TKk>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((linear_tn_x_kernel<TNn, TKk>), dim3(512), dim3(256), lds, st, a);
     FMMT_CHECK_LAUNCH();
     return 0;
 }
@@ -1173,10 +1396,48 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     if (ty == 0 && i < n) out[i] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
 }
 
-struct TnPlan { int tiles_n, tiles_k, splits, chunk; size_t bytes; };
+struct TnPlan { int tiles_n, tiles_k, splits, chunk; size_t bytes; int tn, tk; };     // tn != 0: linear_tn_x_kernel<tn, tk>
 
-TnPlan tn_plan(int M, int N, int K) {
+// XCD-local plan (bf16, many tokens, channel counts that tile): the tile shape with the best use of the 8 x 64 slots
+TnPlan tn_plan_x(int M, int N, int K) {
+    TnPlan best{0, 0, 0, 0, 0, 0, 0};
+    // Measured on MI355X and NOT the default (FMMT_TN_X=1 enables it): every slab does reach one L2 only, but the step's
+    // stage-2/3 weight gradients take 7.16 ms against 6.57 ms with the straddling split-major order (micro-benchmark, hot
+    // Infinity Cache: 125440 x 1536 x 384 0.254 vs 0.235 ms, 1152 x 384 0.208 vs 0.185 ms).  The second fetch of a slab
+    // is served by the 256 MB Infinity Cache, not by HBM; what the XCD-local form pays is 6-25 % idle workgroup slots
+    // and 244-252 registers.  Kept as the A/B partner for the traffic numbers in profiles/.
+    static const int mode = getenv("FMMT_TN_X") ? atoi(getenv("FMMT_TN_X")) : 0;
+    if (!mode || M <= 16384 || M % 8) return best;
+    const int cand[3][2] = {{192, 96}, {96, 192}, {128, 128}};
+    int best_used = 0;
+    for (int i = 0; i < 3; ++i) {
+        const int tn = cand[i][0], tk = cand[i][1];
+        if (N % tn || K % tk) continue;
+        const int tiles = (N / tn) * (K / tk);
+        if (tiles > 64) continue;
+        const int spx = 64 / tiles, used = spx * tiles;
+        if ((size_t)8 * spx * N * K * 4 > ((size_t)512 << 20)) continue;
+        const int splits = 8 * spx;
+        int chunk = (M + splits - 1) / splits;
+        chunk = (chunk + 63) / 64 * 64;
+        if ((M + chunk - 1) / chunk != splits) continue;                 // every split must own tokens (the finish pass sums all of them)
+        if (chunk < 256) continue;
+        if (used > best_used) {
+            best_used = used;
+            best = TnPlan{N / tn, K / tk, splits, chunk, (size_t)splits * ((size_t)N * K + N) * sizeof(float), tn, tk};
+        }
+    }
+    if (best_used < 48) best.tn = 0;                                      // under 75 % of the slots: the straddling order wins
+    return best;
+}
+
+TnPlan tn_plan(int M, int N, int K, int dtype) {
+    if (dtype == FMMT_BF16) {
+        const TnPlan px = tn_plan_x(M, N, K);
+        if (px.tn) return px;
+    }
     TnPlan pl;
+    pl.tn = pl.tk = 0;
     pl.tiles_n = (N + 127) / 128;
     pl.tiles_k = (K + 127) / 128;
     const int tiles = pl.tiles_n * pl.tiles_k;
@@ -1257,18 +1518,24 @@ extern "C" int fmmt_linear_fwd_splitk(int dtype, int M, int N, int K, const void
     return 0;
 }
 
-extern "C" size_t fmmt_linear_wgrad_workspace(int M, int N, int K) {
+extern "C" size_t fmmt_linear_wgrad_workspace(int dtype, int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    return tn_plan(M, N, K).bytes;
+    return tn_plan(M, N, K, dtype).bytes;
 }
 
 namespace {
 // the split contraction: part_w [splits][N][K], part_b [splits][N] or nullptr (splits == 1: these may be dw / db themselves)
 int launch_tn_plan(int dtype, int M, int N, int K, const void* dy, int lddy, const void* x, int ldx, float* part_w, float* part_b,
                    const float* rowscale, int rows_per_scale, hipStream_t st) {
-    const TnPlan pl = tn_plan(M, N, K);
+    const TnPlan pl = tn_plan(M, N, K, dtype);
     static const int tn_xcd = getenv("FMMT_TN_XCD") ? atoi(getenv("FMMT_TN_XCD")) : 1;
     TnArgs a{M, N, K, dy, lddy, x, ldx, part_w, part_b, rowscale, rows_per_scale, pl.tiles_k, pl.chunk, pl.tiles_n, tn_xcd};
+    if (pl.tn) {
+        if (lddy % 8 || ldx % 8) return FMMT_EINVAL;
+        if (pl.tn == 192) return launch_tn_x<192, 96>(a, st);
+        if (pl.tn == 96) return launch_tn_x<96, 192>(a, st);
+        return launch_tn_x<128, 128>(a, st);
+    }
     dim3 grid(pl.tiles_n * pl.tiles_k * pl.splits);
     static const int tn_cfg = getenv("FMMT_TN_CFG") ? atoi(getenv("FMMT_TN_CFG")) : 0;
     // measured (tests/gpu_gemm_bench.py): 64-token steps win for the compute-heavy stage-2/3 shapes (+15-25 %),
@@ -1296,18 +1563,19 @@ extern "C" int fmmt_linear_wgrad_partials(int dtype, int M, int N, int K,
     if (N % vec || K % vec || lddy % vec || ldx % vec) return FMMT_EINVAL;
     if (rowscale && rows_per_scale <= 0) return FMMT_EINVAL;
     if (!aligned16(dy) || !aligned16(x) || !aligned16(workspace)) return FMMT_EALIGN;
-    const TnPlan pl = tn_plan(M, N, K);
+    const TnPlan pl = tn_plan(M, N, K, dtype);
     if (workspace_bytes < pl.bytes) return FMMT_EWORKSPACE;
     float* part_w = reinterpret_cast<float*>(workspace);
     float* part_b = want_bias ? part_w + (size_t)pl.splits * N * K : nullptr;
     return launch_tn_plan(dtype, M, N, K, dy, lddy, x, ldx, part_w, part_b, rowscale, rows_per_scale, reinterpret_cast<hipStream_t>(stream));
 }
 
-extern "C" int fmmt_linear_wgrad_finish(int M, int N, int K, float* dw, float* db,
+extern "C" int fmmt_linear_wgrad_finish(int dtype, int M, int N, int K, float* dw, float* db,
                                         const void* workspace, size_t workspace_bytes, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || !dw) return FMMT_EINVAL;
+    if (dtype != FMMT_BF16 && dtype != FMMT_F32) return FMMT_EINVAL;
     if (!aligned16(dw) || !aligned16(workspace)) return FMMT_EALIGN;
-    const TnPlan pl = tn_plan(M, N, K);
+    const TnPlan pl = tn_plan(M, N, K, dtype);
     if (workspace_bytes < pl.bytes) return FMMT_EWORKSPACE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const float* part_w = reinterpret_cast<const float*>(workspace);
@@ -1324,7 +1592,7 @@ extern "C" int fmmt_linear_wgrad(int dtype, int M, int N, int K,
                                  float* dw, float* db, const float* rowscale, int rows_per_scale,
                                  void* workspace, size_t workspace_bytes, void* stream) {
     if (!aligned16(dw)) return FMMT_EALIGN;
-    if (M > 0 && N > 0 && K > 0 && tn_plan(M, N, K).splits == 1) {
+    if (M > 0 && N > 0 && K > 0 && (dtype == FMMT_BF16 || dtype == FMMT_F32) && tn_plan(M, N, K, dtype).splits == 1) {
         // single split: the "partials" ARE the result -- let the contraction kernel write dw / db directly
         const int vec = dtype == FMMT_BF16 ? 8 : 4;
         if (dtype != FMMT_BF16 && dtype != FMMT_F32) return FMMT_EINVAL;
@@ -1335,5 +1603,5 @@ extern "C" int fmmt_linear_wgrad(int dtype, int M, int N, int K,
     }
     if (int rc = fmmt_linear_wgrad_partials(dtype, M, N, K, dy, lddy, x, ldx, db != nullptr, rowscale, rows_per_scale,
                                             workspace, workspace_bytes, stream)) return rc;
-    return fmmt_linear_wgrad_finish(M, N, K, dw, db, workspace, workspace_bytes, stream);
+    return fmmt_linear_wgrad_finish(dtype, M, N, K, dw, db, workspace, workspace_bytes, stream);
 }

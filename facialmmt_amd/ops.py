@@ -71,7 +71,7 @@ def wgrad_raw(dy2, x2, want_bias, rowscale=None, rows_per_scale=1):
     lib = _lib.load()
     dw = torch.empty((N, K), dtype=torch.float32, device=dy2.device)
     db = torch.empty((N,), dtype=torch.float32, device=dy2.device) if want_bias else None
-    nbytes = lib.fmmt_linear_wgrad_workspace(M, N, K)
+    nbytes = lib.fmmt_linear_wgrad_workspace(dtype_code(dy2.dtype), M, N, K)
     ws = _ws(nbytes, dy2.device)
     if M <= 768:
         # few-token problems: one entry point (single split -> the contraction kernel writes dw / db itself, no reduce launch)
@@ -80,7 +80,7 @@ def wgrad_raw(dy2, x2, want_bias, rowscale=None, rows_per_scale=1):
         check(rc, f"fmmt_linear_wgrad(M={M},N={N},K={K})")
         return dw, db
     wgrad_partials_raw(dy2, x2, want_bias, ws, nbytes, rowscale, rows_per_scale)
-    rc = lib.fmmt_linear_wgrad_finish(M, N, K, _p(dw), _p(db), _p(ws), nbytes, _st())
+    rc = lib.fmmt_linear_wgrad_finish(dtype_code(dy2.dtype), M, N, K, _p(dw), _p(db), _p(ws), nbytes, _st())
     check(rc, f"fmmt_linear_wgrad_finish(M={M},N={N},K={K})")
     return dw, db
 

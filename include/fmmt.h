@@ -72,8 +72,9 @@ int fmmt_linear_fwd_splitk(int dtype, int M, int N, int K, const void* x, int ld
  *   dw[N,K] (fp32) = sum_m s_m * dy[m,N]^T x[m,K],   db[N] (fp32) = sum_m s_m * dy[m,N]   (db may be NULL)
  * with s_m = rowscale[m / rows_per_scale] (NULL -> 1).  The contraction over M is split across
  * workgroups into fp32 partials in `workspace` and combined in a fixed order (deterministic).
- * Query the workspace size first.  N % 8 == 0 and K % 8 == 0 (bf16) / % 4 (f32). */
-size_t fmmt_linear_wgrad_workspace(int M, int N, int K);
+ * Query the workspace size first (it depends on dtype: the bf16 and fp32 kernels split the tokens differently).
+ * N % 8 == 0 and K % 8 == 0 (bf16) / % 4 (f32). */
+size_t fmmt_linear_wgrad_workspace(int dtype, int M, int N, int K);
 int fmmt_linear_wgrad(int dtype, int M, int N, int K,
                       const void* dy, int lddy, const void* x, int ldx,
                       float* dw, float* db, const float* rowscale, int rows_per_scale,
@@ -81,12 +82,12 @@ int fmmt_linear_wgrad(int dtype, int M, int N, int K,
 /* The same operation as its two launches, for callers that want to time or overlap them separately:
  *   _partials: the split contraction (MFMA kernel) -> fp32 partials in `workspace` (want_bias != 0: also the bias partials);
  *   _finish  : fixed-order sum of the partials into dw (and db, which requires the partials call to have had want_bias).
- * Both must be given the same (M, N, K) and workspace. */
+ * Both must be given the same (dtype, M, N, K) and workspace. */
 int fmmt_linear_wgrad_partials(int dtype, int M, int N, int K,
                                const void* dy, int lddy, const void* x, int ldx, int want_bias,
                                const float* rowscale, int rows_per_scale,
                                void* workspace, size_t workspace_bytes, void* stream);
-int fmmt_linear_wgrad_finish(int M, int N, int K, float* dw, float* db,
+int fmmt_linear_wgrad_finish(int dtype, int M, int N, int K, float* dw, float* db,
                              const void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -118,6 +118,30 @@ def t_wgrad():
         report(f"wgrad rowscale db {dt}", db, (dy.double() * s).sum(0), tol)
 
 
+def t_wgrad_large():
+    """many-token bf16 weight gradients (ragged token counts, bias gradient, DropPath row scale with a dropped sample) against fp32
+    torch matmuls of the same bf16 operands (both sides accumulate exact products in fp32).  Run once more with FMMT_TN_X=1
+    in the environment (tests/test_gpu_ops.py::test_xcd_local_weight_gradient_kernel) it covers the XCD-local kernel's
+    192x96 / 96x192 / 128x128 tiles."""
+    dt, tol = torch.bfloat16, 1e-3
+    for (M, N, K) in [(125440, 1536, 384), (125440, 384, 1536), (125440, 1152, 384), (125440, 384, 384), (31360, 768, 768),
+                      (20008, 1536, 384), (17000, 384, 1536), (31360, 2304, 768), (501760, 192, 384), (62720, 768, 384)]:
+        dy = rnd("dy", (M, N), 1, dtype=dt)
+        x = rnd("x", (M, K), 2, dtype=dt)
+        dw, db = ops.wgrad_raw(dy, x, True)
+        report(f"wgrad large dw {M}x{N}x{K}", dw, dy.float().t() @ x.float(), tol)
+        report(f"wgrad large db {M}x{N}x{K}", db, dy.float().sum(0), tol)
+        dw2, none = ops.wgrad_raw(dy, x, False)
+        RES.append((f"wgrad large no-bias identical {M}x{N}x{K}", bool(torch.equal(dw, dw2)) and none is None))
+        rs = rnd("rs", (M // 196 + 1,), 5).abs() + 0.5
+        rs[1] = 0.0                                            # a dropped sample
+        dw, db = ops.wgrad_raw(dy, x, True, rs, 196)
+        sdy = dy.float() * rs.repeat_interleave(196)[:M, None]
+        report(f"wgrad large rowscale dw {M}x{N}x{K}", dw, sdy.t() @ x.float(), 5e-3)      # s * dy is rounded to bf16 before the MFMA
+        report(f"wgrad large rowscale db {M}x{N}x{K}", db, sdy.sum(0), 5e-3)
+        del dy, x, dw, db, dw2, sdy
+
+
 def t_layernorm():
     for dt, tol in ((torch.float32, 1e-5), (torch.bfloat16, 1.5e-2)):
         for (M, C) in [(100, 96), (77, 192), (50, 384), (33, 768), (20, 1536), (10, 500 if dt == torch.float32 else 504), (1, 96), (1, 768)]:
@@ -327,7 +351,7 @@ def t_speed():
 
 if __name__ == "__main__":
     print(torch.cuda.get_device_name(0), torch.version.hip)
-    for f in (t_linear, t_wgrad, t_layernorm, t_wattn, t_mha, t_misc):
+    for f in (t_linear, t_linear_large, t_wgrad, t_wgrad_large, t_layernorm, t_wattn, t_mha, t_misc):
         section(f)
     bad = [n for n, ok in RES if not ok]
     print(f"\nSUMMARY: {len(RES) - len(bad)} ok, {len(bad)} failed")

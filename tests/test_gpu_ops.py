@@ -16,7 +16,7 @@ def _run(fn_name):
     assert P.RES and not bad, f"{fn_name}: failed cases: {bad}"
 
 
-@pytest.mark.parametrize("case", ["t_linear", "t_linear_large", "t_wgrad", "t_layernorm", "t_wattn", "t_mha", "t_misc"])
+@pytest.mark.parametrize("case", ["t_linear", "t_linear_large", "t_wgrad", "t_wgrad_large", "t_layernorm", "t_wattn", "t_mha", "t_misc"])
 def test_op_parity(case):
     assert torch.cuda.is_available()
     _run(case)
@@ -31,3 +31,21 @@ def test_argument_errors_raise_on_gpu():
         ops.mha_core(torch.zeros(4, 1, 500, device=dev), torch.zeros(4, 1, 1000, device=dev), None, 4, 1.0)
     with pytest.raises(_lib.FmmtError, match="unsupported activation dtype"):
         ops.layer_norm(torch.zeros(4, 96, device=dev, dtype=torch.float16), torch.ones(96, device=dev), torch.zeros(96, device=dev))
+
+
+def test_xcd_local_weight_gradient_kernel():
+    """linear_tn_x_kernel (FMMT_TN_X=1; not the default -- see csrc/gemm.hip::tn_plan_x) in a process of its own, because the
+    switch is read once per process"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from tests import gpu_probe as P\n"
+            "P.section(P.t_wgrad_large)\n"
+            "bad = [n for n, ok in P.RES if not ok]\n"
+            "print('CASES', len(P.RES), 'FAILED', bad)\n"
+            "sys.exit(1 if bad or not P.RES else 0)\n") % root
+    env = dict(os.environ, FMMT_TN_X="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
