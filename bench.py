@@ -203,9 +203,9 @@ class KernelTimer:
         ops.linear_raw = timed_linear_raw
         raw_w = ops.wgrad_partials_raw
 
-        def timed_wgrad_partials_raw(dy2, x2, want_bias, ws, nbytes, rowscale=None, rows_per_scale=1):
+        def timed_wgrad_partials_raw(dy2, x2, want_bias, ws, nbytes, rowscale=None, rows_per_scale=1, x_gelu=False):
             if not timer.enabled or dy2.dtype != torch.bfloat16:
-                return raw_w(dy2, x2, want_bias, ws, nbytes, rowscale, rows_per_scale)
+                return raw_w(dy2, x2, want_bias, ws, nbytes, rowscale, rows_per_scale, x_gelu)
             M, N = dy2.shape
             K = x2.shape[1]
             # same dispatch as csrc/gemm.hip::fmmt_linear_wgrad_partials; the fixed-order sum of the partials
@@ -213,7 +213,7 @@ class KernelTimer:
             name = "linear_tn_kernel<bf16,32,few>" if M <= 4096 else "linear_tn_kernel<bf16,64>" if M <= 262144 else "linear_tn_kernel<bf16,32>"
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            raw_w(dy2, x2, want_bias, ws, nbytes, rowscale, rows_per_scale)
+            raw_w(dy2, x2, want_bias, ws, nbytes, rowscale, rows_per_scale, x_gelu)
             e.record()
             timer.events.append((name, 2.0 * M * N * K, (M * N + M * K) * 2.0 + N * K * 4.0, s, e,
                                  ("tn", M, N, K, 0, bool(want_bias), rowscale is not None)))

@@ -24,8 +24,9 @@ SIGNATURES = {
     "fmmt_linear_splitk_workspace": (_sz, [_i, _i, _i]),
     "fmmt_linear_fwd_splitk": (_i, [_i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _i, _p, _sz, _p]),
     "fmmt_linear_wgrad_workspace": (_sz, [_i, _i, _i, _i]),
-    "fmmt_linear_wgrad": (_i, [_i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p, _i, _p, _sz, _p]),
-    "fmmt_linear_wgrad_partials": (_i, [_i, _i, _i, _i, _p, _i, _p, _i, _i, _p, _i, _p, _sz, _p]),
+    "fmmt_linear_wgrad": (_i, [_i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _p, _sz, _p]),
+    "fmmt_linear_wgrad_partials": (_i, [_i, _i, _i, _i, _p, _i, _p, _i, _i, _p, _i, _i, _p, _sz, _p]),
+    "fmmt_mlp_fwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p]),
     "fmmt_linear_wgrad_finish": (_i, [_i, _i, _i, _i, _p, _p, _p, _sz, _p]),
     "fmmt_layernorm_fwd": (_i, [_i, _i, _i, _p, _p, _p, _f, _p, _p, _p, _i, _p]),
     "fmmt_layernorm_bwd_workspace": (_sz, [_i]),

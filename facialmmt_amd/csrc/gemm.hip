@@ -6,8 +6,7 @@
 // Both keep the *weight* on the MFMA "A" side and the *activation* on the "B" side, so the
 // accumulator fragment of a lane is a run of consecutive output channels of ONE token: the
 // epilogue (bias, GELU, residual, DropPath scale) works on contiguous vectors and stores rows.
-#include "fmmt_common.h"
-#include "../../include/fmmt.h"
+#include "gemm_common.h"
 #include <stdlib.h>
 
 namespace {
@@ -39,127 +38,6 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 // (Identity and banded tile orders were measured on the write-heavy stage-0/1 shapes: within +-3 % of this one.)
-
-struct LinArgs {
-    int M, N, K;
-    const void* x; int ldx;
-    const void* w; int ldw;
-    const float* bias;
-    void* y; int ldy;
-    void* y_pre;
-    int epi;
-    const void* aux; int ldaux;
-    const void* res; int ldres;
-    const float* rowscale; int rows_per_scale;
-    int tiles_n, tiles_m, reserved;
-    int ksplit;        // K range per blockIdx.y (split-K); 0 = no split
-    float* part;       // split-K: fp32 partials [split][M][N] instead of the epilogue
-};
-
-// Output-channel permutation of a wave tile.  MFMA row i = 4*g + r of n-tile nt becomes output channel
-//   full 8-wide chunk c = (4*nt)/8 :  c*32 + g*8 + (4*nt)%8 + r     (4 lanes x 16 B = 64 contiguous bytes per row)
-//   4-wide tail (CW % 8 != 0)      :  (CW/8)*32 + g*4 + r
-// so that every epilogue access of a lane is a 16-byte vector and the four lanes that share a token row
-// cover one contiguous 64-byte span per store instruction.
-template <int CW>
-__device__ __forceinline__ int chan_of(int nt, int g, int r) {
-    const int t0 = nt * 4;
-    return (t0 < (CW / 8) * 8) ? (t0 / 8) * 32 + g * 8 + (t0 % 8) + r : (CW / 8) * 32 + g * 4 + r;
-}
-
-// Epilogue of one wave tile (MT x NT MFMA tiles at rows mbase.., channels nbase..): bias, GELU / GELU',
-// DropPath row scale, residual, 16-byte stores; or raw fp32 partials for the split-K path.
-template <typename T, int MT, int NT, bool BIAS_DONE = false>
-__device__ __forceinline__ void nt_epilogue(const LinArgs& p, f32x4 (&acc)[MT][NT], int mbase, int nbase, int li, int lg) {
-    constexpr int VEC = Vec<T>::N;
-    T* __restrict__ yg = reinterpret_cast<T*>(p.y);
-    T* __restrict__ ypre = reinterpret_cast<T*>(p.y_pre);
-    const T* __restrict__ auxg = reinterpret_cast<const T*>(p.aux);
-    const T* __restrict__ resg = reinterpret_cast<const T*>(p.res);
-        if (p.part) {                                      // split-K: raw fp32 partial sums, finished by another kernel
-            float* pp = p.part + (size_t)blockIdx.y * p.M * p.N;
-#pragma unroll
-            for (int a = 0; a < MT; ++a) {
-                const int m = mbase + a * 16 + li;
-                if (m >= p.M) continue;
-#pragma unroll
-                for (int b = 0; b < NT; ++b) {
-                    const int n = nbase + chan_of<4 * NT>(b, lg, 0);
-                    if (n + 4 <= p.N) *reinterpret_cast<f32x4*>(pp + (size_t)m * p.N + n) = acc[a][b];
-                }
-            }
-            return;
-        }
-        // per lane and token row: CW/VEC vector chunks (fp32: one n-tile = 4 channels = 16 B; bf16: two
-        // n-tiles = 8 channels = 16 B) plus, for bf16 with odd NT, a 4-channel (8-byte) tail
-        constexpr int TPC = VEC / 4;                       // n-tiles per 16-byte chunk
-#pragma unroll
-        for (int a = 0; a < MT; ++a) {
-            const int m = mbase + a * 16 + li;
-            if (m >= p.M) continue;
-            const float rs = row_scale(p.rowscale, m, p.rows_per_scale);
-#pragma unroll
-            for (int b0 = 0; b0 < NT; b0 += TPC) {
-                const int w = (NT - b0 >= TPC) ? VEC : 4;      // chunk width (compile-time after unrolling)
-                const int n = nbase + chan_of<4 * NT>(b0, lg, 0);
-                if (n + w > p.N) continue;
-                float v[VEC];
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) v[e] = (e < w) ? acc[a][b0 + (e >> 2)][e & 3] : 0.f;
-                if (!BIAS_DONE && p.bias) {
-#pragma unroll
-                    for (int e4 = 0; e4 < VEC; e4 += 4)
-                        if (e4 < w) {
-                            const f32x4 bb = *reinterpret_cast<const f32x4*>(p.bias + n + e4);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) v[e4 + r] += bb[r];
-                        }
-                }
-                auto load_chunk = [&](const T* base, int ld, float* out) {
-                    if (w == VEC) {
-                        const Vec<T> t = ldvec<T>(base + (size_t)m * ld + n);
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) out[e] = t.get(e);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) out[e] = to_f32(base[(size_t)m * ld + n + e]);
-                    }
-                };
-                auto store_chunk = [&](T* base, int ld, const float* in) {
-                    if (w == VEC) {
-                        Vec<T> t;
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) t.set(e, in[e]);
-                        stvec<T>(base + (size_t)m * ld + n, t);
-                    } else {
-                        T o[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = from_f32<T>(in[e]);
-                        *reinterpret_cast<uint2*>(base + (size_t)m * ld + n) = *reinterpret_cast<const uint2*>(o);   // bf16 only (VEC == 8)
-                    }
-                };
-                if (p.epi == FMMT_EPI_GELU) {
-                    if (ypre) store_chunk(ypre, p.ldy, v);
-                    gelu_inplace<T>(v, VEC);
-                } else if (p.epi == FMMT_EPI_GELU_BWD) {
-                    float ax[VEC];
-                    load_chunk(auxg, p.ldaux, ax);
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) ax[e] = (e < w) ? ax[e] : 0.f;
-                    gelu_grad_mul_inplace<T>(v, ax, VEC);
-                }
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) v[e] *= rs;
-                if (resg) {
-                    float rx[VEC];
-                    load_chunk(resg, p.ldres, rx);
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) v[e] += (e < w) ? rx[e] : 0.f;
-                }
-                store_chunk(yg, p.ldy, v);
-            }
-        }
-}
 
 // ---------------------------------------------------------------------------------------------
 // NT kernel: 256 threads = 4 waves (2 along M x 2 along N); block tile BM x BN, K step BK.
@@ -948,6 +826,7 @@ struct TnArgs {
     int chunk;          // rows of m per split (multiple of the m step)
     int tiles_n;
     int xcd;            // 1: chunked XCD remap of the (split, tile) work list
+    int x_gelu;         // 1: the x operand holds a pre-activation; contract with gelu(x) (recomputed activation of the fused Mlp)
 };
 
 __device__ __forceinline__ bf16x8 lds_tr_frag(const bf16* s, int pitch, int c0, int li, int lg) {
@@ -1050,6 +929,14 @@ void linear_tn_kernel(TnArgs p) {
                 for (int e = 0; e < VEC; ++e) R.a[i].set(e, R.a[i].get(e) * R.s[i]);
             }
             const int cs = SWZ ? ((((c >> 4) ^ tn_swz(row)) << 4) | (c & 8)) : c;          // 16-byte vector inside its permuted 32-byte block
+            if (p.x_gelu) {
+                float g[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) g[e] = R.b[i].get(e);
+                gelu_inplace<T>(g, VEC);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) R.b[i].set(e, g[e]);
+            }
             stvec<T>(As + (buf * BMS + row) * PITCH + cs, R.a[i]);
             stvec<T>(Bs + (buf * BMS + row) * PITCH + cs, R.b[i]);
             if (do_bias) {
@@ -1268,6 +1155,14 @@ void linear_tn_x_kernel(TnArgs p) {
 #pragma unroll
         for (int i = 0; i < NVB; ++i) {
             const int v = tid + i * 256;
+            if (p.x_gelu) {
+                float g[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) g[e] = R.b[i].get(e);
+                gelu_inplace<T>(g, VEC);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) R.b[i].set(e, g[e]);
+            }
             stvec<T>(Bs + buf * BMS * PB + b_off(v / CVB, (v % CVB) * VEC), R.b[i]);
         }
     };
@@ -1526,10 +1421,11 @@ extern "C" size_t fmmt_linear_wgrad_workspace(int dtype, int M, int N, int K) {
 namespace {
 // the split contraction: part_w [splits][N][K], part_b [splits][N] or nullptr (splits == 1: these may be dw / db themselves)
 int launch_tn_plan(int dtype, int M, int N, int K, const void* dy, int lddy, const void* x, int ldx, float* part_w, float* part_b,
-                   const float* rowscale, int rows_per_scale, hipStream_t st) {
+                   const float* rowscale, int rows_per_scale, int x_epi, hipStream_t st) {
     const TnPlan pl = tn_plan(M, N, K, dtype);
     static const int tn_xcd = getenv("FMMT_TN_XCD") ? atoi(getenv("FMMT_TN_XCD")) : 1;
-    TnArgs a{M, N, K, dy, lddy, x, ldx, part_w, part_b, rowscale, rows_per_scale, pl.tiles_k, pl.chunk, pl.tiles_n, tn_xcd};
+    if (x_epi != 0 && x_epi != FMMT_EPI_GELU) return FMMT_EINVAL;
+    TnArgs a{M, N, K, dy, lddy, x, ldx, part_w, part_b, rowscale, rows_per_scale, pl.tiles_k, pl.chunk, pl.tiles_n, tn_xcd, x_epi == FMMT_EPI_GELU};
     if (pl.tn) {
         if (lddy % 8 || ldx % 8) return FMMT_EINVAL;
         if (pl.tn == 192) return launch_tn_x<192, 96>(a, st);
@@ -1555,7 +1451,7 @@ int launch_tn_plan(int dtype, int M, int N, int K, const void* dy, int lddy, con
 
 extern "C" int fmmt_linear_wgrad_partials(int dtype, int M, int N, int K,
                                           const void* dy, int lddy, const void* x, int ldx, int want_bias,
-                                          const float* rowscale, int rows_per_scale,
+                                          const float* rowscale, int rows_per_scale, int x_epi,
                                           void* workspace, size_t workspace_bytes, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0) return FMMT_EINVAL;
     if (dtype != FMMT_BF16 && dtype != FMMT_F32) return FMMT_EINVAL;
@@ -1567,7 +1463,7 @@ extern "C" int fmmt_linear_wgrad_partials(int dtype, int M, int N, int K,
     if (workspace_bytes < pl.bytes) return FMMT_EWORKSPACE;
     float* part_w = reinterpret_cast<float*>(workspace);
     float* part_b = want_bias ? part_w + (size_t)pl.splits * N * K : nullptr;
-    return launch_tn_plan(dtype, M, N, K, dy, lddy, x, ldx, part_w, part_b, rowscale, rows_per_scale, reinterpret_cast<hipStream_t>(stream));
+    return launch_tn_plan(dtype, M, N, K, dy, lddy, x, ldx, part_w, part_b, rowscale, rows_per_scale, x_epi, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int fmmt_linear_wgrad_finish(int dtype, int M, int N, int K, float* dw, float* db,
@@ -1589,7 +1485,7 @@ extern "C" int fmmt_linear_wgrad_finish(int dtype, int M, int N, int K, float* d
 
 extern "C" int fmmt_linear_wgrad(int dtype, int M, int N, int K,
                                  const void* dy, int lddy, const void* x, int ldx,
-                                 float* dw, float* db, const float* rowscale, int rows_per_scale,
+                                 float* dw, float* db, const float* rowscale, int rows_per_scale, int x_epi,
                                  void* workspace, size_t workspace_bytes, void* stream) {
     if (!aligned16(dw)) return FMMT_EALIGN;
     if (M > 0 && N > 0 && K > 0 && (dtype == FMMT_BF16 || dtype == FMMT_F32) && tn_plan(M, N, K, dtype).splits == 1) {
@@ -1599,9 +1495,9 @@ extern "C" int fmmt_linear_wgrad(int dtype, int M, int N, int K,
         if (N % vec || K % vec || lddy % vec || ldx % vec) return FMMT_EINVAL;
         if (rowscale && rows_per_scale <= 0) return FMMT_EINVAL;
         if (!aligned16(dy) || !aligned16(x)) return FMMT_EALIGN;
-        return launch_tn_plan(dtype, M, N, K, dy, lddy, x, ldx, dw, db, rowscale, rows_per_scale, reinterpret_cast<hipStream_t>(stream));
+        return launch_tn_plan(dtype, M, N, K, dy, lddy, x, ldx, dw, db, rowscale, rows_per_scale, x_epi, reinterpret_cast<hipStream_t>(stream));
     }
-    if (int rc = fmmt_linear_wgrad_partials(dtype, M, N, K, dy, lddy, x, ldx, db != nullptr, rowscale, rows_per_scale,
+    if (int rc = fmmt_linear_wgrad_partials(dtype, M, N, K, dy, lddy, x, ldx, db != nullptr, rowscale, rows_per_scale, x_epi,
                                             workspace, workspace_bytes, stream)) return rc;
     return fmmt_linear_wgrad_finish(dtype, M, N, K, dw, db, workspace, workspace_bytes, stream);
 }

@@ -1,0 +1,130 @@
+// Pieces of the Linear kernels shared by gemm.hip and mlp_fused.hip: the argument block, the output-channel permutation
+// of a wave tile and the vectorised epilogue (bias, GELU / GELU', DropPath row scale, residual, 16-byte row stores).
+#pragma once
+#include "fmmt_common.h"
+#include "../../include/fmmt.h"
+
+namespace {
+
+struct LinArgs {
+    int M, N, K;
+    const void* x; int ldx;
+    const void* w; int ldw;
+    const float* bias;
+    void* y; int ldy;
+    void* y_pre;
+    int epi;
+    const void* aux; int ldaux;
+    const void* res; int ldres;
+    const float* rowscale; int rows_per_scale;
+    int tiles_n, tiles_m, reserved;
+    int ksplit;        // K range per blockIdx.y (split-K); 0 = no split
+    float* part;       // split-K: fp32 partials [split][M][N] instead of the epilogue
+};
+
+// Output-channel permutation of a wave tile.  MFMA row i = 4*g + r of n-tile nt becomes output channel
+//   full 8-wide chunk c = (4*nt)/8 :  c*32 + g*8 + (4*nt)%8 + r     (4 lanes x 16 B = 64 contiguous bytes per row)
+//   4-wide tail (CW % 8 != 0)      :  (CW/8)*32 + g*4 + r
+// so that every epilogue access of a lane is a 16-byte vector and the four lanes that share a token row
+// cover one contiguous 64-byte span per store instruction.
+template <int CW>
+__device__ __forceinline__ int chan_of(int nt, int g, int r) {
+    const int t0 = nt * 4;
+    return (t0 < (CW / 8) * 8) ? (t0 / 8) * 32 + g * 8 + (t0 % 8) + r : (CW / 8) * 32 + g * 4 + r;
+}
+
+// Epilogue of one wave tile (MT x NT MFMA tiles at rows mbase.., channels nbase..): bias, GELU / GELU',
+// DropPath row scale, residual, 16-byte stores; or raw fp32 partials for the split-K path.
+template <typename T, int MT, int NT, bool BIAS_DONE = false>
+__device__ __forceinline__ void nt_epilogue(const LinArgs& p, f32x4 (&acc)[MT][NT], int mbase, int nbase, int li, int lg) {
+    constexpr int VEC = Vec<T>::N;
+    T* __restrict__ yg = reinterpret_cast<T*>(p.y);
+    T* __restrict__ ypre = reinterpret_cast<T*>(p.y_pre);
+    const T* __restrict__ auxg = reinterpret_cast<const T*>(p.aux);
+    const T* __restrict__ resg = reinterpret_cast<const T*>(p.res);
+        if (p.part) {                                      // split-K: raw fp32 partial sums, finished by another kernel
+            float* pp = p.part + (size_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+                const int m = mbase + a * 16 + li;
+                if (m >= p.M) continue;
+#pragma unroll
+                for (int b = 0; b < NT; ++b) {
+                    const int n = nbase + chan_of<4 * NT>(b, lg, 0);
+                    if (n + 4 <= p.N) *reinterpret_cast<f32x4*>(pp + (size_t)m * p.N + n) = acc[a][b];
+                }
+            }
+            return;
+        }
+        // per lane and token row: CW/VEC vector chunks (fp32: one n-tile = 4 channels = 16 B; bf16: two
+        // n-tiles = 8 channels = 16 B) plus, for bf16 with odd NT, a 4-channel (8-byte) tail
+        constexpr int TPC = VEC / 4;                       // n-tiles per 16-byte chunk
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+            const int m = mbase + a * 16 + li;
+            if (m >= p.M) continue;
+            const float rs = row_scale(p.rowscale, m, p.rows_per_scale);
+#pragma unroll
+            for (int b0 = 0; b0 < NT; b0 += TPC) {
+                const int w = (NT - b0 >= TPC) ? VEC : 4;      // chunk width (compile-time after unrolling)
+                const int n = nbase + chan_of<4 * NT>(b0, lg, 0);
+                if (n + w > p.N) continue;
+                float v[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[e] = (e < w) ? acc[a][b0 + (e >> 2)][e & 3] : 0.f;
+                if (!BIAS_DONE && p.bias) {
+#pragma unroll
+                    for (int e4 = 0; e4 < VEC; e4 += 4)
+                        if (e4 < w) {
+                            const f32x4 bb = *reinterpret_cast<const f32x4*>(p.bias + n + e4);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[e4 + r] += bb[r];
+                        }
+                }
+                auto load_chunk = [&](const T* base, int ld, float* out) {
+                    if (w == VEC) {
+                        const Vec<T> t = ldvec<T>(base + (size_t)m * ld + n);
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) out[e] = t.get(e);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) out[e] = to_f32(base[(size_t)m * ld + n + e]);
+                    }
+                };
+                auto store_chunk = [&](T* base, int ld, const float* in) {
+                    if (w == VEC) {
+                        Vec<T> t;
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) t.set(e, in[e]);
+                        stvec<T>(base + (size_t)m * ld + n, t);
+                    } else {
+                        T o[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = from_f32<T>(in[e]);
+                        *reinterpret_cast<uint2*>(base + (size_t)m * ld + n) = *reinterpret_cast<const uint2*>(o);   // bf16 only (VEC == 8)
+                    }
+                };
+                if (p.epi == FMMT_EPI_GELU) {
+                    if (ypre) store_chunk(ypre, p.ldy, v);
+                    gelu_inplace<T>(v, VEC);
+                } else if (p.epi == FMMT_EPI_GELU_BWD) {
+                    float ax[VEC];
+                    load_chunk(auxg, p.ldaux, ax);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) ax[e] = (e < w) ? ax[e] : 0.f;
+                    gelu_grad_mul_inplace<T>(v, ax, VEC);
+                }
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[e] *= rs;
+                if (resg) {
+                    float rx[VEC];
+                    load_chunk(resg, p.ldres, rx);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) v[e] += (e < w) ? rx[e] : 0.f;
+                }
+                store_chunk(yg, p.ldy, v);
+            }
+        }
+}
+
+}  // namespace

@@ -1,0 +1,283 @@
+// Fused Mlp forward of the Swin stages with few channels (stage 0: C = 96, stage 1: C = 192; hidden 4C):
+//
+//     y = res + rowscale * ( gelu(x . W1^T + b1) . W2^T + b2 )          (Swin_Transformer.py:14-30, :268)
+//
+// in ONE launch, the 4C-wide hidden activation never leaving the CU.  As two launches (fc1 + GELU epilogue, fc2 + residual
+// epilogue) a stage-0 block moves 5.8 GB through HBM for 0.3 TFLOP -- x in, pre-activation AND activation out, activation in
+// again, residual in, y out -- and both launches are HBM streams.  Here x is read once, the pre-activation
+// is written once (training only: the backward's GELU' and the recomputed activation need it), y once: 2.7 GB.
+//
+// Decomposition.  A workgroup of 8 waves walks 256-token tiles; wave w owns tokens [32 w, 32 w + 32) of the tile for BOTH
+// products.  Hidden channels go by in blocks of 32:
+//   product 1   D1[hidden 32][token 32] = W1 block . x^T      (weight on the MFMA A side, tokens on the B side; x fragments
+//               stay in registers for the whole tile, K = C)
+//   epilogue 1  + b1, optional bf16 store of the pre-activation, erf-GELU (packed fast form, fmmt_common.h)
+//   product 2   D2[channel C][token 32] += W2 block . h       where the B operand h is product 1's OWN accumulator: with the
+//               hidden-row permutation chan_of<8> a lane's two 16x16 accumulator tiles hold 8 consecutive hidden channels
+//               of one token, which is exactly the B-fragment layout of a 32-deep K block -- no LDS round trip, no shuffle
+//               (the P.V trick of mha_mfma.hip).
+// The weights stream through an LDS ring shared by the 8 waves: a stage = 64 hidden channels = W1 rows [64][C] (stored per
+// 32-wide K slice, 64-byte rows), W2 columns as two [C][32] blocks, and the 64 bias values; filled by direct global->LDS DMA,
+// two stages in flight behind the one in use, counted vmcnt + one raw s_barrier per stage, and -- as in
+// linear_nt_p256_kernel -- the ring keeps running across tile boundaries.  Weights come from L2 (144 / 576 KB per tile,
+// re-read by every workgroup); activations are the HBM traffic.
+//
+// Accumulation orders equal those of the two-launch path (K ascending in both products, bf16 rounding of h before product 2),
+// so the result is bit-identical to fmmt_linear_fwd(GELU) followed by fmmt_linear_fwd(residual): tests/gpu_probe.py::t_mlp_fused.
+#include "gemm_common.h"
+
+namespace {
+
+struct MlpArgs {
+    int M;
+    const bf16* x;
+    const bf16* w1;
+    const float* b1;
+    const bf16* w2;
+    const float* b2;
+    const bf16* res;
+    const float* rowscale;
+    int rows_per_scale;
+    bf16* y;
+    bf16* h_pre;
+    bf16* h_act;
+    int tiles;
+};
+
+// (Two workgroups per CU at C = 96 -- 76.8 KB of LDS each, registers forced to 128 -- were measured: the inference form gains
+//  13 %, the training forms, whose time goes into the hidden-tensor stores, lose 0-19 % to the 20 spilled registers.)
+template <int C>
+__global__ __launch_bounds__(512) void mlp_fused_fwd_kernel(MlpArgs p) {
+    using T = bf16;
+    constexpr int H = 4 * C, HS = 64, NS = H / HS;          // hidden channels per ring stage, stages per tile
+    constexpr int KS = C / 32;                              // K steps of product 1
+    constexpr int NT2 = C / 16, CW2 = 4 * NT2;              // product 2: 16-row output-channel tiles per wave, channels per lane
+    constexpr int W1_EL = KS * HS * 32, W2_EL = 2 * C * 32; // elements per stage
+    constexpr int STAGE_B = (W1_EL + W2_EL) * 2 + 1024;     // bytes: + a 1 KB slot for the 64 bias values (256 B used)
+    constexpr int NBUF = 3;
+    constexpr int NI = KS * (HS / 16) + 2 * (C / 16);       // DMA instructions per stage (16 rows x 64 B each), dealt round-robin
+    static_assert(NI % 8 == 0, "uniform DMA count per wave");
+    constexpr int CNT = NI / 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    auto swz = [](int row) { return ((row >> 3) ^ (row >> 2)) & 3; };       // 16-byte chunk swizzle of 64-byte rows (as linear_nt_deep32)
+    const int r16 = lane >> 2, c4 = lane & 3;
+
+    auto issue = [&](int slot, int hs) {
+        char* base = smem + slot * STAGE_B;
+#pragma unroll
+        for (int i = 0; i < CNT; ++i) {
+            const int j = i * 8 + wave;                      // wave-uniform
+            const T* src;
+            T* dst;
+            if (j < KS * 4) {                                // W1: K slice ks, hidden rows r0 .. r0 + 15 of the stage
+                const int ks = j >> 2, r0 = (j & 3) * 16, r = r0 + r16;
+                src = p.w1 + (size_t)(hs * HS + r) * C + ks * 32 + ((c4 ^ swz(r)) << 3);
+                dst = reinterpret_cast<T*>(base) + ks * (HS * 32) + r0 * 32;
+            } else {                                         // W2: hidden block b, output-channel rows r0 .. r0 + 15
+                const int q = j - KS * 4, b = q / (C / 16), r0 = (q % (C / 16)) * 16, r = r0 + r16;
+                src = p.w2 + (size_t)r * H + hs * HS + b * 32 + ((c4 ^ swz(r)) << 3);
+                dst = reinterpret_cast<T*>(base) + W1_EL + b * (C * 32) + r0 * 32;
+            }
+            __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)dst, 16, 0, 0);
+        }
+        if (wave == 7) {                                     // 64 bias values (lanes 16.. re-read the last 16 bytes into the slot's unused tail)
+            const float* bsrc = p.b1 + hs * HS + min(lane, 15) * 4;
+            __builtin_amdgcn_global_load_lds((gptr_t*)bsrc, (lptr_t*)(base + (W1_EL + W2_EL) * 2), 16, 0, 0);
+        }
+    };
+    // Stage s has landed when all but the youngest N of this wave's memory operations are complete, N = what was issued after
+    // stage s's DMA and may still fly: the next stage's DMA (CNT, + 1 bias slab for wave 7) and -- CDNA4's vmcnt counts
+    // stores too -- the four pre-activation stores of the stage computed in between.  Only a LOWER bound on that number is
+    // safe (too large an N would let stage s itself count as "young"): the stores are counted only when every lane of the
+    // wave certainly issued them (no ragged tail, pre-activation requested); elsewhere the wait is merely stricter.
+    auto wait_landed = [&](bool one_ahead, int stores) {      // stores: 0, 4 or 8 vector stores certainly issued by the previous step
+        if (!one_ahead) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (stores == 8) {
+            if (wave == 7) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT + 9) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT + 8) : "memory");
+        } else if (stores == 4) {
+            if (wave == 7) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT + 5) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT + 4) : "memory");
+        } else {
+            if (wave == 7) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT + 1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT) : "memory");
+        }
+    };
+
+    // fragment offsets (elements) inside a stage
+    int w1off[2], w2off[NT2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int r = chan_of<8>(nt, li >> 2, li & 3);       // hidden row inside a 32-block: lg*8 + 4*nt + r after the MFMA
+        w1off[nt] = r * 32 + ((lg ^ swz(r)) << 3);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt) {
+        const int r = chan_of<CW2>(nt, li >> 2, li & 3);
+        w2off[nt] = W1_EL + r * 32 + ((lg ^ swz(r)) << 3);
+    }
+
+    const int G = gridDim.x;
+    const int ntile = (int)blockIdx.x < p.tiles ? (p.tiles - (int)blockIdx.x + G - 1) / G : 0;
+    const int nsteps = ntile * NS;
+    int ihs = 0, islot = 0;
+    auto issue_next = [&]() {
+        issue(islot, ihs);
+        islot = islot + 1 == NBUF ? 0 : islot + 1;
+        ihs = ihs + 1 == NS ? 0 : ihs + 1;
+    };
+#pragma unroll
+    for (int s = 0; s < NBUF - 1; ++s)
+        if (s < nsteps) issue_next();
+
+    bf16x8 xf[2][KS];
+    auto load_x = [&](int tile) {
+        const int t0 = tile * 256 + wave * 32;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int tok = min(t0 + mt * 16 + li, p.M - 1);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) xf[mt][ks] = *reinterpret_cast<const bf16x8*>(p.x + (size_t)tok * C + ks * 32 + lg * 8);
+        }
+    };
+    f32x4 acc2[2][NT2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) acc2[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int tile = blockIdx.x, hs = 0, cslot = 0;
+    if (ntile > 0) load_x(tile);
+    for (int s = 0; s < nsteps; ++s) {
+        // hs > 0: the previous step belonged to this tile and stored its four pre-activation vectors (a tile's first step
+        // follows the previous tile's epilogue instead: more, not fewer, younger operations -- the plain count stays safe)
+        const bool full = hs > 0 && tile * 256 + wave * 32 + 32 <= p.M;
+        wait_landed(s + 1 < nsteps, full ? 4 * (int)(p.h_pre != nullptr) + 4 * (int)(p.h_act != nullptr) : 0);
+        __builtin_amdgcn_s_barrier();                        // stage s is in LDS for every wave; the stage read in step s - 1 is free
+        if (s + NBUF - 1 < nsteps) issue_next();
+        const T* sb = reinterpret_cast<const T*>(smem + cslot * STAGE_B);
+        const float* bs = reinterpret_cast<const float*>(smem + cslot * STAGE_B + (W1_EL + W2_EL) * 2);
+        const int t0 = tile * 256 + wave * 32;
+        // a token's 64 hidden values of this stage are one 128-byte line of h_pre / h_act: block 0's half is held back and
+        // written together with block 1's, so that the two 64-byte halves reach L2 back to back
+        bf16x8 keep_pre[2], keep_act[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            f32x4 acc1[2][2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) acc1[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                bf16x8 wf[2];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) wf[nt] = *reinterpret_cast<const bf16x8*>(sb + ks * (HS * 32) + blk * (32 * 32) + w1off[nt]);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) acc1[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt][ks], acc1[mt][nt], 0, 0, 0);
+            }
+            // epilogue 1: this lane holds, per token tile, hidden channels hbase .. hbase + 7 of token li
+            const f32x4 bb0 = *reinterpret_cast<const f32x4*>(bs + blk * 32 + lg * 8);
+            const f32x4 bb1 = *reinterpret_cast<const f32x4*>(bs + blk * 32 + lg * 8 + 4);
+            bf16x8 hf[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                float v[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = acc1[mt][0][r] + bb0[r];
+                    v[4 + r] = acc1[mt][1][r] + bb1[r];
+                }
+                const int tok = t0 + mt * 16 + li;
+                bf16x8 pre8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pre8[e] = (bf16)v[e];
+                gelu_inplace<T>(v, 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hf[mt][e] = (bf16)v[e];
+                if (blk == 0) {
+                    keep_pre[mt] = pre8;
+                    keep_act[mt] = hf[mt];
+                } else if (tok < p.M) {
+                    const size_t off = (size_t)tok * H + hs * HS + lg * 8;
+                    if (p.h_pre) {
+                        *reinterpret_cast<bf16x8*>(p.h_pre + off) = keep_pre[mt];
+                        *reinterpret_cast<bf16x8*>(p.h_pre + off + 32) = pre8;
+                    }
+                    if (p.h_act) {
+                        *reinterpret_cast<bf16x8*>(p.h_act + off) = keep_act[mt];
+                        *reinterpret_cast<bf16x8*>(p.h_act + off + 32) = hf[mt];
+                    }
+                }
+            }
+            // product 2: K block = these 32 hidden channels
+#pragma unroll
+            for (int nt = 0; nt < NT2; ++nt) {
+                const bf16x8 wf2 = *reinterpret_cast<const bf16x8*>(sb + blk * (C * 32) + w2off[nt]);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) acc2[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf2, hf[mt], acc2[mt][nt], 0, 0, 0);
+            }
+        }
+        cslot = cslot + 1 == NBUF ? 0 : cslot + 1;
+        if (++hs == NS) {
+            // tile done: the x fragments are dead -- fetch the next tile's while this one's result is finished and stored
+            const int next = tile + G;
+            if (next < p.tiles) load_x(next);
+            LinArgs e{};
+            e.M = p.M;
+            e.N = C;
+            e.bias = p.b2;
+            e.y = p.y;
+            e.ldy = C;
+            e.res = p.res;
+            e.ldres = C;
+            e.rowscale = p.rowscale;
+            e.rows_per_scale = p.rows_per_scale;
+            nt_epilogue<T, 2, NT2>(e, acc2, t0, 0, li, lg);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT2; ++nt) acc2[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            hs = 0;
+            tile = next;
+        }
+    }
+}
+
+template <int C>
+int launch_mlp(const MlpArgs& a, hipStream_t st) {
+    constexpr size_t lds = (size_t)3 * (((C / 32) * 64 * 32 + 2 * C * 32) * 2 + 1024);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_fwd_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int grid = a.tiles < 256 ? a.tiles : 256;
+    hipLaunchKernelGGL((mlp_fused_fwd_kernel<C>), dim3(grid), dim3(512), lds, st, a);
+    FMMT_CHECK_LAUNCH();
+    return 0;
+}
+
+bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int fmmt_mlp_fwd(int dtype, int M, int C, const void* x, const void* w1, const float* b1, const void* w2, const float* b2,
+                            const void* res, const float* rowscale, int rows_per_scale, void* y, void* h_pre, void* h_act, void* stream) {
+    if (dtype != FMMT_BF16 || M <= 0 || (C != 96 && C != 192)) return FMMT_EINVAL;      // other widths: fmmt_linear_fwd twice
+    if (!x || !w1 || !b1 || !w2 || !b2 || !y) return FMMT_EINVAL;
+    if (rowscale && rows_per_scale <= 0) return FMMT_EINVAL;
+    if (!al16(x) || !al16(w1) || !al16(b1) || !al16(w2) || !al16(b2) || !al16(y) || (res && !al16(res)) || (h_pre && !al16(h_pre)) || (h_act && !al16(h_act))) return FMMT_EALIGN;
+    MlpArgs a{M, (const bf16*)x, (const bf16*)w1, b1, (const bf16*)w2, b2, (const bf16*)res, rowscale, rows_per_scale, (bf16*)y, (bf16*)h_pre, (bf16*)h_act, (M + 255) / 256};
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    return C == 96 ? launch_mlp<96>(a, st) : launch_mlp<192>(a, st);
+}

@@ -55,17 +55,17 @@ def linear_raw(x2, w, bias, *, epi=EPI_NONE, y_pre=None, aux=None, res=None, row
     return y
 
 
-def wgrad_partials_raw(dy2, x2, want_bias, ws, nbytes, rowscale=None, rows_per_scale=1):
+def wgrad_partials_raw(dy2, x2, want_bias, ws, nbytes, rowscale=None, rows_per_scale=1, x_gelu=False):
     """the split contraction of the weight gradient (one MFMA kernel launch) into fp32 partials in `ws`"""
     M, N = dy2.shape
     K = x2.shape[1]
     rc = _lib.load().fmmt_linear_wgrad_partials(dtype_code(dy2.dtype), M, N, K, _p(dy2), N, _p(x2), K, 1 if want_bias else 0,
-                                                _p(rowscale), rows_per_scale, _p(ws), nbytes, _st())
+                                                _p(rowscale), rows_per_scale, EPI_GELU if x_gelu else EPI_NONE, _p(ws), nbytes, _st())
     check(rc, f"fmmt_linear_wgrad_partials(M={M},N={N},K={K})")
 
 
-def wgrad_raw(dy2, x2, want_bias, rowscale=None, rows_per_scale=1):
-    """dw[N,K] fp32 = (s*dy2)^T @ x2 ; db[N] fp32 = colsum(s*dy2)."""
+def wgrad_raw(dy2, x2, want_bias, rowscale=None, rows_per_scale=1, x_gelu=False):
+    """dw[N,K] fp32 = (s*dy2)^T @ x2 ; db[N] fp32 = colsum(s*dy2).  x_gelu: x2 holds a pre-activation, contract with gelu(x2)."""
     M, N = dy2.shape
     K = x2.shape[1]
     lib = _lib.load()
@@ -76,10 +76,10 @@ def wgrad_raw(dy2, x2, want_bias, rowscale=None, rows_per_scale=1):
     if M <= 768:
         # few-token problems: one entry point (single split -> the contraction kernel writes dw / db itself, no reduce launch)
         rc = lib.fmmt_linear_wgrad(dtype_code(dy2.dtype), M, N, K, _p(dy2), N, _p(x2), K, _p(dw), _p(db), _p(rowscale), rows_per_scale,
-                                   _p(ws), nbytes, _st())
+                                   EPI_GELU if x_gelu else EPI_NONE, _p(ws), nbytes, _st())
         check(rc, f"fmmt_linear_wgrad(M={M},N={N},K={K})")
         return dw, db
-    wgrad_partials_raw(dy2, x2, want_bias, ws, nbytes, rowscale, rows_per_scale)
+    wgrad_partials_raw(dy2, x2, want_bias, ws, nbytes, rowscale, rows_per_scale, x_gelu)
     rc = lib.fmmt_linear_wgrad_finish(dtype_code(dy2.dtype), M, N, K, _p(dw), _p(db), _p(ws), nbytes, _st())
     check(rc, f"fmmt_linear_wgrad_finish(M={M},N={N},K={K})")
     return dw, db
@@ -158,6 +158,30 @@ def linear(x, weight, bias=None, res=None, rowscale=None, rows_per_scale=1):
 # MLP:  y = res + rowscale * (gelu(x W1^T + b1) W2^T + b2)      (Mlp of Swin; fc1/gelu/fc2 of the
 # cross-modal layer).  GELU lives in fc1's epilogue, GELU' in the epilogue of fc2's input-gradient GEMM.
 # ------------------------------------------------------------------------------------------------
+def mlp_fused_raw(x2, w1l, b1, w2l, b2, res2, rowscale, rows_per_scale, h_pre, h_act=None):
+    """one launch: y = res + rowscale * (gelu(x W1^T + b1) W2^T + b2); h_pre / h_act (or None) receive the pre-activation / activation"""
+    M, C = x2.shape
+    y = torch.empty((M, C), dtype=x2.dtype, device=x2.device)
+    rc = _lib.load().fmmt_mlp_fwd(dtype_code(x2.dtype), M, C, _p(x2), _p(w1l), _p(b1), _p(w2l), _p(b2), _p(res2), _p(rowscale), rows_per_scale,
+                                  _p(y), _p(h_pre), _p(h_act), _st())
+    check(rc, f"fmmt_mlp_fwd(M={M},C={C})")
+    return y
+
+
+import os as _os
+
+_MLP_FUSED = _os.environ.get("FMMT_MLP_FUSED", "1") != "0"       # A/B switch (read once): 0 = always the two-launch form
+# 1: the fused forward also stores the activation and the weight gradient reads it; 0: only the pre-activation is stored and
+# the weight-gradient kernel recomputes gelu() while staging its operand
+_MLP_SAVE_H = _os.environ.get("FMMT_MLP_SAVE_H", "1") != "0"
+
+
+def _mlp_fusable(x2, w1, w2, b1, b2):
+    C = x2.shape[1]
+    return (_MLP_FUSED and x2.dtype == torch.bfloat16 and C in (96, 192) and w1.shape == (4 * C, C) and w2.shape == (C, 4 * C)
+            and b1 is not None and b2 is not None and x2.shape[0] >= 4096)
+
+
 class MlpFn(Function):
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, res, rowscale, rows_per_scale):
@@ -167,9 +191,15 @@ class MlpFn(Function):
         w1l, w2l = _lp(w1, x.dtype), _lp(w2, x.dtype)
         train = any(ctx.needs_input_grad)      # grad mode is off inside Function.forward; this is the reliable signal
         h_pre = torch.empty((x2.shape[0], w1.shape[0]), dtype=x.dtype, device=x.device) if train else None
-        h = linear_raw(x2, w1l, b1.detach(), epi=EPI_GELU, y_pre=h_pre)
         res2 = res.reshape(-1, w2.shape[0]).contiguous() if res is not None else None
-        y = linear_raw(h, w2l, b2.detach(), res=res2, rowscale=rowscale, rows_per_scale=rows_per_scale)
+        if _mlp_fusable(x2, w1, w2, b1, b2):
+            # Swin stages 0 / 1: the whole Mlp in one launch, hidden activation kept on chip (csrc/mlp_fused.hip); the
+            # backward recomputes gelu(h_pre) inside the weight-gradient kernel instead of reading a stored activation
+            h = torch.empty_like(h_pre) if (train and _MLP_SAVE_H) else None
+            y = mlp_fused_raw(x2, w1l, b1.detach().float().contiguous(), w2l, b2.detach().float().contiguous(), res2, rowscale, rows_per_scale, h_pre, h)
+        else:
+            h = linear_raw(x2, w1l, b1.detach(), epi=EPI_GELU, y_pre=h_pre)
+            y = linear_raw(h, w2l, b2.detach(), res=res2, rowscale=rowscale, rows_per_scale=rows_per_scale)
         ctx.save_for_backward(x2, w1, w2, h_pre, h, rowscale)
         ctx.rps = rows_per_scale
         ctx.has_res = res is not None
@@ -183,7 +213,7 @@ class MlpFn(Function):
         # d(h_pre) = (s * dy @ W2) * gelu'(h_pre)   [fused epilogue]
         dh = linear_raw(dy2, _lp(w2, dy2.dtype, transpose=True), None, epi=EPI_GELU_BWD, aux=h_pre, rowscale=rowscale,
                         rows_per_scale=ctx.rps)
-        dw2, db2 = wgrad_raw(dy2, h, True, rowscale, ctx.rps)
+        dw2, db2 = wgrad_raw(dy2, h, True, rowscale, ctx.rps) if h is not None else wgrad_raw(dy2, h_pre, True, rowscale, ctx.rps, x_gelu=True)
         dx = linear_raw(dh, _lp(w1, dy2.dtype, transpose=True), None).reshape(ctx.xshape) if ctx.needs_input_grad[0] else None
         dw1, db1 = wgrad_raw(dh, x2, True)
         return dx, dw1, db1, dw2, db2, (dy if ctx.has_res else None), None, None

@@ -72,12 +72,14 @@ int fmmt_linear_fwd_splitk(int dtype, int M, int N, int K, const void* x, int ld
  *   dw[N,K] (fp32) = sum_m s_m * dy[m,N]^T x[m,K],   db[N] (fp32) = sum_m s_m * dy[m,N]   (db may be NULL)
  * with s_m = rowscale[m / rows_per_scale] (NULL -> 1).  The contraction over M is split across
  * workgroups into fp32 partials in `workspace` and combined in a fixed order (deterministic).
+ * x_epi = FMMT_EPI_GELU contracts with gelu(x) instead of x: the weight gradient of the second Linear of an Mlp whose
+ * activation was not stored (fmmt_mlp_fwd keeps only the pre-activation); 0 = plain.
  * Query the workspace size first (it depends on dtype: the bf16 and fp32 kernels split the tokens differently).
  * N % 8 == 0 and K % 8 == 0 (bf16) / % 4 (f32). */
 size_t fmmt_linear_wgrad_workspace(int dtype, int M, int N, int K);
 int fmmt_linear_wgrad(int dtype, int M, int N, int K,
                       const void* dy, int lddy, const void* x, int ldx,
-                      float* dw, float* db, const float* rowscale, int rows_per_scale,
+                      float* dw, float* db, const float* rowscale, int rows_per_scale, int x_epi,
                       void* workspace, size_t workspace_bytes, void* stream);
 /* The same operation as its two launches, for callers that want to time or overlap them separately:
  *   _partials: the split contraction (MFMA kernel) -> fp32 partials in `workspace` (want_bias != 0: also the bias partials);
@@ -85,10 +87,21 @@ int fmmt_linear_wgrad(int dtype, int M, int N, int K,
  * Both must be given the same (dtype, M, N, K) and workspace. */
 int fmmt_linear_wgrad_partials(int dtype, int M, int N, int K,
                                const void* dy, int lddy, const void* x, int ldx, int want_bias,
-                               const float* rowscale, int rows_per_scale,
+                               const float* rowscale, int rows_per_scale, int x_epi,
                                void* workspace, size_t workspace_bytes, void* stream);
 int fmmt_linear_wgrad_finish(int dtype, int M, int N, int K, float* dw, float* db,
                              const void* workspace, size_t workspace_bytes, void* stream);
+
+/* Fused Mlp forward for the narrow Swin stages (C = 96 / 192, hidden 4C; bf16 only):
+ *   y[M,C] = res[M,C] + rowscale[m / rows_per_scale] * ( gelu(x[M,C] . w1[4C,C]^T + b1) . w2[C,4C]^T + b2 )
+ * replaces Mlp.forward (Swin_Transformer.py:14-30) together with the residual add and DropPath of the block (:268) in ONE
+ * launch; the hidden activation stays on chip.  h_pre (bf16 [M,4C], may be NULL in inference) receives the pre-activation
+ * x . w1^T + b1, which is all the backward needs (GELU' via FMMT_EPI_GELU_BWD, the activation recomputed inside
+ * fmmt_linear_wgrad with x_epi = FMMT_EPI_GELU); h_act (bf16 [M,4C], may be NULL) additionally receives the activation
+ * gelu(.) for callers that prefer reading it back to recomputing it.  Result bit-identical to fmmt_linear_fwd(FMMT_EPI_GELU) followed by
+ * fmmt_linear_fwd(res, rowscale).  Other widths return FMMT_EINVAL (use the two-launch form). */
+int fmmt_mlp_fwd(int dtype, int M, int C, const void* x, const void* w1, const float* b1, const void* w2, const float* b2,
+                 const void* res, const float* rowscale, int rows_per_scale, void* y, void* h_pre, void* h_act, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm.  Replaces nn.LayerNorm (eps 1e-5) at Swin_Transformer.py:198,204,239,268 (norm1/2),

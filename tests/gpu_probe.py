@@ -142,6 +142,68 @@ def t_wgrad_large():
         del dy, x, dw, db, dw2, sdy
 
 
+def t_mlp_fused():
+    """fmmt_mlp_fwd (Swin stage 0 / 1 Mlp in one launch) against the two-launch form -- bit-identical by construction -- and
+    against an fp32 torch restatement; ragged token counts, with / without residual, DropPath scale, pre-activation output;
+    then the module-level backward (activation recomputed inside the weight-gradient kernel) against fp32 autograd"""
+    dt = torch.bfloat16
+    for (M, C) in [(2007040 // 8, 96), (4096 + 40, 96), (501760 // 4, 192), (5000, 192), (256, 96), (300, 192)]:
+        x = rnd("x", (M, C), 1, dtype=dt)
+        w1 = rnd("w1", (4 * C, C), 2, C ** -0.5, dtype=dt)
+        b1 = rnd("b1", (4 * C,), 3, 0.1)
+        w2 = rnd("w2", (C, 4 * C), 4, (4 * C) ** -0.5, dtype=dt)
+        b2 = rnd("b2", (C,), 5, 0.1)
+        res = rnd("res", (M, C), 6, dtype=dt)
+        rs = rnd("rs", (M // 49 + 1,), 7).abs() + 0.5
+        rs[0] = 0.0
+        for variant in ("full", "plain"):
+            r_, s_ = (res, rs) if variant == "full" else (None, None)
+            hp_f = torch.empty((M, 4 * C), dtype=dt, device=dev)
+            y_f = ops.mlp_fused_raw(x, w1, b1, w2, b2, r_, s_, 49, hp_f)
+            hp_u = torch.empty((M, 4 * C), dtype=dt, device=dev)
+            h_u = ops.linear_raw(x, w1, b1, epi=EPI_GELU, y_pre=hp_u)
+            y_u = ops.linear_raw(h_u, w2, b2, res=r_, rowscale=s_, rows_per_scale=49)
+            RES.append((f"mlp fused == two launches {variant} {M}x{C}", bool(torch.equal(y_f, y_u)) and bool(torch.equal(hp_f, hp_u))))
+            if not RES[-1][1]:
+                print(f"FAIL mlp fused vs two launches {variant} {M}x{C}: y {(y_f.float() - y_u.float()).abs().max().item():.3e} "
+                      f"pre {(hp_f.float() - hp_u.float()).abs().max().item():.3e}", flush=True)
+            y_n = ops.mlp_fused_raw(x, w1, b1, w2, b2, r_, s_, 49, None)             # inference form: no pre-activation output
+            RES.append((f"mlp fused no-pre identical {variant} {M}x{C}", bool(torch.equal(y_n, y_f))))
+            ha = torch.empty((M, 4 * C), dtype=dt, device=dev)
+            y_a = ops.mlp_fused_raw(x, w1, b1, w2, b2, r_, s_, 49, hp_f, ha)         # both hidden tensors stored
+            RES.append((f"mlp fused + activation identical {variant} {M}x{C}", bool(torch.equal(y_a, y_f)) and bool(torch.equal(ha, h_u))))
+            del ha, y_a
+            pre = x.float() @ w1.float().t() + b1
+            ref = torch.nn.functional.gelu(pre).to(dt).float() @ w2.float().t() + b2
+            if variant == "full":
+                ref = res.float() + rs.repeat_interleave(49)[:M, None] * ref
+            report(f"mlp fused vs fp32 {variant} {M}x{C}", y_f, ref, 2e-2)
+            report(f"mlp fused pre vs fp32 {variant} {M}x{C}", hp_f, pre, 2e-2)
+        del x, res, hp_f, hp_u, h_u, y_f, y_u, y_n, pre, ref
+    # autograd through ops.mlp (fused forward; GELU' from the pre-activation; activation recomputed in the weight gradient)
+    for (M, C) in [(12544, 96), (6272, 192)]:
+        x = rnd("x", (M, C), 1, dtype=dt).requires_grad_(True)
+        w1 = rnd("w1", (4 * C, C), 2, C ** -0.5).requires_grad_(True)
+        b1 = rnd("b1", (4 * C,), 3, 0.1).requires_grad_(True)
+        w2 = rnd("w2", (C, 4 * C), 4, (4 * C) ** -0.5).requires_grad_(True)
+        b2 = rnd("b2", (C,), 5, 0.1).requires_grad_(True)
+        res = rnd("res", (M, C), 6, dtype=dt).requires_grad_(True)
+        rs = rnd("rs", (M // 49,), 7).abs() + 0.5
+        y = ops.mlp(x, w1, b1, w2, b2, res, rs, 49)
+        dy = rnd("dy", (M, C), 8, dtype=dt)
+        y.backward(dy)
+        xr = x.detach().float().requires_grad_(True)
+        w1r, b1r, w2r, b2r = (t.detach().clone().requires_grad_(True) for t in (w1, b1, w2, b2))
+        rr = res.detach().float().requires_grad_(True)
+        h = torch.nn.functional.gelu(xr @ w1r.to(dt).float().t() + b1r)
+        yr = rr + rs.repeat_interleave(49)[:, None] * (h @ w2r.to(dt).float().t() + b2r)
+        yr.backward(dy.float())
+        report(f"mlp autograd y {M}x{C}", y, yr, 2e-2)
+        for name, g, r in (("dx", x.grad, xr.grad), ("dw1", w1.grad, w1r.grad), ("db1", b1.grad, b1r.grad), ("dw2", w2.grad, w2r.grad),
+                           ("db2", b2.grad, b2r.grad), ("dres", res.grad, rr.grad)):
+            report(f"mlp autograd {name} {M}x{C}", g, r, 4e-2)
+
+
 def t_layernorm():
     for dt, tol in ((torch.float32, 1e-5), (torch.bfloat16, 1.5e-2)):
         for (M, C) in [(100, 96), (77, 192), (50, 384), (33, 768), (20, 1536), (10, 500 if dt == torch.float32 else 504), (1, 96), (1, 768)]:
@@ -351,7 +413,7 @@ def t_speed():
 
 if __name__ == "__main__":
     print(torch.cuda.get_device_name(0), torch.version.hip)
-    for f in (t_linear, t_linear_large, t_wgrad, t_wgrad_large, t_layernorm, t_wattn, t_mha, t_misc):
+    for f in (t_linear, t_linear_large, t_wgrad, t_wgrad_large, t_mlp_fused, t_layernorm, t_wattn, t_mha, t_misc):
         section(f)
     bad = [n for n, ok in RES if not ok]
     print(f"\nSUMMARY: {len(RES) - len(bad)} ok, {len(bad)} failed")
