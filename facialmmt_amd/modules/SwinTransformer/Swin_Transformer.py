@@ -6,7 +6,8 @@ with strict=True), same AssertionErrors for shape violations.  The arithmetic is
 forward is a sequence of calls into the C ABI (facialmmt_amd/ops.py -> include/fmmt.h).
 
 What differs by design (results identical, see oracle/ and tests/):
-  * torch.roll / window_partition / window_reverse (ref :33-62,244,261) never run: the attention
+  * torch.roll / window_partition / window_reverse (ref :33-62,244,261) do not exist here (the two module-level helper
+    functions of the reference have no counterpart in this file: nothing would call them): the attention
     kernel addresses shifted windows directly in token order;
   * residual adds and DropPath scaling are epilogues of the proj / fc2 GEMMs; GELU is fc1's epilogue;
   * PatchMerging's 2x2 gather + concat (ref :316-323) is folded into its LayerNorm kernel;
@@ -74,20 +75,6 @@ class Mlp(nn.Module):
     def forward(self, x, res=None, rowscale=None, rows_per_scale=1):
         _require(self.drop.p == 0.0 or not self.training, "Mlp dropout p > 0 in training")
         return ops.mlp(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, res, rowscale, rows_per_scale)
-
-
-def window_partition(x, window_size):
-    """(B,H,W,C) -> (nW*B, ws, ws, C).  Kept for API completeness (ref :33-45); the model never calls it."""
-    B, H, W, C = x.shape
-    x = x.view(B, H // window_size, window_size, W // window_size, window_size, C)
-    return x.permute(0, 1, 3, 2, 4, 5).contiguous().view(-1, window_size, window_size, C)
-
-
-def window_reverse(windows, window_size, H, W):
-    """(nW*B, ws, ws, C) -> (B,H,W,C).  Kept for API completeness (ref :48-62); the model never calls it."""
-    B = int(windows.shape[0] / (H * W / window_size / window_size))
-    x = windows.view(B, H // window_size, W // window_size, window_size, window_size, -1)
-    return x.permute(0, 1, 3, 2, 4, 5).contiguous().view(B, H, W, -1)
 
 
 class WindowAttention(nn.Module):

@@ -61,7 +61,7 @@ def _batch(dev, cfg, rank, micro):
     return tuple(b)
 
 
-def _worker(rank, world, port, mode, ret):
+def _worker(rank, world, port, mode, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda:0")
@@ -91,16 +91,16 @@ def _worker(rank, world, port, mode, ret):
         for i in range(STEPS):
             step(_batch(dev, cfg, rank, i))
     torch.cuda.synchronize()
-    ret[rank] = {k: v.detach().cpu() for k, v in mm.named_parameters()}
+    # results travel through files: a multiprocessing.Manager forked from a parent that already holds a HIP context dies
+    torch.save({k: v.detach().cpu() for k, v in mm.named_parameters()}, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("mode", ["hooks", "graphs"])
-def test_two_rank_target_step_equals_mean_gradient_step(mode):
+def test_two_rank_target_step_equals_mean_gradient_step(mode, tmp_path):
     world = 2
-    mgr = mp.Manager()
-    ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), mode, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), mode, str(tmp_path)), nprocs=world, join=True)
+    ret = [torch.load(os.path.join(str(tmp_path), f"rank{r}.pt"), weights_only=True) for r in range(world)]
     # single-process reference: SGD on the mean over ranks (and sum over micro-steps / accumulation) of the per-utterance gradients
     import torch.nn.functional as F
     from facialmmt_amd.train_step import select_frames
