@@ -8,6 +8,7 @@
 // epilogue (bias, GELU, residual, DropPath scale) works on contiguous vectors and stores rows.
 #include "gemm_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -827,6 +828,8 @@ struct TnArgs {
     int tiles_n;
     int xcd;            // 1: chunked XCD remap of the (split, tile) work list
     int x_gelu;         // 1: the x operand holds a pre-activation; contract with gelu(x) (recomputed activation of the fused Mlp)
+    int* hdr;           // workspace header: hdr[0] receives the number of splits written (read by the finish pass); may be NULL
+    int splits;
 };
 
 __device__ __forceinline__ bf16x8 lds_tr_frag(const bf16* s, int pitch, int c0, int li, int lg) {
@@ -894,6 +897,7 @@ void linear_tn_kernel(TnArgs p) {
     const int tile_n = tile / p.tiles_k, tile_k = tile % p.tiles_k;
     const int n0 = tile_n * 128, k0 = tile_k * 128;
     const int mbeg = split * p.chunk, mend = min(p.M, mbeg + p.chunk);
+    if (p.hdr && blockIdx.x == 0 && tid == 0) p.hdr[0] = p.splits;
 
     const T* __restrict__ dyg = reinterpret_cast<const T*>(p.dy);
     const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
@@ -905,6 +909,9 @@ void linear_tn_kernel(TnArgs p) {
 #pragma unroll
     for (int e = 0; e < VEC; ++e) colsum[e] = 0.f;
 
+    // (PMC, profiles/r02: 3.7 VALU instructions per MFMA.  Dropping the ones that guard -- unconditional loads for interior
+    //  steps, one wave-uniform division per step for the DropPath sample index -- was measured in-step, same call, twice:
+    //  7.29 / 7.30 ms against 6.92 / 6.72 ms for the stage-2/3 launches, 5.4 against 4.6 for stage 0/1: slower, not kept.)
     auto gload = [&](Regs& R, int mb) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -1057,122 +1064,90 @@ int launch_tn(const TnArgs& a, dim3 grid, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// XCD-local TN kernel (bf16 weight gradients of the many-token Swin launches whose output fits 64 tiles).
-// Same arithmetic as linear_tn_kernel<bf16,64,false,2>, different decomposition:
-//  * the output tile shape is a template parameter (192 x 96, 96 x 192, 128 x 128: all 64 FLOP per loaded byte), chosen per
-//    (N, K) so that `tiles` divides the 64 workgroup slots of an XCD as evenly as possible (1536 x 384 -> 32 tiles of
-//    192 x 96: two splits per XCD, every slot used; 128 x 128 would be 36 tiles: one split and 28 idle slots, or two
-//    straddling splits);
-//  * workgroup b (observed on XCD b % 8, slot b / 8) takes split (b % 8) * spx + slot / tiles, tile slot % tiles: ALL output
-//    tiles of a split run on ONE XCD at the same time, so every token slab of dy and x is fetched into exactly one L2.  With
-//    the split-major chunked order of linear_tn_kernel 1.75 splits shared an XCD and most slabs crossed the fabric twice
-//    (PMC, stage-2 launches: 2 x FETCH_SIZE + WRITE_SIZE = 1.8 x the algorithmic bytes).  A different placement is slower,
-//    never wrong.
-//  * operand A (dy) is staged with a fixed column chunk per thread (row = tid / CV + i * (256 / CV)), so the bias gradient
-//    is still a per-thread column sum although 192 / 8 = 24 does not divide 256.
+// DMA-staged TN kernel (bf16 weight gradients of the many-token launches without DropPath scale): the ring of the persistent NT
+// kernel applied to the token contraction.  One 8-wave workgroup per CU owns one (output tile, token split): TNn (256 / 192)
+// output rows (channels of dy) x 128 output columns (channels of x); waves 4 x 2, wave tile TNn/4 x 64.
+//  * a stage = 64 tokens of both operands in their natural [token][channel] layout, filled by direct global->LDS DMA; three
+//    stages, two in flight; counted vmcnt + one raw s_barrier per stage; no register pass, no ds_write at all (the
+//    register-staged kernel spends ~800 LDS cycles per pair of 64-token steps on ds_write_b128 against 1024 MFMA cycles);
+//  * fragments by ds_read_b64_tr_b16 as before.  The DMA image of a stage is lane-linear, so the conflict-free layout is made
+//    on the SOURCE side: the 32-byte column blocks of a token row are permuted by sigma_row (block ^ g(row) for the first
+//    eight blocks, 8 + ((block & 3) ^ g2(row)) for blocks 8-11 of a 384-byte row), an involution the fragment read applies
+//    again.  With 256- and 512-byte rows every row starts on bank 0; with 384-byte rows on bank 0 / 32 alternately, which the
+//    same g() absorbs (h(row) = g(row) ^ 4 (row & 1) is still a bijection on the eight rows of an LDS cycle).
+//  * bias gradient without a register pass: one extra MFMA per 16-row dy fragment against a B fragment of ones, the fragments
+//    dealt out over the k-tiles and the two k-waves so that no workgroup carries more than one of them per wave.
+//  * token counts are multiples of 64 (every Swin launch is); anything else, DropPath scale, recomputed activation: the
+//    register-staged kernel.
 // ---------------------------------------------------------------------------------------------
-template <int TNn, int TKk>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
-void linear_tn_x_kernel(TnArgs p) {
+__device__ __forceinline__ int tn_swz2(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); }
+template <int CH>                                           // CH channels per row -> CH / 16 blocks of 32 bytes
+__device__ __forceinline__ int tn_sigma(int row, int blk) {
+    if constexpr (CH == 192) return blk < 8 ? (blk ^ tn_swz(row)) : 8 + ((blk & 3) ^ tn_swz2(row));
+    else return blk ^ tn_swz(row);                          // 8 or 16 blocks: low three bits
+}
+
+template <int TNn>
+__global__ __launch_bounds__(512) void linear_tn_dma_kernel(TnArgs p) {
     using T = bf16;
-    constexpr int BMS = 64, VEC = 8;
-    constexpr int PA = TNn == 128 ? 128 : (TNn == 192 ? 208 : 96);      // LDS row pitch in elements (128: XOR-swizzled; 192: padded; 96: as is)
-    constexpr int PB = TKk == 128 ? 128 : (TKk == 192 ? 208 : 96);
-    constexpr int CVA = TNn / VEC, CVB = TKk / VEC;                     // 16-byte vectors per row
-    constexpr int TPRA = 256 / CVA, NVA = (BMS + TPRA - 1) / TPRA;      // A: fixed column chunk per thread, rows tid / CVA + i * TPRA
-    constexpr int NVB = BMS * CVB / 256;                                // B: v = tid + i * 256
-    static_assert(BMS * CVB % 256 == 0, "B operand staging");
-    constexpr int FA = TNn / 32, FB = TKk / 32;                         // 16-wide fragments per wave (2 x 2 waves)
-
+    constexpr int TKk = 128, BT = 64, NBUF = 3;
+    constexpr int CPRA = TNn / 8, CPRB = TKk / 8;           // 16-byte chunks per token row
+    constexpr int A_EL = BT * TNn, B_EL = BT * TKk, STAGE = A_EL + B_EL;
+    constexpr int NIA = BT * CPRA / 64, NIB = BT * CPRB / 64, NI = NIA + NIB;   // DMA instructions per stage
+    static_assert(NI % 8 == 0, "uniform DMA count per wave");
+    constexpr int CNT = NI / 8;
+    constexpr int FA = TNn / 64, FB = 4;                    // 16-wide fragments per wave: 4 x 2 waves, wave tile (TNn / 4) x 64
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* As = reinterpret_cast<T*>(smem);                                 // [2][BMS][PA]
-    T* Bs = As + 2 * BMS * PA;                                          // [2][BMS][PB]
-    float* bsum = reinterpret_cast<float*>(smem);                       // [TPRA][TNn], aliases As after the token loop
+    T* S = reinterpret_cast<T*>(smem);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave >> 1, wk = wave & 1;
     const int li = lane & 15, lg = lane >> 4;
     const int tiles = p.tiles_n * p.tiles_k;
-    const int spx = 64 / tiles;                                         // splits per XCD
-    const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
-    if (slot >= spx * tiles) return;
-    const int split = xcd * spx + slot / tiles, tile = slot % tiles;
+    const int logical = p.xcd ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int split = logical / tiles, tile = logical - split * tiles;
     const int tile_n = tile / p.tiles_k, tile_k = tile % p.tiles_k;
     const int n0 = tile_n * TNn, k0 = tile_k * TKk;
     const int mbeg = split * p.chunk, mend = min(p.M, mbeg + p.chunk);
-
+    if (p.hdr && blockIdx.x == 0 && tid == 0) p.hdr[0] = p.splits;
     const T* __restrict__ dyg = reinterpret_cast<const T*>(p.dy);
     const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
-    const bool do_bias = (p.part_b != nullptr) && (tile_k == 0);
-    const bool a_thread = tid < TPRA * CVA;
-    const int a_row0 = tid / CVA, a_c = (tid % CVA) * VEC;
 
-    struct Regs { Vec<T> a[NVA], b[NVB]; float s[NVA]; };
-    Regs R0, R1;
-    float colsum[VEC];
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    auto issue = [&](int slot, int mb) {
+        T* base = S + slot * STAGE;
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) colsum[e] = 0.f;
-
-    auto a_off = [&](int row, int c) {                                  // element offset of the 16-byte vector (row, c) in an A buffer
-        if constexpr (TNn == 128) return row * PA + ((((c >> 4) ^ tn_swz(row)) << 4) | (c & 8));
-        else return row * PA + c;
-    };
-    auto b_off = [&](int row, int c) {
-        if constexpr (TKk == 128) return row * PB + ((((c >> 4) ^ tn_swz(row)) << 4) | (c & 8));
-        else return row * PB + c;
-    };
-    auto gload = [&](Regs& R, int mb) {
-#pragma unroll
-        for (int i = 0; i < NVA; ++i) {
-            const int row = a_row0 + i * TPRA;
-            const int m = mb + row;
-            const bool mv = a_thread && row < BMS && m < mend;
-            R.a[i] = mv ? ldvec<T>(dyg + (size_t)m * p.lddy + n0 + a_c) : zerovec<T>();
-            if (p.rowscale) R.s[i] = mv ? p.rowscale[m / p.rows_per_scale] : 0.f;      // applied in lstore (see linear_tn_kernel)
-        }
-#pragma unroll
-        for (int i = 0; i < NVB; ++i) {
-            const int v = tid + i * 256;
-            const int row = v / CVB, c = (v % CVB) * VEC;
-            const int m = mb + row;
-            R.b[i] = m < mend ? ldvec<T>(xg + (size_t)m * p.ldx + k0 + c) : zerovec<T>();
-        }
-    };
-    auto lstore = [&](Regs& R, int buf) {
-#pragma unroll
-        for (int i = 0; i < NVA; ++i) {
-            const int row = a_row0 + i * TPRA;
-            if (p.rowscale) {
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) R.a[i].set(e, R.a[i].get(e) * R.s[i]);
+        for (int i = 0; i < CNT; ++i) {
+            const int j = i * 8 + wave;                      // wave-uniform
+            const T* src;
+            T* dst;
+            if (j < NIA) {
+                const int q = j * 64 + lane, row = q / CPRA, pos = q - row * CPRA;          // LDS slot (row, pos) of this lane
+                const int gpos = (tn_sigma<TNn>(row, pos >> 1) << 1) | (pos & 1);           // the global chunk that belongs there
+                src = dyg + (size_t)(mb + row) * p.lddy + n0 + gpos * 8;
+                dst = base + j * 512;
+            } else {
+                const int q = (j - NIA) * 64 + lane, row = q / CPRB, pos = q - row * CPRB;
+                const int gpos = (tn_sigma<TKk>(row, pos >> 1) << 1) | (pos & 1);
+                src = xg + (size_t)(mb + row) * p.ldx + k0 + gpos * 8;
+                dst = base + A_EL + (j - NIA) * 512;
             }
-            if (a_thread && row < BMS) stvec<T>(As + buf * BMS * PA + a_off(row, a_c), R.a[i]);
-            if (do_bias) {
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) colsum[e] += R.a[i].get(e);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NVB; ++i) {
-            const int v = tid + i * 256;
-            if (p.x_gelu) {
-                float g[VEC];
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) g[e] = R.b[i].get(e);
-                gelu_inplace<T>(g, VEC);
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) R.b[i].set(e, g[e]);
-            }
-            stvec<T>(Bs + buf * BMS * PB + b_off(v / CVB, (v % CVB) * VEC), R.b[i]);
+            __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)dst, 16, 0, 0);
         }
     };
-    auto frag = [&](const T* base, int pitch, bool swz, int row0, int c0) {
-        // ds_read_b64_tr_b16 pair: token rows row0 + lg*8 + (li>>2) and + 4, channels c0 .. c0 + 15 (see lds_tr_frag_swz)
+    auto wait_landed = [&](bool one_ahead) {
+        if (one_ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    auto frag = [&](const T* base, auto CHv, int row0, int c0) {
+        constexpr int CH = decltype(CHv)::value;
         const int r = row0 + lg * 8 + (li >> 2);
-        const T* a0 = swz ? base + r * pitch + (((c0 >> 4) ^ tn_swz(r)) << 4) + (li & 3) * 4 : base + r * pitch + c0 + (li & 3) * 4;
+        const T* a0 = base + r * CH + (tn_sigma<CH>(r, c0 >> 4) << 4) + (li & 3) * 4;
         typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
         s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * pitch));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * CH));      // row + 4: same permutation
         union { struct { s16x4 lo, hi; } s; bf16x8 v; } u;
         u.s.lo = lo;
         u.s.hi = hi;
@@ -1184,41 +1159,57 @@ void linear_tn_x_kernel(TnArgs p) {
     for (int a = 0; a < FA; ++a)
 #pragma unroll
         for (int b = 0; b < FB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto compute = [&](int cur) {
-        const T* asb = As + cur * BMS * PA;
-        const T* bsb = Bs + cur * BMS * PB;
+    // bias gradient: fragment a of this wave's dy rows is summed by the workgroup of k-tile (a % tiles_k), wave column (a / tiles_k) & 1
+    f32x4 accb[FA];
+    bool mine[FA];
 #pragma unroll
-        for (int kk = 0; kk < BMS / 32; ++kk) {
+    for (int a = 0; a < FA; ++a) {
+        accb[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+        mine[a] = p.part_b != nullptr && (a % p.tiles_k) == tile_k && ((a / p.tiles_k) & 1) == wk;
+    }
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+
+    auto compute = [&](int slot) {
+        const T* asb = S + slot * STAGE;
+        const T* bsb = asb + A_EL;
+#pragma unroll
+        for (int kk = 0; kk < BT / 32; ++kk) {
             bf16x8 af[FA], bf_[FB];
 #pragma unroll
-            for (int a = 0; a < FA; ++a) af[a] = frag(asb, PA, TNn == 128, kk * 32, wn * (TNn / 2) + a * 16);
+            for (int a = 0; a < FA; ++a) af[a] = frag(asb, std::integral_constant<int, TNn>{}, kk * 32, wn * (TNn / 4) + a * 16);
 #pragma unroll
-            for (int b = 0; b < FB; ++b) bf_[b] = frag(bsb, PB, TKk == 128, kk * 32, wk * (TKk / 2) + b * 16);
+            for (int b = 0; b < FB; ++b) bf_[b] = frag(bsb, std::integral_constant<int, TKk>{}, kk * 32, wk * 64 + b * 16);
 #pragma unroll
-            for (int a = 0; a < FA; ++a)
+            for (int a = 0; a < FA; ++a) {
 #pragma unroll
                 for (int b = 0; b < FB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf_[b], acc[a][b], 0, 0, 0);
+                if (mine[a]) accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], ones, accb[a], 0, 0, 0);
+            }
         }
     };
 
-    const int nsteps = (mend - mbeg + BMS - 1) / BMS;
-    if (nsteps > 0) {
-        gload(R0, mbeg);
-        lstore(R0, 0);
-    }
-    // two token steps in flight behind the one being multiplied (register sets R0 / R1), as linear_tn_kernel with PF = 2
-    if (nsteps > 1) gload(R0, mbeg + BMS);
-    if (nsteps > 2) gload(R1, mbeg + 2 * BMS);
-    __syncthreads();
-    auto iter = [&](int st, Regs& R) {
-        compute(st & 1);
-        if (st + 1 < nsteps) lstore(R, (st & 1) ^ 1);
-        if (st + 3 < nsteps) gload(R, mbeg + (st + 3) * BMS);
-        __syncthreads();
-    };
-    for (int st = 0; st < nsteps; st += 2) {
-        iter(st, R0);
-        if (st + 1 < nsteps) iter(st + 1, R1);
+    const int nsteps = (mend - mbeg) / BT;                   // whole steps only (M % 64 == 0, chunk % 64 == 0)
+    int islot = 0, im = mbeg;
+#pragma unroll
+    for (int s = 0; s < NBUF - 1; ++s)
+        if (s < nsteps) {
+            issue(islot, im);
+            islot = islot + 1 == NBUF ? 0 : islot + 1;
+            im += BT;
+        }
+    int cslot = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        wait_landed(s + 1 < nsteps);
+        __builtin_amdgcn_s_barrier();
+        if (s + NBUF - 1 < nsteps) {
+            issue(islot, im);
+            islot = islot + 1 == NBUF ? 0 : islot + 1;
+            im += BT;
+        }
+        compute(cslot);
+        cslot = cslot + 1 == NBUF ? 0 : cslot + 1;
     }
 
     float* pw = p.part_w + (size_t)split * p.N * p.K;
@@ -1226,39 +1217,31 @@ void linear_tn_x_kernel(TnArgs p) {
     for (int a = 0; a < FA; ++a)
 #pragma unroll
         for (int b = 0; b < FB; ++b) {
-            const int k = k0 + wk * (TKk / 2) + b * 16 + li;
+            const int k = k0 + wk * 64 + b * 16 + li;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int n = n0 + wn * (TNn / 2) + a * 16 + lg * 4 + r;
+                const int n = n0 + wn * (TNn / 4) + a * 16 + lg * 4 + r;
                 pw[(size_t)n * p.K + k] = acc[a][b][r];
             }
         }
-    if (do_bias) {                                                       // uniform per workgroup; the token loop ended with a barrier
-        if (a_thread) {
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) bsum[a_row0 * TNn + a_c + e] = colsum[e];
+    for (int a = 0; a < FA; ++a)
+        if (mine[a] && li == 0) {                            // every column of the ones-product holds the row sum
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p.part_b[(size_t)split * p.N + n0 + wn * (TNn / 4) + a * 16 + lg * 4 + r] = accb[a][r];
         }
-        __syncthreads();
-        if (tid < TNn) {
-            float t = 0.f;
-            for (int g = 0; g < TPRA; ++g) t += bsum[g * TNn + tid];
-            p.part_b[(size_t)split * p.N + n0 + tid] = t;
-        }
-    }
 }
 
-template <int TNn, int TKk>
-int launch_tn_x(const TnArgs& a, hipStream_t st) {
-    constexpr int PA = TNn == 128 ? 128 : (TNn == 192 ? 208 : 96), PB = TKk == 128 ? 128 : (TKk == 192 ? 208 : 96);
-    constexpr size_t lds = (size_t)2 * 64 * (PA + PB) * 2;
-    static_assert(lds >= (size_t)(256 / (TNn / 8)) * TNn * 4, "column-sum scratch aliases the A buffers");
+template <int TNn>
+int launch_tn_dma(const TnArgs& a, int grid, hipStream_t st) {
+    constexpr size_t lds = (size_t)3 * 64 * (TNn + 128) * 2;
     static bool attr_set = false;
-    if (lds > 65536 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_tn_x_kernel<TNn, TKk>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_tn_dma_kernel<TNn>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((linear_tn_x_kernel<TNn, TKk>), dim3(512), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((linear_tn_dma_kernel<TNn>), dim3(grid), dim3(512), lds, st, a);
     FMMT_CHECK_LAUNCH();
     return 0;
 }
@@ -1271,9 +1254,10 @@ int launch_tn_x(const TnArgs& a, hipStream_t st) {
 
 // out[i] = sum_s part[s][i] : 256 threads = 64 outputs x 4 split groups, fixed-order tree (deterministic).
 // One launch finishes both the weight gradient (blocks [0, wblocks)) and, if present, the bias gradient.
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n, int splits,
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n, const int* __restrict__ hdr,
                                                               int wblocks, const float* __restrict__ part2, float* __restrict__ out2, size_t n2) {
     __shared__ float red[4][64];
+    const int splits = hdr[0];                               // written by the contraction kernel that filled the partials
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     int blk = blockIdx.x;
     if (blk >= wblocks) {                                  // bias gradient blocks
@@ -1291,46 +1275,13 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     if (ty == 0 && i < n) out[i] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
 }
 
-struct TnPlan { int tiles_n, tiles_k, splits, chunk; size_t bytes; int tn, tk; };     // tn != 0: linear_tn_x_kernel<tn, tk>
+struct TnPlan { int tiles_n, tiles_k, splits, chunk; size_t bytes; int tn, tk; };     // tn != 0: linear_tn_dma_kernel<tn>
 
-// XCD-local plan (bf16, many tokens, channel counts that tile): the tile shape with the best use of the 8 x 64 slots
-TnPlan tn_plan_x(int M, int N, int K) {
-    TnPlan best{0, 0, 0, 0, 0, 0, 0};
-    // Measured on MI355X and NOT the default (FMMT_TN_X=1 enables it): every slab does reach one L2 only, but the step's
-    // stage-2/3 weight gradients take 7.16 ms against 6.57 ms with the straddling split-major order (micro-benchmark, hot
-    // Infinity Cache: 125440 x 1536 x 384 0.254 vs 0.235 ms, 1152 x 384 0.208 vs 0.185 ms).  The second fetch of a slab
-    // is served by the 256 MB Infinity Cache, not by HBM; what the XCD-local form pays is 6-25 % idle workgroup slots
-    // and 244-252 registers.  Kept as the A/B partner for the traffic numbers in profiles/.
-    static const int mode = getenv("FMMT_TN_X") ? atoi(getenv("FMMT_TN_X")) : 0;
-    if (!mode || M <= 16384 || M % 8) return best;
-    const int cand[3][2] = {{192, 96}, {96, 192}, {128, 128}};
-    int best_used = 0;
-    for (int i = 0; i < 3; ++i) {
-        const int tn = cand[i][0], tk = cand[i][1];
-        if (N % tn || K % tk) continue;
-        const int tiles = (N / tn) * (K / tk);
-        if (tiles > 64) continue;
-        const int spx = 64 / tiles, used = spx * tiles;
-        if ((size_t)8 * spx * N * K * 4 > ((size_t)512 << 20)) continue;
-        const int splits = 8 * spx;
-        int chunk = (M + splits - 1) / splits;
-        chunk = (chunk + 63) / 64 * 64;
-        if ((M + chunk - 1) / chunk != splits) continue;                 // every split must own tokens (the finish pass sums all of them)
-        if (chunk < 256) continue;
-        if (used > best_used) {
-            best_used = used;
-            best = TnPlan{N / tn, K / tk, splits, chunk, (size_t)splits * ((size_t)N * K + N) * sizeof(float), tn, tk};
-        }
-    }
-    if (best_used < 48) best.tn = 0;                                      // under 75 % of the slots: the straddling order wins
-    return best;
-}
-
+// (An XCD-local decomposition -- tile shapes 192 x 96 / 96 x 192 / 128 x 128 chosen so that all tiles of a token split fill
+//  whole XCDs, every dy / x slab fetched into exactly one L2 -- was written, tested and measured: the stage-2/3 launches of the
+//  step took 7.16 ms against 6.57 ms with this split-major order (same call).  The second fetch of a slab is served by the
+//  256 MB Infinity Cache; what the XCD-local form paid was 6-25 % idle workgroup slots and 244-252 registers.  Not kept.)
 TnPlan tn_plan(int M, int N, int K, int dtype) {
-    if (dtype == FMMT_BF16) {
-        const TnPlan px = tn_plan_x(M, N, K);
-        if (px.tn) return px;
-    }
     TnPlan pl;
     pl.tn = pl.tk = 0;
     pl.tiles_n = (N + 127) / 128;
@@ -1413,25 +1364,69 @@ extern "C" int fmmt_linear_fwd_splitk(int dtype, int M, int N, int K, const void
     return 0;
 }
 
+namespace {
+// DMA-staged plan (linear_tn_dma_kernel): tile TNn x 128 with TNn = 256 / 192, one workgroup per CU, splits = 256 / tiles
+TnPlan tn_plan_dma(int M, int N, int K) {
+    TnPlan pl{0, 0, 0, 0, 0, 0, 0};
+    // Measured and NOT the default (FMMT_TN_DMA=1): correct, no LDS stores at all, and slower on the stage-2 shapes (same call:
+    // 125440 x 1152 x 384 0.239 vs 0.196 ms, 1536 x 384 0.272 vs 0.246, 384 x 1536 0.328 vs 0.258; the step's stage-2/3
+    // weight gradients 7.31 vs 6.85 ms; 31360 x 2304 x 768 0.190 vs 0.206 is the one win).  PMC: its waves sit parked in
+    // s_waitcnt / s_barrier for 68 % of their cycles (register-staged kernel: 32 %): two 40-48 KB stages in flight per CU
+    // are fewer bytes than two workgroups with two register sets each keep in flight, and at 64-85 FLOP per loaded byte the
+    // contraction lives on bytes in flight.
+    static const int mode = getenv("FMMT_TN_DMA") ? atoi(getenv("FMMT_TN_DMA")) : 0;
+    if (!mode || M <= 16384 || M % 64 || K % 128) return pl;
+    const int tn = N % 256 == 0 ? 256 : (N % 192 == 0 ? 192 : 0);
+    if (!tn) return pl;
+    const int tiles = (N / tn) * (K / 128);
+    if (tiles > 128) return pl;
+    int splits = 256 / tiles;
+    while (splits > 1 && (size_t)splits * N * K * 4 > ((size_t)512 << 20)) --splits;
+    int chunk = (M + splits - 1) / splits;
+    chunk = (chunk + 63) / 64 * 64;
+    splits = (M + chunk - 1) / chunk;
+    if (chunk < 512) return pl;
+    pl = TnPlan{N / tn, K / 128, splits, chunk, 0, tn, 128};
+    return pl;
+}
+
+// Workspace: [256-byte header | bias partials smax x N | weight partials smax x N x K], smax = the larger split count of the
+// plans a (dtype, M, N, K) launch may take.  Which plan a launch takes also depends on its operands (DropPath scale ...), so
+// the contraction kernel records the split count it wrote in the header and the finish pass reads it from there.
+constexpr size_t TN_HDR = 256;
+int tn_smax(int M, int N, int K, int dtype) {
+    int smax = tn_plan(M, N, K, dtype).splits;
+    if (dtype == FMMT_BF16) {
+        const TnPlan pd = tn_plan_dma(M, N, K);
+        if (pd.tn && pd.splits > smax) smax = pd.splits;
+    }
+    return smax;
+}
+size_t tn_ws_bytes(int M, int N, int K, int dtype) { return TN_HDR + (size_t)tn_smax(M, N, K, dtype) * ((size_t)N * K + N) * sizeof(float); }
+
+}  // namespace
+
 extern "C" size_t fmmt_linear_wgrad_workspace(int dtype, int M, int N, int K) {
-    if (M <= 0 || N <= 0 || K <= 0) return 0;
-    return tn_plan(M, N, K, dtype).bytes;
+    if (M <= 0 || N <= 0 || K <= 0 || (dtype != FMMT_BF16 && dtype != FMMT_F32)) return 0;
+    return tn_ws_bytes(M, N, K, dtype);
 }
 
 namespace {
 // the split contraction: part_w [splits][N][K], part_b [splits][N] or nullptr (splits == 1: these may be dw / db themselves)
 int launch_tn_plan(int dtype, int M, int N, int K, const void* dy, int lddy, const void* x, int ldx, float* part_w, float* part_b,
-                   const float* rowscale, int rows_per_scale, int x_epi, hipStream_t st) {
-    const TnPlan pl = tn_plan(M, N, K, dtype);
+                   const float* rowscale, int rows_per_scale, int x_epi, int* hdr, hipStream_t st) {
     static const int tn_xcd = getenv("FMMT_TN_XCD") ? atoi(getenv("FMMT_TN_XCD")) : 1;
     if (x_epi != 0 && x_epi != FMMT_EPI_GELU) return FMMT_EINVAL;
-    TnArgs a{M, N, K, dy, lddy, x, ldx, part_w, part_b, rowscale, rows_per_scale, pl.tiles_k, pl.chunk, pl.tiles_n, tn_xcd, x_epi == FMMT_EPI_GELU};
-    if (pl.tn) {
-        if (lddy % 8 || ldx % 8) return FMMT_EINVAL;
-        if (pl.tn == 192) return launch_tn_x<192, 96>(a, st);
-        if (pl.tn == 96) return launch_tn_x<96, 192>(a, st);
-        return launch_tn_x<128, 128>(a, st);
+    if (dtype == FMMT_BF16 && hdr && !rowscale && !x_epi && lddy % 8 == 0 && ldx % 8 == 0) {
+        const TnPlan pd = tn_plan_dma(M, N, K);
+        if (pd.tn) {
+            TnArgs a{M, N, K, dy, lddy, x, ldx, part_w, part_b, nullptr, 1, pd.tiles_k, pd.chunk, pd.tiles_n, tn_xcd, 0, hdr, pd.splits};
+            const int grid = pd.tiles_n * pd.tiles_k * pd.splits;
+            return pd.tn == 256 ? launch_tn_dma<256>(a, grid, st) : launch_tn_dma<192>(a, grid, st);
+        }
     }
+    const TnPlan pl = tn_plan(M, N, K, dtype);
+    TnArgs a{M, N, K, dy, lddy, x, ldx, part_w, part_b, rowscale, rows_per_scale, pl.tiles_k, pl.chunk, pl.tiles_n, tn_xcd, x_epi == FMMT_EPI_GELU, hdr, pl.splits};
     dim3 grid(pl.tiles_n * pl.tiles_k * pl.splits);
     static const int tn_cfg = getenv("FMMT_TN_CFG") ? atoi(getenv("FMMT_TN_CFG")) : 0;
     // measured (tests/gpu_gemm_bench.py): 64-token steps win for the compute-heavy stage-2/3 shapes (+15-25 %),
@@ -1459,11 +1454,13 @@ extern "C" int fmmt_linear_wgrad_partials(int dtype, int M, int N, int K,
     if (N % vec || K % vec || lddy % vec || ldx % vec) return FMMT_EINVAL;
     if (rowscale && rows_per_scale <= 0) return FMMT_EINVAL;
     if (!aligned16(dy) || !aligned16(x) || !aligned16(workspace)) return FMMT_EALIGN;
-    const TnPlan pl = tn_plan(M, N, K, dtype);
-    if (workspace_bytes < pl.bytes) return FMMT_EWORKSPACE;
-    float* part_w = reinterpret_cast<float*>(workspace);
-    float* part_b = want_bias ? part_w + (size_t)pl.splits * N * K : nullptr;
-    return launch_tn_plan(dtype, M, N, K, dy, lddy, x, ldx, part_w, part_b, rowscale, rows_per_scale, x_epi, reinterpret_cast<hipStream_t>(stream));
+    if (workspace_bytes < tn_ws_bytes(M, N, K, dtype)) return FMMT_EWORKSPACE;
+    const int smax = tn_smax(M, N, K, dtype);
+    int* hdr = reinterpret_cast<int*>(workspace);
+    float* part_b = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + TN_HDR);
+    float* part_w = part_b + (size_t)smax * N;
+    return launch_tn_plan(dtype, M, N, K, dy, lddy, x, ldx, part_w, want_bias ? part_b : nullptr, rowscale, rows_per_scale, x_epi, hdr,
+                          reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int fmmt_linear_wgrad_finish(int dtype, int M, int N, int K, float* dw, float* db,
@@ -1471,14 +1468,15 @@ extern "C" int fmmt_linear_wgrad_finish(int dtype, int M, int N, int K, float* d
     if (M <= 0 || N <= 0 || K <= 0 || !dw) return FMMT_EINVAL;
     if (dtype != FMMT_BF16 && dtype != FMMT_F32) return FMMT_EINVAL;
     if (!aligned16(dw) || !aligned16(workspace)) return FMMT_EALIGN;
-    const TnPlan pl = tn_plan(M, N, K, dtype);
-    if (workspace_bytes < pl.bytes) return FMMT_EWORKSPACE;
+    if (workspace_bytes < tn_ws_bytes(M, N, K, dtype)) return FMMT_EWORKSPACE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const float* part_w = reinterpret_cast<const float*>(workspace);
+    const int smax = tn_smax(M, N, K, dtype);
+    const int* hdr = reinterpret_cast<const int*>(workspace);
+    const float* part_b = reinterpret_cast<const float*>(reinterpret_cast<const char*>(workspace) + TN_HDR);
+    const float* part_w = part_b + (size_t)smax * N;
     const size_t nw = (size_t)N * K;
     const int wblocks = (int)((nw + 63) / 64), bblocks = db ? (N + 63) / 64 : 0;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(wblocks + bblocks), dim3(256), 0, st, part_w, dw, nw, pl.splits,
-                       wblocks, part_w + (size_t)pl.splits * N * K, db, (size_t)N);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(wblocks + bblocks), dim3(256), 0, st, part_w, dw, nw, hdr, wblocks, part_b, db, (size_t)N);
     FMMT_CHECK_LAUNCH();
     return 0;
 }
@@ -1488,14 +1486,13 @@ extern "C" int fmmt_linear_wgrad(int dtype, int M, int N, int K,
                                  float* dw, float* db, const float* rowscale, int rows_per_scale, int x_epi,
                                  void* workspace, size_t workspace_bytes, void* stream) {
     if (!aligned16(dw)) return FMMT_EALIGN;
-    if (M > 0 && N > 0 && K > 0 && (dtype == FMMT_BF16 || dtype == FMMT_F32) && tn_plan(M, N, K, dtype).splits == 1) {
+    if (M > 0 && N > 0 && K > 0 && (dtype == FMMT_BF16 || dtype == FMMT_F32) && tn_smax(M, N, K, dtype) == 1) {
         // single split: the "partials" ARE the result -- let the contraction kernel write dw / db directly
         const int vec = dtype == FMMT_BF16 ? 8 : 4;
-        if (dtype != FMMT_BF16 && dtype != FMMT_F32) return FMMT_EINVAL;
         if (N % vec || K % vec || lddy % vec || ldx % vec) return FMMT_EINVAL;
         if (rowscale && rows_per_scale <= 0) return FMMT_EINVAL;
         if (!aligned16(dy) || !aligned16(x)) return FMMT_EALIGN;
-        return launch_tn_plan(dtype, M, N, K, dy, lddy, x, ldx, dw, db, rowscale, rows_per_scale, x_epi, reinterpret_cast<hipStream_t>(stream));
+        return launch_tn_plan(dtype, M, N, K, dy, lddy, x, ldx, dw, db, rowscale, rows_per_scale, x_epi, nullptr, reinterpret_cast<hipStream_t>(stream));
     }
     if (int rc = fmmt_linear_wgrad_partials(dtype, M, N, K, dy, lddy, x, ldx, db != nullptr, rowscale, rows_per_scale, x_epi,
                                             workspace, workspace_bytes, stream)) return rc;

@@ -39,7 +39,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert lib.fmmt_mha_fwd(1, 8, 8, 1, 500, 4, None, 500, None, None, 500, 1.0, None, 0.0, 0, None, None, 500, None, None) == -1
     assert lib.fmmt_layernorm_fwd(1, 8, 100, None, None, None, 1e-5, None, None, None, 0, None) == -1
     assert lib.fmmt_linear_wgrad_workspace(1, 2007040, 288, 96) > 0
-    assert lib.fmmt_linear_wgrad_workspace(0, 125440, 1536, 384) == 14 * (1536 * 384 + 1536) * 4
+    assert lib.fmmt_linear_wgrad_workspace(0, 125440, 1536, 384) == 256 + 14 * (1536 * 384 + 1536) * 4     # header + fp32 plan's splits
     assert lib.fmmt_window_attn_bwd_workspace(3) == 3 * 257 * 49 * 49 * 4
 
 
