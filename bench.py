@@ -403,6 +403,10 @@ def main():
     if ddp:
         broadcast_parameters(mm)
         broadcast_parameters(swin)
+        torch.cuda.synchronize()                            # no collective in flight when the step's graphs are captured
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
     lr_of = lambda s: min(1.0, (s + 1) / 100.0)            # linear warm-up (transformers.get_linear_schedule_with_warmup, train.py:333-339)
     aux_step = None
     if args.graphs == 2:
