@@ -76,7 +76,7 @@ def pick_concurrent_stream(device, candidates: int = 8, cycles: int = 4_000_000)
     single = min(timed(lambda: torch.cuda._sleep(cycles)) for _ in range(3))
     best, best_ratio, keep = None, float("inf"), []
     for _ in range(candidates):
-        s = torch.cuda.Stream(device=device)
+        s = distinct_stream(device, keep)
         keep.append(s)                                     # keep candidates alive so that the next one is a new stream
 
         def pair():
@@ -90,6 +90,44 @@ def pick_concurrent_stream(device, candidates: int = 8, cycles: int = 4_000_000)
         if ratio < 1.3:
             break
     return best, best_ratio
+
+
+def distinct_stream(device, avoid=()):
+    """A side stream that is a different HIP stream from every stream in `avoid` and from the current one.
+    torch.cuda.Stream() hands out entries of a per-device pool of 32 round-robin: in a process that has created a few dozen
+    streams a "new" stream can BE the capture stream or another branch's stream, and a fork / join between a stream and
+    itself inside a graph capture has crashed the HIP runtime (intermittent segmentation fault in the capture of a step when
+    the whole GPU test suite ran in one process).  So: compare the raw handles and keep drawing."""
+    taken = {s.cuda_stream for s in avoid if s is not None} | {torch.cuda.current_stream(device).cuda_stream}
+    keep = []
+    for _ in range(64):
+        s = torch.cuda.Stream(device=device)
+        if s.cuda_stream not in taken:
+            return s
+        keep.append(s)
+    raise RuntimeError("distinct_stream: the stream pool only returns streams that are already in use")
+
+
+class capture_window:
+    """Garbage collection fenced off a graph capture: collect NOW (cycles left by earlier steps may own HIP graphs, streams
+    and pool memory whose destructors call into the HIP runtime), then keep the cyclic collector off until the capture ends.
+    torch.cuda.graph stopped collecting on entry (torch >= 2.9 only does with torch.compiler.config.force_cudagraph_gc), and a
+    collection that fires in the middle of a capture destroys such objects while the stream is capturing: measured here as an
+    intermittent abort / segmentation fault of the process (faulthandler: "Garbage-collecting" inside the capture of a step
+    that followed other graph-capturing steps), two runs in five of the whole GPU suite."""
+
+    def __enter__(self):
+        import gc
+        self._was = gc.isenabled()
+        gc.collect()
+        gc.disable()
+        return self
+
+    def __exit__(self, *exc):
+        import gc
+        if self._was:
+            gc.enable()
+        return False
 
 
 class _Branch(torch.nn.Module):
@@ -149,9 +187,9 @@ def graph_multimodal(mm, sample_args, autocast_dtype=None, overlap_text=True, pa
         torch.cuda.current_stream().wait_stream(side)
     # independent halves of the fusion stack (audio / vision encoder, the two directions of each cross-modal encoder) are
     # captured as parallel branches of the fusion graphs: models._pair
-    mm.pair_stream = torch.cuda.Stream(device=ids.device) if parallel_fusion else None
+    mm.pair_stream = distinct_stream(ids.device, (side,)) if parallel_fusion else None
     ctx = torch.autocast("cuda", dtype=autocast_dtype, cache_enabled=False) if autocast_dtype is not None else contextlib.nullcontext()
-    with ctx:
+    with ctx, capture_window():
         gtext, gfusion = torch.cuda.make_graphed_callables(
             (text, fusion),
             ((ids, attn_mask, sep_mask, utt_idx), (text_feat, text_mask, audio, audio_mask, vision, vision_mask)),
@@ -410,14 +448,15 @@ class GraphedTargetStep:
         self.mm.text_stream = None
         # inside ONE graph the fork / join below become parallel branches; which hardware queue the branches replay on is the
         # runtime's choice at replay time, not a property of the stream object used during capture
-        self.text_stream = torch.cuda.Stream(device=dev) if overlap_text else None
-        self.mm.pair_stream = torch.cuda.Stream(device=dev) if parallel_fusion else None
+        # warm-up / capture stream and the two branch streams: three different HIP streams (distinct_stream)
+        cap = distinct_stream(dev)
+        self.text_stream = distinct_stream(dev, (cap,)) if overlap_text else None
+        self.mm.pair_stream = distinct_stream(dev, (cap, self.text_stream)) if parallel_fusion else None
         # -- warm-up on a side stream (lazy initialisations: kernel attributes, shadow caches, optimizer state), undone below
         snap = [(t, t.detach().clone()) for m in (self.swin, self.mm) for t in list(m.parameters()) + list(m.buffers())]
         if masters is not None:
             snap += [(t, t.detach().clone()) for t in masters.masters]
         rng = torch.cuda.get_rng_state(dev)
-        cap = torch.cuda.Stream(device=dev)
         cap.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(cap):
             for _ in range(warmup_iters):
@@ -433,10 +472,11 @@ class GraphedTargetStep:
         torch.cuda.set_rng_state(rng, dev)
         # -- capture
         self.graph_a, self.graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_a):
-            self.loss, self.new_mask = self._fwd_bwd()
-        with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
-            self._update()
+        with capture_window():
+            with torch.cuda.graph(self.graph_a, stream=cap):
+                self.loss, self.new_mask = self._fwd_bwd()
+            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), stream=cap):
+                self._update()
         self.swin.zero_grad(set_to_none=True)              # drop the references; the graph's pool keeps the buffers
         self.mm.pair_stream = None
         self.flat.zero_grad()                              # the capture itself executes nothing
@@ -514,7 +554,7 @@ class GraphedAuxStep:
         self.accumulate = args.aux_accumulation_steps > 1
         snap = [(t, t.detach().clone()) for t in list(self.swin.parameters()) + list(self.swin.buffers())]
         rng = torch.cuda.get_rng_state(dev)
-        cap = torch.cuda.Stream(device=dev)
+        cap = distinct_stream(dev)
         cap.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(cap):
             for _ in range(warmup_iters):
@@ -528,10 +568,11 @@ class GraphedAuxStep:
         self.flat.zero_grad()
         torch.cuda.set_rng_state(rng, dev)
         self.graph_a, self.graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_a):
-            self.loss = self._fwd_bwd()
-        with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
-            self._update()
+        with capture_window():
+            with torch.cuda.graph(self.graph_a, stream=cap):
+                self.loss = self._fwd_bwd()
+            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), stream=cap):
+                self._update()
         self.flat.zero_grad()
 
     def _fwd_bwd(self):

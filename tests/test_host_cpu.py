@@ -287,3 +287,33 @@ def test_bench_contract_flags_and_loud_failure_without_gpu():
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0 and "no CPU fallback" in r.stderr
     assert not r.stdout.strip().startswith("{")            # no metric line from a run that measured nothing
+
+
+def test_capture_window_fences_the_cyclic_collector():
+    """train_step.capture_window: collect before a graph capture, collector off inside, previous state restored after
+    (also when the body raises, and when the collector was already off)."""
+    import gc
+    from facialmmt_amd.train_step import capture_window
+
+    class Node:
+        pass
+    a, b = Node(), Node()
+    a.other, b.other = b, a
+    import weakref
+    seen = weakref.ref(a)
+    del a, b
+    assert gc.isenabled()
+    with capture_window():
+        assert seen() is None and not gc.isenabled()
+    assert gc.isenabled()
+    with pytest.raises(ValueError):
+        with capture_window():
+            raise ValueError("x")
+    assert gc.isenabled()
+    gc.disable()
+    try:
+        with capture_window():
+            assert not gc.isenabled()
+        assert not gc.isenabled()
+    finally:
+        gc.enable()
