@@ -1087,22 +1087,61 @@ __device__ __forceinline__ int tn_sigma(int row, int blk) {
     else return blk ^ tn_swz(row);                          // 8 or 16 blocks: low three bits
 }
 
-template <int TNn>
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// The twelve transposing fragment reads of one 32-token stage (24 ds_read_b64_tr_b16) and the wait for them, as ONE inline-asm
+// statement.  Why not the builtin: hipcc's wait-count insertion treats a ds_read_tr intrinsic as possibly aliasing every LDS-DMA
+// write in flight and puts `s_waitcnt vmcnt(0)` in front of the first fragment read of every stage -- i.e. it waits for the
+// stage issued a few instructions earlier, and the ring never has more than the current stage in flight (found in the ISA of
+// the first version of this kernel: 68 % of its wave cycles parked in waits).  Inline asm is opaque to that pass; the statement
+// carries its own lgkmcnt(0), so its outputs are valid wherever the compiler uses them.
+#define FMMT_TR2(o0, o1, ad, im) "ds_read_b64_tr_b16 %" #o0 ", %" #ad "\n\tds_read_b64_tr_b16 %" #o1 ", %" #ad " offset:%" #im "\n\t"
+template <int FA, int OFFA, int OFFB>
+__device__ __forceinline__ void tn_read12(s16x4 (&o)[24], const unsigned (&ad)[12]) {
+    static_assert(FA == 8 || FA == 6, "fragment split");
+    if constexpr (FA == 8) {
+        asm volatile(FMMT_TR2(0, 1, 24, 36) FMMT_TR2(2, 3, 25, 36) FMMT_TR2(4, 5, 26, 36) FMMT_TR2(6, 7, 27, 36)
+                     FMMT_TR2(8, 9, 28, 36) FMMT_TR2(10, 11, 29, 36) FMMT_TR2(12, 13, 30, 36) FMMT_TR2(14, 15, 31, 36)
+                     FMMT_TR2(16, 17, 32, 37) FMMT_TR2(18, 19, 33, 37) FMMT_TR2(20, 21, 34, 37) FMMT_TR2(22, 23, 35, 37)
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]),
+                       "=&v"(o[8]), "=&v"(o[9]), "=&v"(o[10]), "=&v"(o[11]), "=&v"(o[12]), "=&v"(o[13]), "=&v"(o[14]), "=&v"(o[15]),
+                       "=&v"(o[16]), "=&v"(o[17]), "=&v"(o[18]), "=&v"(o[19]), "=&v"(o[20]), "=&v"(o[21]), "=&v"(o[22]), "=&v"(o[23])
+                     : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5]), "v"(ad[6]), "v"(ad[7]),
+                       "v"(ad[8]), "v"(ad[9]), "v"(ad[10]), "v"(ad[11]), "n"(OFFA), "n"(OFFB)
+                     : "memory");
+    } else {
+        asm volatile(FMMT_TR2(0, 1, 24, 36) FMMT_TR2(2, 3, 25, 36) FMMT_TR2(4, 5, 26, 36) FMMT_TR2(6, 7, 27, 36)
+                     FMMT_TR2(8, 9, 28, 36) FMMT_TR2(10, 11, 29, 36) FMMT_TR2(12, 13, 30, 37) FMMT_TR2(14, 15, 31, 37)
+                     FMMT_TR2(16, 17, 32, 37) FMMT_TR2(18, 19, 33, 37) FMMT_TR2(20, 21, 34, 37) FMMT_TR2(22, 23, 35, 37)
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]),
+                       "=&v"(o[8]), "=&v"(o[9]), "=&v"(o[10]), "=&v"(o[11]), "=&v"(o[12]), "=&v"(o[13]), "=&v"(o[14]), "=&v"(o[15]),
+                       "=&v"(o[16]), "=&v"(o[17]), "=&v"(o[18]), "=&v"(o[19]), "=&v"(o[20]), "=&v"(o[21]), "=&v"(o[22]), "=&v"(o[23])
+                     : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5]), "v"(ad[6]), "v"(ad[7]),
+                       "v"(ad[8]), "v"(ad[9]), "v"(ad[10]), "v"(ad[11]), "n"(OFFA), "n"(OFFB)
+                     : "memory");
+    }
+}
+
+// TNn x TKk output tile, 32 tokens per stage, NBUF stages, waves WN x (8 / WN), 12 fragments per wave
+template <int TNn, int TKk, int NBUF, int WN>
 __global__ __launch_bounds__(512) void linear_tn_dma_kernel(TnArgs p) {
     using T = bf16;
-    constexpr int TKk = 128, BT = 64, NBUF = 3;
+    constexpr int BT = 32, WK = 8 / WN;
     constexpr int CPRA = TNn / 8, CPRB = TKk / 8;           // 16-byte chunks per token row
     constexpr int A_EL = BT * TNn, B_EL = BT * TKk, STAGE = A_EL + B_EL;
     constexpr int NIA = BT * CPRA / 64, NIB = BT * CPRB / 64, NI = NIA + NIB;   // DMA instructions per stage
-    static_assert(NI % 8 == 0, "uniform DMA count per wave");
-    constexpr int CNT = NI / 8;
-    constexpr int FA = TNn / 64, FB = 4;                    // 16-wide fragments per wave: 4 x 2 waves, wave tile (TNn / 4) x 64
+    static_assert((BT * CPRA) % 64 == 0 && (BT * CPRB) % 64 == 0, "whole DMA instructions per operand");
+    constexpr int CNT = NI / 8, REM = NI % 8;               // waves below REM issue one more
+    constexpr int FA = TNn / (16 * WN), FB = TKk / (16 * WK);   // 16-wide fragments per wave
+    static_assert(TNn % (16 * WN) == 0 && TKk % (16 * WK) == 0 && FA + FB == 12 && NBUF >= 2 && NBUF <= 5, "tile");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* S = reinterpret_cast<T*>(smem);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave >> 1, wk = wave & 1;
+    const int wn = wave / WK, wk = wave % WK;
     const int li = lane & 15, lg = lane >> 4;
     const int tiles = p.tiles_n * p.tiles_k;
     const int logical = p.xcd ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
@@ -1113,80 +1152,105 @@ __global__ __launch_bounds__(512) void linear_tn_dma_kernel(TnArgs p) {
     if (p.hdr && blockIdx.x == 0 && tid == 0) p.hdr[0] = p.splits;
     const T* __restrict__ dyg = reinterpret_cast<const T*>(p.dy);
     const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
+    const bool extra = wave < REM;
 
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
+    auto issue_one = [&](T* base, int j, int mb) {
+        const T* src;
+        T* dst;
+        if (j < NIA) {
+            const int q = j * 64 + lane, row = q / CPRA, pos = q - row * CPRA;          // LDS slot (row, pos) of this lane
+            const int gpos = (tn_sigma<TNn>(row, pos >> 1) << 1) | (pos & 1);           // the global chunk that belongs there
+            src = dyg + (size_t)(mb + row) * p.lddy + n0 + gpos * 8;
+            dst = base + j * 512;
+        } else {
+            const int q = (j - NIA) * 64 + lane, row = q / CPRB, pos = q - row * CPRB;
+            const int gpos = (tn_sigma<TKk>(row, pos >> 1) << 1) | (pos & 1);
+            src = xg + (size_t)(mb + row) * p.ldx + k0 + gpos * 8;
+            dst = base + A_EL + (j - NIA) * 512;
+        }
+        __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)dst, 16, 0, 0);
+    };
     auto issue = [&](int slot, int mb) {
         T* base = S + slot * STAGE;
 #pragma unroll
-        for (int i = 0; i < CNT; ++i) {
-            const int j = i * 8 + wave;                      // wave-uniform
-            const T* src;
-            T* dst;
-            if (j < NIA) {
-                const int q = j * 64 + lane, row = q / CPRA, pos = q - row * CPRA;          // LDS slot (row, pos) of this lane
-                const int gpos = (tn_sigma<TNn>(row, pos >> 1) << 1) | (pos & 1);           // the global chunk that belongs there
-                src = dyg + (size_t)(mb + row) * p.lddy + n0 + gpos * 8;
-                dst = base + j * 512;
-            } else {
-                const int q = (j - NIA) * 64 + lane, row = q / CPRB, pos = q - row * CPRB;
-                const int gpos = (tn_sigma<TKk>(row, pos >> 1) << 1) | (pos & 1);
-                src = xg + (size_t)(mb + row) * p.ldx + k0 + gpos * 8;
-                dst = base + A_EL + (j - NIA) * 512;
-            }
-            __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)dst, 16, 0, 0);
+        for (int i = 0; i < CNT; ++i) issue_one(base, i * 8 + wave, mb);                // wave-uniform instruction index
+        if constexpr (REM != 0)
+            if (extra) issue_one(base, CNT * 8 + wave, mb);
+    };
+    // the stage about to be consumed has landed when at most (NBUF - 2) later stages of this wave are still in flight
+    auto wait_landed = [&](bool steady) {
+        if (!steady) { wait_vm<0>(); return; }
+        if constexpr (REM != 0) {
+            if (extra) wait_vm<(NBUF - 2) * (CNT + 1)>();
+            else wait_vm<(NBUF - 2) * CNT>();
+        } else {
+            wait_vm<(NBUF - 2) * CNT>();
         }
     };
-    auto wait_landed = [&](bool one_ahead) {
-        if (one_ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-    auto frag = [&](const T* base, auto CHv, int row0, int c0) {
-        constexpr int CH = decltype(CHv)::value;
-        const int r = row0 + lg * 8 + (li >> 2);
-        const T* a0 = base + r * CH + (tn_sigma<CH>(r, c0 >> 4) << 4) + (li & 3) * 4;
-        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * CH));      // row + 4: same permutation
-        union { struct { s16x4 lo, hi; } s; bf16x8 v; } u;
-        u.s.lo = lo;
-        u.s.hi = hi;
-        return u.v;
-    };
+
+    // byte offsets of this lane's twelve fragments inside a stage: token row lg*8 + (li>>2) (+4 through the instruction offset),
+    // 32-byte column block permuted by the row's key (tn_sigma), 8 bytes at (li & 3) inside it
+    //
+    // bias gradient: 16-channel block a of this wave row's dy channels is summed by exactly one (k-tile, k-wave) pair, the one
+    // with a % (tiles_k * WK) == wk * tiles_k + tile_k: at most two blocks per wave (FA <= 2 WK).  The wave ROTATES its fragment
+    // order so that its first block sits at position 0 (and the second, which exists only for tiles_k == 1, at position WK):
+    // the extra MFMA against a ones fragment then hangs off fixed positions behind loop-invariant flags -- selecting the
+    // position at run time made the compiler copy accumulators around every MFMA row.
+    static_assert(FA > WK && FA <= 2 * WK, "positions 0 and WK");
+    const int o0 = wk * p.tiles_k + tile_k;
+    const bool has0 = p.part_b != nullptr && o0 < FA;
+    const bool has1 = has0 && p.tiles_k == 1 && o0 + WK < FA;
+    const int rot = has0 ? o0 : 0;
+    auto block_of = [&](int j) { const int a = j + rot; return a >= FA ? a - FA : a; };
+    unsigned foff[12];
+    {
+        const int r0 = lg * 8 + (li >> 2);
+#pragma unroll
+        for (int a = 0; a < FA; ++a) {
+            const int c0 = wn * (TNn / WN) + block_of(a) * 16;
+            foff[a] = (unsigned)(r0 * TNn + (tn_sigma<TNn>(r0, c0 >> 4) << 4) + (li & 3) * 4) * 2u;
+        }
+#pragma unroll
+        for (int b = 0; b < FB; ++b) {
+            const int c0 = wk * (TKk / WK) + b * 16;
+            foff[FA + b] = (unsigned)(A_EL + r0 * TKk + (tn_sigma<TKk>(r0, c0 >> 4) << 4) + (li & 3) * 4) * 2u;
+        }
+    }
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t*)S;
 
     f32x4 acc[FA][FB];
 #pragma unroll
     for (int a = 0; a < FA; ++a)
 #pragma unroll
         for (int b = 0; b < FB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // bias gradient: fragment a of this wave's dy rows is summed by the workgroup of k-tile (a % tiles_k), wave column (a / tiles_k) & 1
-    f32x4 accb[FA];
-    bool mine[FA];
-#pragma unroll
-    for (int a = 0; a < FA; ++a) {
-        accb[a] = f32x4{0.f, 0.f, 0.f, 0.f};
-        mine[a] = p.part_b != nullptr && (a % p.tiles_k) == tile_k && ((a / p.tiles_k) & 1) == wk;
-    }
+    f32x4 accb0 = f32x4{0.f, 0.f, 0.f, 0.f}, accb1 = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 ones;
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
 
     auto compute = [&](int slot) {
-        const T* asb = S + slot * STAGE;
-        const T* bsb = asb + A_EL;
+        const unsigned sbase = lds0 + (unsigned)slot * (unsigned)(STAGE * 2);
+        unsigned ad[12];
 #pragma unroll
-        for (int kk = 0; kk < BT / 32; ++kk) {
-            bf16x8 af[FA], bf_[FB];
+        for (int f = 0; f < 12; ++f) ad[f] = foff[f] + sbase;
+        s16x4 o[24];
+        tn_read12<FA, 8 * TNn, 8 * TKk>(o, ad);
+        bf16x8 fr[12];
 #pragma unroll
-            for (int a = 0; a < FA; ++a) af[a] = frag(asb, std::integral_constant<int, TNn>{}, kk * 32, wn * (TNn / 4) + a * 16);
+        for (int f = 0; f < 12; ++f) {
+            union { struct { s16x4 lo, hi; } s; bf16x8 v; } u;
+            u.s.lo = o[2 * f];
+            u.s.hi = o[2 * f + 1];
+            fr[f] = u.v;
+        }
 #pragma unroll
-            for (int b = 0; b < FB; ++b) bf_[b] = frag(bsb, std::integral_constant<int, TKk>{}, kk * 32, wk * 64 + b * 16);
+        for (int a = 0; a < FA; ++a) {
 #pragma unroll
-            for (int a = 0; a < FA; ++a) {
-#pragma unroll
-                for (int b = 0; b < FB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf_[b], acc[a][b], 0, 0, 0);
-                if (mine[a]) accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], ones, accb[a], 0, 0, 0);
-            }
+            for (int b = 0; b < FB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[a], fr[FA + b], acc[a][b], 0, 0, 0);
+            if (a == 0 && has0) accb0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[0], ones, accb0, 0, 0, 0);
+            if (a == WK && has1) accb1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[WK], ones, accb1, 0, 0, 0);
         }
     };
 
@@ -1201,7 +1265,7 @@ __global__ __launch_bounds__(512) void linear_tn_dma_kernel(TnArgs p) {
         }
     int cslot = 0;
     for (int s = 0; s < nsteps; ++s) {
-        wait_landed(s + 1 < nsteps);
+        wait_landed(s + NBUF - 2 < nsteps);                  // steady: NBUF - 2 later stages have been issued
         __builtin_amdgcn_s_barrier();
         if (s + NBUF - 1 < nsteps) {
             issue(islot, im);
@@ -1217,31 +1281,35 @@ __global__ __launch_bounds__(512) void linear_tn_dma_kernel(TnArgs p) {
     for (int a = 0; a < FA; ++a)
 #pragma unroll
         for (int b = 0; b < FB; ++b) {
-            const int k = k0 + wk * 64 + b * 16 + li;
+            const int k = k0 + wk * (TKk / WK) + b * 16 + li;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int n = n0 + wn * (TNn / 4) + a * 16 + lg * 4 + r;
+                const int n = n0 + wn * (TNn / WN) + block_of(a) * 16 + lg * 4 + r;
                 pw[(size_t)n * p.K + k] = acc[a][b][r];
             }
         }
+    if (li == 0 && has0) {                                   // every column of the ones-product holds the row sum
+        float* pb = p.part_b + (size_t)split * p.N + n0 + wn * (TNn / WN) + lg * 4;
 #pragma unroll
-    for (int a = 0; a < FA; ++a)
-        if (mine[a] && li == 0) {                            // every column of the ones-product holds the row sum
+        for (int r = 0; r < 4; ++r) pb[block_of(0) * 16 + r] = accb0[r];
+        if (has1) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) p.part_b[(size_t)split * p.N + n0 + wn * (TNn / 4) + a * 16 + lg * 4 + r] = accb[a][r];
+            for (int r = 0; r < 4; ++r) pb[block_of(WK) * 16 + r] = accb1[r];
         }
+    }
 }
 
-template <int TNn>
+template <int TNn, int TKk, int NBUF, int WN>
 int launch_tn_dma(const TnArgs& a, int grid, hipStream_t st) {
-    constexpr size_t lds = (size_t)3 * 64 * (TNn + 128) * 2;
+    constexpr size_t lds = (size_t)NBUF * 32 * (TNn + TKk) * 2;
+    static_assert(lds <= 160 * 1024, "LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_tn_dma_kernel<TNn>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_tn_dma_kernel<TNn, TKk, NBUF, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((linear_tn_dma_kernel<TNn>), dim3(grid), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((linear_tn_dma_kernel<TNn, TKk, NBUF, WN>), dim3(grid), dim3(512), lds, st, a);
     FMMT_CHECK_LAUNCH();
     return 0;
 }
@@ -1374,11 +1442,14 @@ TnPlan tn_plan_dma(int M, int N, int K) {
     // s_waitcnt / s_barrier for 68 % of their cycles (register-staged kernel: 32 %): two 40-48 KB stages in flight per CU
     // are fewer bytes than two workgroups with two register sets each keep in flight, and at 64-85 FLOP per loaded byte the
     // contraction lives on bytes in flight.
-    static const int mode = getenv("FMMT_TN_DMA") ? atoi(getenv("FMMT_TN_DMA")) : 0;
-    if (!mode || M <= 16384 || M % 64 || K % 128) return pl;
-    const int tn = N % 256 == 0 ? 256 : (N % 192 == 0 ? 192 : 0);
+    static const int mode = getenv("FMMT_TN_DMA") ? atoi(getenv("FMMT_TN_DMA")) : 1;
+    if (!mode || M <= 16384 || M % 64) return pl;
+    int tn = 0, tk = 0;
+    if (N % 256 == 0 && K % 256 == 0) tn = 256, tk = 256;
+    else if (N % 192 == 0 && K % 384 == 0) tn = 192, tk = 384;
+    if (tn && (N / tn) * (K / tk) < 4) tn = 0;              // two or three tiles: > 64 splits, the partial sums outweigh the operands
     if (!tn) return pl;
-    const int tiles = (N / tn) * (K / 128);
+    const int tiles = (N / tn) * (K / tk);
     if (tiles > 128) return pl;
     int splits = 256 / tiles;
     while (splits > 1 && (size_t)splits * N * K * 4 > ((size_t)512 << 20)) --splits;
@@ -1386,7 +1457,7 @@ TnPlan tn_plan_dma(int M, int N, int K) {
     chunk = (chunk + 63) / 64 * 64;
     splits = (M + chunk - 1) / chunk;
     if (chunk < 512) return pl;
-    pl = TnPlan{N / tn, K / 128, splits, chunk, 0, tn, 128};
+    pl = TnPlan{N / tn, K / tk, splits, chunk, 0, tn, tk};
     return pl;
 }
 
@@ -1422,7 +1493,7 @@ int launch_tn_plan(int dtype, int M, int N, int K, const void* dy, int lddy, con
         if (pd.tn) {
             TnArgs a{M, N, K, dy, lddy, x, ldx, part_w, part_b, nullptr, 1, pd.tiles_k, pd.chunk, pd.tiles_n, tn_xcd, 0, hdr, pd.splits};
             const int grid = pd.tiles_n * pd.tiles_k * pd.splits;
-            return pd.tn == 256 ? launch_tn_dma<256>(a, grid, st) : launch_tn_dma<192>(a, grid, st);
+            return pd.tk == 256 ? launch_tn_dma<256, 256, 4, 2>(a, grid, st) : launch_tn_dma<192, 384, 4, 2>(a, grid, st);
         }
     }
     const TnPlan pl = tn_plan(M, N, K, dtype);

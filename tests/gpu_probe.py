@@ -120,12 +120,14 @@ def t_wgrad():
 
 def t_wgrad_large():
     """many-token bf16 weight gradients (ragged token counts, bias gradient, DropPath row scale with a dropped sample) against fp32
-    torch matmuls of the same bf16 operands (both sides accumulate exact products in fp32).  Run once more with FMMT_TN_DMA=1
-    in the environment (tests/test_gpu_ops.py::test_dma_staged_weight_gradient_kernel) it covers the DMA-staged kernel's
-    256x128 / 192x128 tiles (bias gradient through the ones-fragment MFMA; scaled launches fall back)."""
+    torch matmuls of the same bf16 operands (both sides accumulate exact products in fp32).  The unscaled launches of the
+    stage-2/3 shapes take the DMA-staged kernel (256x256 / 192x384 tiles, bias gradient through the ones-fragment MFMA), the
+    scaled ones and the other shapes the register-staged kernel; tests/test_gpu_ops.py runs the list once more with
+    FMMT_TN_DMA=0 (everything register-staged)."""
     dt, tol = torch.bfloat16, 1e-3
     for (M, N, K) in [(125440, 1536, 384), (125440, 384, 1536), (125440, 1152, 384), (125440, 384, 384), (31360, 768, 768),
-                      (20008, 1536, 384), (17000, 384, 1536), (31360, 2304, 768), (501760, 192, 384), (62720, 768, 384)]:
+                      (20008, 1536, 384), (17000, 384, 1536), (31360, 2304, 768), (501760, 192, 384), (62720, 768, 384),
+                      (31360, 768, 3072), (125440, 384, 768), (31360, 768, 1536), (20480, 1024, 256)]:
         dy = rnd("dy", (M, N), 1, dtype=dt)
         x = rnd("x", (M, K), 2, dtype=dt)
         dw, db = ops.wgrad_raw(dy, x, True)

@@ -33,9 +33,10 @@ def test_argument_errors_raise_on_gpu():
         ops.layer_norm(torch.zeros(4, 96, device=dev, dtype=torch.float16), torch.ones(96, device=dev), torch.zeros(96, device=dev))
 
 
-def test_dma_staged_weight_gradient_kernel():
-    """linear_tn_dma_kernel (FMMT_TN_DMA=1; not the default -- see csrc/gemm.hip::tn_plan_dma) in a process of its own, because
-    the switch is read once per process"""
+def test_register_staged_weight_gradient_kernel_on_the_large_shapes():
+    """the many-token stage-2/3 weight gradients take linear_tn_dma_kernel (256x256 / 192x384 tiles) by default -- covered by
+    gpu_probe.t_wgrad_large in the main run; FMMT_TN_DMA=0 sends the same shapes through the register-staged linear_tn_kernel
+    (the path every launch with a DropPath scale or a recomputed activation still takes).  Own process: the switch is read once."""
     import os
     import subprocess
     import sys
@@ -46,6 +47,6 @@ def test_dma_staged_weight_gradient_kernel():
             "bad = [n for n, ok in P.RES if not ok]\n"
             "print('CASES', len(P.RES), 'FAILED', bad)\n"
             "sys.exit(1 if bad or not P.RES else 0)\n") % root
-    env = dict(os.environ, FMMT_TN_DMA="1")
+    env = dict(os.environ, FMMT_TN_DMA="0")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
