@@ -455,7 +455,41 @@ void linear_nt_deep32_kernel(LinArgs p) {
 //    tile i * 256 + (b % 8) * 32 + b / 8 -- each XCD works on a contiguous run of 32 tiles, so a token panel is fetched
 //    into one XCD's L2 once per round.
 // ---------------------------------------------------------------------------------------------
-template <int BN, int BK, int NBUF>
+// All fragment reads of one 32-deep K block (NT weight + 8 token fragments, ds_read_b128) and the wait for them as ONE inline-asm
+// statement.  Left to itself hipcc loads a token fragment, waits lgkmcnt(0), issues its four MFMAs, loads the next ... -- the
+// LDS latency is exposed once per four MFMAs; batched, once per 32-48.  (Same device as tn_read12 below.)
+#define FMMT_RD(o, ad) "ds_read_b128 %" #o ", %" #ad "\n\t"
+template <int NF>
+__device__ __forceinline__ void nt_read_frags(bf16x8 (&o)[NF], const unsigned (&ad)[NF]) {
+    static_assert(NF >= 10 && NF <= 12, "fragments per K block");
+    if constexpr (NF == 12) {
+        asm volatile(FMMT_RD(0, 12) FMMT_RD(1, 13) FMMT_RD(2, 14) FMMT_RD(3, 15) FMMT_RD(4, 16) FMMT_RD(5, 17) FMMT_RD(6, 18) FMMT_RD(7, 19)
+                     FMMT_RD(8, 20) FMMT_RD(9, 21) FMMT_RD(10, 22) FMMT_RD(11, 23) "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]),
+                       "=&v"(o[8]), "=&v"(o[9]), "=&v"(o[10]), "=&v"(o[11])
+                     : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5]), "v"(ad[6]), "v"(ad[7]),
+                       "v"(ad[8]), "v"(ad[9]), "v"(ad[10]), "v"(ad[11])
+                     : "memory");
+    } else if constexpr (NF == 11) {
+        asm volatile(FMMT_RD(0, 11) FMMT_RD(1, 12) FMMT_RD(2, 13) FMMT_RD(3, 14) FMMT_RD(4, 15) FMMT_RD(5, 16) FMMT_RD(6, 17) FMMT_RD(7, 18)
+                     FMMT_RD(8, 19) FMMT_RD(9, 20) FMMT_RD(10, 21) "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]),
+                       "=&v"(o[8]), "=&v"(o[9]), "=&v"(o[10])
+                     : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5]), "v"(ad[6]), "v"(ad[7]),
+                       "v"(ad[8]), "v"(ad[9]), "v"(ad[10])
+                     : "memory");
+    } else {
+        asm volatile(FMMT_RD(0, 10) FMMT_RD(1, 11) FMMT_RD(2, 12) FMMT_RD(3, 13) FMMT_RD(4, 14) FMMT_RD(5, 15) FMMT_RD(6, 16) FMMT_RD(7, 17)
+                     FMMT_RD(8, 18) FMMT_RD(9, 19) "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]),
+                       "=&v"(o[8]), "=&v"(o[9])
+                     : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5]), "v"(ad[6]), "v"(ad[7]),
+                       "v"(ad[8]), "v"(ad[9])
+                     : "memory");
+    }
+}
+
+template <int BN, int BK, int NBUF, bool BATCH = true>
 __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
     using T = bf16;
     constexpr int BM = 256, PITCH = BK, MT = 8, NT = BN / 64, WN = BN / 4, CW = 4 * NT;
@@ -538,7 +572,26 @@ __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
         const int r = wm * 128 + a * 16 + li;
         xoff[a] = (BN + r) * PITCH + ((lg ^ key(r)) << 3);
     }
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t*)S;
     auto compute = [&](int slot) {
+        if constexpr (BATCH) {
+            const unsigned sbase = lds0 + (unsigned)slot * (unsigned)(STAGE * 2);
+#pragma unroll
+            for (int kk = 0; kk < BK / 32; ++kk) {
+                // second half of a 64-wide K step: chunk index + 4 -> the swizzled chunk offset flips bit 2 (32 elements = 64 bytes)
+                unsigned ad[NT + MT];
+#pragma unroll
+                for (int b = 0; b < NT; ++b) ad[b] = (((unsigned)woff[b] * 2u) ^ (kk ? 64u : 0u)) + sbase;
+#pragma unroll
+                for (int a = 0; a < MT; ++a) ad[NT + a] = (((unsigned)xoff[a] * 2u) ^ (kk ? 64u : 0u)) + sbase;
+                bf16x8 fr[NT + MT];
+                nt_read_frags<NT + MT>(fr, ad);
+#pragma unroll
+                for (int a = 0; a < MT; ++a)
+#pragma unroll
+                    for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[b], fr[NT + a], acc[a][b], 0, 0, 0);
+            }
+        } else {
         const T* sb = S + slot * STAGE;
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk) {
@@ -552,6 +605,7 @@ __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
             for (int a = 0; a < MT; ++a)
 #pragma unroll
                 for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b], xf[a], acc[a][b], 0, 0, 0);
+        }
         }
     };
 
@@ -606,12 +660,12 @@ __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
     }
 }
 
-template <int BN, int BK, int NBUF>
-int launch_p256(const LinArgs& a, hipStream_t st) {
+template <int BN, int BK, int NBUF, bool BATCH>
+int launch_p256_b(const LinArgs& a, hipStream_t st) {
     constexpr size_t lds = (size_t)NBUF * (BN + 256) * BK * 2 + 2 * 256 * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_nt_p256_kernel<BN, BK, NBUF>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_nt_p256_kernel<BN, BK, NBUF, BATCH>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -619,9 +673,15 @@ int launch_p256(const LinArgs& a, hipStream_t st) {
     LinArgs p = a;
     p.tiles_m = (a.M + 255) / 256;
     p.tiles_n = a.N / BN;
-    hipLaunchKernelGGL((linear_nt_p256_kernel<BN, BK, NBUF>), dim3(256), dim3(512), lds, st, p);
+    hipLaunchKernelGGL((linear_nt_p256_kernel<BN, BK, NBUF, BATCH>), dim3(256), dim3(512), lds, st, p);
     FMMT_CHECK_LAUNCH();
     return 0;
+}
+template <int BN, int BK, int NBUF>
+int launch_p256(const LinArgs& a, hipStream_t st) {
+    // FMMT_NT_P256_BATCH=0: fragment reads left to the compiler's schedule (A/B switch)
+    static const int batch = getenv("FMMT_NT_P256_BATCH") ? atoi(getenv("FMMT_NT_P256_BATCH")) : 1;
+    return batch ? launch_p256_b<BN, BK, NBUF, true>(a, st) : launch_p256_b<BN, BK, NBUF, false>(a, st);
 }
 
 // Tile choice for the persistent kernel: the widest channel tile that divides N, unless a narrower one fills the last
@@ -897,7 +957,7 @@ void linear_tn_kernel(TnArgs p) {
     const int tile_n = tile / p.tiles_k, tile_k = tile % p.tiles_k;
     const int n0 = tile_n * 128, k0 = tile_k * 128;
     const int mbeg = split * p.chunk, mend = min(p.M, mbeg + p.chunk);
-    if (p.hdr && blockIdx.x == 0 && tid == 0) p.hdr[0] = p.splits;
+    if (p.hdr && blockIdx.x == 0 && tid == 0) { p.hdr[0] = p.splits; p.hdr[1] = 0; }
 
     const T* __restrict__ dyg = reinterpret_cast<const T*>(p.dy);
     const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
@@ -1149,7 +1209,7 @@ __global__ __launch_bounds__(512) void linear_tn_dma_kernel(TnArgs p) {
     const int tile_n = tile / p.tiles_k, tile_k = tile % p.tiles_k;
     const int n0 = tile_n * TNn, k0 = tile_k * TKk;
     const int mbeg = split * p.chunk, mend = min(p.M, mbeg + p.chunk);
-    if (p.hdr && blockIdx.x == 0 && tid == 0) p.hdr[0] = p.splits;
+    if (p.hdr && blockIdx.x == 0 && tid == 0) { p.hdr[0] = p.splits; p.hdr[1] = TNn; }     // TNn != 0: fragment-order partials
     const T* __restrict__ dyg = reinterpret_cast<const T*>(p.dy);
     const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
     const bool extra = wave < REM;
@@ -1276,18 +1336,14 @@ __global__ __launch_bounds__(512) void linear_tn_dma_kernel(TnArgs p) {
         cslot = cslot + 1 == NBUF ? 0 : cslot + 1;
     }
 
-    float* pw = p.part_w + (size_t)split * p.N * p.K;
+    // partial sums in FRAGMENT order: [split][tile][wave][block a][b][lane] x 4 floats -- one 1 KB store per accumulator tile
+    // (row-major order would be 4-byte stores to four rows per instruction); the finish pass undoes the permutation while it
+    // sums (reduce_partials_kernel, layout id in the workspace header)
+    float* pw = p.part_w + (size_t)split * p.N * p.K + (size_t)tile * (TNn * TKk) + (size_t)wave * (FA * FB * 256) + lane * 4;
 #pragma unroll
     for (int a = 0; a < FA; ++a)
 #pragma unroll
-        for (int b = 0; b < FB; ++b) {
-            const int k = k0 + wk * (TKk / WK) + b * 16 + li;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = n0 + wn * (TNn / WN) + block_of(a) * 16 + lg * 4 + r;
-                pw[(size_t)n * p.K + k] = acc[a][b][r];
-            }
-        }
+        for (int b = 0; b < FB; ++b) *reinterpret_cast<f32x4*>(pw + (block_of(a) * FB + b) * 256) = acc[a][b];
     if (li == 0 && has0) {                                   // every column of the ones-product holds the row sum
         float* pb = p.part_b + (size_t)split * p.N + n0 + wn * (TNn / WN) + lg * 4;
 #pragma unroll
@@ -1320,12 +1376,30 @@ int launch_tn_dma(const TnArgs& a, int grid, hipStream_t st) {
 //  stage-2/3 shapes (472-550 vs 464-591 TF/s), so it is not kept.  What did help: sizing the split count to
 //  exactly one round of co-resident workgroups, +13 % on those shapes.)
 
-// out[i] = sum_s part[s][i] : 256 threads = 64 outputs x 4 split groups, fixed-order tree (deterministic).
+// out[i] = sum_s part[s][i] : 256 threads = 64 float4 outputs x 4 split groups, fixed-order tree (deterministic).
 // One launch finishes both the weight gradient (blocks [0, wblocks)) and, if present, the bias gradient.
+// hdr[0] = number of splits, hdr[1] = layout of the weight partials as written by the contraction kernel: 0 = row-major
+// [N][K]; 256 / 192 = fragment order of linear_tn_dma_kernel<256,256> / <192,384> (undone here, K = row length of dW).
+__device__ __forceinline__ size_t tn_frag_dest(int layout, size_t q, int K, int r) {
+    // q = float4 index inside one split's partials: ((((tile * 8 + wave) * FA + a) * FB + b) * 64 + lane)
+    const int TNn = layout, TKk = layout == 256 ? 256 : 384, FA = layout == 256 ? 8 : 6, FB = layout == 256 ? 4 : 6;
+    const int lane = (int)(q & 63);
+    size_t t = q >> 6;
+    const int b = (int)(t % FB); t /= FB;
+    const int a = (int)(t % FA); t /= FA;
+    const int wave = (int)(t & 7);
+    const int tile = (int)(t >> 3);
+    const int tiles_k = K / TKk, tile_n = tile / tiles_k, tile_k = tile - tile_n * tiles_k;
+    const int wn = wave >> 2, wk = wave & 3;                 // waves 2 x 4
+    const int n = tile_n * TNn + wn * (TNn / 2) + a * 16 + (lane >> 4) * 4 + r;
+    const int k = tile_k * TKk + wk * (TKk / 4) + b * 16 + (lane & 15);
+    return (size_t)n * K + k;
+}
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n, const int* __restrict__ hdr,
-                                                              int wblocks, const float* __restrict__ part2, float* __restrict__ out2, size_t n2) {
-    __shared__ float red[4][64];
+                                                              int wblocks, const float* __restrict__ part2, float* __restrict__ out2, size_t n2, int K) {
+    __shared__ f32x4 red[4][64];
     const int splits = hdr[0];                               // written by the contraction kernel that filled the partials
+    int layout = hdr[1];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     int blk = blockIdx.x;
     if (blk >= wblocks) {                                  // bias gradient blocks
@@ -1333,14 +1407,22 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
         part = part2;
         out = out2;
         n = n2;
+        layout = 0;
     }
-    const size_t i = (size_t)blk * 64 + tx;
-    float t = 0.f;
-    if (i < n)
-        for (int s = ty; s < splits; s += 4) t += part[(size_t)s * n + i];
+    const size_t q = (size_t)blk * 64 + tx;                  // float4 index; n % 4 == 0
+    f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (q * 4 < n)
+        for (int s = ty; s < splits; s += 4) t += *reinterpret_cast<const f32x4*>(part + (size_t)s * n + q * 4);
     red[ty][tx] = t;
     __syncthreads();
-    if (ty == 0 && i < n) out[i] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+    if (ty == 0 && q * 4 < n) {
+        const f32x4 v = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+        if (layout == 0) *reinterpret_cast<f32x4*>(out + q * 4) = v;
+        else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[tn_frag_dest(layout, q, K, r)] = v[r];
+        }
+    }
 }
 
 struct TnPlan { int tiles_n, tiles_k, splits, chunk; size_t bytes; int tn, tk; };     // tn != 0: linear_tn_dma_kernel<tn>
@@ -1546,8 +1628,9 @@ extern "C" int fmmt_linear_wgrad_finish(int dtype, int M, int N, int K, float* d
     const float* part_b = reinterpret_cast<const float*>(reinterpret_cast<const char*>(workspace) + TN_HDR);
     const float* part_w = part_b + (size_t)smax * N;
     const size_t nw = (size_t)N * K;
-    const int wblocks = (int)((nw + 63) / 64), bblocks = db ? (N + 63) / 64 : 0;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(wblocks + bblocks), dim3(256), 0, st, part_w, dw, nw, hdr, wblocks, part_b, db, (size_t)N);
+    if (nw % 4 || N % 4) return FMMT_EINVAL;
+    const int wblocks = (int)((nw / 4 + 63) / 64), bblocks = db ? (N / 4 + 63) / 64 : 0;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(wblocks + bblocks), dim3(256), 0, st, part_w, dw, nw, hdr, wblocks, part_b, db, (size_t)N, K);
     FMMT_CHECK_LAUNCH();
     return 0;
 }
