@@ -162,6 +162,26 @@ def p256_tile(M, N, K, kw):
     return best
 
 
+def tn_dma_tile(M, N, K, scaled, rows_per_scale, x_gelu):
+    """mirror of csrc/gemm.hip::tn_plan_dma + launch_tn_plan (DMA-staged weight-gradient kernel): "256,256" / "192,384" or None"""
+    if os.environ.get("FMMT_TN_DMA", "1") == "0" or x_gelu or M <= 16384 or M % 64:
+        return None
+    if N % 256 == 0 and K % 256 == 0:
+        tn, tk = 256, 256
+    elif N % 192 == 0 and K % 384 == 0:
+        tn, tk = 192, 384
+    else:
+        return None
+    tiles = (N // tn) * (K // tk)
+    if tiles < 4 or tiles > 128:
+        return None
+    splits = 256 // tiles
+    chunk = (-(-M // splits) + 63) // 64 * 64
+    if chunk < 512 or (scaled and (os.environ.get("FMMT_TN_DMA_SCALED", "1") == "0" or chunk // rows_per_scale + 2 > 1024)):
+        return None
+    return f"{tn},{tk}"
+
+
 class KernelTimer:
     """HIP-event timing of one kernel family on the launch stream, live inside the timed region."""
 
@@ -211,6 +231,9 @@ class KernelTimer:
             # same dispatch as csrc/gemm.hip::fmmt_linear_wgrad_partials; the fixed-order sum of the partials
             # (fmmt_linear_wgrad_finish) is a separate launch and is not inside these events
             name = "linear_tn_kernel<bf16,32,few>" if M <= 4096 else "linear_tn_kernel<bf16,64>" if M <= 262144 else "linear_tn_kernel<bf16,32>"
+            dma = tn_dma_tile(M, N, K, rowscale is not None, rows_per_scale, x_gelu)
+            if dma:
+                name = f"linear_tn_dma_kernel<{dma},4,2,{'true' if rowscale is not None else 'false'}>"
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             raw_w(dy2, x2, want_bias, ws, nbytes, rowscale, rows_per_scale, x_gelu)
@@ -614,7 +637,7 @@ def kernel_symbol(bn):
         return bn
     if bn.startswith("p256x"):
         w = bn[5:]
-        return f"linear_nt_p256_kernel<{w},64,{3 if w == '128' else 2}>"
+        return f"linear_nt_p256_kernel<{w},64,{3 if w == '128' else 2},true>"
     if bn.startswith("deep256") and bn != "deep256x128x64":         # deep256x{128,96}x32[,nkN]
         width = "128" if bn.startswith("deep256x128") else "96"
         return f"linear_nt_deep32_kernel<{bn[-1] if ',nk' in bn else '0'},{width}>"

@@ -1184,8 +1184,13 @@ __device__ __forceinline__ void tn_read12(s16x4 (&o)[24], const unsigned (&ad)[1
     }
 }
 
-// TNn x TKk output tile, 32 tokens per stage, NBUF stages, waves WN x (8 / WN), 12 fragments per wave
-template <int TNn, int TKk, int NBUF, int WN>
+// TNn x TKk output tile, 32 tokens per stage, NBUF stages, waves WN x (8 / WN), 12 fragments per wave.
+// SCALED: DropPath row scale s[token / rows_per_scale] on dy.  The DMA image of a dy stage is scaled IN LDS, one stage ahead of
+// the fragment reads (each element once per workgroup; on the fragments it would be once per wave that reads it): at step s
+// the waves scale stage s + 1 -- 512 threads x 16 (12) elements, fp32 multiply, RNE back to bf16 -- and then contract stage s;
+// the barrier of step s + 1 publishes it.  Two stages stay in flight instead of three.  The slice of the scale vector a
+// token split needs sits in LDS behind the ring (host side: at most 1024 samples per split, else the register-staged kernel).
+template <int TNn, int TKk, int NBUF, int WN, bool SCALED = false>
 __global__ __launch_bounds__(512) void linear_tn_dma_kernel(TnArgs p) {
     using T = bf16;
     constexpr int BT = 32, WK = 8 / WN;
@@ -1324,16 +1329,97 @@ __global__ __launch_bounds__(512) void linear_tn_dma_kernel(TnArgs p) {
             im += BT;
         }
     int cslot = 0;
-    for (int s = 0; s < nsteps; ++s) {
-        wait_landed(s + NBUF - 2 < nsteps);                  // steady: NBUF - 2 later stages have been issued
-        __builtin_amdgcn_s_barrier();
-        if (s + NBUF - 1 < nsteps) {
-            issue(islot, im);
-            islot = islot + 1 == NBUF ? 0 : islot + 1;
-            im += BT;
+    if constexpr (!SCALED) {
+        for (int s = 0; s < nsteps; ++s) {
+            wait_landed(s + NBUF - 2 < nsteps);              // steady: NBUF - 2 later stages have been issued
+            __builtin_amdgcn_s_barrier();
+            if (s + NBUF - 1 < nsteps) {
+                issue(islot, im);
+                islot = islot + 1 == NBUF ? 0 : islot + 1;
+                im += BT;
+            }
+            compute(cslot);
+            cslot = cslot + 1 == NBUF ? 0 : cslot + 1;
         }
-        compute(cslot);
-        cslot = cslot + 1 == NBUF ? 0 : cslot + 1;
+    } else {
+        static_assert(NBUF >= 3, "scaled ring");
+        constexpr int EPT = TNn / 16;                        // elements per thread and stage: 32 rows x 16 threads per row
+        static_assert(EPT == 16 || EPT == 12, "scale pass");
+        const int rps = p.rows_per_scale;
+        float* sc = reinterpret_cast<float*>(smem + (size_t)NBUF * STAGE * sizeof(T));
+        const int samp0 = mbeg / rps, nsamp = (mend - 1) / rps - samp0 + 1;
+        for (int i = tid; i < nsamp; i += 512) sc[i] = p.rowscale[samp0 + i];
+        const int srow = tid >> 4;
+        int sidx = (mbeg + srow) / rps - samp0, srem = (mbeg + srow) % rps;
+        const unsigned sc0 = (unsigned)(uintptr_t)(lptr_t*)sc;
+        const unsigned soff = lds0 + (unsigned)((srow * TNn + (tid & 15) * EPT) * 2);
+        auto scale2 = [](unsigned w, float sv) -> unsigned {  // two bf16 in a dword -> scaled, rounded to nearest even
+            const float lo = __uint_as_float(w << 16) * sv, hi = __uint_as_float(w & 0xffff0000u) * sv;
+            typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+            union { bf16x2_t v; unsigned u; } r;
+            r.v = bf16x2_t{(__bf16)lo, (__bf16)hi};
+            return r.u;
+        };
+        auto scale_stage = [&](int slot) {
+            const unsigned a = soff + (unsigned)slot * (unsigned)(STAGE * 2), sa = sc0 + (unsigned)sidx * 4u;
+            u32x4 v0;
+            float sv;
+            if constexpr (EPT == 16) {
+                u32x4 v1;
+                asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b32 %2, %4\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(v0), "=&v"(v1), "=&v"(sv) : "v"(a), "v"(sa) : "memory");
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v0[e] = scale2(v0[e], sv); v1[e] = scale2(v1[e], sv); }
+                asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:16" ::"v"(a), "v"(v0), "v"(v1) : "memory");
+            } else {
+                u32x2 v1;
+                asm volatile("ds_read_b128 %0, %3\n\tds_read_b64 %1, %3 offset:16\n\tds_read_b32 %2, %4\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(v0), "=&v"(v1), "=&v"(sv) : "v"(a), "v"(sa) : "memory");
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v0[e] = scale2(v0[e], sv);
+                v1[0] = scale2(v1[0], sv);
+                v1[1] = scale2(v1[1], sv);
+                asm volatile("ds_write_b128 %0, %1\n\tds_write_b64 %0, %2 offset:16" ::"v"(a), "v"(v0), "v"(v1) : "memory");
+            }
+            srem += BT;
+            while (srem >= rps) {
+                srem -= rps;
+                ++sidx;
+            }
+        };
+        // stages issued beyond the one that has to have landed: `later`
+        auto wait_later = [&](int later) {
+            if (later <= 0) { wait_vm<0>(); return; }
+            if constexpr (REM != 0) {
+                if (extra) wait_vm<CNT + 1>();
+                else wait_vm<CNT>();
+            } else {
+                wait_vm<CNT>();
+            }
+        };
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // prologue: the scale slice and the first stages (once)
+        __builtin_amdgcn_s_barrier();
+        if (nsteps > 0) scale_stage(0);
+        // 192 x 384: the two waves of a SIMD (w and w + 4) take the two jobs of a step in opposite order, one scales while the
+        // other's MFMAs run (measured +3-8 % on the stage-2 shapes, -8 % with the 256 x 256 tile, which keeps one order)
+        const bool scale_first = TNn == 192 ? wave < 4 : true;
+        for (int s = 0; s < nsteps; ++s) {
+            // stage s + 1 has to have landed; issued so far: up to stage s + NBUF - 2
+            if (s + 1 < nsteps) wait_later(NBUF >= 4 && s + 2 < nsteps ? 1 : 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's scaled rows are in LDS before anyone passes the barrier
+            __builtin_amdgcn_s_barrier();
+            if (s + NBUF - 1 < nsteps) {
+                issue(islot, im);
+                islot = islot + 1 == NBUF ? 0 : islot + 1;
+                im += BT;
+            }
+            const int nslot = cslot + 1 == NBUF ? 0 : cslot + 1;
+            const bool more = s + 1 < nsteps;
+            if (more && scale_first) scale_stage(nslot);
+            compute(cslot);
+            if (more && !scale_first) scale_stage(nslot);
+            cslot = nslot;
+        }
     }
 
     // partial sums in FRAGMENT order: [split][tile][wave][block a][b][lane] x 4 floats -- one 1 KB store per accumulator tile
@@ -1355,17 +1441,17 @@ __global__ __launch_bounds__(512) void linear_tn_dma_kernel(TnArgs p) {
     }
 }
 
-template <int TNn, int TKk, int NBUF, int WN>
+template <int TNn, int TKk, int NBUF, int WN, bool SCALED = false>
 int launch_tn_dma(const TnArgs& a, int grid, hipStream_t st) {
-    constexpr size_t lds = (size_t)NBUF * 32 * (TNn + TKk) * 2;
+    constexpr size_t lds = (size_t)NBUF * 32 * (TNn + TKk) * 2 + (SCALED ? 4096 : 0);
     static_assert(lds <= 160 * 1024, "LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_tn_dma_kernel<TNn, TKk, NBUF, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_tn_dma_kernel<TNn, TKk, NBUF, WN, SCALED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((linear_tn_dma_kernel<TNn, TKk, NBUF, WN>), dim3(grid), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((linear_tn_dma_kernel<TNn, TKk, NBUF, WN, SCALED>), dim3(grid), dim3(512), lds, st, a);
     FMMT_CHECK_LAUNCH();
     return 0;
 }
@@ -1570,11 +1656,15 @@ int launch_tn_plan(int dtype, int M, int N, int K, const void* dy, int lddy, con
                    const float* rowscale, int rows_per_scale, int x_epi, int* hdr, hipStream_t st) {
     static const int tn_xcd = getenv("FMMT_TN_XCD") ? atoi(getenv("FMMT_TN_XCD")) : 1;
     if (x_epi != 0 && x_epi != FMMT_EPI_GELU) return FMMT_EINVAL;
-    if (dtype == FMMT_BF16 && hdr && !rowscale && !x_epi && lddy % 8 == 0 && ldx % 8 == 0) {
+    if (dtype == FMMT_BF16 && hdr && !x_epi && lddy % 8 == 0 && ldx % 8 == 0) {
         const TnPlan pd = tn_plan_dma(M, N, K);
-        if (pd.tn) {
-            TnArgs a{M, N, K, dy, lddy, x, ldx, part_w, part_b, nullptr, 1, pd.tiles_k, pd.chunk, pd.tiles_n, tn_xcd, 0, hdr, pd.splits};
+        // scaled launches: the split's slice of the scale vector has to fit the 4 KB behind the ring
+        static const int dma_scaled = getenv("FMMT_TN_DMA_SCALED") ? atoi(getenv("FMMT_TN_DMA_SCALED")) : 1;
+        const bool scaled_ok = !rowscale || (dma_scaled && rows_per_scale > 0 && pd.tn && pd.chunk / rows_per_scale + 2 <= 1024);
+        if (pd.tn && scaled_ok) {
+            TnArgs a{M, N, K, dy, lddy, x, ldx, part_w, part_b, rowscale, rows_per_scale, pd.tiles_k, pd.chunk, pd.tiles_n, tn_xcd, 0, hdr, pd.splits};
             const int grid = pd.tiles_n * pd.tiles_k * pd.splits;
+            if (rowscale) return pd.tk == 256 ? launch_tn_dma<256, 256, 4, 2, true>(a, grid, st) : launch_tn_dma<192, 384, 4, 2, true>(a, grid, st);
             return pd.tk == 256 ? launch_tn_dma<256, 256, 4, 2>(a, grid, st) : launch_tn_dma<192, 384, 4, 2>(a, grid, st);
         }
     }

@@ -119,6 +119,52 @@ __global__ void scale_kernel(size_t nvec, const T* __restrict__ x, float alpha, 
 
 bool dt_ok(int dtype) { return dtype == FMMT_BF16 || dtype == FMMT_F32; }
 
+
+// Column sums of a [M][N] matrix (bias gradient of a Linear whose GEMMs are the vendor library's: the text encoder).
+// block = 4 column chunks (8 columns, 16 bytes each) x 64 row lanes: a lane strides over the rows with 16-byte loads, the 64
+// partial sums of a column meet in LDS.  One launch, no atomics, fixed summation order.
+template <typename T, typename TO>
+__global__ __launch_bounds__(256) void colsum_kernel(int M, int N, const T* __restrict__ x, int ldx, TO* __restrict__ out) {
+    constexpr int V = 16 / sizeof(T);                       // columns per chunk
+    __shared__ float red[64][4 * V + 1];
+    const int c = threadIdx.x & 3, r = threadIdx.x >> 2;
+    const int col = (blockIdx.x * 4 + c) * V;
+    float acc[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] = 0.f;
+    if (col < N) {
+        const T* px = x + col;
+        int m = r;
+#pragma unroll 1
+        for (; m + 192 < M; m += 256) {                      // four loads in flight per lane
+            T v[4][V];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) *reinterpret_cast<uint4*>(v[u]) = *reinterpret_cast<const uint4*>(px + (size_t)(m + 64 * u) * ldx);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < V; ++e) acc[e] += (float)v[u][e];
+        }
+        for (; m < M; m += 64) {
+            T v[V];
+            *reinterpret_cast<uint4*>(v) = *reinterpret_cast<const uint4*>(px + (size_t)m * ldx);
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[e] += (float)v[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) red[r][c * V + e] = acc[e];
+    __syncthreads();
+    if (threadIdx.x < 4 * V) {
+        const int oc = blockIdx.x * 4 * V + threadIdx.x;
+        if (oc < N) {
+            float t = 0.f;
+#pragma unroll 8
+            for (int i = 0; i < 64; ++i) t += red[i][threadIdx.x];
+            out[oc] = (TO)t;
+        }
+    }
+}
 }  // namespace
 
 extern "C" int fmmt_version(void) { return 1; }
@@ -201,6 +247,25 @@ extern "C" int fmmt_scale(int dtype, size_t n, const void* x, float alpha, void*
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == FMMT_BF16) hipLaunchKernelGGL(scale_kernel<bf16>, dim3((unsigned)blocks), dim3(256), 0, st, nvec, (const bf16*)x, alpha, (bf16*)y);
     else hipLaunchKernelGGL(scale_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, nvec, (const float*)x, alpha, (float*)y);
+    FMMT_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int fmmt_colsum(int dtype, int out_dtype, int M, int N, const void* x, int ldx, void* out, void* stream) {
+    if (M <= 0 || N <= 0) return FMMT_EINVAL;
+    if (dtype != FMMT_BF16 && dtype != FMMT_F32) return FMMT_EINVAL;
+    if (out_dtype != dtype && out_dtype != FMMT_F32) return FMMT_EINVAL;
+    const int vec = dtype == FMMT_BF16 ? 8 : 4;
+    if (N % vec || ldx % vec) return FMMT_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) != 0) return FMMT_EALIGN;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)((N + 4 * vec - 1) / (4 * vec)));
+    if (dtype == FMMT_BF16) {
+        if (out_dtype == FMMT_BF16) hipLaunchKernelGGL((colsum_kernel<bf16, bf16>), grid, dim3(256), 0, st, M, N, (const bf16*)x, ldx, (bf16*)out);
+        else hipLaunchKernelGGL((colsum_kernel<bf16, float>), grid, dim3(256), 0, st, M, N, (const bf16*)x, ldx, (float*)out);
+    } else {
+        hipLaunchKernelGGL((colsum_kernel<float, float>), grid, dim3(256), 0, st, M, N, (const float*)x, ldx, (float*)out);
+    }
     FMMT_CHECK_LAUNCH();
     return 0;
 }

@@ -158,6 +158,39 @@ def linear(x, weight, bias=None, res=None, rowscale=None, rows_per_scale=1):
 # MLP:  y = res + rowscale * (gelu(x W1^T + b1) W2^T + b2)      (Mlp of Swin; fc1/gelu/fc2 of the
 # cross-modal layer).  GELU lives in fc1's epilogue, GELU' in the epilogue of fc2's input-gradient GEMM.
 # ------------------------------------------------------------------------------------------------
+def colsum_raw(x2, out_dtype=None):
+    """out[n] = sum_m x2[m][n] (fmmt_colsum): x2 (M, N) contiguous bf16 / fp32; result in out_dtype (x2's dtype or fp32)"""
+    M, N = x2.shape
+    out_dtype = out_dtype or x2.dtype
+    out = torch.empty((N,), dtype=out_dtype, device=x2.device)
+    check(_lib.load().fmmt_colsum(dtype_code(x2.dtype), dtype_code(out_dtype), M, N, _p(x2), N, _p(out), _st()), f"fmmt_colsum(M={M},N={N})")
+    return out
+
+
+class VendorLinearFn(torch.autograd.Function):
+    """y = x W^T + b with the vendor library's GEMMs (torch.nn.functional.linear / matmul) and fmmt_colsum for the bias gradient:
+    the text encoder's Linear layers (few thousand tokens: hipBLASLt's ground; its autograd formula spends a memset and a
+    multi-block reduction, 25 us, on every bias gradient).  dx and dW are the calls autograd would make, bit for bit."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = dy.matmul(weight)
+        if ctx.needs_input_grad[1]:
+            dw = dy2.t().mm(x.reshape(-1, x.shape[-1]))
+        if ctx.needs_input_grad[2]:
+            db = colsum_raw(dy2.contiguous())
+        return dx, dw, db
+
+
 def mlp_fused_raw(x2, w1l, b1, w2l, b2, res2, rowscale, rows_per_scale, h_pre, h_act=None):
     """one launch: y = res + rowscale * (gelu(x W1^T + b1) W2^T + b2); h_pre / h_act (or None) receive the pre-activation / activation"""
     M, C = x2.shape

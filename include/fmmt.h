@@ -214,6 +214,12 @@ int fmmt_posemb_scale_fwd(int dtype, int L, int B, int E, const void* x, const f
 /* y = alpha * x elementwise (backward of the embedding scale); n elements, n % 8 == 0. */
 int fmmt_scale(int dtype, size_t n, const void* x, float alpha, void* y, void* stream);
 
+/* out[n] = sum_m x[m][n]: the bias gradient `grad_output.sum(0)` of a Linear whose GEMMs stay with the vendor library -- the
+ * text encoder's 146 Linear layers (src/models.py:75-91: RobertaModel / BertModel; torch's own reduction takes a memset and a
+ * multi-block reduce_kernel per layer, 25 us against 4).  x: [M][N] (dtype), row pitch ldx; out: N values of out_dtype
+ * (dtype, or FMMT_F32); N % (16 / sizeof(dtype)) == 0; one launch, fixed summation order. */
+int fmmt_colsum(int dtype, int out_dtype, int M, int N, const void* x, int ldx, void* out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Input pre-step fused into PatchEmbed's gather.  Replaces, for one batch of square uint8 face
  * crops (n, S, S, 3) in image (HWC) layout, the chain the reference runs per frame on the host and caches as a

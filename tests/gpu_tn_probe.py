@@ -36,6 +36,19 @@ for (M, N, K) in SHAPES:
     e1.record(); torch.cuda.synchronize()
     full = e0.elapsed_time(e1) / 10
     tot += full
-    print(f"  tn {M:7d}x{N:5d}x{K:5d}: partials {best*1e3:7.1f} us {2.0*M*N*K/best/1e9:6.1f} TF/s | with reduce {full*1e3:7.1f} us", flush=True)
+    rps = 196 if M > 100000 else 49
+    rs = torch.full((M // rps,), 1.0 / 0.9, device=dev)
+    rs[::7] = 0.0
+    ops.wgrad_partials_raw(dy, x, True, ws, nbytes, rs, rps); torch.cuda.synchronize()
+    bs = 1e9
+    for rep in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            ops.wgrad_partials_raw(dy, x, True, ws, nbytes, rs, rps)
+        e1.record(); torch.cuda.synchronize()
+        bs = min(bs, e0.elapsed_time(e1) / 10)
+    tot += bs
+    print(f"  tn {M:7d}x{N:5d}x{K:5d}: partials {best*1e3:7.1f} us {2.0*M*N*K/best/1e9:6.1f} TF/s | with reduce {full*1e3:7.1f} us | DropPath-scaled partials {bs*1e3:7.1f} us {2.0*M*N*K/bs/1e9:6.1f} TF/s", flush=True)
 if not bare:
     print(f"  total with reduce {tot*1e3:.1f} us   FMMT_TN_DMA={os.environ.get('FMMT_TN_DMA', '')}")

@@ -198,3 +198,37 @@ def test_eval_after_graph_capture_runs_eager_branches(dev):
     mm.train()
     with torch.no_grad():
         assert mm(*call).shape == want.shape                     # and the graphs are used again in training mode
+
+
+@pytest.mark.gpu
+def test_colsum_and_vendor_linear_bias_gradient(dev):
+    """fmmt_colsum against torch.sum (ragged row counts, bf16 -> bf16 / fp32, fp32), and train_step.VendorLinear: forward, dx and dW
+    are the library calls autograd makes (bit-identical to nn.Linear), db is the column sum (same fp32 accumulation, one rounding)"""
+    from facialmmt_amd import ops
+    from facialmmt_amd.train_step import VendorLinear, use_colsum_bias_gradients
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for (M, N, dt) in [(2048, 1024, torch.bfloat16), (2048, 4096, torch.bfloat16), (777, 1032, torch.bfloat16), (63, 8, torch.bfloat16),
+                       (1000, 516, torch.float32)]:
+        x = torch.randn(M, N, generator=g).to(dev, dt)
+        ref = x.float().sum(0)
+        for od in {dt, torch.float32}:
+            out = ops.colsum_raw(x, od)
+            tol = 2e-2 if od == torch.bfloat16 else 1e-4
+            assert out.dtype == od and torch.allclose(out.float(), ref, rtol=tol, atol=tol * ref.abs().max().item()), (M, N, dt, od)
+    seq = torch.nn.Sequential(torch.nn.Linear(256, 512), torch.nn.GELU(), torch.nn.Linear(512, 256)).to(dev, torch.bfloat16)
+    import copy
+    fast = copy.deepcopy(seq)
+    assert use_colsum_bias_gradients(fast) == 2 and isinstance(fast[0], VendorLinear) and list(fast.state_dict()) == list(seq.state_dict())
+    x = torch.randn(4, 300, 256, generator=g).to(dev, torch.bfloat16)
+    outs = []
+    for m in (seq, fast):
+        xi = x.clone().requires_grad_(True)
+        y = m(xi)
+        y.square().mean().backward()
+        outs.append((y, xi.grad, [p.grad for p in m.parameters()]))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for (n, _), a, b in zip(seq.named_parameters(), outs[0][2], outs[1][2]):
+        if n.endswith("weight"):
+            assert torch.equal(a, b), n
+        else:
+            assert torch.allclose(a.float(), b.float(), rtol=2e-2, atol=1e-2 * a.float().abs().max().item()), n

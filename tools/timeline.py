@@ -1,0 +1,75 @@
+"""Timeline of one steady-state training step from a rocprofv3 --kernel-trace CSV: wall, busy (union of kernel intervals),
+sum of kernel durations, how much of the wall has 0 / 1 / >= 2 kernels in flight, per-queue busy time, and the kernels that
+run ALONE for the longest total time (critical-path candidates).  usage: timeline.py DIR [marker-kernel-substring]"""
+import csv, glob, sys, collections
+
+d = sys.argv[1]
+marker = sys.argv[2] if len(sys.argv) > 2 else "patch_embed_u8"
+f = sorted(glob.glob(d + "/**/*kernel_trace.csv", recursive=True))[0]
+rows = []
+with open(f) as fh:
+    for r in csv.DictReader(fh):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "0"), r.get("Stream_Id", "0")))
+rows.sort()
+marks = [s for s, e, n, q, st in rows if marker in n]
+print(f"{len(rows)} kernels, {len(marks)} markers")
+if len(marks) < 6:
+    sys.exit("not enough markers")
+k = len(marks) - 4                                   # a late replayed step (before the eager probe passes: pick by regular spacing)
+gaps = [marks[i + 1] - marks[i] for i in range(len(marks) - 1)]
+med = sorted(gaps)[len(gaps) // 2]
+cands = [i for i in range(len(gaps)) if abs(gaps[i] - med) < 0.05 * med]
+i = cands[len(cands) // 2]
+t0, t1 = marks[i], marks[i + 1]
+step = [(s, e, n, q, st) for s, e, n, q, st in rows if s >= t0 and s < t1]
+print(f"step window {(t1 - t0) / 1e6:.2f} ms, {len(step)} kernels, median marker spacing {med / 1e6:.2f} ms")
+ev = []
+for s, e, n, q, st in step:
+    ev.append((s, 1, n)); ev.append((min(e, t1), -1, n))
+ev.sort()
+active = collections.Counter(); cur = 0; last = t0
+hist = collections.Counter(); alone = collections.Counter()
+for t, dlt, n in ev:
+    if t > last:
+        hist[min(cur, 3)] += t - last
+        if cur == 1:
+            alone[[a for a, c in active.items() if c > 0][0]] += t - last
+    last = t
+    cur += dlt
+    active[n] += dlt
+hist[min(cur, 3)] += t1 - last
+tot = t1 - t0
+print("in flight: " + "  ".join(f"{k}{'+' if k == 3 else ''}: {v / 1e6:6.2f} ms ({100 * v / tot:4.1f} %)" for k, v in sorted(hist.items())))
+print(f"sum of kernel durations {sum(e - s for s, e, *_ in step) / 1e6:.2f} ms")
+byq = collections.Counter()
+for s, e, n, q, st in step:
+    byq[(q, st)] += e - s
+print("per (queue, stream) kernel time: " + "  ".join(f"{k}: {v / 1e6:.2f} ms" for k, v in sorted(byq.items(), key=lambda kv: -kv[1])[:6]))
+print("kernels running alone, total ms:")
+for n, v in alone.most_common(28):
+    print(f"  {v / 1e6:7.3f}  {n[:110]}")
+# idle gaps
+idle = []
+cur = 0; last = t0
+for t, dlt, n in ev:
+    if cur == 0 and t > last:
+        idle.append((t - last, last - t0))
+    last = t; cur += dlt
+idle.sort(reverse=True)
+print("largest idle gaps (us @ offset ms): " + "  ".join(f"{g / 1e3:.1f}@{o / 1e6:.1f}" for g, o in idle[:12]) + f"   total idle {sum(g for g, _ in idle) / 1e6:.2f} ms in {len(idle)} gaps")
+# context of the tiny launches: most common (previous kernel, next kernel) on the same queue
+if len(sys.argv) > 3:
+    for pat in sys.argv[3].split(","):
+        ctx = collections.Counter()
+        byqueue = collections.defaultdict(list)
+        for s, e, n, q, st in step:
+            byqueue[q].append(n)
+        for q, names in byqueue.items():
+            for j, n in enumerate(names):
+                if pat in n:
+                    pv = names[j - 1][:60] if j else "-"
+                    nx = names[j + 1][:60] if j + 1 < len(names) else "-"
+                    ctx[(q, pv, nx)] += 1
+        print(f"context of '{pat}':")
+        for (q, pv, nx), c in ctx.most_common(14):
+            print(f"  {c:4d}  q{q}  after [{pv}]  before [{nx}]")
