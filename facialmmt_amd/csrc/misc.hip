@@ -165,6 +165,57 @@ __global__ __launch_bounds__(256) void colsum_kernel(int M, int N, const T* __re
         }
     }
 }
+
+// Batched cast (+ transpose) of parameter matrices into their bf16 shadows: ONE launch refreshes every weight shadow a training
+// step uses (the per-weight casts and transposes were ~360 launches of 4-9 us inside the step's graph).  One 64 x 64 tile per
+// block; the block finds its matrix by bisection over the tile offsets.
+struct CastDesc {
+    const void* src;    // [rows][src_ld] fp32 or bf16
+    void* dst;          // bf16: [rows][cols], or [cols][rows] when transposing
+    int rows, cols, src_ld, flags;      // flags: bit 0 transpose, bit 1 source is fp32
+    int tile_begin, tiles_c;
+};
+__global__ __launch_bounds__(256) void cast_batch_kernel(const CastDesc* __restrict__ desc, int n) {
+    __shared__ bf16 tile[64][66];
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (desc[mid].tile_begin <= (int)blockIdx.x) lo = mid;
+        else hi = mid - 1;
+    }
+    const CastDesc d = desc[lo];
+    const int t = (int)blockIdx.x - d.tile_begin, tr = t / d.tiles_c, tc = t - tr * d.tiles_c;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const bool f32 = d.flags & 2, tp = d.flags & 1;
+    const float* sf = reinterpret_cast<const float*>(d.src);
+    const bf16* sb = reinterpret_cast<const bf16*>(d.src);
+    bf16* dst = reinterpret_cast<bf16*>(d.dst);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = tr * 64 + ty + 16 * i;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = tc * 64 + tx + 16 * j;
+            if (r < d.rows && c < d.cols) {
+                const size_t o = (size_t)r * d.src_ld + c;
+                const bf16 v = f32 ? (bf16)sf[o] : sb[o];
+                if (tp) tile[ty + 16 * i][tx + 16 * j] = v;
+                else dst[(size_t)r * d.cols + c] = v;
+            }
+        }
+    }
+    if (!tp) return;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tc * 64 + ty + 16 * i;                 // source column = destination row
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = tr * 64 + tx + 16 * j;             // source row = destination column
+            if (r < d.rows && c < d.cols) dst[(size_t)c * d.rows + r] = tile[tx + 16 * j][ty + 16 * i];
+        }
+    }
+}
 }  // namespace
 
 extern "C" int fmmt_version(void) { return 1; }
@@ -266,6 +317,14 @@ extern "C" int fmmt_colsum(int dtype, int out_dtype, int M, int N, const void* x
     } else {
         hipLaunchKernelGGL((colsum_kernel<float, float>), grid, dim3(256), 0, st, M, N, (const float*)x, ldx, (float*)out);
     }
+    FMMT_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int fmmt_cast_batch(int n_desc, int n_tiles, const void* desc, void* stream) {
+    if (n_desc <= 0 || n_tiles <= 0 || !desc) return FMMT_EINVAL;
+    hipLaunchKernelGGL(cast_batch_kernel, dim3((unsigned)n_tiles), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const CastDesc*>(desc), n_desc);
     FMMT_CHECK_LAUNCH();
     return 0;
 }

@@ -100,6 +100,10 @@ def _lp(w: torch.Tensor, dtype, transpose: bool = False) -> torch.Tensor:
         return wd.contiguous()
     capturing = wd.is_cuda and torch.cuda.is_current_stream_capturing()
     key = (w.storage_offset(), tuple(w.shape), tuple(w.stride()), dtype, transpose)
+    if capturing:
+        pin = _PINNED.get(id(base))
+        if pin is not None and key in pin:
+            return pin[key]                                  # refreshed by PinnedShadows.refresh() at the head of the graph
     sub = None if capturing else _CAST_CACHE.get(id(base))   # inside a hipGraph the cast must be part of the graph
     if sub is not None:
         hit = sub.get(key)
@@ -114,6 +118,64 @@ def _lp(w: torch.Tensor, dtype, transpose: bool = False) -> torch.Tensor:
         weakref.finalize(base, _CAST_CACHE.pop, id(base), None)
     sub[key] = (w._version, out)
     return out
+
+
+_PINNED: dict = {}              # id(parameter) -> {key: static shadow}: consulted only while a graph is being captured
+
+
+class PinnedShadows:
+    """Static bf16 shadows (W and W^T) of the parameters a captured training step reads, refreshed by ONE launch.
+
+    Inside a HIP graph a shadow cannot come from the version-keyed cache (a replay does not bump versions), so every Linear
+    re-cast -- and, for the input-gradient GEMM, re-transposed -- its weight inside the graph: ~250 cast and ~110 transpose
+    launches of 4-9 us per step (2.2 ms of the step's 76).  Here the shadows every `_lp` call of the eager warm-up passes
+    produced (the cache knows exactly which (view, dtype, transpose) combinations the step uses) become static tensors;
+    while a graph is captured `_lp` hands them out without launching anything, and `refresh()` -- captured at the head of the
+    graph -- rebuilds all of them from the current parameter values with fmmt_cast_batch.  Eager calls never see them."""
+
+    def __init__(self, params):
+        import numpy as np
+        recs, self.keep = [], []
+        tiles = 0
+        for p in params:
+            sub = _CAST_CACHE.get(id(p))
+            if not sub or not p.is_cuda or p.dtype not in (torch.float32, torch.bfloat16):
+                continue
+            pins = _PINNED.setdefault(id(p), {})
+            if not pins:
+                weakref.finalize(p, _PINNED.pop, id(p), None)
+            for key, (_, shadow) in sub.items():
+                off, shape, stride, dtype, transpose = key
+                if dtype != torch.bfloat16 or len(shape) != 2 or stride[1] != 1:
+                    continue
+                rows, cols = shape
+                dst = pins.get(key)                          # shared with another captured step over the same parameters
+                if dst is None:
+                    dst = pins[key] = torch.empty_like(shadow)   # [rows, cols] or [cols, rows], contiguous
+                self.keep.append((p, dst))
+                tr, tc = (rows + 63) // 64, (cols + 63) // 64
+                recs.append((p.data_ptr() + off * p.element_size(), dst.data_ptr(), rows, cols, stride[0],
+                             (1 if transpose else 0) | (2 if p.dtype == torch.float32 else 0), tiles, tc))
+                tiles += tr * tc
+        self.n, self.tiles = len(recs), tiles
+        self.desc = None
+        if recs:
+            arr = np.zeros(len(recs), dtype=np.dtype([("src", "<u8"), ("dst", "<u8"), ("rows", "<i4"), ("cols", "<i4"), ("ld", "<i4"),
+                                                      ("flags", "<i4"), ("tb", "<i4"), ("tc", "<i4")]))
+            for i, r in enumerate(recs):
+                arr[i] = r
+            self.desc = torch.from_numpy(arr.view(np.uint8).copy()).to(self.keep[0][1].device)
+
+    def refresh(self):
+        if self.desc is not None:
+            check(_lib.load().fmmt_cast_batch(self.n, self.tiles, _p(self.desc), _st()), "fmmt_cast_batch")
+
+    def release(self):
+        for p, dst in self.keep:
+            pins = _PINNED.get(id(p))
+            if pins:
+                for k in [k for k, v in pins.items() if v is dst]:
+                    del pins[k]
 
 
 # ------------------------------------------------------------------------------------------------

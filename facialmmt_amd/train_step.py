@@ -436,6 +436,34 @@ def _reset_optimizer_state(opt):
                 v.zero_()
 
 
+def _pin_shadows(modules):
+    """ops.PinnedShadows over the parameters of `modules` (FMMT_PIN_SHADOWS=0: per-weight casts inside the graph, as before)"""
+    import os
+    if os.environ.get("FMMT_PIN_SHADOWS", "1") == "0":
+        return None
+    from . import ops
+    seen, params = set(), []
+    for m in modules:
+        for p in m.parameters():
+            if id(p) not in seen:
+                seen.add(id(p))
+                params.append(p)
+    return ops.PinnedShadows(params)
+
+
+def _bump_versions(params):
+    """A graph replay updates parameters in place without autograd noticing: bump their version counters, so that eager code
+    that caches by version (ops._lp: the bf16 weight shadows of an eval() pass after training) rebuilds what it cached."""
+    inc = getattr(torch._C, "_increment_version", None)
+    if inc is None:
+        return
+    try:
+        inc(params)
+    except TypeError:
+        for p in params:
+            inc(p)
+
+
 class GraphedTargetStep:
     """The whole target-task step as TWO HIP graphs, replayed per step with one host call each:
 
@@ -485,6 +513,7 @@ class GraphedTargetStep:
         # runtime's choice at replay time, not a property of the stream object used during capture
         # warm-up / capture stream and the two branch streams: three different HIP streams (distinct_stream)
         cap = distinct_stream(dev)
+        self.shadows = None                                 # set after the warm-up passes, before capture
         self.text_stream = distinct_stream(dev, (cap,)) if overlap_text else None
         self.mm.pair_stream = distinct_stream(dev, (cap, self.text_stream)) if parallel_fusion else None
         # -- warm-up on a side stream (lazy initialisations: kernel attributes, shadow caches, optimizer state), undone below
@@ -506,6 +535,7 @@ class GraphedTargetStep:
         self.flat.zero_grad()
         torch.cuda.set_rng_state(rng, dev)
         # -- capture
+        self.shadows = _pin_shadows([self.swin, self.mm])
         self.graph_a, self.graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with capture_window():
             with torch.cuda.graph(self.graph_a, stream=cap):
@@ -526,6 +556,8 @@ class GraphedTargetStep:
         ac = ctx if ctx is not None else contextlib.nullcontext
         main = torch.cuda.current_stream()
         pending = None
+        if self.shadows is not None:
+            self.shadows.refresh()                          # every bf16 weight shadow of the step, one launch (ops.PinnedShadows)
         if self.text_stream is not None:
             self.text_stream.wait_stream(main)             # fork: the text branch does not depend on the visual path
             with torch.cuda.stream(self.text_stream), ac():
@@ -567,6 +599,7 @@ class GraphedTargetStep:
         if self.i_batch % self.args.trg_accumulation_steps == 0:
             self.flat.exchange_all()                       # no-op at world size 1
             self.graph_b.replay()
+            _bump_versions(self.flat.params)                # a replay changes the parameters behind autograd's back
             if self.sched is not None:
                 self.sched.step()
         return self.loss, self.new_mask
@@ -580,6 +613,7 @@ class GraphedAuxStep:
         from .parallel import GradientAverager
         self.swin, self.opt, self.sched, self.args = swin_model, optimizer, scheduler, args
         self.images, self.labels = images.clone(), labels.clone()
+        self.shadows = None
         self.i_batch = 0
         dev = images.device
         self.flat = averager if averager is not None else GradientAverager(self.swin.parameters(), hooks=False)
@@ -603,6 +637,7 @@ class GraphedAuxStep:
         _reset_optimizer_state(self.opt)
         self.flat.zero_grad()
         torch.cuda.set_rng_state(rng, dev)
+        self.shadows = _pin_shadows([self.swin])
         self.graph_a, self.graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with capture_window():
             with torch.cuda.graph(self.graph_a, stream=cap):
@@ -613,6 +648,8 @@ class GraphedAuxStep:
         self.flat.zero_grad()
 
     def _fwd_bwd(self):
+        if self.shadows is not None:
+            self.shadows.refresh()
         loss = self.swin(self.images, False, self.labels, F.cross_entropy) / self.args.aux_accumulation_steps
         loss.backward()
         _hand_over_gradients(self.pairs, self.flat_view_of, self.accumulate)
@@ -638,6 +675,7 @@ class GraphedAuxStep:
         if self.i_batch % self.args.aux_accumulation_steps == 0:
             self.flat.exchange_all()
             self.graph_b.replay()
+            _bump_versions(self.flat.params)
             if self.sched is not None:
                 self.sched.step()
         return self.loss

@@ -220,6 +220,15 @@ int fmmt_scale(int dtype, size_t n, const void* x, float alpha, void* y, void* s
  * (dtype, or FMMT_F32); N % (16 / sizeof(dtype)) == 0; one launch, fixed summation order. */
 int fmmt_colsum(int dtype, int out_dtype, int M, int N, const void* x, int ldx, void* out, void* stream);
 
+/* Batched refresh of bf16 weight shadows: one launch casts (fp32 -> bf16, or copies bf16) and optionally transposes n_desc
+ * parameter matrices.  The reference keeps fp32 nn.Parameters (train.py:336-349 builds the optimizer over them); the bf16 GEMMs
+ * read bf16 shadows W and W^T of them, which a training step has to rebuild after every optimizer step -- per weight that
+ * was ~360 launches per step.  desc: DEVICE array of n_desc records
+ *   { const void* src; void* dst; int32 rows, cols, src_ld, flags, tile_begin, tiles_c; }   (40 bytes, natural alignment)
+ * flags bit 0: dst is [cols][rows] (transpose), bit 1: src is fp32 (else bf16); 64 x 64 tiles, tiles_c = ceil(cols / 64),
+ * tile_begin = tiles of all earlier records; n_tiles = their total.  The caller builds the table once. */
+int fmmt_cast_batch(int n_desc, int n_tiles, const void* desc, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Input pre-step fused into PatchEmbed's gather.  Replaces, for one batch of square uint8 face
  * crops (n, S, S, 3) in image (HWC) layout, the chain the reference runs per frame on the host and caches as a

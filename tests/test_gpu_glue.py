@@ -232,3 +232,36 @@ def test_colsum_and_vendor_linear_bias_gradient(dev):
             assert torch.equal(a, b), n
         else:
             assert torch.allclose(a.float(), b.float(), rtol=2e-2, atol=1e-2 * a.float().abs().max().item()), n
+
+
+@pytest.mark.gpu
+def test_cast_batch_and_pinned_shadows(dev):
+    """fmmt_cast_batch through ops.PinnedShadows: every (view, transpose) shadow the eager cache knows -- full matrices, row
+    slices of a fused in_proj weight, odd sizes (7 x 768 head, K = 48 patch embedding), fp32 and bf16 sources -- equals
+    w.to(bf16)[.t()] after refresh(), tracks in-place parameter updates, and is handed out only while a graph is captured"""
+    from facialmmt_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(9)
+    ps = [torch.nn.Parameter(torch.randn(sh, generator=g).to(dev, dt)) for sh, dt in
+          [((96, 48), torch.float32), ((7, 768), torch.float32), ((2304, 768), torch.float32), ((130, 70), torch.float32), ((192, 96), torch.bfloat16)]]
+    views = [ps[2][:768], ps[2][768:]]                       # in_proj-style row slices of one parameter
+    for w in ps + views:
+        ops._lp(w, torch.bfloat16)
+        ops._lp(w, torch.bfloat16, transpose=True)
+    pin = ops.PinnedShadows(ps)
+    assert pin.n == 2 * 6 + 1                                # the bf16 parameter needs no plain shadow, only the transposed one
+    for rnd in range(2):
+        pin.refresh()
+        torch.cuda.synchronize()
+        for w in ps + views:
+            base = w._base if w._base is not None else w
+            for tp in (False, True):
+                key = (w.storage_offset(), tuple(w.shape), tuple(w.stride()), torch.bfloat16, tp)
+                if w.dtype == torch.bfloat16 and not tp:
+                    continue
+                ref = w.detach().to(torch.bfloat16)
+                assert torch.equal(ops._PINNED[id(base)][key], ref.t().contiguous() if tp else ref), (tuple(w.shape), tp, rnd)
+        with torch.no_grad():
+            for p in ps:
+                p.mul_(1.5).add_(0.25)
+    assert ops._lp(ps[0], torch.bfloat16) is not ops._PINNED[id(ps[0])][(0, (96, 48), (48, 1), torch.bfloat16, False)]
+    pin.release()
