@@ -555,7 +555,10 @@ def main():
                 f.write(timer.shape_report(args.steps) + "\n")
         roof = None
         if fams:
-            bn, (cnt, fl, by, sec) = max(fams.items(), key=lambda kv: kv[1][3])
+            # the dominant kernel = the family with the most GPU time among the many-token launches (the few-token GEMMs of the
+            # fusion stack are launch-bound 10-25 us kernels: many of them, no roofline to speak of)
+            big = {k: v for k, v in fams.items() if v[3] / v[0] >= 40e-6} or fams
+            bn, (cnt, fl, by, sec) = max(big.items(), key=lambda kv: kv[1][3])
             kname = kernel_symbol(bn)
             traffic, traffic_src = None, None                # PMC counters cannot be read in-process: taken from the committed PMC summary
             try:

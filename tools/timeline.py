@@ -73,3 +73,11 @@ if len(sys.argv) > 3:
         print(f"context of '{pat}':")
         for (q, pv, nx), c in ctx.most_common(14):
             print(f"  {c:4d}  q{q}  after [{pv}]  before [{nx}]")
+cnt = collections.Counter(); tim = collections.Counter()
+for s_, e_, n, q, st in step:
+    cnt[n] += 1; tim[n] += e_ - s_
+print("launch census of the step (count, total ms, avg us):")
+for n, c in cnt.most_common(45):
+    print(f"  {c:5d} {tim[n] / 1e6:7.3f} {tim[n] / c / 1e3:7.1f}  {n[:120]}")
+small = sum(c for n, c in cnt.items() if tim[n] / c < 8e3); smallt = sum(tim[n] for n, c in cnt.items() if tim[n] / c < 8e3)
+print(f"kernels averaging < 8 us: {small} launches, {smallt / 1e6:.2f} ms")
