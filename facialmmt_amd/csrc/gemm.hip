@@ -489,7 +489,7 @@ __device__ __forceinline__ void nt_read_frags(bf16x8 (&o)[NF], const unsigned (&
     }
 }
 
-template <int BN, int BK, int NBUF, bool BATCH = true>
+template <int BN, int BK, int NBUF, bool BATCH = true, bool HASOP = false>
 __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
     using T = bf16;
     constexpr int BM = 256, PITCH = BK, MT = 8, NT = BN / 64, WN = BN / 4, CW = 4 * NT;
@@ -632,9 +632,15 @@ __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
         if (s < nsteps) issue_next();
     // compute-side cursor
     int ct = first, ck = 0, cpar = 0, cslot = 0;
+    EpiPre<MT, NT> pre;
     for (int s = 0; s < nsteps; ++s) {
         wait_landed(min(nsteps - 1 - s, NBUF - 2));
         __builtin_amdgcn_s_barrier();                      // every wave's part of stage s is in LDS; stage s - 1 is free
+        if constexpr (HASOP) {
+            // residual / GELU' operand / DropPath scale of THIS tile: loaded now, in front of this step's DMA, used after the
+            // step's MFMAs
+            if (ck == nk - 1) nt_epilogue_prefetch<MT, NT>(p, pre, (ct / p.tiles_n) * BM + wm * 128, (ct % p.tiles_n) * BN + wn * WN, li, lg);
+        }
         if (s + NBUF - 1 < nsteps) issue_next();
         compute(cslot);
         cslot = cslot + 1 == NBUF ? 0 : cslot + 1;
@@ -648,7 +654,8 @@ __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
                     for (int a = 0; a < MT; ++a) acc[a][b] += bb;
                 }
             }
-            nt_epilogue<T, MT, NT, true>(p, acc, m0 + wm * 128, n0 + wn * WN, li, lg);
+            if constexpr (HASOP) nt_epilogue<T, MT, NT, true, true>(p, acc, m0 + wm * 128, n0 + wn * WN, li, lg, &pre);
+            else nt_epilogue<T, MT, NT, true>(p, acc, m0 + wm * 128, n0 + wn * WN, li, lg);
 #pragma unroll
             for (int a = 0; a < MT; ++a)
 #pragma unroll
@@ -660,12 +667,12 @@ __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
     }
 }
 
-template <int BN, int BK, int NBUF, bool BATCH>
+template <int BN, int BK, int NBUF, bool BATCH, bool HASOP>
 int launch_p256_b(const LinArgs& a, hipStream_t st) {
     constexpr size_t lds = (size_t)NBUF * (BN + 256) * BK * 2 + 2 * 256 * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_nt_p256_kernel<BN, BK, NBUF, BATCH>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_nt_p256_kernel<BN, BK, NBUF, BATCH, HASOP>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -673,7 +680,7 @@ int launch_p256_b(const LinArgs& a, hipStream_t st) {
     LinArgs p = a;
     p.tiles_m = (a.M + 255) / 256;
     p.tiles_n = a.N / BN;
-    hipLaunchKernelGGL((linear_nt_p256_kernel<BN, BK, NBUF, BATCH>), dim3(256), dim3(512), lds, st, p);
+    hipLaunchKernelGGL((linear_nt_p256_kernel<BN, BK, NBUF, BATCH, HASOP>), dim3(256), dim3(512), lds, st, p);
     FMMT_CHECK_LAUNCH();
     return 0;
 }
@@ -681,7 +688,12 @@ template <int BN, int BK, int NBUF>
 int launch_p256(const LinArgs& a, hipStream_t st) {
     // FMMT_NT_P256_BATCH=0: fragment reads left to the compiler's schedule (A/B switch)
     static const int batch = getenv("FMMT_NT_P256_BATCH") ? atoi(getenv("FMMT_NT_P256_BATCH")) : 1;
-    return batch ? launch_p256_b<BN, BK, NBUF, true>(a, st) : launch_p256_b<BN, BK, NBUF, false>(a, st);
+    if constexpr (BN != 256) {
+        // launches with an M x N epilogue operand or a DropPath scale: operand prefetched into registers (48 / 32 of them:
+        // no room beside the 128 accumulators of the 256-wide tile)
+        if (a.res || a.aux || a.rowscale) return launch_p256_b<BN, BK, NBUF, true, true>(a, st);
+    }
+    return batch ? launch_p256_b<BN, BK, NBUF, true, false>(a, st) : launch_p256_b<BN, BK, NBUF, false, false>(a, st);
 }
 
 // Tile choice for the persistent kernel: the widest channel tile that divides N, unless a narrower one fills the last
@@ -698,7 +710,14 @@ int p256_plan(const LinArgs& a) {
     // (profiles/r02_gemm_shapes.txt): plain / bias / GELU + pre-activation launches gain 5-50 % over the two-workgroup
     // 256 x 128 kernels (125440 x 1536 x 384 GELU: 0.439 -> 0.295 ms), launches with such loads lose 0-25 %: those stay
     // on the older kernels.  FMMT_NT_P256=2 sends them here as well (A/B switch).
-    if (mode == 1 && (a.res || a.aux || a.rowscale)) return 0;
+    // FMMT_NT_P256_OPS=1 (A/B switch, default 0): such launches come here too, on the 192- / 128-wide tiles, with the operand
+    // prefetched into registers one K step before the epilogue (HASOP).  Measured, same call: residual + scale 321 -> 262 us
+    // (501760 x 192 x 768), 210 -> 201 (125440 x 384 x 1536), but GELU' 338 -> 391 / 530 -> 614 us: the GELU' epilogue is
+    // ~11 k VALU cycles per wave tile against 4.6 k MFMA cycles of a K = 384 tile, and one workgroup per CU has no second
+    // workgroup whose K loop could run under it.  Total over the step's shapes: +1 %.  Not the default.
+    static const int ops_mode = getenv("FMMT_NT_P256_OPS") ? atoi(getenv("FMMT_NT_P256_OPS")) : 0;
+    const bool has_op = a.res || a.aux || a.rowscale;
+    if (has_op && mode == 1 && (!ops_mode || (a.res && a.aux) || a.ldres % 8 || a.ldaux % 8)) return 0;
     const int tm = (a.M + 255) / 256;
     int best = 0;
     double best_cost = 0;
@@ -707,6 +726,7 @@ int p256_plan(const LinArgs& a) {
     for (int i = 0; i < 3; ++i) {
         const int bn = cand[i];
         if (a.N % bn) continue;
+        if (has_op && bn == 256) continue;
         if (mode > 2 && mode != bn) continue;
         const int tiles = tm * (a.N / bn);
         if (tiles < 256) continue;
@@ -1679,7 +1699,9 @@ int launch_tn_plan(int dtype, int M, int N, int K, const void* dy, int lddy, con
     // ones, at unchanged occupancy (200 / 160 registers); FMMT_TN_PF=1 selects the single-step prefetch
     static const int tn_pf = getenv("FMMT_TN_PF") ? atoi(getenv("FMMT_TN_PF")) : 3;
     if (dtype == FMMT_BF16) {
-        if (M <= 4096) return launch_tn<bf16, 32, true>(a, grid, st);
+        // few-token problems: FMMT_TN_FEW64=1 (A/B switch) takes 64-token steps with two register sets in flight
+        static const int few64 = getenv("FMMT_TN_FEW64") ? atoi(getenv("FMMT_TN_FEW64")) : 0;
+        if (M <= 4096) return few64 ? launch_tn<bf16, 64, true, 2>(a, grid, st) : launch_tn<bf16, 32, true>(a, grid, st);
         if (bms64) return tn_pf >= 2 ? launch_tn<bf16, 64, false, 2>(a, grid, st) : launch_tn<bf16, 64>(a, grid, st);
         return tn_pf >= 3 ? launch_tn<bf16, 32, false, 2>(a, grid, st) : launch_tn<bf16, 32>(a, grid, st);
     }

@@ -33,10 +33,38 @@ __device__ __forceinline__ int chan_of(int nt, int g, int r) {
     return (t0 < (CW / 8) * 8) ? (t0 / 8) * 32 + g * 8 + (t0 % 8) + r : (CW / 8) * 32 + g * 4 + r;
 }
 
+// The M x N epilogue operand of a wave tile (residual OR GELU' pre-activation; bf16) and the DropPath scale of its rows, loaded
+// into registers ahead of the epilogue: the persistent kernel issues these loads at the head of a tile's LAST K step, in front
+// of that step's DMA, so that the in-order vmcnt has them back when the accumulators are ready (an epilogue that loads its
+// operand itself stalls every wave of the workgroup for a full memory latency per tile -- a third of a K = 384 tile's life).
+template <int MT, int NT>
+struct EpiPre {
+    bf16x8 full[MT][NT / 2 > 0 ? NT / 2 : 1];
+    bf16x4 tail[MT];
+    float rs[MT];
+};
+template <int MT, int NT>
+__device__ __forceinline__ void nt_epilogue_prefetch(const LinArgs& p, EpiPre<MT, NT>& pre, int mbase, int nbase, int li, int lg) {
+    const bf16* __restrict__ src = reinterpret_cast<const bf16*>(p.epi == FMMT_EPI_GELU_BWD ? p.aux : p.res);
+    const int ld = p.epi == FMMT_EPI_GELU_BWD ? p.ldaux : p.ldres;
+#pragma unroll
+    for (int a = 0; a < MT; ++a) {
+        const int m = min(mbase + a * 16 + li, p.M - 1);     // ragged last panel: a valid row, never stored
+        pre.rs[a] = row_scale(p.rowscale, m, p.rows_per_scale);
+        if (src) {
+#pragma unroll
+            for (int c = 0; c < NT / 2; ++c)
+                pre.full[a][c] = *reinterpret_cast<const bf16x8*>(src + (size_t)m * ld + nbase + chan_of<4 * NT>(2 * c, lg, 0));
+            if constexpr (NT % 2) pre.tail[a] = *reinterpret_cast<const bf16x4*>(src + (size_t)m * ld + nbase + chan_of<4 * NT>(NT - 1, lg, 0));
+        }
+    }
+}
+
 // Epilogue of one wave tile (MT x NT MFMA tiles at rows mbase.., channels nbase..): bias, GELU / GELU',
 // DropPath row scale, residual, 16-byte stores; or raw fp32 partials for the split-K path.
-template <typename T, int MT, int NT, bool BIAS_DONE = false>
-__device__ __forceinline__ void nt_epilogue(const LinArgs& p, f32x4 (&acc)[MT][NT], int mbase, int nbase, int li, int lg) {
+template <typename T, int MT, int NT, bool BIAS_DONE = false, bool PRE = false>
+__device__ __forceinline__ void nt_epilogue(const LinArgs& p, f32x4 (&acc)[MT][NT], int mbase, int nbase, int li, int lg,
+                                            const EpiPre<MT, NT>* pre = nullptr) {
     constexpr int VEC = Vec<T>::N;
     T* __restrict__ yg = reinterpret_cast<T*>(p.y);
     T* __restrict__ ypre = reinterpret_cast<T*>(p.y_pre);
@@ -63,7 +91,9 @@ __device__ __forceinline__ void nt_epilogue(const LinArgs& p, f32x4 (&acc)[MT][N
         for (int a = 0; a < MT; ++a) {
             const int m = mbase + a * 16 + li;
             if (m >= p.M) continue;
-            const float rs = row_scale(p.rowscale, m, p.rows_per_scale);
+            float rs;
+            if constexpr (PRE) rs = pre->rs[a];
+            else rs = row_scale(p.rowscale, m, p.rows_per_scale);
 #pragma unroll
             for (int b0 = 0; b0 < NT; b0 += TPC) {
                 const int w = (NT - b0 >= TPC) ? VEC : 4;      // chunk width (compile-time after unrolling)
@@ -82,6 +112,16 @@ __device__ __forceinline__ void nt_epilogue(const LinArgs& p, f32x4 (&acc)[MT][N
                         }
                 }
                 auto load_chunk = [&](const T* base, int ld, float* out) {
+                    if constexpr (PRE) {                     // bf16 only: the operand is already in registers
+                        if (w == VEC) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) out[e] = (float)pre->full[a][b0 / 2][e];
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) out[e] = (float)pre->tail[a][e];
+                        }
+                        return;
+                    }
                     if (w == VEC) {
                         const Vec<T> t = ldvec<T>(base + (size_t)m * ld + n);
 #pragma unroll
