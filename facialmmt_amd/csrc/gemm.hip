@@ -455,6 +455,8 @@ void linear_nt_deep32_kernel(LinArgs p) {
 //    tile i * 256 + (b % 8) * 32 + b / 8 -- each XCD works on a contiguous run of 32 tiles, so a token panel is fetched
 //    into one XCD's L2 once per round.
 // ---------------------------------------------------------------------------------------------
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 // All fragment reads of one 32-deep K block (NT weight + 8 token fragments, ds_read_b128) and the wait for them as ONE inline-asm
 // statement.  Left to itself hipcc loads a token fragment, waits lgkmcnt(0), issues its four MFMAs, loads the next ... -- the
 // LDS latency is exposed once per four MFMAs; batched, once per 32-48.  (Same device as tn_read12 below.)
@@ -543,16 +545,24 @@ __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
             __builtin_amdgcn_global_load_lds((gptr_t*)bsrc, (lptr_t*)(bias_s + par * 256), 16, 0, 0);
         }
     };
-    auto wait_landed = [&](int ahead) {                    // the oldest stage in flight has landed; `ahead` younger ones may fly
-        if (ahead <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (ahead == 1) {
-            if (cnt_hi) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT_LO + 1) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT_LO) : "memory");
-        } else {
-            if (cnt_hi) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (CNT_LO + 1)) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CNT_LO) : "memory");
-        }
+    // The oldest stage in flight has landed when at most `ahead` younger stages -- and the `stores` epilogue stores this wave
+    // issued after them -- are still outstanding (FMMT_NT_P256_STORES=1; vmcnt counts stores too and retires in issue order).
+    // Comparing K = 384 with K = 1536 tiles of the same width puts the cost of a tile switch at 3.7 K steps (38 % of a K = 384
+    // tile's life); the write acknowledgements the first wait after an epilogue sits out were the suspect -- measured, same call:
+    // no difference with the stores left in flight, so the default keeps the plain count.
+    constexpr int NS = 8 * ((NT + 1) / 2);                 // store instructions per wave and output tensor: per token fragment NT/2 x 16 B (+ 8 B tail)
+    auto wait_landed = [&](int ahead, int stores) {
+        auto go = [&](auto A) {
+            constexpr int a = decltype(A)::value;
+            if (stores == 0) { if (cnt_hi) wait_vm<a * (CNT_LO + 1)>(); else wait_vm<a * CNT_LO>(); }
+            else if (stores == 1) { if (cnt_hi) wait_vm<a * (CNT_LO + 1) + NS>(); else wait_vm<a * CNT_LO + NS>(); }
+            else { if (cnt_hi) wait_vm<a * (CNT_LO + 1) + 2 * NS>(); else wait_vm<a * CNT_LO + 2 * NS>(); }
+        };
+        if (ahead <= 0) go(std::integral_constant<int, 0>{});
+        else if (ahead == 1) go(std::integral_constant<int, 1>{});
+        else go(std::integral_constant<int, 2>{});
     };
+    static_assert(2 * (CNT_LO + 2) + 2 * NS <= 63, "vmcnt immediate");
     static_assert(NBUF >= 2 && NBUF <= 4, "ring depth");
     static_assert(NI % 8 == 0 || NI % 8 <= 7, "wave 7 never owns a high count plus the bias slab");
 
@@ -632,9 +642,11 @@ __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
         if (s < nsteps) issue_next();
     // compute-side cursor
     int ct = first, ck = 0, cpar = 0, cslot = 0;
+    int st_pending = 0;                                    // output tensors this wave stored since its last wait (0, 1, 2)
     EpiPre<MT, NT> pre;
     for (int s = 0; s < nsteps; ++s) {
-        wait_landed(min(nsteps - 1 - s, NBUF - 2));
+        wait_landed(min(nsteps - 1 - s, NBUF - 2), st_pending);
+        st_pending = 0;
         __builtin_amdgcn_s_barrier();                      // every wave's part of stage s is in LDS; stage s - 1 is free
         if constexpr (HASOP) {
             // residual / GELU' operand / DropPath scale of THIS tile: loaded now, in front of this step's DMA, used after the
@@ -660,6 +672,8 @@ __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
             for (int a = 0; a < MT; ++a)
 #pragma unroll
                 for (int b = 0; b < NT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // a wave whose 128 rows are all inside M issued exactly NS stores per output tensor (ragged panel: unknown -> 0)
+            if (p.reserved && m0 + wm * 128 + 128 <= p.M) st_pending = (p.epi == FMMT_EPI_GELU && p.y_pre) ? 2 : 1;
             ck = 0;
             ct += G;
             cpar ^= 1;
@@ -680,6 +694,8 @@ int launch_p256_b(const LinArgs& a, hipStream_t st) {
     LinArgs p = a;
     p.tiles_m = (a.M + 255) / 256;
     p.tiles_n = a.N / BN;
+    static const int st_aware = getenv("FMMT_NT_P256_STORES") ? atoi(getenv("FMMT_NT_P256_STORES")) : 0;
+    p.reserved = st_aware;                                 // 1: the wait after an epilogue leaves its stores in flight (A/B switch; measured: no difference)
     hipLaunchKernelGGL((linear_nt_p256_kernel<BN, BK, NBUF, BATCH, HASOP>), dim3(256), dim3(512), lds, st, p);
     FMMT_CHECK_LAUNCH();
     return 0;
@@ -1144,6 +1160,161 @@ int launch_tn(const TnArgs& a, dim3 grid, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Few-token TN kernel (bf16; the fusion stack's and the embedding heads' weight gradients: 150-2048 tokens, N and K
+// multiples of 64).  With so few tokens one (output tile, all tokens) workgroup is a CHAIN of dependent load -> MFMA steps
+// (640 tokens = 20 steps of 32: 17 us for 0.75 GFLOP), and splitting the tokens over workgroups costs a second launch.
+// Here the eight waves of a workgroup split the tokens of one 64 x 64 output tile among themselves -- each wave stages its
+// own 32-token slabs in a wave-private LDS region (no barriers: a wave's LDS operations execute in order), 80 tokens per
+// wave for 640 -- and add their accumulators in a fixed-order tree through LDS at the end.  One launch, deterministic.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void linear_tn_few_kernel(TnArgs p) {
+    using T = bf16;
+    constexpr int WS = 2 * 32 * 64;                        // elements of a wave's staging region: dy slab, x slab (32 tokens x 64 channels)
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // 80 KB: 8 staging regions (64 KB); the reduction tree reuses it
+    T* stage = reinterpret_cast<T*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int tile_n = blockIdx.x / p.tiles_k, tile_k = blockIdx.x % p.tiles_k;
+    const int n0 = tile_n * 64, k0 = tile_k * 64;
+    if (p.hdr && blockIdx.x == 0 && tid == 0) { p.hdr[0] = 1; p.hdr[1] = 0; }
+    const T* __restrict__ dyg = reinterpret_cast<const T*>(p.dy);
+    const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
+    const bool do_bias = p.part_b != nullptr && tile_k == 0;
+    const int mbeg = wave * p.chunk, mend = min(p.M, mbeg + p.chunk);
+    const int nsteps = mend > mbeg ? (mend - mbeg + 31) / 32 : 0;
+    T* my = stage + wave * WS;
+
+    // a lane moves 16 bytes: token row lane / 8 (+ 8 i), 16-byte chunk lane % 8 of the 128-byte slab row
+    const int lr = lane >> 3, lc = lane & 7;
+    auto f = [](int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); };   // 32-byte block permutation: conflict-free transpose reads
+    bf16x8 ra[4], rb[4];
+    auto load = [&](int m0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + lr + 8 * i;
+            if (m < mend) {
+                ra[i] = *reinterpret_cast<const bf16x8*>(dyg + (size_t)m * p.lddy + n0 + lc * 8);
+                rb[i] = *reinterpret_cast<const bf16x8*>(xg + (size_t)m * p.ldx + k0 + lc * 8);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { ra[i][e] = (bf16)0.f; rb[i][e] = (bf16)0.f; }
+            }
+        }
+    };
+    auto put = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = lr + 8 * i;
+            const int o = r * 64 + ((((lc >> 1) ^ f(r)) << 1) | (lc & 1)) * 8;
+            *reinterpret_cast<bf16x8*>(my + o) = ra[i];
+            *reinterpret_cast<bf16x8*>(my + 32 * 64 + o) = rb[i];
+        }
+    };
+    auto frag = [&](const T* base, int c0) {
+        const int r = lg * 8 + (li >> 2);
+        const T* a0 = base + r * 64 + (((c0 >> 4) ^ f(r)) << 4) + (li & 3) * 4;
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * 64));          // row + 4: same permutation
+        union { struct { s16x4 lo, hi; } s; bf16x8 v; } u;
+        u.s.lo = lo;
+        u.s.hi = hi;
+        return u.v;
+    };
+
+    f32x4 acc[4][4], accb[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        accb[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+
+    if (nsteps > 0) load(mbeg);
+    for (int s = 0; s < nsteps; ++s) {
+        put();                                             // after the previous step's fragment reads: same wave, in order
+        if (s + 1 < nsteps) load(mbeg + (s + 1) * 32);     // in flight under this step's MFMAs
+        bf16x8 af[4], bf_[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) af[a] = frag(my, a * 16);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) bf_[b] = frag(my + 32 * 64, b * 16);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf_[b], acc[a][b], 0, 0, 0);
+            if (do_bias) accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], ones, accb[a], 0, 0, 0);
+        }
+    }
+
+    // fixed-order tree over the eight waves: (0+4, 1+5, 2+6, 3+7), then (0+2, 1+3), then 0+1.  A sender parks its 20 fragments
+    // (16 of the tile + 4 bias sums: 20 KB) in LDS; the staging bytes are free once every wave has left the loop.
+    float* red = reinterpret_cast<float*>(smem);           // 4 senders x 20 x 256 floats = 80 KB
+#pragma unroll
+    for (int half = 4; half >= 1; half >>= 1) {
+        __syncthreads();
+        if (wave >= half && wave < 2 * half) {
+            float* dst = red + (size_t)(wave - half) * (20 * 256) + lane * 4;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) *reinterpret_cast<f32x4*>(dst + (a * 4 + b) * 256) = acc[a][b];
+                *reinterpret_cast<f32x4*>(dst + (16 + a) * 256) = accb[a];
+            }
+        }
+        __syncthreads();
+        if (wave < half) {
+            const float* src = red + (size_t)wave * (20 * 256) + lane * 4;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] += *reinterpret_cast<const f32x4*>(src + (a * 4 + b) * 256);
+                accb[a] += *reinterpret_cast<const f32x4*>(src + (16 + a) * 256);
+            }
+        }
+    }
+    if (wave != 0) return;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int k = k0 + b * 16 + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p.part_w[(size_t)(n0 + a * 16 + lg * 4 + r) * p.K + k] = acc[a][b][r];
+        }
+    if (do_bias && li == 0) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p.part_b[n0 + a * 16 + lg * 4 + r] = accb[a][r];
+    }
+}
+
+int launch_tn_few(int M, int N, int K, const void* dy, int lddy, const void* x, int ldx, float* dw, float* db, int* hdr, hipStream_t st) {
+    constexpr int lds = 80 * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_tn_few_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    TnArgs a{M, N, K, dy, lddy, x, ldx, dw, db, nullptr, 1, K / 64, (M + 7) / 8, N / 64, 0, 0, hdr, 1};
+    hipLaunchKernelGGL(linear_tn_few_kernel, dim3((N / 64) * (K / 64)), dim3(512), lds, st, a);
+    FMMT_CHECK_LAUNCH();
+    return 0;
+}
+
+// eligibility of linear_tn_few_kernel: bf16, 129..2048 tokens, whole 64 x 64 tiles, at least 8 of them, 16-byte rows
+bool tn_few_ok(int M, int N, int K, int dtype) {
+    static const int on = getenv("FMMT_TN_FEW") ? atoi(getenv("FMMT_TN_FEW")) : 1;
+    return on && dtype == FMMT_BF16 && M > 128 && M <= 2048 && N % 64 == 0 && K % 64 == 0 && (N / 64) * (K / 64) >= 8;
+}
+
+// ---------------------------------------------------------------------------------------------
 // DMA-staged TN kernel (bf16 weight gradients of the many-token launches without DropPath scale): the ring of the persistent NT
 // kernel applied to the token contraction.  One 8-wave workgroup per CU owns one (output tile, token split): TNn (256 / 192)
 // output rows (channels of dy) x 128 output columns (channels of x); waves 4 x 2, wave tile TNn/4 x 64.
@@ -1167,7 +1338,6 @@ __device__ __forceinline__ int tn_sigma(int row, int blk) {
     else return blk ^ tn_swz(row);                          // 8 or 16 blocks: low three bits
 }
 
-template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // The twelve transposing fragment reads of one 32-token stage (24 ds_read_b64_tr_b16) and the wait for them, as ONE inline-asm
 // statement.  Why not the builtin: hipcc's wait-count insertion treats a ds_read_tr intrinsic as possibly aliasing every LDS-DMA
@@ -1676,6 +1846,8 @@ int launch_tn_plan(int dtype, int M, int N, int K, const void* dy, int lddy, con
                    const float* rowscale, int rows_per_scale, int x_epi, int* hdr, hipStream_t st) {
     static const int tn_xcd = getenv("FMMT_TN_XCD") ? atoi(getenv("FMMT_TN_XCD")) : 1;
     if (x_epi != 0 && x_epi != FMMT_EPI_GELU) return FMMT_EINVAL;
+    if (tn_few_ok(M, N, K, dtype) && !rowscale && !x_epi && lddy % 8 == 0 && ldx % 8 == 0)
+        return launch_tn_few(M, N, K, dy, lddy, x, ldx, part_w, part_b, hdr, st);     // one split: part_w / part_b may be dw / db themselves
     if (dtype == FMMT_BF16 && hdr && !x_epi && lddy % 8 == 0 && ldx % 8 == 0) {
         const TnPlan pd = tn_plan_dma(M, N, K);
         // scaled launches: the split's slice of the scale vector has to fit the 4 KB behind the ring
@@ -1752,7 +1924,8 @@ extern "C" int fmmt_linear_wgrad(int dtype, int M, int N, int K,
                                  float* dw, float* db, const float* rowscale, int rows_per_scale, int x_epi,
                                  void* workspace, size_t workspace_bytes, void* stream) {
     if (!aligned16(dw)) return FMMT_EALIGN;
-    if (M > 0 && N > 0 && K > 0 && (dtype == FMMT_BF16 || dtype == FMMT_F32) && tn_smax(M, N, K, dtype) == 1) {
+    const bool few = M > 0 && N > 0 && K > 0 && tn_few_ok(M, N, K, dtype) && !rowscale && !x_epi && lddy % 8 == 0 && ldx % 8 == 0;
+    if (M > 0 && N > 0 && K > 0 && (dtype == FMMT_BF16 || dtype == FMMT_F32) && (few || tn_smax(M, N, K, dtype) == 1)) {
         // single split: the "partials" ARE the result -- let the contraction kernel write dw / db directly
         const int vec = dtype == FMMT_BF16 ? 8 : 4;
         if (N % vec || K % vec || lddy % vec || ldx % vec) return FMMT_EINVAL;

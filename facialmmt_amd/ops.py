@@ -73,8 +73,9 @@ def wgrad_raw(dy2, x2, want_bias, rowscale=None, rows_per_scale=1, x_gelu=False)
     db = torch.empty((N,), dtype=torch.float32, device=dy2.device) if want_bias else None
     nbytes = lib.fmmt_linear_wgrad_workspace(dtype_code(dy2.dtype), M, N, K)
     ws = _ws(nbytes, dy2.device)
-    if M <= 768:
-        # few-token problems: one entry point (single split -> the contraction kernel writes dw / db itself, no reduce launch)
+    if M <= 2048:
+        # few-token problems: one entry point (single split -> the contraction kernel writes dw / db itself, no reduce launch;
+        # 769..2048 tokens: one launch where linear_tn_few_kernel applies, partials + finish inside the library otherwise)
         rc = lib.fmmt_linear_wgrad(dtype_code(dy2.dtype), M, N, K, _p(dy2), N, _p(x2), K, _p(dw), _p(db), _p(rowscale), rows_per_scale,
                                    EPI_GELU if x_gelu else EPI_NONE, _p(ws), nbytes, _st())
         check(rc, f"fmmt_linear_wgrad(M={M},N={N},K={K})")

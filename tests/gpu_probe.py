@@ -102,7 +102,8 @@ def t_linear_large():
 def t_wgrad():
     for dt, tol in ((torch.float32, 2e-5), (torch.bfloat16, 2e-2)):
         for (M, N, K) in [(500, 96, 96), (3136, 288, 96), (777, 384, 96), (1000, 96, 384), (100, 512, 1024), (6272, 96, 48),
-                          (1, 96, 96), (7, 768, 768), (769, 768, 768), (5000, 96, 384)]:     # single token; both sides of the 768-row direct/split boundary
+                          (1, 96, 96), (7, 768, 768), (769, 768, 768), (5000, 96, 384),      # single token; both sides of the 768-row direct/split boundary
+                          (640, 768, 768), (664, 1536, 768), (2048, 768, 1024), (1328, 3072, 768), (129, 512, 512), (2047, 512, 576), (1000, 448, 512)]:   # linear_tn_few_kernel (bf16): wave-split tokens, ragged tails
             dy = rnd("dy", (M, N), 1, dtype=dt)
             x = rnd("x", (M, K), 2, dtype=dt)
             dw, db = ops.wgrad_raw(dy, x, True)
