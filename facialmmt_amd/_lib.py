@@ -44,6 +44,7 @@ SIGNATURES = {
     "fmmt_scale": (_i, [_i, _sz, _p, _f, _p, _p]),
     "fmmt_colsum": (_i, [_i, _i, _i, _i, _p, _i, _p, _p]),
     "fmmt_cast_batch": (_i, [_i, _i, _p, _p]),
+    "fmmt_adamw_batch": (_i, [_i, _i, _p, _p, _p, _p, _f, _f, _f, _f, _f, _p]),
     "fmmt_resize_table": (_i, [_i, _i, _i, _p, _p]),
     "fmmt_resize_band_rows": (_i, [_p, _i]),
     "fmmt_patch_embed_u8": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p]),

@@ -216,6 +216,80 @@ __global__ __launch_bounds__(256) void cast_batch_kernel(const CastDesc* __restr
         }
     }
 }
+
+// Clip + AdamW + low-precision shadow in ONE launch over every tensor the step's optimizer updates (train.py:135-143:
+// clip_grad_norm_ -> optimizer.step(); AdamW as torch.optim.AdamW: decoupled weight decay, bias-corrected moments, no amsgrad).
+//   coef = min(1, max_norm / (total_norm + 1e-6))            (torch.nn.utils.clip_grad_norm_)
+//   g' = coef g;  p *= 1 - lr wd;  m = b1 m + (1 - b1) g';  v = b2 v + (1 - b2) g'^2
+//   p -= (lr / (1 - b1^t)) m / (sqrt(v) / sqrt(1 - b2^t) + eps);   low = bf16(p) where the tensor has a bf16 twin
+// lr, t and total_norm are device scalars (graph replays), the gradients are read once and NOT written back: against
+// clip_grad_norm_ + fused AdamW + the multi-tensor re-rounding of the bf16 text encoder this saves the scaling pass over the
+// gradients (read + write) and one pass over the fp32 parameters.
+struct AdamDesc {
+    float* p; const float* g; float* m; float* v; bf16* low;    // low may be null
+    long long n;
+    int blk_begin, pad;
+};
+__global__ __launch_bounds__(256) void adamw_batch_kernel(const AdamDesc* __restrict__ desc, int n_desc, const float* __restrict__ lr_p,
+                                                          const float* __restrict__ step_p, const float* __restrict__ norm_p,
+                                                          float beta1, float beta2, float eps, float wd, float max_norm) {
+    int lo = 0, hi = n_desc - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (desc[mid].blk_begin <= (int)blockIdx.x) lo = mid;
+        else hi = mid - 1;
+    }
+    const AdamDesc d = desc[lo];
+    const float lr = *lr_p, t = *step_p;
+    const float coef = norm_p ? fminf(1.0f, max_norm / (*norm_p + 1e-6f)) : 1.0f;
+    const float bc1 = 1.0f - powf(beta1, t), bc2s = sqrtf(1.0f - powf(beta2, t));
+    const float step_size = lr / bc1, decay = 1.0f - lr * wd;
+    const long long base = (long long)((int)blockIdx.x - d.blk_begin) * 4096;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long long o = base + (long long)(i * 256 + threadIdx.x) * 4;
+        if (o >= d.n) break;
+        if (o + 4 <= d.n && ((reinterpret_cast<uintptr_t>(d.p + o) | reinterpret_cast<uintptr_t>(d.g + o) | reinterpret_cast<uintptr_t>(d.m + o) |
+                              reinterpret_cast<uintptr_t>(d.v + o)) & 15) == 0) {
+            f32x4 p = *reinterpret_cast<const f32x4*>(d.p + o), g = *reinterpret_cast<const f32x4*>(d.g + o);
+            f32x4 m = *reinterpret_cast<const f32x4*>(d.m + o), v = *reinterpret_cast<const f32x4*>(d.v + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float ge = g[e] * coef;
+                p[e] *= decay;
+                m[e] = beta1 * m[e] + (1.0f - beta1) * ge;
+                v[e] = beta2 * v[e] + (1.0f - beta2) * ge * ge;
+                p[e] -= step_size * (m[e] / (sqrtf(v[e]) / bc2s + eps));
+            }
+            *reinterpret_cast<f32x4*>(d.p + o) = p;
+            *reinterpret_cast<f32x4*>(d.m + o) = m;
+            *reinterpret_cast<f32x4*>(d.v + o) = v;
+            if (d.low) {
+                if ((reinterpret_cast<uintptr_t>(d.low + o) & 7) == 0) {
+                    bf16x4 l;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) l[e] = (bf16)p[e];
+                    *reinterpret_cast<bf16x4*>(d.low + o) = l;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) d.low[o + e] = (bf16)p[e];
+                }
+            }
+        } else {
+            for (long long j = o; j < d.n && j < o + 4; ++j) {
+                const float ge = d.g[j] * coef;
+                float p = d.p[j] * decay;
+                const float m = beta1 * d.m[j] + (1.0f - beta1) * ge;
+                const float v = beta2 * d.v[j] + (1.0f - beta2) * ge * ge;
+                p -= step_size * (m / (sqrtf(v) / bc2s + eps));
+                d.p[j] = p;
+                d.m[j] = m;
+                d.v[j] = v;
+                if (d.low) d.low[j] = (bf16)p;
+            }
+        }
+    }
+}
 }  // namespace
 
 extern "C" int fmmt_version(void) { return 1; }
@@ -325,6 +399,15 @@ extern "C" int fmmt_cast_batch(int n_desc, int n_tiles, const void* desc, void* 
     if (n_desc <= 0 || n_tiles <= 0 || !desc) return FMMT_EINVAL;
     hipLaunchKernelGGL(cast_batch_kernel, dim3((unsigned)n_tiles), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        reinterpret_cast<const CastDesc*>(desc), n_desc);
+    FMMT_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int fmmt_adamw_batch(int n_desc, int n_blocks, const void* desc, const float* lr, const float* step, const float* total_norm,
+                                float beta1, float beta2, float eps, float weight_decay, float max_norm, void* stream) {
+    if (n_desc <= 0 || n_blocks <= 0 || !desc || !lr || !step) return FMMT_EINVAL;
+    hipLaunchKernelGGL(adamw_batch_kernel, dim3((unsigned)n_blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const AdamDesc*>(desc), n_desc, lr, step, total_norm, beta1, beta2, eps, weight_decay, max_norm);
     FMMT_CHECK_LAUNCH();
     return 0;
 }

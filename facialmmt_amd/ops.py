@@ -230,6 +230,12 @@ def colsum_raw(x2, out_dtype=None):
     return out
 
 
+def adamw_batch(n, blocks, desc, lr, step, total_norm, beta1, beta2, eps, weight_decay, max_norm):
+    """fmmt_adamw_batch: clip + AdamW + bf16 twins over the tensors of a descriptor table (train_step.FusedClipAdamW)"""
+    check(_lib.load().fmmt_adamw_batch(n, blocks, _p(desc), _p(lr), _p(step), _p(total_norm), float(beta1), float(beta2), float(eps),
+                                       float(weight_decay), float(max_norm), _st()), "fmmt_adamw_batch")
+
+
 class VendorLinearFn(torch.autograd.Function):
     """y = x W^T + b with the vendor library's GEMMs (torch.nn.functional.linear / matmul) and fmmt_colsum for the bias gradient:
     the text encoder's Linear layers (few thousand tokens: hipBLASLt's ground; its autograd formula spends a memset and a

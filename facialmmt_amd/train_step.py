@@ -436,6 +436,58 @@ def _reset_optimizer_state(opt):
                 v.zero_()
 
 
+class FusedClipAdamW:
+    """clip_grad_norm_ + torch.optim.AdamW.step() (+ the bf16 re-rounding of parameters stepped through fp32 masters) as one
+    multi-tensor norm and ONE kernel launch (fmmt_adamw_batch): the gradients are read once and not scaled in place, the fp32
+    parameters are not read a second time for their bf16 twins.  Takes its hyper-parameters from an existing torch AdamW
+    (one parameter group, tensor learning rate on the device as `capturable=True` keeps it, so a LambdaLR scheduler keeps
+    working); keeps its own moments and step counter -- `optimizer.state` stays empty while this is in use."""
+
+    @staticmethod
+    def eligible(opt, params):
+        import os
+        if os.environ.get("FMMT_FUSED_ADAMW", "1") == "0" or type(opt) is not torch.optim.AdamW or len(opt.param_groups) != 1:
+            return False
+        g = opt.param_groups[0]
+        return (torch.is_tensor(g["lr"]) and g["lr"].is_cuda and not g.get("amsgrad", False) and not g.get("maximize", False)
+                and all(p.dtype == torch.float32 and p.is_cuda for p in params))
+
+    def __init__(self, opt, params, grad_of, low_of, max_norm):
+        import numpy as np
+        g = opt.param_groups[0]
+        self.lr, (self.b1, self.b2), self.eps, self.wd = g["lr"], g["betas"], g["eps"], g["weight_decay"]
+        self.max_norm = float(max_norm)
+        dev = params[0].device
+        self.step = torch.zeros((), dtype=torch.float32, device=dev)
+        self.grads = [grad_of[p] for p in params]
+        self.m = [torch.zeros_like(p) for p in params]
+        self.v = [torch.zeros_like(p) for p in params]
+        self.norm = torch.zeros((), dtype=torch.float32, device=dev)
+        recs, blocks = [], 0
+        self.keep = (params, [low_of.get(id(p)) for p in params])
+        for p, gr, m, v, low in zip(params, self.grads, self.m, self.v, self.keep[1]):
+            assert gr.dtype == torch.float32 and gr.is_contiguous() and p.is_contiguous() and (low is None or (low.dtype == torch.bfloat16 and low.is_contiguous()))
+            recs.append((p.data_ptr(), gr.data_ptr(), m.data_ptr(), v.data_ptr(), low.data_ptr() if low is not None else 0, p.numel(), blocks, 0))
+            blocks += (p.numel() + 4095) // 4096
+        arr = np.zeros(len(recs), dtype=np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("low", "<u8"), ("n", "<i8"), ("bb", "<i4"), ("pad", "<i4")]))
+        for i, r in enumerate(recs):
+            arr[i] = r
+        self.desc = torch.from_numpy(arr.view(np.uint8).copy()).to(dev)
+        self.n, self.blocks = len(recs), blocks
+
+    def reset(self):
+        self.step.zero_()
+        torch._foreach_zero_(self.m)
+        torch._foreach_zero_(self.v)
+
+    @torch.no_grad()
+    def update(self):
+        from . import ops
+        self.step.add_(1.0)
+        self.norm.copy_(torch.nn.utils.get_total_norm(self.grads, 2.0, foreach=True))
+        ops.adamw_batch(self.n, self.blocks, self.desc, self.lr, self.step, self.norm, self.b1, self.b2, self.eps, self.wd, self.max_norm)
+
+
 def _pin_shadows(modules):
     """ops.PinnedShadows over the parameters of `modules` (FMMT_PIN_SHADOWS=0: per-weight casts inside the graph, as before)"""
     import os
@@ -507,6 +559,9 @@ class GraphedTargetStep:
         self.pairs = [(low_of.get(id(p), p), p) for p in self.flat.params]     # (parameter the model differentiates, parameter the optimizer steps)
         for l, m in self.pairs:
             l.grad = None
+        self.fused = None
+        if FusedClipAdamW.eligible(optimizer, self.flat.params):
+            self.fused = FusedClipAdamW(optimizer, self.flat.params, self.flat_view_of, low_of, args.clip)
         self.accumulate = args.trg_accumulation_steps > 1
         self.mm.text_stream = None
         # inside ONE graph the fork / join below become parallel branches; which hardware queue the branches replay on is the
@@ -532,6 +587,8 @@ class GraphedTargetStep:
         _restore(snap)
         del snap
         _reset_optimizer_state(self.opt)
+        if self.fused is not None:
+            self.fused.reset()
         self.flat.zero_grad()
         torch.cuda.set_rng_state(rng, dev)
         # -- capture
@@ -578,12 +635,15 @@ class GraphedTargetStep:
         return loss.detach(), new_mask
 
     def _update(self):
-        for p in self.flat.params:                           # the optimizer reads the static flat buffers
-            p.grad = self.flat_view_of[p]
-        torch.nn.utils.clip_grad_norm_(self.flat.params, self.args.clip)
-        self.opt.step()
-        if self.masters is not None:
-            self.masters.sync_low()
+        if self.fused is not None:                           # norm + one launch: clip, AdamW, bf16 twins (FusedClipAdamW)
+            self.fused.update()
+        else:
+            for p in self.flat.params:                       # the optimizer reads the static flat buffers
+                p.grad = self.flat_view_of[p]
+            torch.nn.utils.clip_grad_norm_(self.flat.params, self.args.clip)
+            self.opt.step()
+            if self.masters is not None:
+                self.masters.sync_low()
         if self.accumulate:
             self.flat.zero_grad()
         for l, _ in self.pairs:                              # the next backward must produce fresh gradient tensors

@@ -229,6 +229,16 @@ int fmmt_colsum(int dtype, int out_dtype, int M, int N, const void* x, int ldx, 
  * tile_begin = tiles of all earlier records; n_tiles = their total.  The caller builds the table once. */
 int fmmt_cast_batch(int n_desc, int n_tiles, const void* desc, void* stream);
 
+/* Gradient clipping + AdamW + bf16 re-rounding of the parameters in one launch over every tensor of the step's optimizer.
+ * Replaces `clip_grad_norm_(model.parameters(), clip)` (its scaling pass; the norm itself is the caller's, a device scalar) and
+ * `optimizer.step()` with torch.optim.AdamW semantics (train.py:135-143, 336-349), and the re-rounding of bf16 parameters that
+ * are stepped through fp32 masters.  desc: DEVICE array of n_desc records
+ *   { float* p; const float* g; float* m; float* v; bf16* low_or_null; int64 n; int32 blk_begin, pad; }      (56 bytes)
+ * one block per 4096 elements, blk_begin = blocks of all earlier records, n_blocks = their total.  lr, step (the 1-based
+ * step count t as a float) and total_norm (may be NULL: no clipping) are DEVICE scalars, so the call can sit in a HIP graph. */
+int fmmt_adamw_batch(int n_desc, int n_blocks, const void* desc, const float* lr, const float* step, const float* total_norm,
+                     float beta1, float beta2, float eps, float weight_decay, float max_norm, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Input pre-step fused into PatchEmbed's gather.  Replaces, for one batch of square uint8 face
  * crops (n, S, S, 3) in image (HWC) layout, the chain the reference runs per frame on the host and caches as a

@@ -153,3 +153,44 @@ def test_bf16_text_encoder_with_fp32_masters_tracks_fp32_run():
         assert abs(a - b) <= 3e-2 * max(1.0, abs(a)), (l0, l1)
     moved = [k for k in p0 if not k.startswith("roberta.") and (p0[k] - p1[k]).abs().max().item() > 5e-2 * max(1.0, p0[k].abs().max().item())]
     assert not moved, moved[:5]
+
+
+def test_fused_clip_adamw_matches_torch():
+    """train_step.FusedClipAdamW (fmmt_adamw_batch) against clip_grad_norm_ + torch.optim.AdamW over four steps with a moving
+    learning rate: fp32 parameters of odd sizes and unaligned views, one of them with a bf16 twin; a step that clips and one
+    that does not"""
+    from facialmmt_amd.train_step import FusedClipAdamW
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(3)
+    shapes = [(1024, 300), (7,), (4097,), (33, 5), (5000,)]
+    base = torch.randn(20000, generator=g).to(dev)
+    ref = [torch.nn.Parameter(torch.randn(sh, generator=g).to(dev)) for sh in shapes]
+    mine = [torch.nn.Parameter(p.detach().clone()) for p in ref[:-1]] + [torch.nn.Parameter(base[3:5003].detach())]   # a 12-byte-offset view
+    with torch.no_grad():
+        mine[-1].copy_(ref[-1])
+    low = mine[0].detach().to(torch.bfloat16)
+    grads = {p: torch.zeros_like(p) for p in mine}
+    lr = torch.tensor(1e-2, device=dev)
+    opt_ref = torch.optim.AdamW(ref, lr=1e-2, weight_decay=0.05, betas=(0.9, 0.98), eps=1e-6)
+    opt_mine = torch.optim.AdamW(mine, lr=lr, weight_decay=0.05, betas=(0.9, 0.98), eps=1e-6, fused=True, capturable=True)
+    assert FusedClipAdamW.eligible(opt_mine, mine)
+    fused = FusedClipAdamW(opt_mine, mine, grads, {id(mine[0]): low}, max_norm=1.0)
+    for step in range(4):
+        scale = 10.0 if step % 2 == 0 else 1e-3                  # clipped / not clipped
+        for pr, pm in zip(ref, mine):
+            gr = torch.randn(pr.shape, generator=g).to(dev) * scale
+            pr.grad = gr.clone()
+            grads[pm].copy_(gr)
+        cur = 1e-2 * (step + 1) / 4
+        for grp in opt_ref.param_groups:
+            grp["lr"] = cur
+        lr.fill_(cur)
+        torch.nn.utils.clip_grad_norm_(ref, 1.0)
+        opt_ref.step()
+        fused.update()
+    torch.cuda.synchronize()
+    for pr, pm in zip(ref, mine):
+        assert torch.allclose(pr, pm, rtol=2e-6, atol=2e-7), (pr - pm).abs().max()
+    assert torch.equal(low, mine[0].detach().to(torch.bfloat16))
+    fused.reset()
+    assert float(fused.step) == 0 and all(float(m.abs().max()) == 0 for m in fused.m)
