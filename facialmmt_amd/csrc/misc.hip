@@ -226,9 +226,9 @@ __global__ __launch_bounds__(256) void cast_batch_kernel(const CastDesc* __restr
 // clip_grad_norm_ + fused AdamW + the multi-tensor re-rounding of the bf16 text encoder this saves the scaling pass over the
 // gradients (read + write) and one pass over the fp32 parameters.
 struct AdamDesc {
-    float* p; const float* g; float* m; float* v; bf16* low;    // low may be null
+    float* p; const void* g; float* m; float* v; bf16* low;     // low may be null
     long long n;
-    int blk_begin, pad;
+    int blk_begin, g_bf16;                                      // g_bf16: the gradient is bf16 (the twin's own .grad), else fp32
 };
 __global__ __launch_bounds__(256) void adamw_batch_kernel(const AdamDesc* __restrict__ desc, int n_desc, const float* __restrict__ lr_p,
                                                           const float* __restrict__ step_p, const float* __restrict__ norm_p,
@@ -249,9 +249,19 @@ __global__ __launch_bounds__(256) void adamw_batch_kernel(const AdamDesc* __rest
     for (int i = 0; i < 4; ++i) {
         const long long o = base + (long long)(i * 256 + threadIdx.x) * 4;
         if (o >= d.n) break;
-        if (o + 4 <= d.n && ((reinterpret_cast<uintptr_t>(d.p + o) | reinterpret_cast<uintptr_t>(d.g + o) | reinterpret_cast<uintptr_t>(d.m + o) |
-                              reinterpret_cast<uintptr_t>(d.v + o)) & 15) == 0) {
-            f32x4 p = *reinterpret_cast<const f32x4*>(d.p + o), g = *reinterpret_cast<const f32x4*>(d.g + o);
+        const float* gf = reinterpret_cast<const float*>(d.g);
+        const bf16* gb = reinterpret_cast<const bf16*>(d.g);
+        const bool g_ok = d.g_bf16 ? (reinterpret_cast<uintptr_t>(gb + o) & 7) == 0 : (reinterpret_cast<uintptr_t>(gf + o) & 15) == 0;
+        if (o + 4 <= d.n && g_ok && ((reinterpret_cast<uintptr_t>(d.p + o) | reinterpret_cast<uintptr_t>(d.m + o) |
+                                       reinterpret_cast<uintptr_t>(d.v + o)) & 15) == 0) {
+            f32x4 p = *reinterpret_cast<const f32x4*>(d.p + o), g;
+            if (d.g_bf16) {
+                const bf16x4 t = *reinterpret_cast<const bf16x4*>(gb + o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] = (float)t[e];
+            } else {
+                g = *reinterpret_cast<const f32x4*>(gf + o);
+            }
             f32x4 m = *reinterpret_cast<const f32x4*>(d.m + o), v = *reinterpret_cast<const f32x4*>(d.v + o);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -277,7 +287,7 @@ __global__ __launch_bounds__(256) void adamw_batch_kernel(const AdamDesc* __rest
             }
         } else {
             for (long long j = o; j < d.n && j < o + 4; ++j) {
-                const float ge = d.g[j] * coef;
+                const float ge = (d.g_bf16 ? (float)gb[j] : gf[j]) * coef;
                 float p = d.p[j] * decay;
                 const float m = beta1 * d.m[j] + (1.0f - beta1) * ge;
                 const float v = beta2 * d.v[j] + (1.0f - beta2) * ge * ge;

@@ -631,6 +631,8 @@ class GraphedTargetStep:
             logits = mm.fusion_branch(pending[0], pending[1], audio, audio_mask, vis_concat, new_mask)
         loss = F.cross_entropy(logits.float(), labels) / args.trg_accumulation_steps
         loss.backward()
+        # (Letting the fused update read the model's own .grad tensors instead -- no hand-over, 2.8 GB less traffic -- was
+        #  tried: the ~870 gradient tensors then stay allocated across the graph and the step got 2.8 ms SLOWER; not kept.)
         _hand_over_gradients(self.pairs, self.flat_view_of, self.accumulate)
         return loss.detach(), new_mask
 

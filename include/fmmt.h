@@ -233,7 +233,7 @@ int fmmt_cast_batch(int n_desc, int n_tiles, const void* desc, void* stream);
  * Replaces `clip_grad_norm_(model.parameters(), clip)` (its scaling pass; the norm itself is the caller's, a device scalar) and
  * `optimizer.step()` with torch.optim.AdamW semantics (train.py:135-143, 336-349), and the re-rounding of bf16 parameters that
  * are stepped through fp32 masters.  desc: DEVICE array of n_desc records
- *   { float* p; const float* g; float* m; float* v; bf16* low_or_null; int64 n; int32 blk_begin, pad; }      (56 bytes)
+ *   { float* p; const void* g; float* m; float* v; bf16* low_or_null; int64 n; int32 blk_begin, g_is_bf16; }  (56 bytes)
  * one block per 4096 elements, blk_begin = blocks of all earlier records, n_blocks = their total.  lr, step (the 1-based
  * step count t as a float) and total_norm (may be NULL: no clipping) are DEVICE scalars, so the call can sit in a HIP graph. */
 int fmmt_adamw_batch(int n_desc, int n_blocks, const void* desc, const float* lr, const float* step, const float* total_norm,
