@@ -643,7 +643,7 @@ def kernel_symbol(bn):
         return bn
     if bn.startswith("p256x"):
         w = bn[5:]
-        return f"linear_nt_p256_kernel<{w},64,{3 if w == '128' else 2},true>"
+        return f"linear_nt_p256_kernel<{w},64,{3 if w == '128' else 2},true,false>"
     if bn.startswith("deep256") and bn != "deep256x128x64":         # deep256x{128,96}x32[,nkN]
         width = "128" if bn.startswith("deep256x128") else "96"
         return f"linear_nt_deep32_kernel<{bn[-1] if ',nk' in bn else '0'},{width}>"

@@ -681,6 +681,7 @@ class GraphedAuxStep:
         self.flat = averager if averager is not None else GradientAverager(self.swin.parameters(), hooks=False)
         self.flat_view_of = {p: p.grad for p in self.flat.params}
         self.pairs = [(p, p) for p in self.flat.params]
+        self.fused = FusedClipAdamW(optimizer, self.flat.params, self.flat_view_of, {}, args.clip) if FusedClipAdamW.eligible(optimizer, self.flat.params) else None
         for p in self.flat.params:
             p.grad = None
         self.accumulate = args.aux_accumulation_steps > 1
@@ -697,6 +698,8 @@ class GraphedAuxStep:
         _restore(snap)
         del snap
         _reset_optimizer_state(self.opt)
+        if self.fused is not None:
+            self.fused.reset()
         self.flat.zero_grad()
         torch.cuda.set_rng_state(rng, dev)
         self.shadows = _pin_shadows([self.swin])
@@ -718,10 +721,13 @@ class GraphedAuxStep:
         return loss.detach()
 
     def _update(self):
-        for p in self.flat.params:
-            p.grad = self.flat_view_of[p]
-        torch.nn.utils.clip_grad_norm_(self.flat.params, self.args.clip)
-        self.opt.step()
+        if self.fused is not None:
+            self.fused.update()
+        else:
+            for p in self.flat.params:
+                p.grad = self.flat_view_of[p]
+            torch.nn.utils.clip_grad_norm_(self.flat.params, self.args.clip)
+            self.opt.step()
         if self.accumulate:
             self.flat.zero_grad()
         for p in self.flat.params:                           # the next backward must produce fresh gradient tensors
