@@ -66,11 +66,12 @@ class MultiheadAttention(nn.Module):
         p = self.attn_dropout if self.training else 0.0
         # fresh seed per call, drawn on the device: no host sync, and a captured hipGraph re-draws it on replay
         seed = torch.randint(0, 2 ** 62, (1,), device=query.device, dtype=torch.int64) if p > 0 else 0
-        q = self.in_proj_q(query)
         if key is value or (key.data_ptr() == value.data_ptr() and key.shape == value.shape):
-            kv = self.in_proj_kv(key)                                           # one GEMM, N = 2E, [k | v]
+            # two GEMMs (q: N = E; [k | v]: N = 2E) whose weight gradients land in one packed (3E, E) gradient: ops.InProjFn
+            q, kv = ops.in_proj_q_kv(query, key, self.in_proj_weight, self.in_proj_bias)
             ctx = ops.mha_core(q, kv, None, self.num_heads, self.scaling, p, seed)
         else:
+            q = self.in_proj_q(query)
             ctx = ops.mha_core(q, self.in_proj_k(key), self.in_proj_v(value), self.num_heads, self.scaling, p, seed)
         return ops.linear(ctx, self.out_proj.weight, self.out_proj.bias, res)
 

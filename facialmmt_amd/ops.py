@@ -64,13 +64,17 @@ def wgrad_partials_raw(dy2, x2, want_bias, ws, nbytes, rowscale=None, rows_per_s
     check(rc, f"fmmt_linear_wgrad_partials(M={M},N={N},K={K})")
 
 
-def wgrad_raw(dy2, x2, want_bias, rowscale=None, rows_per_scale=1, x_gelu=False):
+def wgrad_raw(dy2, x2, want_bias, rowscale=None, rows_per_scale=1, x_gelu=False, out=None):
     """dw[N,K] fp32 = (s*dy2)^T @ x2 ; db[N] fp32 = colsum(s*dy2).  x_gelu: x2 holds a pre-activation, contract with gelu(x2)."""
     M, N = dy2.shape
     K = x2.shape[1]
     lib = _lib.load()
-    dw = torch.empty((N, K), dtype=torch.float32, device=dy2.device)
-    db = torch.empty((N,), dtype=torch.float32, device=dy2.device) if want_bias else None
+    if out is not None:                                  # contiguous fp32 destinations (row slices of a packed weight gradient)
+        dw, db = out
+        assert dw.shape == (N, K) and dw.dtype == torch.float32 and dw.is_contiguous() and (not want_bias or (db.shape == (N,) and db.is_contiguous()))
+    else:
+        dw = torch.empty((N, K), dtype=torch.float32, device=dy2.device)
+        db = torch.empty((N,), dtype=torch.float32, device=dy2.device) if want_bias else None
     nbytes = lib.fmmt_linear_wgrad_workspace(dtype_code(dy2.dtype), M, N, K)
     ws = _ws(nbytes, dy2.device)
     if M <= 2048:
@@ -215,6 +219,51 @@ class LinearFn(Function):
 
 def linear(x, weight, bias=None, res=None, rowscale=None, rows_per_scale=1):
     return LinearFn.apply(x, weight, bias, res, rowscale, rows_per_scale)
+
+
+class InProjFn(Function):
+    """q = query W[:E]^T + b[:E],  [k | v] = key W[E:]^T + b[E:]  for the packed in-projection of the cross-modal attention
+    (multihead_attention.py:137-158: in_proj_q / in_proj_kv slice in_proj_weight (3E, E)).  As two Linear calls on parameter
+    slices, autograd's SliceBackward zero-fills a full-size gradient per slice, copies the slice in and adds the two -- ten
+    small launches per attention for weight and bias; here the two weight-gradient launches write straight into the row
+    ranges of ONE (3E, E) gradient."""
+
+    @staticmethod
+    def forward(ctx, query, key, weight, bias):
+        _need_cuda(query, "in_proj")
+        E = weight.shape[1]
+        q2 = query.reshape(-1, E).contiguous()
+        k2 = key.reshape(-1, E).contiguous()
+        wq, wkv = weight[:E], weight[E:]
+        bq, bkv = (bias.detach()[:E], bias.detach()[E:]) if bias is not None else (None, None)
+        q = linear_raw(q2, _lp(wq, query.dtype), bq)
+        kv = linear_raw(k2, _lp(wkv, key.dtype), bkv)
+        ctx.save_for_backward(q2, k2, weight)
+        ctx.has_bias = bias is not None
+        ctx.shapes = (query.shape, key.shape)
+        return q.reshape(*query.shape[:-1], E), kv.reshape(*key.shape[:-1], 2 * E)
+
+    @staticmethod
+    def backward(ctx, dq, dkv):
+        q2, k2, weight = ctx.saved_tensors
+        E = weight.shape[1]
+        dq2 = dq.reshape(-1, E).contiguous()
+        dkv2 = dkv.reshape(-1, 2 * E).contiguous()
+        dquery = dkey = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dquery = linear_raw(dq2, _lp(weight[:E], dq2.dtype, transpose=True), None).reshape(ctx.shapes[0])
+        if ctx.needs_input_grad[1]:
+            dkey = linear_raw(dkv2, _lp(weight[E:], dkv2.dtype, transpose=True), None).reshape(ctx.shapes[1])
+        if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
+            dw = torch.empty((3 * E, E), dtype=torch.float32, device=dq2.device)
+            db = torch.empty((3 * E,), dtype=torch.float32, device=dq2.device) if ctx.has_bias else None
+            wgrad_raw(dq2, q2, ctx.has_bias, out=(dw[:E], db[:E] if db is not None else None))
+            wgrad_raw(dkv2, k2, ctx.has_bias, out=(dw[E:], db[E:] if db is not None else None))
+        return dquery, dkey, dw, db
+
+
+def in_proj_q_kv(query, key, weight, bias):
+    return InProjFn.apply(query, key, weight, bias)
 
 
 # ------------------------------------------------------------------------------------------------
