@@ -1315,21 +1315,21 @@ bool tn_few_ok(int M, int N, int K, int dtype) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// DMA-staged TN kernel (bf16 weight gradients of the many-token launches without DropPath scale): the ring of the persistent NT
-// kernel applied to the token contraction.  One 8-wave workgroup per CU owns one (output tile, token split): TNn (256 / 192)
-// output rows (channels of dy) x 128 output columns (channels of x); waves 4 x 2, wave tile TNn/4 x 64.
-//  * a stage = 64 tokens of both operands in their natural [token][channel] layout, filled by direct global->LDS DMA; three
-//    stages, two in flight; counted vmcnt + one raw s_barrier per stage; no register pass, no ds_write at all (the
-//    register-staged kernel spends ~800 LDS cycles per pair of 64-token steps on ds_write_b128 against 1024 MFMA cycles);
-//  * fragments by ds_read_b64_tr_b16 as before.  The DMA image of a stage is lane-linear, so the conflict-free layout is made
-//    on the SOURCE side: the 32-byte column blocks of a token row are permuted by sigma_row (block ^ g(row) for the first
-//    eight blocks, 8 + ((block & 3) ^ g2(row)) for blocks 8-11 of a 384-byte row), an involution the fragment read applies
-//    again.  With 256- and 512-byte rows every row starts on bank 0; with 384-byte rows on bank 0 / 32 alternately, which the
-//    same g() absorbs (h(row) = g(row) ^ 4 (row & 1) is still a bijection on the eight rows of an LDS cycle).
-//  * bias gradient without a register pass: one extra MFMA per 16-row dy fragment against a B fragment of ones, the fragments
-//    dealt out over the k-tiles and the two k-waves so that no workgroup carries more than one of them per wave.
-//  * token counts are multiples of 64 (every Swin launch is); anything else, DropPath scale, recomputed activation: the
-//    register-staged kernel.
+// DMA-staged TN kernel (bf16 weight gradients of the many-token stage-2/3 launches): the ring of the persistent NT kernel applied
+// to the token contraction.  One 8-wave workgroup per CU owns one (output tile, token split): 256 x 256 or 192 x 384 output
+// channels (dy channels x x channels), waves 2 x 4, twelve 16-wide fragments per wave.
+//  * a stage = 32 tokens of both operands in their natural [token][channel] layout, filled by direct global->LDS DMA; four
+//    stages, three in flight; counted vmcnt + one raw s_barrier per stage; no register pass, no ds_write at all;
+//  * fragments by ds_read_b64_tr_b16, issued from ONE inline-asm statement per stage (tn_read12: why).  The DMA image of a
+//    stage is lane-linear, so the conflict-free layout is made on the SOURCE side: the 32-byte column blocks of a token row
+//    are permuted by sigma_row (block ^ g(row) for blocks whose low three bits it can flip, 8 + ((block & 3) ^ g2(row)) for
+//    blocks 8-11 of a 384-byte row), an involution the fragment read applies again.  With 256-, 512- and 768-byte rows every
+//    row starts on bank 0; with 384-byte rows on bank 0 / 32 alternately, which the same g() absorbs;
+//  * bias gradient without a register pass: one extra MFMA against a B fragment of ones at fixed fragment positions;
+//  * partial sums leave in fragment order (1 KB per store); reduce_partials_kernel undoes the permutation;
+//  * DropPath scale: the SCALED instantiation rescales the dy stage in LDS one stage ahead;
+//  * token counts are multiples of 64 (every Swin launch is); anything else, a recomputed activation, fewer than four tiles:
+//    the register-staged kernel.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int tn_swz2(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); }
 template <int CH>                                           // CH channels per row -> CH / 16 blocks of 32 bytes
@@ -1646,12 +1646,6 @@ int launch_tn_dma(const TnArgs& a, int grid, hipStream_t st) {
     return 0;
 }
 
-// (A DMA-staged variant of the TN kernel -- global_load_lds tiles with an XOR-swizzled chunk order for the
-//  transposing reads, DropPath scale applied to the fragments, bias gradient as an extra MFMA against ones --
-//  was written and measured: bit-for-bit correct but 3-9 % slower than this register-staged kernel on the
-//  stage-2/3 shapes (472-550 vs 464-591 TF/s), so it is not kept.  What did help: sizing the split count to
-//  exactly one round of co-resident workgroups, +13 % on those shapes.)
-
 // out[i] = sum_s part[s][i] : 256 threads = 64 float4 outputs x 4 split groups, fixed-order tree (deterministic).
 // One launch finishes both the weight gradient (blocks [0, wblocks)) and, if present, the bias gradient.
 // hdr[0] = number of splits, hdr[1] = layout of the weight partials as written by the contraction kernel: 0 = row-major
@@ -1794,12 +1788,11 @@ namespace {
 // DMA-staged plan (linear_tn_dma_kernel): tile TNn x 128 with TNn = 256 / 192, one workgroup per CU, splits = 256 / tiles
 TnPlan tn_plan_dma(int M, int N, int K) {
     TnPlan pl{0, 0, 0, 0, 0, 0, 0};
-    // Measured and NOT the default (FMMT_TN_DMA=1): correct, no LDS stores at all, and slower on the stage-2 shapes (same call:
-    // 125440 x 1152 x 384 0.239 vs 0.196 ms, 1536 x 384 0.272 vs 0.246, 384 x 1536 0.328 vs 0.258; the step's stage-2/3
-    // weight gradients 7.31 vs 6.85 ms; 31360 x 2304 x 768 0.190 vs 0.206 is the one win).  PMC: its waves sit parked in
-    // s_waitcnt / s_barrier for 68 % of their cycles (register-staged kernel: 32 %): two 40-48 KB stages in flight per CU
-    // are fewer bytes than two workgroups with two register sets each keep in flight, and at 64-85 FLOP per loaded byte the
-    // contraction lives on bytes in flight.
+    // Default on (FMMT_TN_DMA=0: everything register-staged).  History: the first version of this kernel (256 / 192 x 128 tiles,
+    // the builtin ds_read_tr) measured 3-9 % SLOWER than the register-staged kernel with 68 % of its wave cycles parked in
+    // waits -- hipcc had put s_waitcnt vmcnt(0) in front of every stage's first fragment read, so the ring never had a second
+    // stage in flight.  With the reads in inline asm, 128 FLOP per staged byte and four 32-token stages: 860-1105 TF/s against
+    // 550-630.
     static const int mode = getenv("FMMT_TN_DMA") ? atoi(getenv("FMMT_TN_DMA")) : 1;
     if (!mode || M <= 16384 || M % 64) return pl;
     int tn = 0, tk = 0;
