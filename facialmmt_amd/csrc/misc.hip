@@ -300,6 +300,112 @@ __global__ __launch_bounds__(256) void adamw_batch_kernel(const AdamDesc* __rest
         }
     }
 }
+
+// LayerNorm backward for a bf16 module with bf16 affine parameters (the text encoder's 49 LayerNorms: torch's own backward is
+// three launches -- input gradient, partial and final gamma / beta sums: 39 us in the step).  One wave per token row, rows
+// grid-strided; the row statistics are recomputed from x in fp32 (the forward is torch's layer_norm, nothing of it is saved but
+// x); per-block partial sums of d gamma / d beta, finished by lnp_reduce_kernel in a fixed order, written in bf16.
+__global__ __launch_bounds__(256) void lnp_bwd_kernel(int M, int C, float eps, const bf16* __restrict__ dy, const bf16* __restrict__ x,
+                                                      const bf16* __restrict__ gamma, bf16* __restrict__ dx, float* __restrict__ part) {
+    constexpr int MAXV = 4;                                 // 8-element vectors per lane: C <= 2048
+    __shared__ float red[4][2][64 * 8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = C / 8;                                   // vectors per row
+    float dg[MAXV][8], db[MAXV][8];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dg[i][e] = db[i][e] = 0.f;
+    const float invC = 1.0f / (float)C;
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        bf16x8 xv[MAXV], gv[MAXV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int v = lane + 64 * i;
+            if (v < nv) {
+                xv[i] = *reinterpret_cast<const bf16x8*>(x + (size_t)row * C + v * 8);
+                gv[i] = *reinterpret_cast<const bf16x8*>(dy + (size_t)row * C + v * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += (float)xv[i][e];
+            }
+        }
+        const float mean = wave_sum(s) * invC;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i)
+            if (lane + 64 * i < nv) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = (float)xv[i][e] - mean; q += d * d; }
+            }
+        const float rstd = rsqrtf(wave_sum(q) * invC + eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int v = lane + 64 * i;
+            if (v < nv) {
+                const bf16x8 gm = *reinterpret_cast<const bf16x8*>(gamma + v * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xh = ((float)xv[i][e] - mean) * rstd, dyv = (float)gv[i][e], g = dyv * (float)gm[e];
+                    s1 += g;
+                    s2 += g * xh;
+                    dg[i][e] += dyv * xh;
+                    db[i][e] += dyv;
+                }
+            }
+        }
+        s1 = wave_sum(s1) * invC;
+        s2 = wave_sum(s2) * invC;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int v = lane + 64 * i;
+            if (v < nv) {
+                const bf16x8 gm = *reinterpret_cast<const bf16x8*>(gamma + v * 8);
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xh = ((float)xv[i][e] - mean) * rstd, g = (float)gv[i][e] * (float)gm[e];
+                    o[e] = (bf16)(rstd * (g - s1 - xh * s2));
+                }
+                *reinterpret_cast<bf16x8*>(dx + (size_t)row * C + v * 8) = o;
+            }
+        }
+    }
+    // the four waves of the block, one 64-vector slab at a time: partial [block][2][C]
+    float* pb = part + (size_t)blockIdx.x * 2 * C;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        if (64 * i >= nv) break;
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red[wave][0][lane * 8 + e] = dg[i][e];
+            red[wave][1][lane * 8 + e] = db[i][e];
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < 2 * 512; t += 256) {
+            const int which = t >> 9, col = t & 511, ch = i * 512 + col;
+            if (ch < C) pb[which * C + ch] = (red[0][which][col] + red[1][which][col]) + (red[2][which][col] + red[3][which][col]);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void lnp_reduce_kernel(const float* __restrict__ part, int nblocks, int C, bf16* __restrict__ dgamma, bf16* __restrict__ dbeta) {
+    const int i = blockIdx.x * 256 + threadIdx.x;           // column of the [2][C] pair
+    if (i >= 2 * C) return;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int b = 0;
+    for (; b + 4 <= nblocks; b += 4) {
+        a0 += part[(size_t)b * 2 * C + i];
+        a1 += part[(size_t)(b + 1) * 2 * C + i];
+        a2 += part[(size_t)(b + 2) * 2 * C + i];
+        a3 += part[(size_t)(b + 3) * 2 * C + i];
+    }
+    for (; b < nblocks; ++b) a0 += part[(size_t)b * 2 * C + i];
+    const float t = (a0 + a1) + (a2 + a3);
+    if (i < C) dgamma[i] = (bf16)t;
+    else dbeta[i - C] = (bf16)t;
+}
 }  // namespace
 
 extern "C" int fmmt_version(void) { return 1; }
@@ -418,6 +524,30 @@ extern "C" int fmmt_adamw_batch(int n_desc, int n_blocks, const void* desc, cons
     if (n_desc <= 0 || n_blocks <= 0 || !desc || !lr || !step) return FMMT_EINVAL;
     hipLaunchKernelGGL(adamw_batch_kernel, dim3((unsigned)n_blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        reinterpret_cast<const AdamDesc*>(desc), n_desc, lr, step, total_norm, beta1, beta2, eps, weight_decay, max_norm);
+    FMMT_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" size_t fmmt_layernorm_bwd_bf16_workspace(int M, int C) {
+    if (M <= 0 || C <= 0) return 0;
+    const int blocks = M / 4 < 1 ? 1 : (M / 4 > 256 ? 256 : M / 4);
+    return (size_t)blocks * 2 * (size_t)C * sizeof(float);
+}
+
+extern "C" int fmmt_layernorm_bwd_bf16(int M, int C, float eps, const void* dy, const void* x, const void* gamma, void* dx,
+                                       void* dgamma, void* dbeta, void* workspace, size_t workspace_bytes, void* stream) {
+    if (M <= 0 || C <= 0 || C % 8 || C > 2048) return FMMT_EINVAL;
+    if (!dy || !x || !gamma || !dx || !dgamma || !dbeta || !workspace) return FMMT_EINVAL;
+    if (workspace_bytes < fmmt_layernorm_bwd_bf16_workspace(M, C)) return FMMT_EWORKSPACE;
+    if (((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(dx)) & 15) != 0)
+        return FMMT_EALIGN;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int blocks = M / 4 < 1 ? 1 : (M / 4 > 256 ? 256 : M / 4);
+    hipLaunchKernelGGL(lnp_bwd_kernel, dim3(blocks), dim3(256), 0, st, M, C, eps, (const bf16*)dy, (const bf16*)x, (const bf16*)gamma, (bf16*)dx,
+                       reinterpret_cast<float*>(workspace));
+    FMMT_CHECK_LAUNCH();
+    hipLaunchKernelGGL(lnp_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, reinterpret_cast<const float*>(workspace), blocks, C,
+                       (bf16*)dgamma, (bf16*)dbeta);
     FMMT_CHECK_LAUNCH();
     return 0;
 }

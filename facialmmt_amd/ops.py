@@ -279,6 +279,35 @@ def colsum_raw(x2, out_dtype=None):
     return out
 
 
+class PlmLayerNormFn(torch.autograd.Function):
+    """torch's layer_norm forward, fmmt_layernorm_bwd_bf16 backward (bf16 activations and bf16 affine parameters: the text
+    encoder's LayerNorms).  torch's backward is three launches (input gradient, partial and final gamma / beta sums); this is
+    two, and saves nothing but x (the row statistics are recomputed in fp32)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        ctx.save_for_backward(x, weight)
+        ctx.eps = eps
+        return torch.nn.functional.layer_norm(x, (x.shape[-1],), weight, bias, eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        C = x.shape[-1]
+        x2 = x.reshape(-1, C).contiguous()
+        dy2 = dy.reshape(-1, C).contiguous()
+        M = x2.shape[0]
+        lib = _lib.load()
+        dx = torch.empty_like(x2)
+        dw = torch.empty_like(weight)
+        db = torch.empty_like(weight)
+        nbytes = lib.fmmt_layernorm_bwd_bf16_workspace(M, C)
+        ws = _ws(nbytes, x.device)
+        check(lib.fmmt_layernorm_bwd_bf16(M, C, float(ctx.eps), _p(dy2), _p(x2), _p(weight.detach().contiguous()), _p(dx), _p(dw), _p(db),
+                                          _p(ws), nbytes, _st()), f"fmmt_layernorm_bwd_bf16(M={M},C={C})")
+        return dx.reshape(x.shape), dw, db, None
+
+
 def adamw_batch(n, blocks, desc, lr, step, total_norm, beta1, beta2, eps, weight_decay, max_norm):
     """fmmt_adamw_batch: clip + AdamW + bf16 twins over the tensors of a descriptor table (train_step.FusedClipAdamW)"""
     check(_lib.load().fmmt_adamw_batch(n, blocks, _p(desc), _p(lr), _p(step), _p(total_norm), float(beta1), float(beta2), float(eps),

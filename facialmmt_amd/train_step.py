@@ -314,6 +314,17 @@ class VendorLinear(torch.nn.Linear):
         return ops.VendorLinearFn.apply(x, self.weight, self.bias)
 
 
+class VendorLayerNorm(torch.nn.LayerNorm):
+    """nn.LayerNorm of a bf16 text encoder: torch's forward, fmmt_layernorm_bwd_bf16 backward (ops.PlmLayerNormFn)"""
+
+    def forward(self, x):
+        if (self.weight is None or self.bias is None or not x.is_cuda or x.dtype != torch.bfloat16 or self.weight.dtype != torch.bfloat16
+                or len(self.normalized_shape) != 1 or x.shape[-1] % 8 or x.shape[-1] > 2048 or not torch.is_grad_enabled()):
+            return super().forward(x)
+        from . import ops
+        return ops.PlmLayerNormFn.apply(x, self.weight, self.bias, self.eps)
+
+
 def use_colsum_bias_gradients(module):
     """Re-class every nn.Linear of `module` (a Hugging Face text encoder) as VendorLinear: the bias gradients of its ~146 Linear
     layers then cost one 4 us launch each instead of a memset + a multi-block reduction (measured: 3.2 + 0.8 ms per step).
@@ -322,10 +333,13 @@ def use_colsum_bias_gradients(module):
     if os.environ.get("FMMT_PLM_COLSUM", "1") == "0":
         return 0
     n = 0
+    ln = os.environ.get("FMMT_PLM_LN", "1") != "0"
     for m in module.modules():
         if type(m) is torch.nn.Linear and m.bias is not None:
             m.__class__ = VendorLinear
             n += 1
+        elif ln and type(m) is torch.nn.LayerNorm and m.elementwise_affine and m.bias is not None:
+            m.__class__ = VendorLayerNorm                    # two backward launches instead of three (fmmt_layernorm_bwd_bf16)
     return n
 
 

@@ -220,6 +220,14 @@ int fmmt_scale(int dtype, size_t n, const void* x, float alpha, void* y, void* s
  * (dtype, or FMMT_F32); N % (16 / sizeof(dtype)) == 0; one launch, fixed summation order. */
 int fmmt_colsum(int dtype, int out_dtype, int M, int N, const void* x, int ldx, void* out, void* stream);
 
+/* LayerNorm backward of a bf16 module with bf16 affine parameters: the text encoder's LayerNorms (transformers'
+ * RobertaSelfOutput / RobertaOutput / embeddings LayerNorm, src/models.py:75-91), whose forward stays torch's layer_norm.
+ * Replaces torch's three backward launches by two; the row statistics are recomputed from x (nothing but x is saved).
+ * dy, x, dx: bf16 [M][C]; gamma, dgamma, dbeta: bf16 [C]; C % 8 == 0, C <= 2048; workspace: fmmt_layernorm_bwd_bf16_workspace. */
+size_t fmmt_layernorm_bwd_bf16_workspace(int M, int C);
+int fmmt_layernorm_bwd_bf16(int M, int C, float eps, const void* dy, const void* x, const void* gamma, void* dx,
+                            void* dgamma, void* dbeta, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Batched refresh of bf16 weight shadows: one launch casts (fp32 -> bf16, or copies bf16) and optionally transposes n_desc
  * parameter matrices.  The reference keeps fp32 nn.Parameters (train.py:336-349 builds the optimizer over them); the bf16 GEMMs
  * read bf16 shadows W and W^T of them, which a training step has to rebuild after every optimizer step -- per weight that

@@ -265,3 +265,40 @@ def test_cast_batch_and_pinned_shadows(dev):
                 p.mul_(1.5).add_(0.25)
     assert ops._lp(ps[0], torch.bfloat16) is not ops._PINNED[id(ps[0])][(0, (96, 48), (48, 1), torch.bfloat16, False)]
     pin.release()
+
+
+@pytest.mark.gpu
+def test_bf16_layernorm_backward_for_the_text_encoder(dev):
+    """fmmt_layernorm_bwd_bf16 behind train_step.VendorLayerNorm against torch's own LayerNorm backward on the same bf16 module
+    (and both against an fp32 evaluation): hidden sizes 1024 / 768 / 200, ragged row counts; same keys, same forward bits."""
+    from facialmmt_amd.train_step import VendorLayerNorm
+    g = torch.Generator(device="cpu").manual_seed(11)
+    for (rows, C) in [((4, 512), 1024), ((3, 77), 768), ((1, 5), 200), ((2049,), 1024)]:
+        ref = torch.nn.LayerNorm(C, eps=1e-5).to(dev, torch.bfloat16)
+        with torch.no_grad():
+            ref.weight.copy_(torch.randn(C, generator=g).to(dev) * 0.2 + 1.0)
+            ref.bias.copy_(torch.randn(C, generator=g).to(dev) * 0.1)
+        import copy
+        fast = copy.deepcopy(ref)
+        fast.__class__ = VendorLayerNorm
+        assert list(fast.state_dict()) == list(ref.state_dict())
+        x = (torch.randn(*rows, C, generator=g) * 2.0 + 0.5).to(dev, torch.bfloat16)
+        dy = torch.randn(*rows, C, generator=g).to(dev, torch.bfloat16)
+        outs = []
+        for m in (ref, fast):
+            xi = x.clone().requires_grad_(True)
+            y = m(xi)
+            y.backward(dy)
+            outs.append((y, xi.grad, m.weight.grad, m.bias.grad))
+        x32 = x.float().requires_grad_(True)
+        y32 = torch.nn.functional.layer_norm(x32, (C,), ref.weight.float(), ref.bias.float(), 1e-5)
+        gw32, gb32 = (dy.float() * ((x32 - x32.mean(-1, keepdim=True)) * torch.rsqrt(x32.var(-1, unbiased=False, keepdim=True) + 1e-5))).reshape(-1, C).sum(0), dy.float().reshape(-1, C).sum(0)
+        y32.backward(dy.float())
+        assert torch.equal(outs[0][0], outs[1][0])
+        for got, want in ((outs[1][1], x32.grad), (outs[1][2], gw32), (outs[1][3], gb32)):
+            scale = want.abs().max().item()
+            assert (got.float() - want.detach()).abs().max().item() <= 1.5e-2 * scale, (rows, C)
+        # no worse than torch's own bf16 backward against the fp32 evaluation
+        e_ref = (outs[0][1].float() - x32.grad).abs().max().item()
+        e_new = (outs[1][1].float() - x32.grad).abs().max().item()
+        assert e_new <= 1.5 * e_ref + 1e-3 * x32.grad.abs().max().item()
