@@ -545,24 +545,19 @@ __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
             __builtin_amdgcn_global_load_lds((gptr_t*)bsrc, (lptr_t*)(bias_s + par * 256), 16, 0, 0);
         }
     };
-    // The oldest stage in flight has landed when at most `ahead` younger stages -- and the `stores` epilogue stores this wave
-    // issued after them -- are still outstanding (FMMT_NT_P256_STORES=1; vmcnt counts stores too and retires in issue order).
-    // Comparing K = 384 with K = 1536 tiles of the same width puts the cost of a tile switch at 3.7 K steps (38 % of a K = 384
-    // tile's life); the write acknowledgements the first wait after an epilogue sits out were the suspect -- measured, same call:
-    // no difference with the stores left in flight, so the default keeps the plain count.
-    constexpr int NS = 8 * ((NT + 1) / 2);                 // store instructions per wave and output tensor: per token fragment NT/2 x 16 B (+ 8 B tail)
+    // The oldest stage in flight has landed when at most `ahead` younger stages -- and the `stores` store instructions this wave
+    // issued AFTER the newest of them -- are still outstanding (vmcnt counts stores too and retires in issue order; an
+    // under-count only makes the wait stricter).
     auto wait_landed = [&](int ahead, int stores) {
-        auto go = [&](auto A) {
-            constexpr int a = decltype(A)::value;
-            if (stores == 0) { if (cnt_hi) wait_vm<a * (CNT_LO + 1)>(); else wait_vm<a * CNT_LO>(); }
-            else if (stores == 1) { if (cnt_hi) wait_vm<a * (CNT_LO + 1) + NS>(); else wait_vm<a * CNT_LO + NS>(); }
-            else { if (cnt_hi) wait_vm<a * (CNT_LO + 1) + 2 * NS>(); else wait_vm<a * CNT_LO + 2 * NS>(); }
-        };
-        if (ahead <= 0) go(std::integral_constant<int, 0>{});
-        else if (ahead == 1) go(std::integral_constant<int, 1>{});
-        else go(std::integral_constant<int, 2>{});
+        const int n = (ahead <= 0 ? 0 : (ahead == 1 ? 1 : 2)) * (CNT_LO + (cnt_hi ? 1 : 0)) + stores;
+        switch (n) {
+#define FMMT_W(N) case N: wait_vm<N>(); break;
+            FMMT_W(1) FMMT_W(2) FMMT_W(3) FMMT_W(4) FMMT_W(5) FMMT_W(6) FMMT_W(7) FMMT_W(8) FMMT_W(9) FMMT_W(10) FMMT_W(11) FMMT_W(12)
+            FMMT_W(13) FMMT_W(14) FMMT_W(15) FMMT_W(16) FMMT_W(17) FMMT_W(18) FMMT_W(19) FMMT_W(20) FMMT_W(21) FMMT_W(22) FMMT_W(23) FMMT_W(24)
+#undef FMMT_W
+            default: wait_vm<0>(); break;                  // 0, or more than the table holds: wait for everything
+        }
     };
-    static_assert(2 * (CNT_LO + 2) + 2 * NS <= 63, "vmcnt immediate");
     static_assert(NBUF >= 2 && NBUF <= 4, "ring depth");
     static_assert(NI % 8 == 0 || NI % 8 <= 7, "wave 7 never owns a high count plus the bias slab");
 
@@ -641,12 +636,28 @@ __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
     for (int s = 0; s < NBUF - 1; ++s)
         if (s < nsteps) issue_next();
     // compute-side cursor
-    int ct = first, ck = 0, cpar = 0, cslot = 0;
-    int st_pending = 0;                                    // output tensors this wave stored since its last wait (0, 1, 2)
+    int ct = first, ck = 0, cpar = 0, cslot = 0, st_prev = 0;
     EpiPre<MT, NT> pre;
+    // Epilogue through LDS.  The accumulator layout gives a store instruction 16 token rows x 64 contiguous bytes; the CU's store
+    // path takes such stores at ~7 B per cycle and, being the vector-memory path the DMA loads use as well, it cannot be hidden:
+    // 125440 x 1152 x 384 took 190 us with the epilogue and 125 us without, spread over the next tile's K steps or not (both
+    // measured).  So a finished tile goes through a small LDS scratch, PR token rows per token-wave group at a time: the waves
+    // write their 16-byte accumulator chunks (bias added, bf16) into row-major [PR][BN] slabs, and read whole rows back -- every
+    // store instruction then writes 1 KB of complete 128-byte lines.  Plain / bias epilogues; GELU + pre-activation, operand and
+    // split-K epilogues keep nt_epilogue.
+    constexpr int PR = BN == 192 ? 32 : 16;                // rows per pass and wave group (LDS budget: 25.6 / 16.9 / 8.7 KB)
+    constexpr int SP = BN * 2 + 16;                        // slab row pitch in bytes
+    constexpr int CPR = BN / 8;                            // 16-byte chunks per row
+    constexpr int NSL = PR * CPR / 256;                    // store instructions per lane and pass (256 lanes per wave group)
+    static_assert((PR * CPR) % 256 == 0, "whole store instructions");
+    char* scratch = smem + (size_t)NBUF * STAGE * sizeof(T) + 2 * 256 * sizeof(float) + (size_t)wm * PR * SP;
+    // (K > 1536: the tile's 48+ K steps dwarf the epilogue and the passes' sixteen barriers cost more than the stores save:
+    //  31360 x 768 x 3072 measured 153 us direct, 165 us through LDS)
+    const bool lds_epi = !HASOP && p.epi == 0 && !p.y_pre && !p.part && !(p.reserved & 4) && p.K <= 1536;
+    T* __restrict__ yg = reinterpret_cast<T*>(p.y);
     for (int s = 0; s < nsteps; ++s) {
-        wait_landed(min(nsteps - 1 - s, NBUF - 2), st_pending);
-        st_pending = 0;
+        wait_landed(min(nsteps - 1 - s, NBUF - 2), st_prev);
+        st_prev = 0;
         __builtin_amdgcn_s_barrier();                      // every wave's part of stage s is in LDS; stage s - 1 is free
         if constexpr (HASOP) {
             // residual / GELU' operand / DropPath scale of THIS tile: loaded now, in front of this step's DMA, used after the
@@ -666,14 +677,53 @@ __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
                     for (int a = 0; a < MT; ++a) acc[a][b] += bb;
                 }
             }
-            if constexpr (HASOP) nt_epilogue<T, MT, NT, true, true>(p, acc, m0 + wm * 128, n0 + wn * WN, li, lg, &pre);
-            else nt_epilogue<T, MT, NT, true>(p, acc, m0 + wm * 128, n0 + wn * WN, li, lg);
+            if (lds_epi) {
+                const int rows_left = p.M - (m0 + wm * 128);             // token rows of this wave group that exist
+#pragma unroll
+                for (int pass = 0; pass < 128 / PR; ++pass) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();                          // the slab's previous rows have been read
+#pragma unroll
+                    for (int f = 0; f < PR / 16; ++f) {
+                        const int a = pass * (PR / 16) + f;
+                        char* row = scratch + (f * 16 + li) * SP + (wn * WN) * 2;
+#pragma unroll
+                        for (int c = 0; c < NT / 2; ++c) {
+                            bf16x8 v;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = (bf16)acc[a][2 * c + (e >> 2)][e & 3];
+                            *reinterpret_cast<bf16x8*>(row + chan_of<CW>(2 * c, lg, 0) * 2) = v;
+                        }
+                        if constexpr (NT % 2) {
+                            bf16x4 v;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = (bf16)acc[a][NT - 1][e];
+                            *reinterpret_cast<bf16x4*>(row + chan_of<CW>(NT - 1, lg, 0) * 2) = v;
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's chunks are in the slab ...
+                    __builtin_amdgcn_s_barrier();                          // ... and so is everybody else's
+#pragma unroll
+                    for (int i = 0; i < NSL; ++i) {
+                        const int q = i * 256 + wn * 64 + lane, r = q / CPR, cc = q - r * CPR;
+                        const int row = pass * PR + r;
+                        if (row < rows_left) {
+                            const bf16x8 v = *reinterpret_cast<const bf16x8*>(scratch + r * SP + cc * 16);
+                            *reinterpret_cast<bf16x8*>(yg + (size_t)(m0 + wm * 128 + row) * p.ldy + n0 + cc * 8) = v;
+                        }
+                    }
+                }
+                // a wave group with all its 128 rows inside M issued exactly (128 / PR) * NSL stores per wave (ragged panel: unknown -> 0)
+                if (rows_left >= 128) st_prev = (128 / PR) * NSL;
+            } else if constexpr (HASOP) {
+                nt_epilogue<T, MT, NT, true, true>(p, acc, m0 + wm * 128, n0 + wn * WN, li, lg, &pre);
+            } else {
+                nt_epilogue<T, MT, NT, true, false, true>(p, acc, m0 + wm * 128, n0 + wn * WN, li, lg);      // no operands: see p256_plan
+            }
 #pragma unroll
             for (int a = 0; a < MT; ++a)
 #pragma unroll
                 for (int b = 0; b < NT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-            // a wave whose 128 rows are all inside M issued exactly NS stores per output tensor (ragged panel: unknown -> 0)
-            if (p.reserved && m0 + wm * 128 + 128 <= p.M) st_pending = (p.epi == FMMT_EPI_GELU && p.y_pre) ? 2 : 1;
             ck = 0;
             ct += G;
             cpar ^= 1;
@@ -683,7 +733,8 @@ __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
 
 template <int BN, int BK, int NBUF, bool BATCH, bool HASOP>
 int launch_p256_b(const LinArgs& a, hipStream_t st) {
-    constexpr size_t lds = (size_t)NBUF * (BN + 256) * BK * 2 + 2 * 256 * sizeof(float);
+    constexpr size_t lds = (size_t)NBUF * (BN + 256) * BK * 2 + 2 * 256 * sizeof(float) + 2 * (BN == 192 ? 32 : 16) * (BN * 2 + 16);   // ring, bias slabs, epilogue scratch
+    static_assert(lds <= 160 * 1024, "LDS");
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_nt_p256_kernel<BN, BK, NBUF, BATCH, HASOP>),
@@ -694,8 +745,9 @@ int launch_p256_b(const LinArgs& a, hipStream_t st) {
     LinArgs p = a;
     p.tiles_m = (a.M + 255) / 256;
     p.tiles_n = a.N / BN;
-    static const int st_aware = getenv("FMMT_NT_P256_STORES") ? atoi(getenv("FMMT_NT_P256_STORES")) : 0;
-    p.reserved = st_aware;                                 // 1: the wait after an epilogue leaves its stores in flight (A/B switch; measured: no difference)
+    // FMMT_NT_P256_LDSEPI=0: epilogue stores straight from the accumulator layout (A/B switch)
+    static const int lds_epi = getenv("FMMT_NT_P256_LDSEPI") ? atoi(getenv("FMMT_NT_P256_LDSEPI")) : 1;
+    p.reserved = lds_epi ? 0 : 4;
     hipLaunchKernelGGL((linear_nt_p256_kernel<BN, BK, NBUF, BATCH, HASOP>), dim3(256), dim3(512), lds, st, p);
     FMMT_CHECK_LAUNCH();
     return 0;
@@ -716,7 +768,7 @@ int launch_p256(const LinArgs& a, hipStream_t st) {
 // round of 256 workgroups better (31360 tokens x 768 channels: 369 tiles of 256 x 256 = 2 rounds at 72 %, 492 tiles of
 // 256 x 192 = 2 rounds at 96 %).  Returns 0 if the shape is not for this kernel.
 int p256_plan(const LinArgs& a) {
-    static const int mode = getenv("FMMT_NT_P256") ? atoi(getenv("FMMT_NT_P256")) : 1;       // 0: off; 2: every epilogue; 256 / 192 / 128: force that tile
+    static const int mode = getenv("FMMT_NT_P256") ? atoi(getenv("FMMT_NT_P256")) : 1;       // 0: off; 256 / 192 / 128: force that tile
     // K % 64 != 0 (Swin stage 0: K = 96, three K steps of 32): only with FMMT_NT_P256_K32=1 (A/B switch)
     static const int k32 = getenv("FMMT_NT_P256_K32") ? atoi(getenv("FMMT_NT_P256_K32")) : 0;
     if (!mode || a.ksplit || a.M < 16384 || a.M % 16 || a.K % 32 || a.K < 96 || a.ldx % 8 || a.ldw % 8) return 0;
@@ -733,7 +785,7 @@ int p256_plan(const LinArgs& a) {
     // workgroup whose K loop could run under it.  Total over the step's shapes: +1 %.  Not the default.
     static const int ops_mode = getenv("FMMT_NT_P256_OPS") ? atoi(getenv("FMMT_NT_P256_OPS")) : 0;
     const bool has_op = a.res || a.aux || a.rowscale;
-    if (has_op && mode == 1 && (!ops_mode || (a.res && a.aux) || a.ldres % 8 || a.ldaux % 8)) return 0;
+    if (has_op && (!ops_mode || (a.res && a.aux) || a.ldres % 8 || a.ldaux % 8)) return 0;
     const int tm = (a.M + 255) / 256;
     int best = 0;
     double best_cost = 0;

@@ -62,7 +62,10 @@ __device__ __forceinline__ void nt_epilogue_prefetch(const LinArgs& p, EpiPre<MT
 
 // Epilogue of one wave tile (MT x NT MFMA tiles at rows mbase.., channels nbase..): bias, GELU / GELU',
 // DropPath row scale, residual, 16-byte stores; or raw fp32 partials for the split-K path.
-template <typename T, int MT, int NT, bool BIAS_DONE = false, bool PRE = false>
+// NOOPS: the launch is known to carry no residual, no GELU' operand and no DropPath scale (the persistent kernel without
+// operand prefetch): their loads are compiled out -- a global load that only EXISTS in the epilogue makes the compiler guard
+// every later reuse of its destination register with s_waitcnt vmcnt(0), also in the K loop's DMA issue.
+template <typename T, int MT, int NT, bool BIAS_DONE = false, bool PRE = false, bool NOOPS = false>
 __device__ __forceinline__ void nt_epilogue(const LinArgs& p, f32x4 (&acc)[MT][NT], int mbase, int nbase, int li, int lg,
                                             const EpiPre<MT, NT>* pre = nullptr) {
     constexpr int VEC = Vec<T>::N;
@@ -92,7 +95,8 @@ __device__ __forceinline__ void nt_epilogue(const LinArgs& p, f32x4 (&acc)[MT][N
             const int m = mbase + a * 16 + li;
             if (m >= p.M) continue;
             float rs;
-            if constexpr (PRE) rs = pre->rs[a];
+            if constexpr (NOOPS) rs = 1.0f;
+            else if constexpr (PRE) rs = pre->rs[a];
             else rs = row_scale(p.rowscale, m, p.rows_per_scale);
 #pragma unroll
             for (int b0 = 0; b0 < NT; b0 += TPC) {
@@ -147,7 +151,7 @@ __device__ __forceinline__ void nt_epilogue(const LinArgs& p, f32x4 (&acc)[MT][N
                 if (p.epi == FMMT_EPI_GELU) {
                     if (ypre) store_chunk(ypre, p.ldy, v);
                     gelu_inplace<T>(v, VEC);
-                } else if (p.epi == FMMT_EPI_GELU_BWD) {
+                } else if (!NOOPS && p.epi == FMMT_EPI_GELU_BWD) {
                     float ax[VEC];
                     load_chunk(auxg, p.ldaux, ax);
 #pragma unroll
@@ -156,7 +160,7 @@ __device__ __forceinline__ void nt_epilogue(const LinArgs& p, f32x4 (&acc)[MT][N
                 }
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) v[e] *= rs;
-                if (resg) {
+                if (!NOOPS && resg) {
                     float rx[VEC];
                     load_chunk(resg, p.ldres, rx);
 #pragma unroll
