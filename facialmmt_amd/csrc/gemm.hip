@@ -653,7 +653,8 @@ __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
     char* scratch = smem + (size_t)NBUF * STAGE * sizeof(T) + 2 * 256 * sizeof(float) + (size_t)wm * PR * SP;
     // (K > 1536: the tile's 48+ K steps dwarf the epilogue and the passes' sixteen barriers cost more than the stores save:
     //  31360 x 768 x 3072 measured 153 us direct, 165 us through LDS)
-    const bool lds_epi = !HASOP && p.epi == 0 && !p.y_pre && !p.part && !(p.reserved & 4) && p.K <= 1536;
+    const bool lds_gelu = p.epi == FMMT_EPI_GELU && !(p.reserved & 8);      // GELU (+ pre-activation): two tensors through the slab
+    const bool lds_epi = !HASOP && (p.epi == 0 || lds_gelu) && (!p.y_pre || lds_gelu) && !p.part && !(p.reserved & 4) && p.K <= 1536;
     T* __restrict__ yg = reinterpret_cast<T*>(p.y);
     for (int s = 0; s < nsteps; ++s) {
         wait_landed(min(nsteps - 1 - s, NBUF - 2), st_prev);
@@ -679,8 +680,9 @@ __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
             }
             if (lds_epi) {
                 const int rows_left = p.M - (m0 + wm * 128);             // token rows of this wave group that exist
-#pragma unroll
-                for (int pass = 0; pass < 128 / PR; ++pass) {
+                T* __restrict__ ypre = reinterpret_cast<T*>(p.y_pre);
+                // one slab round: the waves park `which` (0: the values as they are, 1: their GELU) of PR rows, then store whole rows
+                auto round = [&](int pass, T* dst, bool gelu) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();                          // the slab's previous rows have been read
 #pragma unroll
@@ -689,15 +691,23 @@ __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
                         char* row = scratch + (f * 16 + li) * SP + (wn * WN) * 2;
 #pragma unroll
                         for (int c = 0; c < NT / 2; ++c) {
+                            float t[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) t[e] = acc[a][2 * c + (e >> 2)][e & 3];
+                            if (gelu) gelu_inplace<T>(t, 8);
                             bf16x8 v;
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] = (bf16)acc[a][2 * c + (e >> 2)][e & 3];
+                            for (int e = 0; e < 8; ++e) v[e] = (bf16)t[e];
                             *reinterpret_cast<bf16x8*>(row + chan_of<CW>(2 * c, lg, 0) * 2) = v;
                         }
                         if constexpr (NT % 2) {
+                            float t[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) t[e] = acc[a][NT - 1][e];
+                            if (gelu) gelu_inplace<T>(t, 4);
                             bf16x4 v;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = (bf16)acc[a][NT - 1][e];
+                            for (int e = 0; e < 4; ++e) v[e] = (bf16)t[e];
                             *reinterpret_cast<bf16x4*>(row + chan_of<CW>(NT - 1, lg, 0) * 2) = v;
                         }
                     }
@@ -709,12 +719,18 @@ __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
                         const int row = pass * PR + r;
                         if (row < rows_left) {
                             const bf16x8 v = *reinterpret_cast<const bf16x8*>(scratch + r * SP + cc * 16);
-                            *reinterpret_cast<bf16x8*>(yg + (size_t)(m0 + wm * 128 + row) * p.ldy + n0 + cc * 8) = v;
+                            *reinterpret_cast<bf16x8*>(dst + (size_t)(m0 + wm * 128 + row) * p.ldy + n0 + cc * 8) = v;
                         }
                     }
+                };
+                const bool two = lds_gelu && ypre != nullptr;
+#pragma unroll
+                for (int pass = 0; pass < 128 / PR; ++pass) {
+                    if (two) round(pass, ypre, false);
+                    round(pass, yg, lds_gelu);
                 }
-                // a wave group with all its 128 rows inside M issued exactly (128 / PR) * NSL stores per wave (ragged panel: unknown -> 0)
-                if (rows_left >= 128) st_prev = (128 / PR) * NSL;
+                // a wave group with all its 128 rows inside M issued exactly this many stores per wave (ragged panel: unknown -> 0)
+                if (rows_left >= 128) st_prev = (128 / PR) * NSL * (two ? 2 : 1);
             } else if constexpr (HASOP) {
                 nt_epilogue<T, MT, NT, true, true>(p, acc, m0 + wm * 128, n0 + wn * WN, li, lg, &pre);
             } else {
@@ -747,7 +763,8 @@ int launch_p256_b(const LinArgs& a, hipStream_t st) {
     p.tiles_n = a.N / BN;
     // FMMT_NT_P256_LDSEPI=0: epilogue stores straight from the accumulator layout (A/B switch)
     static const int lds_epi = getenv("FMMT_NT_P256_LDSEPI") ? atoi(getenv("FMMT_NT_P256_LDSEPI")) : 1;
-    p.reserved = lds_epi ? 0 : 4;
+    static const int lds_gelu = getenv("FMMT_NT_P256_LDSGELU") ? atoi(getenv("FMMT_NT_P256_LDSGELU")) : 0;   // measured slower (two tensors, 16-row passes: 32 barriers per tile): 273 -> 296 us
+    p.reserved = (lds_epi ? 0 : 4) | (lds_gelu ? 0 : 8);
     hipLaunchKernelGGL((linear_nt_p256_kernel<BN, BK, NBUF, BATCH, HASOP>), dim3(256), dim3(512), lds, st, p);
     FMMT_CHECK_LAUNCH();
     return 0;
