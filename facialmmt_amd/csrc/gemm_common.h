@@ -171,4 +171,57 @@ __device__ __forceinline__ void nt_epilogue(const LinArgs& p, f32x4 (&acc)[MT][N
         }
 }
 
+// Plain / bias epilogue of a 256-row block tile through an fp32 LDS slab (the K loop's stages are free by then).  Straight from the
+// accumulator layout a store touches 16 token rows x 64 bytes, which the CU's vector-memory path takes at ~7 B per cycle; the
+// stage-0/1 launches, whose K loop is three to six steps, spend much of their life there.  Here the waves park their
+// accumulators, 128 token rows per pass, and all threads then walk the slab row by row, 8 channels (16 bytes of output) per
+// thread, so that every store instruction writes complete 128-byte lines.  Same fp32 values, same rounding as nt_epilogue.
+// (With a residual / GELU' operand or a GELU the same scheme measured 0-14 % SLOWER: two co-resident workgroups already hide one
+// another's epilogue, and the slab's four barriers outweigh what the operand loads gain; those launches keep nt_epilogue.)
+// MT x NT MFMA tiles per wave, waves (256 / (16 MT)) x NWN, block tile 256 x BN, NTHREADS threads.
+template <typename T, int MT, int NT, int NWN, int BN, int NTHREADS>
+__device__ __forceinline__ void nt_epilogue_slab(const LinArgs& p, f32x4 (&acc)[MT][NT], char* lds, int wm, int wn, int li, int lg, int tid,
+                                                 int m0, int n0) {
+    static_assert(sizeof(T) == 2, "bf16 path");
+    constexpr int CW = 4 * NT, WN = BN / NWN, RPW = MT * 16, GPP = 128 / RPW, PITCH = BN * 4 + 16, CPR = BN / 8;
+    constexpr int PER = 128 * CPR / NTHREADS;
+    static_assert(128 % RPW == 0 && (128 * CPR) % NTHREADS == 0, "slab geometry");
+    T* __restrict__ yg = reinterpret_cast<T*>(p.y);
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                          // the K loop's last fragment reads / the previous pass's slab reads are done
+        if (wm / GPP == pass) {
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b)
+                    *reinterpret_cast<f32x4*>(lds + ((wm % GPP) * RPW + a * 16 + li) * PITCH + (wn * WN + chan_of<CW>(b, lg, 0)) * 4) = acc[a][b];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int q = i * NTHREADS + tid, r = q / CPR, cc = q - r * CPR;
+            const int m = m0 + pass * 128 + r, n = n0 + cc * 8;
+            if (m < p.M) {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(lds + r * PITCH + cc * 32);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(lds + r * PITCH + cc * 32 + 16);
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+                if (p.bias) {
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+                }
+                Vec<T> t;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t.set(e, v[e]);
+                stvec<T>(yg + (size_t)m * p.ldy + n, t);
+            }
+        }
+    }
+}
+
 }  // namespace
