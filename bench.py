@@ -147,11 +147,12 @@ def build_models(args, dev, cfg):
 
 def p256_tile(M, N, K, kw):
     """mirror of csrc/gemm.hip::p256_plan (persistent 256-row-tile kernel): channel-tile width, or 0"""
-    if M < 16384 or M % 16 or K % 64 or K < 192 or kw.get("res") is not None or kw.get("aux") is not None or kw.get("rowscale") is not None:
+    has_op = kw.get("res") is not None or kw.get("rowscale") is not None
+    if M < 16384 or M % 16 or K % 64 or K < 192 or kw.get("aux") is not None or (has_op and os.environ.get("FMMT_NT_P256_OPS", "1") == "0"):
         return 0
     tm, best, cost = (M + 255) // 256, 0, 0.0
     for bn, pen in ((256, 1.0), (192, 1.04), (128, 1.10)):
-        if N % bn:
+        if N % bn or (has_op and bn == 256):
             continue
         tiles = tm * (N // bn)
         if tiles < 256:
@@ -211,7 +212,7 @@ class KernelTimer:
                 else:
                     bn = "deep256x96x32" + nk
             if p256:
-                bn = f"p256x{p256}"
+                bn = f"p256x{p256}" + ("op" if (kw.get("res") is not None or kw.get("rowscale") is not None) else "")
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             y = raw(x2, w, bias, **kw)
@@ -642,8 +643,9 @@ def kernel_symbol(bn):
     if bn.startswith("linear_tn"):
         return bn
     if bn.startswith("p256x"):
-        w = bn[5:]
-        return f"linear_nt_p256_kernel<{w},64,{3 if w == '128' else 2},true,false>"
+        op = bn.endswith("op")
+        w = bn[5:-2] if op else bn[5:]
+        return f"linear_nt_p256_kernel<{w},64,{3 if w == '128' else 2},true,{'true' if op else 'false'}>"
     if bn.startswith("deep256") and bn != "deep256x128x64":         # deep256x{128,96}x32[,nkN]
         width = "128" if bn.startswith("deep256x128") else "96"
         return f"linear_nt_deep32_kernel<{bn[-1] if ',nk' in bn else '0'},{width}>"

@@ -797,14 +797,14 @@ int p256_plan(const LinArgs& a) {
     // (profiles/r02_gemm_shapes.txt): plain / bias / GELU + pre-activation launches gain 5-50 % over the two-workgroup
     // 256 x 128 kernels (125440 x 1536 x 384 GELU: 0.439 -> 0.295 ms), launches with such loads lose 0-25 %: those stay
     // on the older kernels.  FMMT_NT_P256=2 sends them here as well (A/B switch).
-    // FMMT_NT_P256_OPS=1 (A/B switch, default 0): such launches come here too, on the 192- / 128-wide tiles, with the operand
-    // prefetched into registers one K step before the epilogue (HASOP).  Measured, same call: residual + scale 321 -> 262 us
-    // (501760 x 192 x 768), 210 -> 201 (125440 x 384 x 1536), but GELU' 338 -> 391 / 530 -> 614 us: the GELU' epilogue is
-    // ~11 k VALU cycles per wave tile against 4.6 k MFMA cycles of a K = 384 tile, and one workgroup per CU has no second
-    // workgroup whose K loop could run under it.  Total over the step's shapes: +1 %.  Not the default.
-    static const int ops_mode = getenv("FMMT_NT_P256_OPS") ? atoi(getenv("FMMT_NT_P256_OPS")) : 0;
+    // FMMT_NT_P256_OPS: 1 (default) = launches with a residual and / or DropPath scale come here too, on the 192- / 128-wide
+    // tiles, with the operand prefetched into registers one K step before the epilogue (HASOP): measured, same call, 321 -> 262 us
+    // (501760 x 192 x 768), 210 -> 201 (125440 x 384 x 1536); 2 = GELU' launches as well: 338 -> 391 / 530 -> 614 us -- that
+    // epilogue is ~11 k VALU cycles per wave tile against 4.6 k MFMA cycles of a K = 384 tile, and one workgroup per CU has no
+    // second workgroup whose K loop could run under it; 0 = none.
+    static const int ops_mode = getenv("FMMT_NT_P256_OPS") ? atoi(getenv("FMMT_NT_P256_OPS")) : 1;
     const bool has_op = a.res || a.aux || a.rowscale;
-    if (has_op && (!ops_mode || (a.res && a.aux) || a.ldres % 8 || a.ldaux % 8)) return 0;
+    if (has_op && (!ops_mode || (a.aux && (ops_mode < 2 || a.res)) || a.ldres % 8 || a.ldaux % 8)) return 0;
     const int tm = (a.M + 255) / 256;
     int best = 0;
     double best_cost = 0;

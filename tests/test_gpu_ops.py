@@ -54,7 +54,7 @@ def test_register_staged_weight_gradient_kernel_on_the_large_shapes():
 
 def test_non_default_gemm_switches_stay_correct():
     """The A/B switches that are off by default keep their code paths: the persistent NT kernel with the epilogue operand
-    prefetched into registers (FMMT_NT_P256_OPS=1), its GELU + pre-activation epilogue through the LDS scratch
+    prefetched into registers for GELU' launches too (FMMT_NT_P256_OPS=2; 0: none), its GELU + pre-activation epilogue through the LDS scratch
     (FMMT_NT_P256_LDSGELU=1), compiler-scheduled fragment reads and direct epilogue stores (FMMT_NT_P256_BATCH=0,
     FMMT_NT_P256_LDSEPI=0: the older forms), 64-token steps and the older
     one-workgroup form for few-token weight gradients (FMMT_TN_FEW64=1, FMMT_TN_FEW=0), unscaled-only DMA weight gradients
@@ -71,7 +71,7 @@ def test_non_default_gemm_switches_stay_correct():
             "bad = [n for n, ok in P.RES if not ok]\n"
             "print('CASES', len(P.RES), 'FAILED', bad)\n"
             "sys.exit(1 if bad or not P.RES else 0)\n") % root
-    for extra in ({"FMMT_NT_P256_OPS": "1", "FMMT_NT_P256_LDSGELU": "1", "FMMT_TN_FEW64": "1", "FMMT_TN_FEW": "0", "FMMT_TN_DMA_SCALED": "0"},
-                  {"FMMT_NT_P256_BATCH": "0", "FMMT_NT_P256_LDSEPI": "0"}):
+    for extra in ({"FMMT_NT_P256_OPS": "2", "FMMT_NT_P256_LDSGELU": "1", "FMMT_TN_FEW64": "1", "FMMT_TN_FEW": "0", "FMMT_TN_DMA_SCALED": "0"},
+                  {"FMMT_NT_P256_BATCH": "0", "FMMT_NT_P256_LDSEPI": "0", "FMMT_NT_P256_OPS": "0", "FMMT_NT_SLAB": "0"}):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, str(extra) + r.stdout[-2000:] + r.stderr[-2000:]
