@@ -427,8 +427,18 @@ void linear_nt_deep32_kernel(LinArgs p) {
         }
     }
     // FMMT_NT_SLAB=0 (p.reserved bit 4): the older epilogue, straight from the accumulator layout (A/B switch)
-    if (p.part || (p.reserved & 16) || p.epi != 0 || p.y_pre || p.res || p.aux || p.rowscale) nt_epilogue<T, MT, NT>(p, acc, m0 + wm * 64, n0 + wn * WN, li, lg);
-    else nt_epilogue_slab<T, MT, NT, 2, BN, 512>(p, acc, smem, wm, wn, li, lg, tid, m0, n0);
+    const bool plain = p.epi == 0 && !p.y_pre && !p.res && !p.aux && !p.rowscale;
+    if (p.part || (p.reserved & 16) || (!plain && (BN != 128 || (p.reserved & 32)))) {
+        nt_epilogue<T, MT, NT>(p, acc, m0 + wm * 64, n0 + wn * WN, li, lg);
+    } else if (plain) {
+        nt_epilogue_slab<T, MT, NT, 2, BN, 512>(p, acc, smem, wm, wn, li, lg, tid, m0, n0);
+    } else {
+        if constexpr (BN == 128) {                         // operand / GELU epilogues: wave-private slab, whole 128-byte lines
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                  // every wave is done with the K loop's stages
+            nt_epilogue_wslab<T>(p, acc, smem + wave * (16 * 272), lane, li, lg, m0 + wm * 64, n0 + wn * WN);
+        }
+    }
 }
 
 // (A "wide-wave" variant -- the same 256 x 128 block computed by four waves with 128 x 64 wave tiles, 0.375 KB of
@@ -924,7 +934,8 @@ int dispatch_nt(const LinArgs& a, hipStream_t st) {
             LinArgs p = a;
             p.tiles_m = (a.M + 255) / 256;
             static const int slab = getenv("FMMT_NT_SLAB") ? atoi(getenv("FMMT_NT_SLAB")) : 1;
-            p.reserved = slab ? 0 : 16;
+            static const int wslab = getenv("FMMT_NT_WSLAB") ? atoi(getenv("FMMT_NT_WSLAB")) : 1;
+            p.reserved = (slab ? 0 : 16) | (wslab ? 0 : 32);
             if (n96) {
                 p.tiles_n = a.N / 96;
                 if (a.K == 192) hipLaunchKernelGGL((linear_nt_deep32_kernel<6, 96>), dim3(p.tiles_m * p.tiles_n), dim3(512), lds96, st, p);

@@ -224,4 +224,66 @@ __device__ __forceinline__ void nt_epilogue_slab(const LinArgs& p, f32x4 (&acc)[
     }
 }
 
+// Every epilogue (GELU + pre-activation, GELU', DropPath scale, residual) of a 64 x 64 WAVE tile through a wave-private fp32
+// slab, one 16-row fragment at a time: 64 channels of bf16 are exactly one 128-byte line, so after the transposition every store
+// AND every load of the residual / GELU' operand is eight complete lines per instruction instead of sixteen 64-byte pieces.
+// No barrier (a wave's LDS operations execute in order), so two co-resident workgroups keep hiding one another's epilogue.
+// Same fp32 arithmetic in the same order as nt_epilogue.  wslab: this wave's 16 x 272 bytes.
+template <typename T>
+__device__ __forceinline__ void nt_epilogue_wslab(const LinArgs& p, f32x4 (&acc)[4][4], char* wslab, int lane, int li, int lg, int mbase, int nbase) {
+    static_assert(sizeof(T) == 2, "bf16 path");
+    constexpr int PITCH = 64 * 4 + 16;
+    T* __restrict__ yg = reinterpret_cast<T*>(p.y);
+    T* __restrict__ ypre = reinterpret_cast<T*>(p.y_pre);
+    const T* __restrict__ auxg = reinterpret_cast<const T*>(p.aux);
+    const T* __restrict__ resg = reinterpret_cast<const T*>(p.res);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) *reinterpret_cast<f32x4*>(wslab + li * PITCH + chan_of<16>(b, lg, 0) * 4) = acc[a][b];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = i * 64 + lane, r = q >> 3, cc = q & 7;
+            const int m = mbase + a * 16 + r, n = nbase + cc * 8;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(wslab + r * PITCH + cc * 32);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(wslab + r * PITCH + cc * 32 + 16);
+            if (m < p.M) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+                if (p.bias) {
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+                }
+                const float rs = row_scale(p.rowscale, m, p.rows_per_scale);
+                auto put = [&](T* base, int ld) {
+                    Vec<T> t;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) t.set(e, v[e]);
+                    stvec<T>(base + (size_t)m * ld + n, t);
+                };
+                if (p.epi == FMMT_EPI_GELU) {
+                    if (ypre) put(ypre, p.ldy);
+                    gelu_inplace<T>(v, 8);
+                } else if (p.epi == FMMT_EPI_GELU_BWD) {
+                    const Vec<T> t = ldvec<T>(auxg + (size_t)m * p.ldaux + n);
+                    float ax[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ax[e] = t.get(e);
+                    gelu_grad_mul_inplace<T>(v, ax, 8);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= rs;
+                if (resg) {
+                    const Vec<T> t = ldvec<T>(resg + (size_t)m * p.ldres + n);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += t.get(e);
+                }
+                put(yg, p.ldy);
+            }
+        }
+    }
+}
+
 }  // namespace
