@@ -317,7 +317,18 @@ __global__ __launch_bounds__(512) void linear_nt_deep_kernel(LinArgs p) {
         compute(cur);
         cur = cur == 2 ? 0 : cur + 1;
     }
-    nt_epilogue<T, MT, NT>(p, acc, m0 + wm * 64, n0 + wn * 64, li, lg);
+    // epilogue through LDS, as in linear_nt_deep32_kernel: plain / bias through the block-wide slab, everything else through
+    // wave-private slabs (FMMT_NT_SLAB=0 / FMMT_NT_WSLAB=0: straight from the accumulator layout)
+    const bool plain = p.epi == 0 && !p.y_pre && !p.res && !p.aux && !p.rowscale;
+    if (p.part || (p.reserved & (plain ? 16 : 32))) {
+        nt_epilogue<T, MT, NT>(p, acc, m0 + wm * 64, n0 + wn * 64, li, lg);
+    } else if (plain) {
+        nt_epilogue_slab<T, MT, NT, 2, BN, 512>(p, acc, smem, wm, wn, li, lg, tid, m0, n0);
+    } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // every wave is done with the K loop's stages
+        nt_epilogue_wslab<T>(p, acc, smem + wave * (16 * 272), lane, li, lg, m0 + wm * 64, n0 + wn * 64);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

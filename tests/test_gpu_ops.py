@@ -72,6 +72,7 @@ def test_non_default_gemm_switches_stay_correct():
             "print('CASES', len(P.RES), 'FAILED', bad)\n"
             "sys.exit(1 if bad or not P.RES else 0)\n") % root
     for extra in ({"FMMT_NT_P256_OPS": "2", "FMMT_NT_P256_LDSGELU": "1", "FMMT_TN_FEW64": "1", "FMMT_TN_FEW": "0", "FMMT_TN_DMA_SCALED": "0"},
-                  {"FMMT_NT_P256_BATCH": "0", "FMMT_NT_P256_LDSEPI": "0", "FMMT_NT_P256_OPS": "0", "FMMT_NT_SLAB": "0"}):
+                  {"FMMT_NT_P256_BATCH": "0", "FMMT_NT_P256_LDSEPI": "0", "FMMT_NT_P256_OPS": "0", "FMMT_NT_SLAB": "0", "FMMT_NT_WSLAB": "0"},
+                  {"FMMT_NT_P256_OPS": "0"}):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, str(extra) + r.stdout[-2000:] + r.stderr[-2000:]
