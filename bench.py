@@ -232,7 +232,7 @@ class KernelTimer:
             # same dispatch as csrc/gemm.hip::fmmt_linear_wgrad_partials; the fixed-order sum of the partials
             # (fmmt_linear_wgrad_finish) is a separate launch and is not inside these events
             name = "linear_tn_kernel<bf16,32,few>" if M <= 4096 else "linear_tn_kernel<bf16,64>" if M <= 262144 else "linear_tn_kernel<bf16,32>"
-            if (os.environ.get("FMMT_TN_FEW", "1") != "0" and 128 < M <= 2048 and N % 64 == 0 and K % 64 == 0 and (N // 64) * (K // 64) >= 8
+            if (os.environ.get("FMMT_TN_FEW", "1") != "0" and 128 < M <= 2048 and N % 64 == 0 and K % 64 == 0 and 8 <= (N // 64) * (K // 64) <= 1024
                     and rowscale is None and not x_gelu):
                 name = "linear_tn_few_kernel"
             dma = tn_dma_tile(M, N, K, rowscale is not None, rows_per_scale, x_gelu)

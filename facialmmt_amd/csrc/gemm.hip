@@ -1406,7 +1406,9 @@ int launch_tn_few(int M, int N, int K, const void* dy, int lddy, const void* x, 
 // eligibility of linear_tn_few_kernel: bf16, 129..2048 tokens, whole 64 x 64 tiles, at least 8 of them, 16-byte rows
 bool tn_few_ok(int M, int N, int K, int dtype) {
     static const int on = getenv("FMMT_TN_FEW") ? atoi(getenv("FMMT_TN_FEW")) : 1;
-    return on && dtype == FMMT_BF16 && M > 128 && M <= 2048 && N % 64 == 0 && K % 64 == 0 && (N / 64) * (K / 64) >= 8;
+    // (at most 1024 tiles: the embedding head's 512 x 37632 gradient -- 4704 tiles of 640 tokens -- took 767 us here against 292 us
+    //  with the 128 x 128-tile kernel, whose workgroups reuse each staged token slab four times as often)
+    return on && dtype == FMMT_BF16 && M > 128 && M <= 2048 && N % 64 == 0 && K % 64 == 0 && (N / 64) * (K / 64) >= 8 && (N / 64) * (K / 64) <= 1024;
 }
 
 // ---------------------------------------------------------------------------------------------

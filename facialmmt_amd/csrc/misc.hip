@@ -390,22 +390,25 @@ __global__ __launch_bounds__(256) void lnp_bwd_kernel(int M, int C, float eps, c
         }
     }
 }
-__global__ __launch_bounds__(256) void lnp_reduce_kernel(const float* __restrict__ part, int nblocks, int C, bf16* __restrict__ dgamma, bf16* __restrict__ dbeta) {
-    const int i = blockIdx.x * 256 + threadIdx.x;           // column of the [2][C] pair
-    if (i >= 2 * C) return;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int b = 0;
-    for (; b + 4 <= nblocks; b += 4) {
-        a0 += part[(size_t)b * 2 * C + i];
-        a1 += part[(size_t)(b + 1) * 2 * C + i];
-        a2 += part[(size_t)(b + 2) * 2 * C + i];
-        a3 += part[(size_t)(b + 3) * 2 * C + i];
+__global__ __launch_bounds__(1024) void lnp_reduce_kernel(const float* __restrict__ part, int nblocks, int C, bf16* __restrict__ dgamma, bf16* __restrict__ dbeta) {
+    // 1024 threads = 32 columns x 32 partial groups, fixed-order tree (256 threads x one column each was 21 us: eight workgroups)
+    __shared__ float red[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + tx;                     // column of the [2][C] pair
+    float a = 0.f;
+    if (i < 2 * C)
+        for (int b = ty; b < nblocks; b += 32) a += part[(size_t)b * 2 * C + i];
+    red[ty][tx] = a;
+    __syncthreads();
+    if (ty == 0 && i < 2 * C) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 32; ++g) t += red[g][tx];
+        if (i < C) dgamma[i] = (bf16)t;
+        else dbeta[i - C] = (bf16)t;
     }
-    for (; b < nblocks; ++b) a0 += part[(size_t)b * 2 * C + i];
-    const float t = (a0 + a1) + (a2 + a3);
-    if (i < C) dgamma[i] = (bf16)t;
-    else dbeta[i - C] = (bf16)t;
 }
+
 }  // namespace
 
 extern "C" int fmmt_version(void) { return 1; }
@@ -546,7 +549,7 @@ extern "C" int fmmt_layernorm_bwd_bf16(int M, int C, float eps, const void* dy, 
     hipLaunchKernelGGL(lnp_bwd_kernel, dim3(blocks), dim3(256), 0, st, M, C, eps, (const bf16*)dy, (const bf16*)x, (const bf16*)gamma, (bf16*)dx,
                        reinterpret_cast<float*>(workspace));
     FMMT_CHECK_LAUNCH();
-    hipLaunchKernelGGL(lnp_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, reinterpret_cast<const float*>(workspace), blocks, C,
+    hipLaunchKernelGGL(lnp_reduce_kernel, dim3((2 * C + 31) / 32), dim3(1024), 0, st, reinterpret_cast<const float*>(workspace), blocks, C,
                        (bf16*)dgamma, (bf16*)dbeta);
     FMMT_CHECK_LAUNCH();
     return 0;
