@@ -904,7 +904,10 @@ int dispatch_nt(const LinArgs& a, hipStream_t st) {
     const bool n96 = (a.N % 96 == 0) && (a.N % 128 != 0);
     // few-token problems (cross-modal encoder: 152..1280 rows; embedding head: 640 rows) use 64-row tiles so
     // that twice as many workgroups share the work; the multi-million-token Swin GEMMs use 128-row tiles
-    if (a.M <= 4096) return n96 ? dispatch_nt_bk<T, 64, 96>(a, st) : dispatch_nt_bk<T, 64, 128>(a, st);
+    // (few rows but tens of thousands of output channels -- the input gradient of the 37632 -> 512 embedding head: there are
+    //  workgroups enough, 128-row tiles read each weight slab half as often; FMMT_NT_WIDE64=1 keeps the 64-row tiles for it)
+    static const int wide64 = getenv("FMMT_NT_WIDE64") ? atoi(getenv("FMMT_NT_WIDE64")) : 0;
+    if (a.M <= 4096 && (a.N < 16384 || a.M < 256 || wide64)) return n96 ? dispatch_nt_bk<T, 64, 96>(a, st) : dispatch_nt_bk<T, 64, 128>(a, st);
     if constexpr (sizeof(T) == 2) {
         if (const int bn = p256_plan(a)) {
             // FMMT_NT_P256_RING: 1 (default) = K step 64, ring of 2 (3 for 128-wide tiles); 0 = K step 32, ring of 4.

@@ -77,7 +77,8 @@ def t_linear_large():
     for (M, N, K) in [(65536 + 77, 384, 384), (70000, 1536, 384), (65536, 384, 1536), (66000, 128, 256), (65600, 768, 192),
                       (65536 + 77, 192, 192), (70000, 576, 192), (65600, 96, 384), (65536, 96, 288), (66000, 288, 768),
                       (65536 + 77, 384, 96), (70000, 288, 96), (65600, 96, 96),
-                      (31360, 768, 3072), (31360 + 16, 2304, 768), (20000, 1536, 384), (125440, 1152, 384), (31360, 384, 1536)]:   # persistent 256-row-tile kernel: partial rounds, ragged panel
+                      (31360, 768, 3072), (31360 + 16, 2304, 768), (20000, 1536, 384), (125440, 1152, 384), (31360, 384, 1536),   # persistent 256-row-tile kernel: partial rounds, ragged panel
+                      (640, 37632, 512), (300, 16384, 64)]:   # few rows, very wide output (input gradient of the embedding head): 128-row tiles
         x = rnd("x", (M, K), 1, dtype=dt)
         w = rnd("w", (N, K), 2, K ** -0.5, dtype=dt)
         b = rnd("b", (N,), 3, 0.1)
