@@ -17,7 +17,8 @@ struct LinArgs {
     const void* aux; int ldaux;
     const void* res; int ldres;
     const float* rowscale; int rows_per_scale;
-    int tiles_n, tiles_m, reserved;
+    int tiles_n, tiles_m;
+    int reserved;      // launcher-to-kernel A/B bits: 4 direct p256 epilogue, 8 no GELU slab, 16 no block slab, 32 no wave slab
     int ksplit;        // K range per blockIdx.y (split-K); 0 = no split
     float* part;       // split-K: fp32 partials [split][M][N] instead of the epilogue
 };
