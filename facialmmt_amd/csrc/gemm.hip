@@ -1106,6 +1106,15 @@ void linear_tn_kernel(TnArgs p) {
     // (PMC, profiles/r02: 3.7 VALU instructions per MFMA.  Dropping the ones that guard -- unconditional loads for interior
     //  steps, one wave-uniform division per step for the DropPath sample index -- was measured in-step, same call, twice:
     //  7.29 / 7.30 ms against 6.92 / 6.72 ms for the stage-2/3 launches, 5.4 against 4.6 for stage 0/1: slower, not kept.)
+    // DropPath sample index of this thread's token rows, advanced by BMS per gload() (the calls walk the split's steps in order):
+    // one division per thread instead of one per vector and step
+    int sidx[NV], srem[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int m = mbeg + (tid + i * 256) / CV;
+        sidx[i] = p.rowscale ? m / p.rows_per_scale : 0;
+        srem[i] = p.rowscale ? m - sidx[i] * p.rows_per_scale : 0;
+    }
     auto gload = [&](Regs& R, int mb) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -1116,7 +1125,14 @@ void linear_tn_kernel(TnArgs p) {
             // the DropPath scale is only *fetched* here and applied in lstore(), after the MFMA block: applying it
             // right away makes every tile load wait for two dependent HBM round trips (measured: 2x slower launches)
             R.a[i] = (mv && n0 + c < p.N) ? ldvec<T>(dyg + (size_t)m * p.lddy + n0 + c) : zerovec<T>();
-            if (p.rowscale) R.s[i] = mv ? p.rowscale[m / p.rows_per_scale] : 0.f;
+            if (p.rowscale) {
+                R.s[i] = mv ? p.rowscale[sidx[i]] : 0.f;
+                srem[i] += BMS;
+                while (srem[i] >= p.rows_per_scale) {
+                    srem[i] -= p.rows_per_scale;
+                    ++sidx[i];
+                }
+            }
             R.b[i] = (mv && k0 + c < p.K) ? ldvec<T>(xg + (size_t)m * p.ldx + k0 + c) : zerovec<T>();
         }
     };
