@@ -701,7 +701,43 @@ __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
                     for (int a = 0; a < MT; ++a) acc[a][b] += bb;
                 }
             }
-            if (lds_epi) {
+            // (GELU + pre-activation through the same slabs: FMMT_NT_P256_LDSGELU=1; measured 281 -> 292 us, off)
+            if (BN == 256 && !HASOP && !p.part && !(p.reserved & 4) && !p.y_pre && (p.epi == 0 || (p.epi == FMMT_EPI_GELU && lds_gelu))) {
+                // 256-wide tile: a wave's 64 channels are one 128-byte line, so the transposition is wave-private -- 16 token rows
+                // at a time through this wave's own 2.3 KB slab, no barrier -- and serves GELU + pre-activation (two tensors) too
+                if constexpr (BN == 256) {
+                    char* ws = smem + (size_t)NBUF * STAGE * sizeof(T) + 2 * 256 * sizeof(float) + wave * (16 * 144);
+                    T* __restrict__ ypre = reinterpret_cast<T*>(p.y_pre);
+                    const int mw = m0 + wm * 128, nw = n0 + wn * WN;
+                    const int rr = lane >> 3, rc = lane & 7;           // read side: 8 rows x 8 chunks of 16 bytes per instruction
+                    auto emit = [&](int a, T* dst, bool gelu) {
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            float t[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) t[e] = acc[a][2 * c + (e >> 2)][e & 3];
+                            if (gelu) gelu_inplace<T>(t, 8);
+                            bf16x8 v;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = (bf16)t[e];
+                            *reinterpret_cast<bf16x8*>(ws + li * 144 + chan_of<CW>(2 * c, lg, 0) * 2) = v;
+                        }
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int m = mw + a * 16 + h * 8 + rr;
+                            const bf16x8 v = *reinterpret_cast<const bf16x8*>(ws + (h * 8 + rr) * 144 + rc * 16);
+                            if (m < p.M) *reinterpret_cast<bf16x8*>(dst + (size_t)m * p.ldy + nw + rc * 8) = v;
+                        }
+                    };
+                    const bool two = p.epi == FMMT_EPI_GELU && ypre != nullptr;
+#pragma unroll
+                    for (int a = 0; a < MT; ++a) {
+                        if (two) emit(a, ypre, false);
+                        emit(a, yg, p.epi == FMMT_EPI_GELU);
+                    }
+                    if (mw + 128 <= p.M) st_prev = MT * 2 * (two ? 2 : 1);
+                }
+            } else if (lds_epi) {
                 const int rows_left = p.M - (m0 + wm * 128);             // token rows of this wave group that exist
                 T* __restrict__ ypre = reinterpret_cast<T*>(p.y_pre);
                 // one slab round: the waves park `which` (0: the values as they are, 1: their GELU) of PR rows, then store whole rows
@@ -772,7 +808,7 @@ __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
 
 template <int BN, int BK, int NBUF, bool BATCH, bool HASOP>
 int launch_p256_b(const LinArgs& a, hipStream_t st) {
-    constexpr size_t lds = (size_t)NBUF * (BN + 256) * BK * 2 + 2 * 256 * sizeof(float) + 2 * (BN == 192 ? 32 : 16) * (BN * 2 + 16);   // ring, bias slabs, epilogue scratch
+    constexpr size_t lds = (size_t)NBUF * (BN + 256) * BK * 2 + 2 * 256 * sizeof(float) + (BN == 256 ? 8 * 16 * 144 : 2 * (BN == 192 ? 32 : 16) * (BN * 2 + 16));   // ring, bias slabs, epilogue scratch (BN = 256: wave-private slabs)
     static_assert(lds <= 160 * 1024, "LDS");
     static bool attr_set = false;
     if (!attr_set) {
