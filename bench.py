@@ -66,6 +66,7 @@ def parse():
     ap.add_argument("--parallel-fusion", type=int, default=1, help="capture independent halves of the fusion stack as parallel graph branches")
     ap.add_argument("--force-ddp", action="store_true", help="run the data-parallel gradient exchange path even with one process (exercises the N>1 code path on one GPU)")
     ap.add_argument("--shape-report", default=None, help="write a per-GEMM-shape timing table to this file (development aid)")
+    ap.add_argument("--host-input-leg", type=int, default=1, help="after the timed region, also time the steps with the batch handed over in pinned host memory (PCIe-inclusive rate; reported, never `value`)")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames in the CPU-baseline Swin sample")
     a = ap.parse_args()
     if a.config == 3:
@@ -526,6 +527,36 @@ def main():
     idle_issue_ms = (time.perf_counter() - t1) * 1e3
     torch.cuda.synchronize()
 
+    # After the timed region (not part of `value`): the same steps with every batch tensor handed over in PINNED HOST memory, as
+    # the reference's DataLoader does (train.py:290-314: `.to(device)` per tensor) -- the step's own copy into its static input
+    # tensors then crosses PCIe.  Every rank runs it (the step holds the all-reduce at N > 1); rank 0 reports its own clock.
+    pcie = None
+    if args.graphs == 2 and args.host_input_leg:
+        try:
+            pin = lambda ts: tuple(t.detach().cpu().pin_memory() if torch.is_tensor(t) else t for t in ts)
+            hb, hab = pin(batch), (pin(aux_batch) if aux_batch is not None else None)
+
+            def host_step():
+                if aux_step is not None:
+                    aux_step(*hab)
+                return step(hb)
+
+            host_step()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for _ in range(args.steps):
+                host_step()
+            torch.cuda.synchronize()
+            h_ms = (time.perf_counter() - t2) / args.steps * 1e3
+            nbytes = sum(t.numel() * t.element_size() for t in hb + (hab or ()) if torch.is_tensor(t))
+            pcie = {"value": round(args.utts * world / (h_ms * 1e-3), 3), "unit": "utterances/s", "ms_per_step": round(h_ms, 2),
+                    "host_bytes_per_step_per_gpu": nbytes,
+                    "note": "batch tensors in pinned host memory, copied into the step's static inputs on the step's stream (not overlapped); rank 0's clock; not `value`"}
+            step(batch)                                      # device-resident inputs again for what follows
+            torch.cuda.synchronize()
+        except Exception as e:                               # a reported leg only: never takes the line down
+            pcie = {"error": f"{type(e).__name__}: {e}"}
+
     # After the timed region (not part of `value`): the kernels of the Linear layers bracketed with HIP events in EAGER
     # forward+backward passes on the main stream (inside a graph replay nothing can be bracketed; with --graphs 1 the timed
     # steps themselves are bracketed too, but there the text-encoder graph shares the CUs and stretches every Swin kernel).
@@ -615,6 +646,7 @@ def main():
                        "gradient_allreduce": None if not ddp else f"{args.grad_comm}, {'between the two graphs' if args.graphs == 2 else 'hook-driven, overlapped with backward'}"},
             "roofline": roof,
             "cpu_baseline": None,
+            "pcie_inclusive": pcie,
         }
         if args.graphs == 1:
             line["config"]["second_stream_pair_over_single"] = round(float(getattr(mm, "text_stream_concurrency", 0.0)), 2)

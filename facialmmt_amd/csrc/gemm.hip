@@ -540,6 +540,16 @@ __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
     typedef __attribute__((address_space(3))) void lptr_t;
     auto key = [](int row) { return BK == 64 ? ((row >> 1) & 7) : (((row >> 3) ^ (row >> 2)) & 3); };   // 16-byte chunk swizzle
     const int rl = BK == 64 ? (lane >> 3) : (lane >> 2), cl = BK == 64 ? (lane & 7) : (lane & 3);
+    // Weight rows sit in LDS in FRAGMENT order (K step 64): row wn * WN + b * 16 + i of the stage holds the output channel that
+    // lane i of n-tile b accumulates (chan_of), so that a weight fragment read touches 16 consecutive 128-byte rows like a token
+    // fragment does -- with the rows in channel order the lanes of one ds_read_b128 phase met rows {0-3, 24-27} and {8-11, 16-19},
+    // whose swizzle keys coincide pairwise: 2-way bank conflicts on every 8-channel-chunk fragment (SQ_LDS_BANK_CONFLICT 19 % of
+    // the LDS cycles).  FMMT_NT_P256_WROWS=0 (reserved bit 64): channel order (A/B switch).
+    const bool wperm = BK == 64 && !(p.reserved & 64);
+    auto wchan = [&](int r) {
+        const int w = r / WN, q = r - w * WN;
+        return wperm ? w * WN + chan_of<CW>(q >> 4, (q >> 2) & 3, q & 3) : r;
+    };
 
     // DMA instructions this wave issues per stage (wave 7 carries the bias slab on top)
     const int my_cnt = (NI - wave + 7) / 8 + (wave == 7 ? 1 : 0);
@@ -554,7 +564,7 @@ __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
                 const T* src;
                 if (row0 < BN) {
                     const int r = row0 + rl;
-                    src = wg + (size_t)(n0 + r) * p.ldw + k0 + ((cl ^ key(r)) << 3);
+                    src = wg + (size_t)(n0 + wchan(r)) * p.ldw + k0 + ((cl ^ key(r)) << 3);
                 } else {
                     const int rx = row0 - BN;
                     const int rb = min(m0 + rx, p.M - RPI);                         // ragged last panel: re-read valid rows (never stored)
@@ -592,7 +602,7 @@ __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
     int woff[NT], xoff[MT];                                // element offsets of this lane's fragments inside a stage (K chunk lg)
 #pragma unroll
     for (int b = 0; b < NT; ++b) {
-        const int r = wn * WN + chan_of<CW>(b, li >> 2, li & 3);
+        const int r = wn * WN + (wperm ? b * 16 + li : chan_of<CW>(b, li >> 2, li & 3));
         woff[b] = r * PITCH + ((lg ^ key(r)) << 3);
     }
 #pragma unroll
@@ -823,7 +833,8 @@ int launch_p256_b(const LinArgs& a, hipStream_t st) {
     // FMMT_NT_P256_LDSEPI=0: epilogue stores straight from the accumulator layout (A/B switch)
     static const int lds_epi = getenv("FMMT_NT_P256_LDSEPI") ? atoi(getenv("FMMT_NT_P256_LDSEPI")) : 1;
     static const int lds_gelu = getenv("FMMT_NT_P256_LDSGELU") ? atoi(getenv("FMMT_NT_P256_LDSGELU")) : 0;   // measured slower (two tensors, 16-row passes: 32 barriers per tile): 273 -> 296 us
-    p.reserved = (lds_epi ? 0 : 4) | (lds_gelu ? 0 : 8);
+    static const int wrows = getenv("FMMT_NT_P256_WROWS") ? atoi(getenv("FMMT_NT_P256_WROWS")) : 1;
+    p.reserved = (lds_epi ? 0 : 4) | (lds_gelu ? 0 : 8) | (wrows ? 0 : 64);
     hipLaunchKernelGGL((linear_nt_p256_kernel<BN, BK, NBUF, BATCH, HASOP>), dim3(256), dim3(512), lds, st, p);
     FMMT_CHECK_LAUNCH();
     return 0;
@@ -836,6 +847,11 @@ int launch_p256(const LinArgs& a, hipStream_t st) {
         // launches with an M x N epilogue operand or a DropPath scale: operand prefetched into registers (48 / 32 of them:
         // no room beside the 128 accumulators of the 256-wide tile)
         if (a.res || a.aux || a.rowscale) return launch_p256_b<BN, BK, NBUF, true, true>(a, st);
+        // FMMT_NT_P256_PLAINOP: 1 (default) = operand-free launches whose epilogue stores directly (K > 1536) take the
+        // operand-prefetch instantiation as well -- same-call A/B on 31360 x 768 x 3072: 160.3 -> 153.5 us; 2 = all operand-free
+        // launches (K <= 1536 then lose the LDS epilogue: slower); 0 = none
+        static const int plainop = getenv("FMMT_NT_P256_PLAINOP") ? atoi(getenv("FMMT_NT_P256_PLAINOP")) : 1;
+        if (plainop && !a.part && (a.K > 1536 || plainop > 1)) return launch_p256_b<BN, BK, NBUF, true, true>(a, st);
     }
     return batch ? launch_p256_b<BN, BK, NBUF, true, false>(a, st) : launch_p256_b<BN, BK, NBUF, false, false>(a, st);
 }
@@ -943,7 +959,31 @@ int dispatch_nt(const LinArgs& a, hipStream_t st) {
     // (few rows but tens of thousands of output channels -- the input gradient of the 37632 -> 512 embedding head: there are
     //  workgroups enough, 128-row tiles read each weight slab half as often; FMMT_NT_WIDE64=1 keeps the 64-row tiles for it)
     static const int wide64 = getenv("FMMT_NT_WIDE64") ? atoi(getenv("FMMT_NT_WIDE64")) : 0;
-    if (a.M <= 4096 && (a.N < 16384 || a.M < 256 || wide64)) return n96 ? dispatch_nt_bk<T, 64, 96>(a, st) : dispatch_nt_bk<T, 64, 128>(a, st);
+    if (a.M <= 4096 && (a.N < 16384 || a.M < 256 || wide64)) {
+        if constexpr (sizeof(T) == 2) {
+            // Fewer 64 x 128 tiles than half the CUs (the fusion stack: 152-1328 tokens x 768 channels = 18-126 tiles): such a
+            // launch is a chain of K / 64 steps whose cost is the step's DMA issue (six 1-KB pieces per wave) plus a barrier, on a
+            // mostly idle GPU.  Quarter tiles (32 x 64) put four times the workgroups on the chip, each with half the pieces per
+            // wave and step.  Measured per launch inside a graph (tests/gpu_few_probe.py, same call): 152-640 x 768 x 768 8.5 -> 5.5 us
+            // (hipBLASLt 7.5-8.1), 1328 x 768 x 768 9.2 -> 6.7, 664 x 1536 x 768 9.0 -> 6.5, 512 x 3072 x 768 12.9 -> 9.8,
+            // 512 x 768 x 3072 24.4 -> 16, 1328 x 768 x 3072 25.5 -> 19.5; with 256+ tiles of 64 x 128 the quarter tiles lose
+            // (1328 x 3072 x 768: 14 -> 22 us), and the four-buffer ring does nothing for K = 768.
+            // FMMT_NT_SMALL: 1 (default) = 32 x 64, 2 = 64 x 64 (6.4 us on the first group), 0 = off.
+            static const int small = getenv("FMMT_NT_SMALL") ? atoi(getenv("FMMT_NT_SMALL")) : 1;
+            const int tiles = ((a.M + 63) / 64) * ((a.N + 127) / 128);
+            static const int small_tiles = getenv("FMMT_NT_SMALL_TILES") ? atoi(getenv("FMMT_NT_SMALL_TILES")) : 256;
+            static const int small_r4k = getenv("FMMT_NT_SMALL_R4K") ? atoi(getenv("FMMT_NT_SMALL_R4K")) : 2048;
+            if (small && tiles < small_tiles && a.N % 64 == 0 && a.K % 64 == 0 && a.K >= 128 && !a.ksplit && a.ldx % 8 == 0 && a.ldw % 8 == 0) {
+                if (small == 2) {
+                    if (a.K >= 2048 && 2 * tiles <= 256) return launch_nt<T, 64, 64, 64, 4, true>(a, st);
+                    return launch_nt<T, 64, 64, 64, 2, true>(a, st);
+                }
+                if (a.K >= small_r4k) return launch_nt<T, 32, 64, 64, 4, true>(a, st);
+                return launch_nt<T, 32, 64, 64, 2, true>(a, st);
+            }
+        }
+        return n96 ? dispatch_nt_bk<T, 64, 96>(a, st) : dispatch_nt_bk<T, 64, 128>(a, st);
+    }
     if constexpr (sizeof(T) == 2) {
         if (const int bn = p256_plan(a)) {
             // FMMT_NT_P256_RING: 1 (default) = K step 64, ring of 2 (3 for 128-wide tiles); 0 = K step 32, ring of 4.

@@ -50,24 +50,24 @@ def t_linear():
             b = rnd("b", (N,), 3, 0.1)
             ref = x.double() @ w.double().t() + b.double()
             report(f"linear {dt} {M}x{N}x{K}", ops.linear_raw(x, w, b), ref, tol)
-        M, N, K = 300, 384, 96
-        x = rnd("x", (M, K), 1, dtype=dt)
-        w = rnd("w", (N, K), 2, K ** -0.5, dtype=dt)
-        b = rnd("b", (N,), 3, 0.1)
-        pre = x.double() @ w.double().t() + b.double()
-        ypre = torch.empty((M, N), dtype=dt, device=dev)
-        y = ops.linear_raw(x, w, b, epi=EPI_GELU, y_pre=ypre)
-        report(f"linear gelu {dt}", y, OS.gelu_erf(pre), tol)
-        report(f"linear gelu pre {dt}", ypre, pre, tol)
-        res = rnd("res", (M, N), 4, dtype=dt)
-        rs = rnd("rs", (3,), 5).abs() + 0.5
-        y = ops.linear_raw(x, w, b, res=res, rowscale=rs, rows_per_scale=100)
-        report(f"linear res+rowscale {dt}", y, res.double() + rs.double().repeat_interleave(100)[:, None] * pre, tol)
-        aux = rnd("aux", (M, N), 6, dtype=dt)
-        a64 = aux.double().requires_grad_(True)
-        g = torch.autograd.grad(OS.gelu_erf(a64).sum(), a64)[0]
-        y = ops.linear_raw(x, w, None, epi=EPI_GELU_BWD, aux=aux)
-        report(f"linear gelu_bwd {dt}", y, (x.double() @ w.double().t()) * g, tol)
+        for (M, N, K) in ((300, 384, 96), (300, 768, 768), (166, 768, 3072)):      # the latter two: quarter tiles of the few-token dispatch (bf16)
+            x = rnd("x", (M, K), 1, dtype=dt)
+            w = rnd("w", (N, K), 2, K ** -0.5, dtype=dt)
+            b = rnd("b", (N,), 3, 0.1)
+            pre = x.double() @ w.double().t() + b.double()
+            ypre = torch.empty((M, N), dtype=dt, device=dev)
+            y = ops.linear_raw(x, w, b, epi=EPI_GELU, y_pre=ypre)
+            report(f"linear gelu {dt} {M}x{N}x{K}", y, OS.gelu_erf(pre), tol)
+            report(f"linear gelu pre {dt} {M}x{N}x{K}", ypre, pre, tol)
+            res = rnd("res", (M, N), 4, dtype=dt)
+            rs = rnd("rs", (3,), 5).abs() + 0.5
+            y = ops.linear_raw(x, w, b, res=res, rowscale=rs, rows_per_scale=100)
+            report(f"linear res+rowscale {dt} {M}x{N}x{K}", y, res.double() + rs.double().repeat_interleave(100)[:M, None] * pre, tol)
+            aux = rnd("aux", (M, N), 6, dtype=dt)
+            a64 = aux.double().requires_grad_(True)
+            g = torch.autograd.grad(OS.gelu_erf(a64).sum(), a64)[0]
+            y = ops.linear_raw(x, w, None, epi=EPI_GELU_BWD, aux=aux)
+            report(f"linear gelu_bwd {dt} {M}x{N}x{K}", y, (x.double() @ w.double().t()) * g, tol)
 
 
 def t_linear_large():

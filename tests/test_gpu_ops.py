@@ -58,13 +58,14 @@ def test_non_default_gemm_switches_stay_correct():
     (FMMT_NT_P256_LDSGELU=1), compiler-scheduled fragment reads and direct epilogue stores (FMMT_NT_P256_BATCH=0,
     FMMT_NT_P256_LDSEPI=0: the older forms), 64-token steps and the older
     one-workgroup form for few-token weight gradients (FMMT_TN_FEW64=1, FMMT_TN_FEW=0), unscaled-only DMA weight gradients
-    (FMMT_TN_DMA_SCALED=0).  One process per setting: the switches are read once."""
+    (FMMT_TN_DMA_SCALED=0), operand-free launches through the operand-prefetch instantiation (FMMT_NT_P256_PLAINOP=2), 64 x 64 / 64 x 128 tiles for the few-token NT launches (FMMT_NT_SMALL=2 / 0), weight rows in channel order in the persistent kernel's LDS stages (FMMT_NT_P256_WROWS=0).  One process per setting: the switches are read once."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = ("import sys; sys.path.insert(0, %r)\n"
             "from tests import gpu_probe as P\n"
+            "P.section(P.t_linear)\n"
             "P.section(P.t_linear_large)\n"
             "P.section(P.t_wgrad)\n"
             "P.section(P.t_wgrad_large)\n"
@@ -72,7 +73,7 @@ def test_non_default_gemm_switches_stay_correct():
             "print('CASES', len(P.RES), 'FAILED', bad)\n"
             "sys.exit(1 if bad or not P.RES else 0)\n") % root
     for extra in ({"FMMT_NT_P256_OPS": "2", "FMMT_NT_P256_LDSGELU": "1", "FMMT_TN_FEW64": "1", "FMMT_TN_FEW": "0", "FMMT_TN_DMA_SCALED": "0"},
-                  {"FMMT_NT_P256_BATCH": "0", "FMMT_NT_P256_LDSEPI": "0", "FMMT_NT_P256_OPS": "0", "FMMT_NT_SLAB": "0", "FMMT_NT_WSLAB": "0"},
-                  {"FMMT_NT_P256_OPS": "0"}):
+                  {"FMMT_NT_P256_BATCH": "0", "FMMT_NT_P256_LDSEPI": "0", "FMMT_NT_P256_OPS": "0", "FMMT_NT_SLAB": "0", "FMMT_NT_WSLAB": "0", "FMMT_NT_SMALL": "0"},
+                  {"FMMT_NT_P256_OPS": "0", "FMMT_NT_P256_PLAINOP": "2", "FMMT_NT_SMALL": "2", "FMMT_NT_P256_WROWS": "0"}):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, str(extra) + r.stdout[-2000:] + r.stderr[-2000:]
