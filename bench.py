@@ -206,6 +206,16 @@ class KernelTimer:
             bn = 96 if (N % 96 == 0 and N % 128 != 0) else 128
             bn = f"{bn},96,1" if K == 96 else f"{bn},64,1" if K <= 64 else f"{bn},64,2" if K % 64 == 0 else f"{bn},32,2"
             bn = f"{64 if M <= 4096 else 128},{bn}" + (",glds" if (K % 64 == 0 and K > 64) else "")
+            if M <= 4096 and (N < 16384 or M < 256):
+                tiles = -(-M // 64) * -(-N // 128)
+                small = int(os.environ.get("FMMT_NT_SMALL", "1"))
+                if small and tiles < int(os.environ.get("FMMT_NT_SMALL_TILES", "256")) and N % 64 == 0 and K % 64 == 0 and K >= 128:      # quarter tiles
+                    if small == 2:
+                        bn = f"64,64,64,{4 if (K >= 2048 and 2 * tiles <= 256) else 2},glds"
+                    else:
+                        bn = f"32,64,64,{4 if K >= int(os.environ.get('FMMT_NT_SMALL_R4K', '2048')) else 2},glds"
+                elif K % 64 == 0 and K >= 2048 and tiles <= 256 and os.environ.get("FMMT_NT_GLDS", "1") != "2":
+                    bn = bn.replace(",64,2,glds", ",64,4,glds")
             if M >= 65536 and K % 32 == 0 and K >= 96 and (N % 128 == 0 or N % 96 == 0) and not (K == 96 and kw.get("epi", 0) == 1):
                 nk = ",nk6" if K == 192 else ",nk3" if K == 96 else ""
                 if N % 128 == 0:
@@ -213,7 +223,9 @@ class KernelTimer:
                 else:
                     bn = "deep256x96x32" + nk
             if p256:
-                bn = f"p256x{p256}" + ("op" if (kw.get("res") is not None or kw.get("rowscale") is not None) else "")
+                plainop = int(os.environ.get("FMMT_NT_P256_PLAINOP", "1"))
+                hasop = kw.get("res") is not None or kw.get("rowscale") is not None or kw.get("aux") is not None
+                bn = f"p256x{p256}" + ("op" if p256 != 256 and (hasop or (plainop and (K > 1536 or plainop > 1))) else "")
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             y = raw(x2, w, bias, **kw)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collect the evidence committed under profiles/ (run on the GPU box through gpurun):
 #   tools/profile_round.sh TAG        -> gpurun_out/summ_TAG/{bench.json, bench_config3.json, bench_config4.json, kernel_stats*.md,
-#                                        launch_census.md, pmc_*.md, gemm_shapes.txt}
+#                                        launch_census.md, pmc_*.md, timeline.txt, gemm_shapes.txt, nt_shapes.txt, tn_shapes.txt, few_shapes.txt}
 # PMC passes run WITHOUT HIP graphs (counter collection under graph replay crashes rocprofv3 on this image) and
 # each under its own timeout.
 TAG=${1:-x}
@@ -17,9 +17,9 @@ for c in 3 4; do
 done
 # per-kernel GPU time of the default command minus the CPU leg: 2 eager warm-up passes inside the graph capture + 2 warm-up
 # + 6 timed + 1 idle-queue step (all graph replays) + 3 eager probe passes = 14 passes
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$TAG -o r --output-format csv -- python $R/bench.py --no-cpu-baseline > $O/prof_$TAG.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$TAG -o r --output-format csv -- python $R/bench.py --no-cpu-baseline --host-input-leg 0 > $O/prof_$TAG.log 2>&1
 # the same without the text branch forked onto its own stream: per-kernel durations undisturbed by concurrent text-encoder work
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/profiso_$TAG -o r --output-format csv -- python $R/bench.py --no-cpu-baseline --overlap-text 0 > $O/profiso_$TAG.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/profiso_$TAG -o r --output-format csv -- python $R/bench.py --no-cpu-baseline --host-input-leg 0 --overlap-text 0 > $O/profiso_$TAG.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 400 rocprofv3 --kernel-trace --pmc $c -d $O/pmc_${c}_$TAG -o r --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --graphs 0 > $O/pmc_${c}_$TAG.log 2>&1
 done
@@ -34,6 +34,10 @@ python tools/summarize_prof.py pmc $O/pmc_FETCH_SIZE_$TAG > $S/pmc_fetch.md
 python tools/summarize_prof.py pmc $O/pmc_WRITE_SIZE_$TAG > $S/pmc_write.md
 python tools/summarize_prof.py pmc $O/pmc_MFMA_$TAG > $S/pmc_mfma.md
 python tools/summarize_prof.py pmc $O/pmc_LDS_$TAG > $S/pmc_lds.md
+python tools/timeline.py $O/prof_$TAG > $S/timeline.txt 2>&1
 rm -rf $O/prof_$TAG $O/profiso_$TAG $O/pmc_FETCH_SIZE_$TAG $O/pmc_WRITE_SIZE_$TAG $O/pmc_MFMA_$TAG $O/pmc_LDS_$TAG
 GEMM_BENCH_VENDOR=1 timeout 600 python tests/gpu_gemm_bench.py > $S/gemm_shapes.txt 2>&1
+timeout 300 python tests/gpu_nt_probe.py --vendor > $S/nt_shapes.txt 2>&1
+timeout 300 python tests/gpu_tn_probe.py > $S/tn_shapes.txt 2>&1
+{ FMMT_NT_SMALL=0 timeout 200 python tests/gpu_few_probe.py; timeout 200 python tests/gpu_few_probe.py; } > $S/few_shapes.txt 2>&1
 cut -c1-300 $S/bench.json
