@@ -149,7 +149,7 @@ def build_models(args, dev, cfg):
 def p256_tile(M, N, K, kw):
     """mirror of csrc/gemm.hip::p256_plan (persistent 256-row-tile kernel): channel-tile width, or 0"""
     has_op = kw.get("res") is not None or kw.get("rowscale") is not None
-    if M < 16384 or M % 16 or K % 64 or K < 192 or kw.get("aux") is not None or (has_op and os.environ.get("FMMT_NT_P256_OPS", "1") == "0"):
+    if M < int(os.environ.get("FMMT_NT_P256_MINM", "16384")) or M % 16 or K % 64 or K < 192 or kw.get("aux") is not None or (has_op and os.environ.get("FMMT_NT_P256_OPS", "1") == "0"):
         return 0
     tm, best, cost = (M + 255) // 256, 0, 0.0
     for bn, pen in ((256, 1.0), (192, 1.04), (128, 1.10)):
@@ -166,7 +166,7 @@ def p256_tile(M, N, K, kw):
 
 def tn_dma_tile(M, N, K, scaled, rows_per_scale, x_gelu):
     """mirror of csrc/gemm.hip::tn_plan_dma + launch_tn_plan (DMA-staged weight-gradient kernel): "256,256" / "192,384" or None"""
-    if os.environ.get("FMMT_TN_DMA", "1") == "0" or x_gelu or M <= 16384 or M % 64:
+    if os.environ.get("FMMT_TN_DMA", "1") == "0" or x_gelu or M <= int(os.environ.get("FMMT_TN_DMA_MINM", "8192")) or M % 64:
         return None
     if N % 256 == 0 and K % 256 == 0:
         tn, tk = 256, 256

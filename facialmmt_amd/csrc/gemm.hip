@@ -863,7 +863,8 @@ int p256_plan(const LinArgs& a) {
     static const int mode = getenv("FMMT_NT_P256") ? atoi(getenv("FMMT_NT_P256")) : 1;       // 0: off; 256 / 192 / 128: force that tile
     // K % 64 != 0 (Swin stage 0: K = 96, three K steps of 32): only with FMMT_NT_P256_K32=1 (A/B switch)
     static const int k32 = getenv("FMMT_NT_P256_K32") ? atoi(getenv("FMMT_NT_P256_K32")) : 0;
-    if (!mode || a.ksplit || a.M < 16384 || a.M % 16 || a.K % 32 || a.K < 96 || a.ldx % 8 || a.ldw % 8) return 0;
+    static const int minm = getenv("FMMT_NT_P256_MINM") ? atoi(getenv("FMMT_NT_P256_MINM")) : 16384;      // fewest tokens for this kernel
+    if (!mode || a.ksplit || a.M < minm || a.M % 16 || a.K % 32 || a.K < 96 || a.ldx % 8 || a.ldw % 8) return 0;
     if (a.K % 64 && !k32) return 0;
     // One workgroup per CU has nothing to hide an epilogue's own M x N loads behind (residual, GELU' operand, DropPath
     // scale: the in-order vmcnt also makes them wait for the DMA stages in flight).  Measured on MI355X
@@ -1986,7 +1987,10 @@ TnPlan tn_plan_dma(int M, int N, int K) {
     // stage in flight.  With the reads in inline asm, 128 FLOP per staged byte and four 32-token stages: 860-1105 TF/s against
     // 550-630.
     static const int mode = getenv("FMMT_TN_DMA") ? atoi(getenv("FMMT_TN_DMA")) : 1;
-    if (!mode || M <= 16384 || M % 64) return pl;
+    // FMMT_TN_DMA_MINM: fewest tokens for this kernel, exclusive.  8192 since the 320-frame legs (configs[4]: 15680 stage-3 tokens)
+    // measured 56.2 -> 55.7 ms per step with it, three alternating pairs in one call; 16384 before.
+    static const int minm = getenv("FMMT_TN_DMA_MINM") ? atoi(getenv("FMMT_TN_DMA_MINM")) : 8192;
+    if (!mode || M <= minm || M % 64) return pl;
     int tn = 0, tk = 0;
     if (N % 256 == 0 && K % 256 == 0) tn = 256, tk = 256;
     else if (N % 192 == 0 && K % 384 == 0) tn = 192, tk = 384;
