@@ -26,5 +26,7 @@ def run(model, bwd, tag):
 run(swin, False, "eager")
 run(swin, True, "eager")
 if "--graph" in sys.argv:
-    g = torch.cuda.make_graphed_callables(swin, (x,))
+    from facialmmt_amd.train_step import capture_window
+    with capture_window():                                  # no cyclic GC inside the capture (train_step.capture_window)
+        g = torch.cuda.make_graphed_callables(swin, (x,))
     run(g, True, "hipGraph")
