@@ -541,9 +541,10 @@ def main():
 
     # After the timed region (not part of `value`): the same steps with every batch tensor handed over in PINNED HOST memory, as
     # the reference's DataLoader does (train.py:290-314: `.to(device)` per tensor) -- the step's own copy into its static input
-    # tensors then crosses PCIe.  Every rank runs it (the step holds the all-reduce at N > 1); rank 0 reports its own clock.
+    # tensors then crosses PCIe.  N = 1 only, like the CPU baseline: a reported side figure has no business adding collectives
+    # to the N > 1 runs.
     pcie = None
-    if args.graphs == 2 and args.host_input_leg:
+    if args.graphs == 2 and args.host_input_leg and world == 1:
         try:
             pin = lambda ts: tuple(t.detach().cpu().pin_memory() if torch.is_tensor(t) else t for t in ts)
             hb, hab = pin(batch), (pin(aux_batch) if aux_batch is not None else None)
@@ -563,7 +564,7 @@ def main():
             nbytes = sum(t.numel() * t.element_size() for t in hb + (hab or ()) if torch.is_tensor(t))
             pcie = {"value": round(args.utts * world / (h_ms * 1e-3), 3), "unit": "utterances/s", "ms_per_step": round(h_ms, 2),
                     "host_bytes_per_step_per_gpu": nbytes,
-                    "note": "batch tensors in pinned host memory, copied into the step's static inputs on the step's stream (not overlapped); rank 0's clock; not `value`"}
+                    "note": "batch tensors in pinned host memory, copied into the step's static inputs on the step's stream (not overlapped); N = 1 only; not `value`"}
             step(batch)                                      # device-resident inputs again for what follows
             torch.cuda.synchronize()
         except Exception as e:                               # a reported leg only: never takes the line down
