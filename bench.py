@@ -42,6 +42,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0            # MI355X dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0                # HBM3E peak (spec), same guide
 SWIN_FWD_GFLOP_PER_FRAME = 9.0255    # BASELINE.md section 2 (reference's own flops() formulas x 2)
 
 
@@ -62,7 +63,8 @@ def parse():
     ap.add_argument("--graphs", type=int, default=2, help="2: the whole step as two HIP graphs; 1: only the multimodal model graphed, Swin eager; 0: eager")
     ap.add_argument("--overlap-text", type=int, default=1, help="text encoder on a second HIP stream / graph branch, concurrently with Swin")
     ap.add_argument("--plm-dtype", default="bf16", choices=["bf16", "fp32"], help="parameter dtype of the text encoder in --graphs 2: bf16 with fp32 master weights in the optimizer, or fp32 under autocast")
-    ap.add_argument("--grad-comm", default="fp32", choices=["fp32", "bf16"], help="element type of the gradient all-reduce (N > 1)")
+    ap.add_argument("--grad-comm", default="bf16", choices=["fp32", "bf16"], help="element type of the gradient all-reduce (N > 1): bf16 halves the bytes on the xGMI links (0.87 GB instead of 1.74 GB per step)")
+    ap.add_argument("--other-configs", type=int, default=1, help="N = 1 only: after the timed region also run 4 steps of configs[3] and configs[4] (per-GPU legs, own processes) and report them under `other_configs`")
     ap.add_argument("--parallel-fusion", type=int, default=1, help="capture independent halves of the fusion stack as parallel graph branches")
     ap.add_argument("--force-ddp", action="store_true", help="run the data-parallel gradient exchange path even with one process (exercises the N>1 code path on one GPU)")
     ap.add_argument("--shape-report", default=None, help="write a per-GEMM-shape timing table to this file (development aid)")
@@ -260,6 +262,41 @@ class KernelTimer:
 
         ops.wgrad_partials_raw = timed_wgrad_partials_raw
 
+    # C-ABI entry points that are not Linear layers: (flops, algorithmic bytes) from the call's arguments.  The ctypes function
+    # objects are attributes of the loaded library; replacing an attribute brackets every call the ops / modules make.
+    ABI = {
+        "fmmt_layernorm_fwd": lambda a: (0.0, a[1] * a[2] * (4 if a[0] == 0 else 2) * 2.0),
+        "fmmt_layernorm_bwd": lambda a: (0.0, a[1] * a[2] * (4 if a[0] == 0 else 2) * (4.0 if a[8] else 3.0)),
+        "fmmt_window_attn_fwd": lambda a: (4.0 * a[1] * a[2] * a[3] * 49 * a[4], a[1] * a[2] * a[3] * a[4] * (4 if a[0] == 0 else 2) * 4.0),
+        "fmmt_window_attn_bwd": lambda a: (10.0 * a[1] * a[2] * a[3] * 49 * a[4], a[1] * a[2] * a[3] * a[4] * (4 if a[0] == 0 else 2) * 8.0),
+        "fmmt_mlp_fwd": lambda a: (16.0 * a[1] * a[2] * a[2], a[1] * a[2] * 2.0 * (2 + (1 if a[8] else 0)) + a[1] * 4 * a[2] * 2.0 * ((1 if a[12] else 0) + (1 if a[13] else 0))),
+        # one window: qkv 2*49*C*3C, attention 4*49*49*C, proj 2*49*C*C ; bytes: x in, y out, and the saved LN(x) / attention output
+        "fmmt_window_block_fwd": lambda a: (a[1] * (a[2] // 7) * (a[3] // 7) * (8.0 * 49 * a[4] * a[4] + 4.0 * 49 * 49 * a[4]),
+                                            a[1] * a[2] * a[3] * a[4] * 2.0 * (2 + (1 if a[20] else 0) + (1 if a[21] else 0))),
+    }
+
+    def install_abi(self):
+        from facialmmt_amd import _lib
+        lib = _lib.load()
+        timer = self
+        for name, cost in self.ABI.items():
+            fn = getattr(lib, name)
+
+            def make(name, fn, cost):
+                def timed(*a):
+                    if not timer.enabled:
+                        return fn(*a)
+                    fl, by = cost(a)
+                    tag = name + ("<fp32>" if a[0] == 0 else "") + (f"<C={a[4]}>" if name.startswith("fmmt_window") else f"<C={a[2]}>")
+                    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    s.record()
+                    rc = fn(*a)
+                    e.record()
+                    timer.events.append((tag, fl, by, s, e, ("abi",)))
+                    return rc
+                return timed
+            setattr(lib, name, make(name, fn, cost))
+
     def summary(self):
         out = {}
         for bn, fl, by, s, e, _ in self.events:
@@ -332,7 +369,18 @@ def cpu_baseline(args, cfg):
     t8, nrep = timed(swin_step)
     t_swin = t8 / nF * args.frames
     f8, _ = timed(swin_fwd)
-    f_swin = f8 / nF * args.frames
+    # forward only: the whole utterance's frames in ONE call (no extrapolation); bounded -- a box whose 8-frame forward is already
+    # slow keeps the scaled figure
+    f_swin, fwd_how = f8 / nF * args.frames, f"{nF} frames scaled x{args.frames / nF:g}"
+    if f8 / nF * args.frames < 30.0:
+        xf = synth.tensor("frames_full", (args.frames, 3, 224, 224), seed=2)
+
+        def swin_fwd_full():
+            with torch.no_grad():
+                OS.swin_affwild_logits(sd, xf, training=False)
+        f_swin, _ = timed(swin_fwd_full, reps=1, bound=0.0)
+        fwd_how = f"all {args.frames} frames in one call"
+        del xf
     sweep = {str(cores): round(nF / f8, 2)}
     for th in (32, 64):
         if th <= ncpu:
@@ -403,7 +451,7 @@ def cpu_baseline(args, cfg):
     except OSError:
         pass
     return {"value": round(1.0 / total, 5), "unit": "utterances/s", "cores": cores, "kind": "port",
-            "forward_only": {"value": round(1.0 / total_f, 5), "unit": "utterances/s", "swin_frames_per_s": round(nF / f8, 2)},
+            "forward_only": {"value": round(1.0 / total_f, 5), "unit": "utterances/s", "swin_frames_per_s": round(args.frames / f_swin, 2), "swin_sample": fwd_how},
             "swin_forward_frames_per_s_by_threads": sweep, "host": f"{cpu_name} ({ncpu} hardware threads)",
             "sample": f"oracle fp32 for ONE utterance on {cores} threads, fwd+bwd [fwd only]: Swin+head on {nF} frames (median of {nrep}, scaled x{args.frames / nF:g} to "
                       f"{args.frames} frames: {t_swin:.2f} s [{f_swin:.2f} s]) + 4 cross-modal encoder calls ({t_fus:.2f} s [{f_fus:.2f} s]) + audio/vision self-attention "
@@ -432,7 +480,7 @@ def main():
 
     from facialmmt_amd.config import default_args
     from facialmmt_amd.parallel import GradientAverager, broadcast_parameters
-    from facialmmt_amd.train_step import AuxStep, GraphedAuxStep, GraphedTargetStep, TargetStep
+    from facialmmt_amd.train_step import AuxStep, GraphedAuxStep, GraphedTargetStep, HFAdamW, TargetStep
     cfg = default_args(get_vision_utt_max_lens=args.frames, trg_accumulation_steps=1)
     act = torch.bfloat16 if args.dtype == "bf16" else None
     swin, mm = build_models(args, dev, cfg)
@@ -457,12 +505,13 @@ def main():
         if args.plm_dtype == "bf16" and args.dtype == "bf16":
             masters = MasterWeights(mm.roberta if mm.text_pretrained_model == "roberta" else mm.bert, torch.bfloat16)
         params = step_parameters(mm, masters)
-        flat = GradientAverager(params, hooks=False, comm_dtype=comm)
-        opt = torch.optim.AdamW(params, lr=torch.tensor(cfg.trg_lr, device=dev), weight_decay=cfg.weight_decay, fused=True, capturable=True)
+        flat = GradientAverager(params, hooks=False, comm_dtype=comm, always=args.force_ddp)
+        # the reference's optimizer class and arguments (train.py:307): transformers.AdamW(lr, weight_decay) -> eps 1e-6, HF update order
+        opt = HFAdamW(params, lr=torch.tensor(cfg.trg_lr, device=dev), weight_decay=cfg.weight_decay)
         sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_of)
         if args.aux_images:
             aflat = GradientAverager(swin.parameters(), hooks=False, comm_dtype=comm)
-            aopt = torch.optim.AdamW(swin.parameters(), lr=torch.tensor(cfg.aux_lr, device=dev), fused=True, capturable=True)
+            aopt = HFAdamW(swin.parameters(), lr=torch.tensor(cfg.aux_lr, device=dev))       # train.py:333: no weight decay on the Swin model
             aux_step = GraphedAuxStep(swin, aopt, torch.optim.lr_scheduler.LambdaLR(aopt, lr_of), cfg, *aux_batch, averager=aflat)
         step = GraphedTargetStep(swin, mm, opt, sched, cfg, batch, autocast_dtype=act, overlap_text=bool(args.overlap_text),
                                  parallel_fusion=bool(args.parallel_fusion), averager=flat, masters=masters)
@@ -484,21 +533,24 @@ def main():
             text_params = list(plm.parameters()) + list(mm.text_linear.parameters())
             text_ids = set(map(id, text_params))
             averager = GradientAverager(None, groups=[[p for p in mm.parameters() if id(p) not in text_ids], text_params], comm_dtype=comm)
-        opt = torch.optim.AdamW(mm.parameters(), lr=cfg.trg_lr, weight_decay=cfg.weight_decay, fused=True)
+        opt = HFAdamW(mm.parameters(), lr=cfg.trg_lr, weight_decay=cfg.weight_decay)
         sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_of)
         step = TargetStep(swin, mm, opt, sched, cfg, autocast_dtype=act, averager=averager)
         if args.aux_images:
-            aopt = torch.optim.AdamW(swin.parameters(), lr=cfg.aux_lr, fused=True)
+            aopt = HFAdamW(swin.parameters(), lr=cfg.aux_lr)
             eager_aux = AuxStep(swin, aopt, torch.optim.lr_scheduler.LambdaLR(aopt, lr_of), cfg)
             aux_step = lambda imgs, labels: eager_aux(imgs, labels)
     timer = KernelTimer()
     timer.install()
+    timer.install_abi()
 
     def one_step():
         if aux_step is not None:
             aux_step(*aux_batch)
         return step(batch)
 
+    if ddp and args.graphs == 2:
+        step.time_exchange(True)                            # three events per step around the gradient exchange
     kept = None
     for _ in range(args.warmup):
         _, kept = one_step()
@@ -530,6 +582,26 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # N > 1: how long the gradient exchange took and how much of it the step could not hide behind Swin's backward (events of the
+    # LAST timed step), and the bus rate of the exchange alone (two blocking exchanges of the same buckets after the timed region)
+    xchg = None
+    if ddp and args.graphs == 2:
+        total_ms, exposed_ms = step.exchange_ms()
+        nbytes = sum(b[0].numel() for b in flat.buckets) * (2 if comm is not None else 4)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t3 = time.perf_counter()
+        for _ in range(2):
+            flat.exchange_all()
+        torch.cuda.synchronize()
+        alone_ms = (time.perf_counter() - t3) / 2 * 1e3
+        flat.zero_grad()
+        xchg = {"ranks": dist.get_world_size(), "backend": dist.get_backend(), "wire_dtype": args.grad_comm, "bytes_per_rank": nbytes,
+                "buckets": len(flat.buckets), "ms_issue_to_done": round(total_ms, 3), "ms_exposed_after_swin_backward": round(exposed_ms, 3),
+                "ms_alone": round(alone_ms, 3),
+                "bus_GB_per_s_alone": round(2.0 * (world - 1) / max(world, 1) * nbytes / (alone_ms * 1e-3) / 1e9, 1) if world > 1 else None}
 
     # host cost of issuing one step into an IDLE queue (during the timed loop the host mostly waits for the previous replay
     # of the same graph to drain, so the enqueue time above is back-pressure, not cost)
@@ -601,11 +673,11 @@ def main():
         if args.shape_report:
             with open(args.shape_report, "w") as f:
                 f.write(timer.shape_report(args.steps) + "\n")
-        roof = None
+        roof = roof_hbm = None
         if fams:
             # the dominant kernel = the family with the most GPU time among the many-token launches (the few-token GEMMs of the
             # fusion stack are launch-bound 10-25 us kernels: many of them, no roofline to speak of)
-            big = {k: v for k, v in fams.items() if v[3] / v[0] >= 40e-6} or fams
+            big = {k: v for k, v in fams.items() if v[3] / v[0] >= 40e-6 and not k.startswith("fmmt_")} or fams
             bn, (cnt, fl, by, sec) = max(big.items(), key=lambda kv: kv[1][3])
             kname = kernel_symbol(bn)
             traffic, traffic_src = None, None                # PMC counters cannot be read in-process: taken from the committed PMC summary
@@ -632,8 +704,23 @@ def main():
             if live:
                 roof["in_timed_region_with_text_stream"] = rate(*live)
                 roof["frac_in_timed_region"] = roof["in_timed_region_with_text_stream"]["frac"]
-            roof["families"] = {kernel_symbol(k): {"ms_per_step": round(v[3] / 2 * 1e3, 3), "TFLOP_per_s": round(v[1] / v[3] / 1e12, 1)}
-                                for k, v in sorted(fams.items(), key=lambda kv: -kv[1][3])[:8]}
+            # every bracketed family, Linear or not: time per step, TFLOP/s and algorithmic GB/s; bound = "hbm" where the algorithmic
+            # intensity is below the ridge (2.5 PFLOP/s / 8 TB/s = 312 FLOP/B)
+            def fam(v):
+                d = {"ms_per_step": round(v[3] / 2 * 1e3, 3), "launches_per_step": v[0] // 2, "TFLOP_per_s": round(v[1] / v[3] / 1e12, 1),
+                     "algorithmic_GB_per_s": round(v[2] / v[3] / 1e9, 0)}
+                d["bound"] = "hbm" if v[1] / max(v[2], 1.0) < PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9) else "mfma"
+                d["frac"] = round(v[2] / v[3] / 1e9 / PEAK_HBM_GBS, 3) if d["bound"] == "hbm" else round(v[1] / v[3] / 1e12 / PEAK_BF16_TFLOPS, 3)
+                return d
+            ranked = sorted(fams.items(), key=lambda kv: -kv[1][3])
+            roof["families"] = {kernel_symbol(k): fam(v) for k, v in ranked[:16]}
+            hbm = [(k, v) for k, v in ranked if v[3] / v[0] >= 40e-6 and v[1] / max(v[2], 1.0) < PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)]
+            if hbm:
+                k, v = hbm[0]
+                roof_hbm = {"bound": "hbm", "kernel": kernel_symbol(k), "peak": PEAK_HBM_GBS, "unit": "GB/s", "achieved": round(v[2] / v[3] / 1e9, 0),
+                            "frac": round(v[2] / v[3] / 1e9 / PEAK_HBM_GBS, 3), "avg_launch_us": round(v[3] / v[0] * 1e6, 1),
+                            "algorithmic_bytes_per_launch": round(v[2] / v[0]), "launches_per_step": v[0] // 2, "ms_per_step": round(v[3] / 2 * 1e3, 3),
+                            "note": "largest HBM-bound family of the step (algorithmic bytes / HIP-event time of the same eager passes); peak = 8 TB/s spec (6.3 TB/s is what a float4 copy reaches on this part)"}
         aux_flops = args.aux_images * SWIN_FWD_GFLOP_PER_FRAME * 3 * 1e9
         flops_step = args.utts * (args.frames * SWIN_FWD_GFLOP_PER_FRAME * 3 + (335 + 29.7) * 3) * 1e9 + aux_flops
         which = {1: "configs[1]", 3: "configs[3] (per-GPU leg of batch 16 on 4 GPUs)", 4: "configs[4] (per-GPU leg of batch 8 on 8 GPUs)"}[args.config]
@@ -653,11 +740,14 @@ def main():
                        "parallelism": f"dp{world}", "kept_frame_fraction": round(float(kept.mean().item()), 3),
                        "model_tflops_per_s_per_gpu": round(flops_step / (ms * 1e-3) / 1e12, 1),
                        "host_enqueue_ms_per_step": round(issue_s / args.steps * 1e3, 1), "host_issue_ms_into_idle_queue": round(idle_issue_ms, 1),
-                       "hip_graphs": {2: "whole step: 2 graphs (fwd+bwd | clip+optimizer)", 1: "multimodal model only (Swin eager)", 0: "none"}[args.graphs],
+                       "hip_graphs": {2: "whole step: 3 graphs (fwd + multimodal bwd | Swin bwd | clip+optimizer)", 1: "multimodal model only (Swin eager)", 0: "none"}[args.graphs],
                        "text_encoder_concurrent_with_swin": bool(args.graphs and args.overlap_text),
                        "text_encoder_parameters": "bf16 with fp32 master weights in the optimizer" if (args.graphs == 2 and args.plm_dtype == "bf16" and args.dtype == "bf16") else "fp32 under bf16 autocast",
-                       "gradient_allreduce": None if not ddp else f"{args.grad_comm}, {'between the two graphs' if args.graphs == 2 else 'hook-driven, overlapped with backward'}"},
+                       "gradient_allreduce": None if not ddp else f"{args.grad_comm}, {'issued between the multimodal backward and the Swin backward (graphs A1 | A2), waited for before the optimizer graph' if args.graphs == 2 else 'hook-driven, overlapped with backward'}",
+                       "rccl_ranks_seen": (dist.get_world_size() if dist.is_initialized() else 1),
+                       "exchange_ms_exposed": (xchg or {}).get("ms_exposed_after_swin_backward"), "exchange": xchg},
             "roofline": roof,
+            "roofline_hbm": roof_hbm,
             "cpu_baseline": None,
             "pcie_inclusive": pcie,
         }
@@ -670,6 +760,8 @@ def main():
             line["config"]["dry_run"] = f"ranks share device {local}, backend {backend}: not a measurement"
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, cfg)
+        if world == 1 and args.other_configs and args.config == 1:
+            line["other_configs"] = other_configs(args)
     if dist.is_initialized():
         dist.destroy_process_group()
     if rank == 0:
@@ -683,10 +775,34 @@ def main():
         print(json.dumps(line), flush=True)
 
 
+def other_configs(args):
+    """BASELINE.json configs[3] (BERT-large) and configs[4] (320 frames + auxiliary task): per-GPU legs, 4 timed steps each, each in
+    its own process (own models, own graphs) after this one's timed region -- reported, never part of `value`."""
+    import subprocess
+    out = {}
+    for c in (3, 4):
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", str(c), "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--host-input-leg", "0",
+               "--other-configs", "0", "--dtype", args.dtype, "--graphs", str(args.graphs)]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
+            j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+            out[f"configs[{c}]"] = {"ms_per_step": j["ms_per_step"], "value": j["value"], "unit": j["unit"], "steps": j["steps"], "workload": j["config"]["workload"],
+                                    "dominant_kernel": (j.get("roofline") or {}).get("kernel"), "frac": (j.get("roofline") or {}).get("frac"),
+                                    "traffic": (j.get("roofline") or {}).get("traffic")}
+        except Exception as e:                               # a reported leg only
+            out[f"configs[{c}]"] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
+    return out
+
+
 def kernel_symbol(bn):
     """KernelTimer family tag -> name of the kernel template instantiation as rocprofv3 prints it"""
     if bn.startswith("linear_tn"):
         return bn
+    if bn.startswith("fmmt_"):
+        base, _, rest = bn.partition("<")
+        names = {"fmmt_layernorm_fwd": "ln_fwd_kernel", "fmmt_layernorm_bwd": "ln_bwd_kernel", "fmmt_window_attn_fwd": "wattn_mfma_fwd_kernel",
+                 "fmmt_window_attn_bwd": "wattn_mfma_bwd_kernel", "fmmt_mlp_fwd": "mlp_fused_fwd_kernel", "fmmt_window_block_fwd": "wblock_fwd_kernel"}
+        return names.get(base, base) + ("<" + rest if rest else "")
     if bn.startswith("p256x"):
         op = bn.endswith("op")
         w = bn[5:-2] if op else bn[5:]

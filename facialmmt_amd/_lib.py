@@ -34,8 +34,10 @@ SIGNATURES = {
     "fmmt_window_attn_fwd": (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _i, _f, _p, _p, _p]),
     "fmmt_window_attn_bwd_workspace": (_sz, [_i]),
     "fmmt_window_attn_bwd": (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p, _p, _p, _sz, _p]),
+    "fmmt_window_block_fwd": (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p]),
     "fmmt_mha_fwd": (_i, [_i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i, _f, _p, _f, _u64, _p, _p, _i, _p, _p]),
     "fmmt_mha_bwd": (_i, [_i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i, _f, _p, _f, _u64, _p, _p, _p, _i, _p, _p, _i, _p, _p, _i, _p]),
+    "fmmt_mha_avg_weights": (_i, [_i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _f, _p, _f, _u64, _p, _p, _p, _p]),
     "fmmt_patch_im2col": (_i, [_i, _i, _p, _p, _p]),
     "fmmt_patch_col2im": (_i, [_i, _i, _p, _p, _p]),
     "fmmt_batchnorm1d_fwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p]),
@@ -46,7 +48,7 @@ SIGNATURES = {
     "fmmt_cast_batch": (_i, [_i, _i, _p, _p]),
     "fmmt_layernorm_bwd_bf16_workspace": (_sz, [_i, _i]),
     "fmmt_layernorm_bwd_bf16": (_i, [_i, _i, _f, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
-    "fmmt_adamw_batch": (_i, [_i, _i, _p, _p, _p, _p, _f, _f, _f, _f, _f, _p]),
+    "fmmt_adamw_batch": (_i, [_i, _i, _p, _p, _p, _p, _f, _f, _f, _f, _f, _i, _p]),
     "fmmt_resize_table": (_i, [_i, _i, _i, _p, _p]),
     "fmmt_resize_band_rows": (_i, [_p, _i]),
     "fmmt_patch_embed_u8": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p]),

@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libfmmt_hip.so")
-SOURCES = ["gemm.hip", "layernorm.hip", "attn.hip", "wattn_mfma.hip", "mha_mfma.hip", "misc.hip", "preproc.hip", "mlp_fused.hip"]
+SOURCES = ["gemm.hip", "layernorm.hip", "attn.hip", "wattn_mfma.hip", "wblock.hip", "mha_mfma.hip", "misc.hip", "preproc.hip", "mlp_fused.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast"]
 
 
@@ -24,7 +24,7 @@ def _stale(target, deps):
 
 def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    headers = [os.path.join(CSRC, "fmmt_common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(CSRC, "wattn_args.h"), os.path.join(CSRC, "mha_args.h"), os.path.join(HERE, "..", "include", "fmmt.h")]
+    headers = [os.path.join(CSRC, "fmmt_common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(CSRC, "wattn_args.h"), os.path.join(CSRC, "wattn_geom.h"), os.path.join(CSRC, "mha_args.h"), os.path.join(HERE, "..", "include", "fmmt.h")]
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     jobs = []

@@ -576,6 +576,33 @@ int mha_check(int dtype, int Lq, int Lk, int B, int E, int nH) {
     return 0;
 }
 
+
+// Head-averaged (post-dropout) attention weights, multihead_attention.py:133-134: `attn_weights.view(bsz, heads, tgt, src).sum(1) / heads`.
+// No caller of the reference uses them (CrossmodalTransformer.py:147,151 discard them), so the attention kernels never form
+// the (B*heads, Lq, Lk) tensor; this kernel recomputes the probabilities from q, k and the saved log-sum-exp on request.
+// One block per (query row, batch), thread j owns key j (strided); fp32 arithmetic for either storage type.
+template <typename T>
+__global__ __launch_bounds__(128) void mha_avg_weights_kernel(MhaArgs p, float* __restrict__ w) {
+    extern __shared__ float qs[];                                   // the query row, all heads, pre-scaled
+    const int i = blockIdx.x, b = blockIdx.y, hd = p.E / p.nH;
+    const T* qg = reinterpret_cast<const T*>(p.q) + ((size_t)i * p.B + b) * p.ldq;
+    const T* kg = reinterpret_cast<const T*>(p.k);
+    for (int c = threadIdx.x; c < p.E; c += 128) qs[c] = to_f32(qg[c]) * p.scale;
+    __syncthreads();
+    for (int j = threadIdx.x; j < p.Lk; j += 128) {
+        const T* kr = kg + ((size_t)j * p.B + b) * p.ldkv;
+        const float kb = key_bias(p, b, j);
+        float acc = 0.f;
+        for (int h = 0; h < p.nH; ++h) {
+            const int bh = b * p.nH + h;
+            float s = 0.f;
+            for (int d = 0; d < hd; ++d) s += qs[h * hd + d] * to_f32(kr[h * hd + d]);
+            acc += __expf(s + kb - p.lse[(size_t)bh * p.Lq + i]) * keep_scale(p, bh, i, j);
+        }
+        w[((size_t)b * p.Lq + i) * p.Lk + j] = acc / (float)p.nH;
+    }
+}
+
 }  // namespace
 
 extern "C" int fmmt_window_attn_fwd(int dtype, int n_img, int H, int W, int C, int num_heads, int shift,
@@ -654,6 +681,21 @@ extern "C" int fmmt_window_attn_bwd(int dtype, int n_img, int H, int W, int C, i
 #define K_DQ(T, D) mha_bwd_dq_kernel<T, D>
 #define K_DV(T, D) mha_bwd_dkv_kernel<T, D, 0>
 #define K_DK(T, D) mha_bwd_dkv_kernel<T, D, 1>
+
+extern "C" int fmmt_mha_avg_weights(int dtype, int Lq, int Lk, int B, int E, int num_heads, const void* q, int ldq, const void* k, int ldkv,
+                                    float scale, const float* key_bias, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
+                                    const float* lse, float* weights, void* stream) {
+    if (int e = mha_check(dtype, Lq, Lk, B, E, num_heads)) return e;
+    if (!q || !k || !lse || !weights || dropout_p < 0.f || dropout_p >= 1.f) return FMMT_EINVAL;
+    MhaArgs a{};
+    a.Lq = Lq; a.Lk = Lk; a.B = B; a.E = E; a.nH = num_heads; a.q = q; a.ldq = ldq; a.k = k; a.ldkv = ldkv; a.scale = scale;
+    a.key_bias = key_bias; a.drop_p = dropout_p; a.seed = seed; a.seed_dev = seed_dev; a.lse = const_cast<float*>(lse);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == FMMT_BF16) hipLaunchKernelGGL(mha_avg_weights_kernel<bf16>, dim3(Lq, B), dim3(128), (size_t)E * sizeof(float), st, a, weights);
+    else hipLaunchKernelGGL(mha_avg_weights_kernel<float>, dim3(Lq, B), dim3(128), (size_t)E * sizeof(float), st, a, weights);
+    FMMT_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int fmmt_mha_fwd(int dtype, int Lq, int Lk, int B, int E, int num_heads,
                             const void* q, int ldq, const void* k, const void* v, int ldkv, float scale, const float* key_bias,

@@ -218,10 +218,12 @@ __global__ __launch_bounds__(256) void cast_batch_kernel(const CastDesc* __restr
 }
 
 // Clip + AdamW + low-precision shadow in ONE launch over every tensor the step's optimizer updates (train.py:135-143:
-// clip_grad_norm_ -> optimizer.step(); AdamW as torch.optim.AdamW: decoupled weight decay, bias-corrected moments, no amsgrad).
-//   coef = min(1, max_norm / (total_norm + 1e-6))            (torch.nn.utils.clip_grad_norm_)
-//   g' = coef g;  p *= 1 - lr wd;  m = b1 m + (1 - b1) g';  v = b2 v + (1 - b2) g'^2
-//   p -= (lr / (1 - b1^t)) m / (sqrt(v) / sqrt(1 - b2^t) + eps);   low = bf16(p) where the tensor has a bf16 twin
+// clip_grad_norm_ -> optimizer.step()).  Two flavours of the update, selected by `hf`:
+//   hf = 1  transformers.AdamW, the optimizer the reference constructs (train.py:307,333; defaults eps 1e-6, weight_decay 0):
+//           m = b1 m + (1 - b1) g';  v = b2 v + (1 - b2) g'^2;  p -= lr sqrt(1 - b2^t) / (1 - b1^t) * m / (sqrt(v) + eps)
+//           -- eps is added BEFORE the bias correction -- and the decoupled decay is applied AFTER the update: p += p * (-lr wd)
+//   hf = 0  torch.optim.AdamW: p *= 1 - lr wd first, then p -= (lr / (1 - b1^t)) m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+//   coef = min(1, max_norm / (total_norm + 1e-6)), g' = coef g   (torch.nn.utils.clip_grad_norm_);  low = bf16(p) for bf16 twins
 // lr, t and total_norm are device scalars (graph replays), the gradients are read once and NOT written back: against
 // clip_grad_norm_ + fused AdamW + the multi-tensor re-rounding of the bf16 text encoder this saves the scaling pass over the
 // gradients (read + write) and one pass over the fp32 parameters.
@@ -232,7 +234,7 @@ struct AdamDesc {
 };
 __global__ __launch_bounds__(256) void adamw_batch_kernel(const AdamDesc* __restrict__ desc, int n_desc, const float* __restrict__ lr_p,
                                                           const float* __restrict__ step_p, const float* __restrict__ norm_p,
-                                                          float beta1, float beta2, float eps, float wd, float max_norm) {
+                                                          float beta1, float beta2, float eps, float wd, float max_norm, int hf) {
     int lo = 0, hi = n_desc - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -243,7 +245,8 @@ __global__ __launch_bounds__(256) void adamw_batch_kernel(const AdamDesc* __rest
     const float lr = *lr_p, t = *step_p;
     const float coef = norm_p ? fminf(1.0f, max_norm / (*norm_p + 1e-6f)) : 1.0f;
     const float bc1 = 1.0f - powf(beta1, t), bc2s = sqrtf(1.0f - powf(beta2, t));
-    const float step_size = lr / bc1, decay = 1.0f - lr * wd;
+    const float step_size = hf ? lr * bc2s / bc1 : lr / bc1, decay = hf ? 1.0f : 1.0f - lr * wd;
+    const float den_div = hf ? 1.0f : bc2s, post = hf ? -lr * wd : 0.0f;
     const long long base = (long long)((int)blockIdx.x - d.blk_begin) * 4096;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -269,7 +272,8 @@ __global__ __launch_bounds__(256) void adamw_batch_kernel(const AdamDesc* __rest
                 p[e] *= decay;
                 m[e] = beta1 * m[e] + (1.0f - beta1) * ge;
                 v[e] = beta2 * v[e] + (1.0f - beta2) * ge * ge;
-                p[e] -= step_size * (m[e] / (sqrtf(v[e]) / bc2s + eps));
+                p[e] -= step_size * (m[e] / (sqrtf(v[e]) / den_div + eps));
+                p[e] = fmaf(p[e], post, p[e]);
             }
             *reinterpret_cast<f32x4*>(d.p + o) = p;
             *reinterpret_cast<f32x4*>(d.m + o) = m;
@@ -291,7 +295,8 @@ __global__ __launch_bounds__(256) void adamw_batch_kernel(const AdamDesc* __rest
                 float p = d.p[j] * decay;
                 const float m = beta1 * d.m[j] + (1.0f - beta1) * ge;
                 const float v = beta2 * d.v[j] + (1.0f - beta2) * ge * ge;
-                p -= step_size * (m / (sqrtf(v) / bc2s + eps));
+                p -= step_size * (m / (sqrtf(v) / den_div + eps));
+                p = fmaf(p, post, p);
                 d.p[j] = p;
                 d.m[j] = m;
                 d.v[j] = v;
@@ -411,7 +416,7 @@ __global__ __launch_bounds__(1024) void lnp_reduce_kernel(const float* __restric
 
 }  // namespace
 
-extern "C" int fmmt_version(void) { return 1; }
+extern "C" int fmmt_version(void) { return 3; }     // = the round whose ABI this is (round 3: fmmt_window_block_fwd, hf_semantics of fmmt_adamw_batch)
 
 extern "C" int fmmt_patch_im2col(int dtype, int n_img, const void* img, void* cols, void* stream) {
     if (!dt_ok(dtype) || n_img <= 0) return FMMT_EINVAL;
@@ -523,10 +528,10 @@ extern "C" int fmmt_cast_batch(int n_desc, int n_tiles, const void* desc, void* 
 }
 
 extern "C" int fmmt_adamw_batch(int n_desc, int n_blocks, const void* desc, const float* lr, const float* step, const float* total_norm,
-                                float beta1, float beta2, float eps, float weight_decay, float max_norm, void* stream) {
+                                float beta1, float beta2, float eps, float weight_decay, float max_norm, int hf_semantics, void* stream) {
     if (n_desc <= 0 || n_blocks <= 0 || !desc || !lr || !step) return FMMT_EINVAL;
     hipLaunchKernelGGL(adamw_batch_kernel, dim3((unsigned)n_blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       reinterpret_cast<const AdamDesc*>(desc), n_desc, lr, step, total_norm, beta1, beta2, eps, weight_decay, max_norm);
+                       reinterpret_cast<const AdamDesc*>(desc), n_desc, lr, step, total_norm, beta1, beta2, eps, weight_decay, max_norm, hf_semantics);
     FMMT_CHECK_LAUNCH();
     return 0;
 }

@@ -199,9 +199,17 @@ class SwinTransformerBlock(nn.Module):
         H, W = self.input_resolution
         B, L, C = x.shape
         assert L == H * W, "input feature has wrong size"
-        x, xn = ops.residual_layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        x = self.attn.forward_tokens(xn, B, H, W, self.shift_size, self.attn_mask, res=x, rowscale=self._scale(B, x.device),
-                                     mask_is_shift=self._mask_is_standard())
+        a = self.attn
+        std = self._mask_is_standard()
+        if ops.window_block_fusable(x, C, a.num_heads, a.window_size, self.shift_size, self.attn_mask, std):
+            # stage 0: norm1 -> qkv -> (S)W-MSA -> proj -> residual + DropPath as ONE launch per block half (csrc/wblock.hip)
+            a._check()
+            x = ops.window_block(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias,
+                                 a.relative_position_bias_table, a._index(x.device), self.attn_mask, B, H, W, a.num_heads, self.shift_size,
+                                 float(a.scale), self._scale(B, x.device))
+        else:
+            x, xn = ops.residual_layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+            x = a.forward_tokens(xn, B, H, W, self.shift_size, self.attn_mask, res=x, rowscale=self._scale(B, x.device), mask_is_shift=std)
         x, xn = ops.residual_layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         return self.mlp(xn, res=x, rowscale=self._scale(B, x.device), rows_per_scale=L)
 

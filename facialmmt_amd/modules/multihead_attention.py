@@ -1,10 +1,11 @@
 """Multi-head attention of the cross-modal encoder on the HIP path; host-side mirror of the reference's
 modules/multihead_attention.py (fairseq-style, time-major, packed in_proj_weight (3E,E)).
 
-forward(query, key, value, attn_mask=None) -> (attn, None).  The head-averaged attention weights the
-reference also returns (ref :133-134) are discarded by every caller (CrossmodalTransformer.py:147,151);
-the fused kernel never materialises the (B*nH, Lq, Lk) probability tensor, so None is returned in
-their place.  Unsupported options raise: attn_mask, add_bias_kv, add_zero_attn."""
+forward(query, key, value, attn_mask=None, need_weights=False) -> (attn, attn_weights).  The head-averaged attention weights
+the reference returns (ref :133-134) are discarded by every caller (CrossmodalTransformer.py:147,151) and the fused kernel never
+materialises the (B*nH, Lq, Lk) probability tensor, so by default None is returned in their place; `need_weights=True`
+recomputes them (fmmt_mha_avg_weights: post-dropout probabilities averaged over the heads, (B, Lq, Lk), no gradient).
+Unsupported options raise: attn_mask, add_bias_kv, add_zero_attn."""
 from __future__ import annotations
 
 import torch
@@ -57,8 +58,9 @@ class MultiheadAttention(nn.Module):
     def in_proj_kv(self, key):
         return self._proj(key, self.embed_dim, 3 * self.embed_dim)
 
-    def attend(self, query, key, value, res=None):
-        """out_proj(softmax(q k^T) v) [+ res]; `res` fuses the caller's residual add into the GEMM epilogue."""
+    def attend(self, query, key, value, res=None, need_weights=False):
+        """out_proj(softmax(q k^T) v) [+ res]; `res` fuses the caller's residual add into the GEMM epilogue.
+        need_weights: return (out, head-averaged attention weights (B, Lq, Lk)) instead of out."""
         tgt_len, bsz, embed_dim = query.size()
         assert embed_dim == self.embed_dim
         assert key.size() == value.size()
@@ -68,15 +70,21 @@ class MultiheadAttention(nn.Module):
         seed = torch.randint(0, 2 ** 62, (1,), device=query.device, dtype=torch.int64) if p > 0 else 0
         if key is value or (key.data_ptr() == value.data_ptr() and key.shape == value.shape):
             # two GEMMs (q: N = E; [k | v]: N = 2E) whose weight gradients land in one packed (3E, E) gradient: ops.InProjFn
-            q, kv = ops.in_proj_q_kv(query, key, self.in_proj_weight, self.in_proj_bias)
-            ctx = ops.mha_core(q, kv, None, self.num_heads, self.scaling, p, seed)
+            q, kproj = ops.in_proj_q_kv(query, key, self.in_proj_weight, self.in_proj_bias)
+            vproj = None
         else:
-            q = self.in_proj_q(query)
-            ctx = ops.mha_core(q, self.in_proj_k(key), self.in_proj_v(value), self.num_heads, self.scaling, p, seed)
-        return ops.linear(ctx, self.out_proj.weight, self.out_proj.bias, res)
+            q, kproj, vproj = self.in_proj_q(query), self.in_proj_k(key), self.in_proj_v(value)
+        if not need_weights:
+            ctx = ops.mha_core(q, kproj, vproj, self.num_heads, self.scaling, p, seed)
+            return ops.linear(ctx, self.out_proj.weight, self.out_proj.bias, res)
+        ctx, lse = ops.mha_core(q, kproj, vproj, self.num_heads, self.scaling, p, seed, return_lse=True)
+        weights = ops.mha_avg_weights(q, kproj, lse, self.num_heads, self.scaling, p, seed)
+        return ops.linear(ctx, self.out_proj.weight, self.out_proj.bias, res), weights
 
-    def forward(self, query, key, value, attn_mask=None):
-        """Time x Batch x Channel in, (attn (Lq,B,E), None) out (ref :51-135)."""
+    def forward(self, query, key, value, attn_mask=None, need_weights=False):
+        """Time x Batch x Channel in, (attn (Lq,B,E), attn_weights) out (ref :51-135); attn_weights is None unless need_weights."""
         if attn_mask is not None:
             raise NotImplementedError("facialmmt_amd HIP path: attn_mask (the reference model always passes None)")
+        if need_weights:
+            return self.attend(query, key, value, need_weights=True)
         return self.attend(query, key, value), None

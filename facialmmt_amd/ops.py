@@ -5,6 +5,7 @@ the hot path.  Every op raises if the library is missing or a launch fails (no f
 from __future__ import annotations
 
 import math
+import os as _os
 import weakref
 
 import torch
@@ -308,10 +309,11 @@ class PlmLayerNormFn(torch.autograd.Function):
         return dx.reshape(x.shape), dw, db, None
 
 
-def adamw_batch(n, blocks, desc, lr, step, total_norm, beta1, beta2, eps, weight_decay, max_norm):
-    """fmmt_adamw_batch: clip + AdamW + bf16 twins over the tensors of a descriptor table (train_step.FusedClipAdamW)"""
+def adamw_batch(n, blocks, desc, lr, step, total_norm, beta1, beta2, eps, weight_decay, max_norm, hf=False):
+    """fmmt_adamw_batch: clip + AdamW + bf16 twins over the tensors of a descriptor table (train_step.FusedClipAdamW);
+    hf: transformers.AdamW's update (the reference's optimizer class) instead of torch.optim.AdamW's"""
     check(_lib.load().fmmt_adamw_batch(n, blocks, _p(desc), _p(lr), _p(step), _p(total_norm), float(beta1), float(beta2), float(eps),
-                                       float(weight_decay), float(max_norm), _st()), "fmmt_adamw_batch")
+                                       float(weight_decay), float(max_norm), 1 if hf else 0, _st()), "fmmt_adamw_batch")
 
 
 class VendorLinearFn(torch.autograd.Function):
@@ -347,8 +349,6 @@ def mlp_fused_raw(x2, w1l, b1, w2l, b2, res2, rowscale, rows_per_scale, h_pre, h
     check(rc, f"fmmt_mlp_fwd(M={M},C={C})")
     return y
 
-
-import os as _os
 
 _MLP_FUSED = _os.environ.get("FMMT_MLP_FUSED", "1") != "0"       # A/B switch (read once): 0 = always the two-launch form
 # 1: the fused forward also stores the activation and the weight gradient reads it; 0: only the pre-activation is stored and
@@ -543,64 +543,196 @@ def window_attn_core(qkv, table, index_i32, mask, n_img, H, W, num_heads, shift,
 
 
 # ------------------------------------------------------------------------------------------------
+# the attention half of a Swin block as ONE launch (csrc/wblock.hip): y = x + s * proj(W-MSA(LN(x) Wqkv^T + b))
+# ------------------------------------------------------------------------------------------------
+_WBLOCK = _os.environ.get("FMMT_WBLOCK", "1") != "0"          # A/B switch (read once): 0 = always the four-launch form
+
+
+def window_block_fusable(x, C, num_heads, window_size, shift, mask, mask_is_shift):
+    """the fused kernel covers the bf16 stage-0 geometry (C = 96, head_dim 32, 7x7 windows) with no mask or the standard SW-MSA mask"""
+    return (_WBLOCK and x.is_cuda and x.dtype == torch.bfloat16 and C == 96 and num_heads * 32 == C and tuple(window_size) == (7, 7)
+            and ((shift == 0 and mask is None) or (shift > 0 and mask is not None and mask_is_shift)))
+
+
+def window_block_raw(x2, n_img, H, W, num_heads, shift, ln_g, ln_b, eps, wqkv, bqkv, wproj, bproj, table, index_i32, scale, rowscale, save):
+    """one launch; returns (y, xn, attn_out, mean, rstd, lse); the four saved tensors are None unless `save`"""
+    M, C = x2.shape
+    dev = x2.device
+    y = torch.empty_like(x2)
+    nW = (H // 7) * (W // 7)
+    lse = torch.empty((n_img * nW * num_heads * 49,), dtype=torch.float32, device=dev)
+    xn = torch.empty_like(x2) if save else None
+    o = torch.empty_like(x2) if save else None
+    mean = torch.empty(M, dtype=torch.float32, device=dev) if save else None
+    rstd = torch.empty(M, dtype=torch.float32, device=dev) if save else None
+    rc = _lib.load().fmmt_window_block_fwd(dtype_code(x2.dtype), n_img, H, W, C, num_heads, shift, _p(x2), _p(ln_g), _p(ln_b), float(eps),
+                                           _p(wqkv), _p(bqkv), _p(wproj), _p(bproj), _p(table), _p(index_i32), float(scale), _p(rowscale),
+                                           _p(y), _p(xn), _p(o), _p(mean), _p(rstd), _p(lse), _st())
+    check(rc, f"fmmt_window_block_fwd(n={n_img},H={H},W={W},C={C},heads={num_heads},shift={shift})")
+    return y, xn, o, mean, rstd, lse
+
+
+class WindowBlockFn(Function):
+    """x -> x + rowscale * proj(attn(LN(x) Wqkv^T + bqkv)) + bproj-term, forward = fmmt_window_block_fwd.  The backward runs on what the
+    forward saved (LN(x), attention output, row statistics, log-sum-exp) and recomputes qkv with one GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, eps, wqkv, bqkv, wproj, bproj, table, index_i32, mask, n_img, H, W, num_heads, shift, scale, rowscale):
+        _need_cuda(x, "window_block")
+        C = x.shape[-1]
+        x2 = x.reshape(-1, C).contiguous()
+        train = any(ctx.needs_input_grad)
+        g, b = ln_w.detach().float().contiguous(), ln_b.detach().float().contiguous()
+        tab = table.detach().float().contiguous()
+        y, xn, o, mean, rstd, lse = window_block_raw(
+            x2, n_img, H, W, num_heads, shift, g, b, eps, _lp(wqkv, x.dtype), bqkv.detach().float().contiguous() if bqkv is not None else None,
+            _lp(wproj, x.dtype), bproj.detach().float().contiguous() if bproj is not None else None, tab, index_i32, scale, rowscale, train)
+        if train:
+            m = mask.detach().float().contiguous() if mask is not None else None
+            ctx.save_for_backward(x2, xn, o, mean, rstd, lse, g, wqkv, bqkv, wproj, tab, index_i32, m, rowscale)
+        ctx.cfg = (n_img, H, W, C, num_heads, shift, float(scale), x.shape)
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, xn, o, mean, rstd, lse, g, wqkv, bqkv, wproj, tab, index_i32, m, rowscale = ctx.saved_tensors
+        dx, dg, db, dwq, dbq, dwp, dbp, dtable = window_block_backward(dy, x2, xn, o, mean, rstd, lse, g, wqkv, bqkv, wproj, tab, index_i32, m, rowscale, ctx.cfg)
+        return (dx, dg, db, None, dwq, dbq, dwp, dbp if ctx.needs_input_grad[7] else None, dtable,
+                None, None, None, None, None, None, None, None, None)
+
+
+def window_block_backward(dy, x2, xn, o, mean, rstd, lse, g, wqkv, bqkv, wproj, tab, index_i32, m, rowscale, cfg):
+    """backward of the fused attention half on what its forward saved; returns (dx, dgamma, dbeta, dWqkv, dbqkv, dWproj, dbproj, dtable)"""
+    n_img, H, W, C, num_heads, shift, scale, xshape = cfg
+    lib = _lib.load()
+    dt = x2.dtype
+    dy2 = dy.reshape(-1, C).contiguous()
+    L = H * W
+    # proj: input gradient and weight gradient (DropPath scale on dy)
+    do = linear_raw(dy2, _lp(wproj, dt, transpose=True), None, rowscale=rowscale, rows_per_scale=L)
+    dwp, dbp = wgrad_raw(dy2, o, True, rowscale, L)
+    # attention core on the recomputed qkv
+    qkv = linear_raw(xn, _lp(wqkv, dt), bqkv.detach() if bqkv is not None else None)
+    dqkv = torch.empty_like(qkv)
+    dtable = torch.empty_like(tab)
+    nbytes = lib.fmmt_window_attn_bwd_workspace(num_heads)
+    ws = _ws(nbytes, x2.device)
+    nWm = m.shape[0] if m is not None else 0
+    rc = lib.fmmt_window_attn_bwd(dtype_code(dt), n_img, H, W, C, num_heads, shift, _p(qkv), _p(o), _p(do), _p(lse), _p(tab), _p(index_i32),
+                                  _p(m), nWm, 1 if m is not None else 0, scale, _p(dqkv), _p(dtable), _p(ws), nbytes, _st())
+    check(rc, "fmmt_window_attn_bwd")
+    del qkv, do
+    dxn = linear_raw(dqkv, _lp(wqkv, dt, transpose=True), None)
+    dwq, dbq = wgrad_raw(dqkv, xn, bqkv is not None)
+    del dqkv
+    # LayerNorm backward + the residual branch's gradient
+    dx = torch.empty_like(x2)
+    dg = torch.empty(C, dtype=torch.float32, device=x2.device)
+    db = torch.empty(C, dtype=torch.float32, device=x2.device)
+    nb2 = lib.fmmt_layernorm_bwd_workspace(C)
+    ws2 = _ws(nb2, x2.device)
+    rc = lib.fmmt_layernorm_bwd(dtype_code(dt), x2.shape[0], C, _p(dxn), _p(x2), _p(mean), _p(rstd), _p(g), _p(dy2), _p(dx), _p(dg), _p(db), 0,
+                                _p(ws2), nb2, _st())
+    check(rc, "fmmt_layernorm_bwd(window_block)")
+    return dx.reshape(xshape), dg, db, dwq, dbq, dwp, dbp, dtable
+
+
+def window_block(x, ln_w, ln_b, eps, wqkv, bqkv, wproj, bproj, table, index_i32, mask, n_img, H, W, num_heads, shift, scale, rowscale=None):
+    return WindowBlockFn.apply(x, ln_w, ln_b, eps, wqkv, bqkv, wproj, bproj, table, index_i32, mask, n_img, H, W, num_heads, shift, scale, rowscale)
+
+
+# ------------------------------------------------------------------------------------------------
 # cross-modal multi-head attention core (time-major)
 # ------------------------------------------------------------------------------------------------
+def _mha_ptrs(k, v, E):
+    packed = v is None
+    if packed:
+        return packed, k.shape[0], 2 * E, k.data_ptr(), k.data_ptr() + E * k.element_size()
+    return packed, k.shape[0], E, k.data_ptr(), v.data_ptr()
+
+
+def mha_fwd_raw(q, k, v, num_heads, scale, dropout_p, seed_i, seed_t, key_bias):
+    """fmmt_mha_fwd on contiguous time-major operands; v None = k is the packed [k | v] projection.  Returns (out, lse)."""
+    Lq, B, E = q.shape
+    packed, Lk, ldkv, kp, vp = _mha_ptrs(k, v, E)
+    out = torch.empty_like(q)
+    lse = torch.empty((B * num_heads * Lq,), dtype=torch.float32, device=q.device)
+    rc = _lib.load().fmmt_mha_fwd(dtype_code(q.dtype), Lq, Lk, B, E, num_heads, _p(q), E, kp, vp, ldkv, scale, _p(key_bias),
+                                  dropout_p, seed_i, _p(seed_t), _p(out), E, _p(lse), _st())
+    check(rc, f"fmmt_mha_fwd(Lq={Lq},Lk={Lk},B={B},E={E},heads={num_heads})")
+    return out, lse
+
+
+def mha_bwd_raw(q, k, v, out, dout, lse, num_heads, scale, dropout_p, seed_i, seed_t, key_bias):
+    """fmmt_mha_bwd; returns (dq, dk, dv) with dv None when k is the packed projection (dk then holds [dk | dv])"""
+    Lq, B, E = q.shape
+    packed, Lk, ldkv, kp, vp = _mha_ptrs(k, v, E)
+    dq = torch.empty_like(q)
+    dk = torch.empty_like(k)
+    if packed:
+        dkp, dvp, dv = dk.data_ptr(), dk.data_ptr() + E * k.element_size(), None
+    else:
+        dv = torch.empty_like(v)
+        dkp, dvp = dk.data_ptr(), dv.data_ptr()
+    rc = _lib.load().fmmt_mha_bwd(dtype_code(q.dtype), Lq, Lk, B, E, num_heads, _p(q), E, kp, vp, ldkv, scale, _p(key_bias),
+                                  dropout_p, seed_i, _p(seed_t), _p(out), _p(dout), E, _p(lse), _p(dq), E, dkp, dvp, ldkv, _st())
+    check(rc, "fmmt_mha_bwd")
+    return dq, dk, dv
+
+
 class MhaCoreFn(Function):
     """q: (Lq,B,E); kv: either a packed (Lk,B,2E) tensor [k | v] (v is None) or separate k, v (Lk,B,E)."""
 
     @staticmethod
     def forward(ctx, q, k, v, num_heads, scale, dropout_p, seed, key_bias=None):
         _need_cuda(q, "multihead_attention")
-        lib = _lib.load()
         q = q.contiguous()
         Lq, B, E = q.shape
-        packed = v is None
         k = k.contiguous()
-        if packed:
-            Lk, ldkv = k.shape[0], 2 * E
-            kp, vp = k.data_ptr(), k.data_ptr() + E * k.element_size()
-        else:
-            v = v.contiguous()
-            Lk, ldkv = k.shape[0], E
-            kp, vp = k.data_ptr(), v.data_ptr()
-        out = torch.empty_like(q)
-        lse = torch.empty((B * num_heads * Lq,), dtype=torch.float32, device=q.device)
+        v = v.contiguous() if v is not None else None
         seed_t = seed if isinstance(seed, torch.Tensor) else None          # device int64 word: graph-replay safe
         seed_i = 0 if seed_t is not None else int(seed)
         if key_bias is not None:
             key_bias = key_bias.detach().to(torch.float32).contiguous()
-            assert key_bias.shape == (B, Lk), f"key_bias must be (B, Lk) = ({B}, {Lk}), got {tuple(key_bias.shape)}"
-        rc = lib.fmmt_mha_fwd(dtype_code(q.dtype), Lq, Lk, B, E, num_heads, _p(q), E, kp, vp, ldkv, scale, _p(key_bias),
-                              dropout_p, seed_i, _p(seed_t), _p(out), E, _p(lse), _st())
-        check(rc, f"fmmt_mha_fwd(Lq={Lq},Lk={Lk},B={B},E={E},heads={num_heads})")
+            assert key_bias.shape == (B, k.shape[0]), f"key_bias must be (B, Lk) = ({B}, {k.shape[0]}), got {tuple(key_bias.shape)}"
+        out, lse = mha_fwd_raw(q, k, v, num_heads, scale, dropout_p, seed_i, seed_t, key_bias)
         ctx.save_for_backward(q, k, v, out, lse, seed_t, key_bias)
-        ctx.cfg = (Lq, Lk, B, E, num_heads, scale, dropout_p, seed_i, packed, ldkv)
-        return out
+        ctx.cfg = (num_heads, scale, dropout_p, seed_i)
+        ctx.mark_non_differentiable(lse)
+        return out, lse
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, _dlse):
         q, k, v, out, lse, seed_t, key_bias = ctx.saved_tensors
-        Lq, Lk, B, E, num_heads, scale, dropout_p, seed, packed, ldkv = ctx.cfg
-        lib = _lib.load()
-        dout = dout.contiguous()
-        dq = torch.empty_like(q)
-        dk = torch.empty_like(k)
-        if packed:
-            kp, vp = k.data_ptr(), k.data_ptr() + E * k.element_size()
-            dkp, dvp, dv = dk.data_ptr(), dk.data_ptr() + E * k.element_size(), None
-        else:
-            dv = torch.empty_like(v)
-            kp, vp, dkp, dvp = k.data_ptr(), v.data_ptr(), dk.data_ptr(), dv.data_ptr()
-        rc = lib.fmmt_mha_bwd(dtype_code(q.dtype), Lq, Lk, B, E, num_heads, _p(q), E, kp, vp, ldkv, scale, _p(key_bias),
-                              dropout_p, seed, _p(seed_t), _p(out), _p(dout), E, _p(lse), _p(dq), E, dkp, dvp, ldkv, _st())
-        check(rc, "fmmt_mha_bwd")
+        num_heads, scale, dropout_p, seed = ctx.cfg
+        dq, dk, dv = mha_bwd_raw(q, k, v, out, dout.contiguous(), lse, num_heads, scale, dropout_p, seed, seed_t, key_bias)
         return dq, dk, dv, None, None, None, None, None
 
 
-def mha_core(q, k, v, num_heads, scale, dropout_p=0.0, seed=0, key_bias=None):
+def mha_avg_weights(q, k, lse, num_heads, scale, dropout_p=0.0, seed=0, key_bias=None):
+    """head-averaged post-dropout attention probabilities (B, Lq, Lk) fp32 -- the second return value of the reference's
+    MultiheadAttention.forward (multihead_attention.py:133-134) -- recomputed from q, k (the (Lk,B,E) key projection or the packed
+    (Lk,B,2E) [k | v] one), the log-sum-exp of the forward and the same seed (fmmt_mha_avg_weights).  No gradient."""
+    q = q.detach().contiguous()
+    k = k.detach().contiguous()
+    Lq, B, E = q.shape
+    Lk, ldkv = k.shape[0], k.shape[2]
+    seed_t = seed if isinstance(seed, torch.Tensor) else None
+    seed_i = 0 if seed_t is not None else int(seed)
+    kb = key_bias.detach().to(torch.float32).contiguous() if key_bias is not None else None
+    w = torch.empty((B, Lq, Lk), dtype=torch.float32, device=q.device)
+    rc = _lib.load().fmmt_mha_avg_weights(dtype_code(q.dtype), Lq, Lk, B, E, num_heads, _p(q), E, _p(k), ldkv, scale, _p(kb), float(dropout_p),
+                                          seed_i, _p(seed_t), _p(lse), _p(w), _st())
+    check(rc, f"fmmt_mha_avg_weights(Lq={Lq},Lk={Lk},B={B},E={E},heads={num_heads})")
+    return w
+
+
+def mha_core(q, k, v, num_heads, scale, dropout_p=0.0, seed=0, key_bias=None, return_lse=False):
     """seed: python int, or a 1-element int64 CUDA tensor read by the kernel at run time.
-    key_bias: optional (B, Lk) additive logit bias (extended attention mask), no gradient."""
-    return MhaCoreFn.apply(q, k, v, num_heads, scale, float(dropout_p), seed if isinstance(seed, torch.Tensor) else int(seed), key_bias)
+    key_bias: optional (B, Lk) additive logit bias (extended attention mask), no gradient.
+    return_lse: also return the saved log-sum-exp (B*heads*Lq, fp32; no gradient) -- what mha_avg_weights needs."""
+    out, lse = MhaCoreFn.apply(q, k, v, num_heads, scale, float(dropout_p), seed if isinstance(seed, torch.Tensor) else int(seed), key_bias)
+    return (out, lse) if return_lse else out
 
 
 # ------------------------------------------------------------------------------------------------
@@ -673,20 +805,35 @@ def patch_embed_u8(img_u8: torch.Tensor, mode: str, dtype) -> torch.Tensor:
     return cols
 
 
+def batch_norm_1d_fwd_raw(x, g, b, running_mean, running_var, momentum, eps, training):
+    n, C = x.shape
+    y = torch.empty_like(x)
+    sm = torch.empty(C, dtype=torch.float32, device=x.device)
+    si = torch.empty(C, dtype=torch.float32, device=x.device)
+    rc = _lib.load().fmmt_batchnorm1d_fwd(dtype_code(x.dtype), n, C, _p(x), _p(g), _p(b), _p(running_mean), _p(running_var),
+                                          momentum, eps, int(training), _p(y), _p(sm), _p(si), _st())
+    check(rc, "fmmt_batchnorm1d_fwd")
+    return y, sm, si
+
+
+def batch_norm_1d_bwd_raw(dy, x, g, sm, si, training):
+    n, C = x.shape
+    dx = torch.empty_like(x)
+    dg = torch.empty(C, dtype=torch.float32, device=x.device)
+    db = torch.empty(C, dtype=torch.float32, device=x.device)
+    rc = _lib.load().fmmt_batchnorm1d_bwd(dtype_code(x.dtype), n, C, _p(dy), _p(x), _p(g), _p(sm), _p(si), int(training),
+                                          _p(dx), _p(dg), _p(db), _st())
+    check(rc, "fmmt_batchnorm1d_bwd")
+    return dx, dg, db
+
+
 class BatchNorm1dFn(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, training):
         _need_cuda(x, "batch_norm")
-        lib = _lib.load()
         x = x.contiguous()
-        n, C = x.shape
-        y = torch.empty_like(x)
-        sm = torch.empty(C, dtype=torch.float32, device=x.device)
-        si = torch.empty(C, dtype=torch.float32, device=x.device)
         g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
-        rc = lib.fmmt_batchnorm1d_fwd(dtype_code(x.dtype), n, C, _p(x), _p(g), _p(b), _p(running_mean), _p(running_var),
-                                      momentum, eps, int(training), _p(y), _p(sm), _p(si), _st())
-        check(rc, "fmmt_batchnorm1d_fwd")
+        y, sm, si = batch_norm_1d_fwd_raw(x, g, b, running_mean, running_var, momentum, eps, training)
         ctx.save_for_backward(x, g, sm, si)
         ctx.training = bool(training)
         return y
@@ -694,15 +841,7 @@ class BatchNorm1dFn(Function):
     @staticmethod
     def backward(ctx, dy):
         x, g, sm, si = ctx.saved_tensors
-        lib = _lib.load()
-        dy = dy.contiguous()
-        n, C = x.shape
-        dx = torch.empty_like(x)
-        dg = torch.empty(C, dtype=torch.float32, device=x.device)
-        db = torch.empty(C, dtype=torch.float32, device=x.device)
-        rc = lib.fmmt_batchnorm1d_bwd(dtype_code(x.dtype), n, C, _p(dy), _p(x), _p(g), _p(sm), _p(si), int(ctx.training),
-                                      _p(dx), _p(dg), _p(db), _st())
-        check(rc, "fmmt_batchnorm1d_bwd")
+        dx, dg, db = batch_norm_1d_bwd_raw(dy.contiguous(), x, g, sm, si, ctx.training)
         return dx, dg, db, None, None, None, None, None
 
 

@@ -9,9 +9,11 @@ target step (Swin's target-step gradients are discarded, train.py:20,141, so the
 
 `GradientAverager` is that exchange: parameters are grouped (in reverse registration order, the order backward
 produces them) into ~64 MiB buckets; every `.grad` is a view into its bucket's flat fp32 buffer; a
-post-accumulate hook counts arrivals and, when a bucket is complete, launches ONE asynchronous all-reduce of the
-flat buffer on the stream the gradients were produced on -- so the exchange of the text encoder's buckets (produced
-on the second HIP stream) and of the fusion stack's buckets overlaps with the Swin backward that is still running.
+post-accumulate hook counts arrivals and, when a bucket is complete (and every lower-numbered bucket has been issued),
+launches ONE asynchronous all-reduce of the flat buffer, ordered behind the stream that produced the gradients -- so the
+exchange of the fusion stack's and the text encoder's buckets overlaps with the Swin backward that is still running.
+The graphed step (train_step.GraphedTargetStep) has no hooks: it issues all buckets between its multimodal-backward
+graph and its Swin-backward graph (`exchange_begin` / `exchange_end`).
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): 64 MiB buckets amortise the per-collective latency of an
 8-rank ring while leaving ~27 buckets of the 1.74 GB fp32 gradient to pipeline.  `no_sync()` skips the exchange on
 all but the last micro-step of an accumulation window (trg_accumulation_steps, main.py:60).
@@ -52,23 +54,27 @@ def accumulate(ddp_module, is_last_micro_step: bool):
 class GradientAverager:
     """Bucketed, asynchronous gradient mean over the default process group (see the module docstring).
 
-    Ordering contract (RCCL, like NCCL, needs every rank to issue the collectives of one communicator in the same
-    order): buckets are numbered in construction order and a bucket's all-reduce is issued only after every
-    lower-numbered bucket OF ITS GROUP has been issued -- a bucket that completes early waits in `_ready`.  Each stream
-    group owns its own communicator (`dist.new_group`), because the relative order of two streams' buckets is a
-    property of each rank's timing, not of the model.
+    Ordering contract (RCCL, like NCCL, needs every rank to issue the collectives of a communicator in the same order,
+    and concurrent collectives on DIFFERENT communicators can deadlock when their kernels cannot be co-scheduled or the
+    ranks interleave them differently): there is ONE communicator -- the caller's `process_group` -- and ONE global issue
+    order, the construction order of the buckets (group after group, each group in reverse registration order).  A bucket's
+    all-reduce is issued only after every lower-numbered bucket has been issued; a bucket that completes early waits in
+    `_ready`.  List `groups` in the order their gradients complete in the backward (fusion stack before text encoder):
+    the order is a property of the model, never of a rank's timing.
     Completeness contract (what torch's DDP enforces with an error): when `finish()` is called with the exchange
     enabled, every bucket must have received every one of its gradients.  A parameter that took no part in the step
     (e.g. an unused pooler) leaves its bucket incomplete; `finish()` raises instead of letting the ranks step on
     un-averaged gradients."""
 
-    def __init__(self, params, bucket_mb: int = BUCKET_MB, process_group=None, groups=None, comm_dtype=None, hooks: bool = True):
+    def __init__(self, params, bucket_mb: int = BUCKET_MB, process_group=None, groups=None, comm_dtype=None, hooks: bool = True, always: bool = False):
         """`groups`: optional list of parameter lists whose gradients are produced on different HIP streams (e.g. the
         text branch on the second stream): a bucket never spans two groups, so the stream that completes a bucket
         is the stream that produced all of it.
         `comm_dtype`: torch.bfloat16 halves the bytes on the wire (1.74 GB -> 0.87 GB for the multimodal model): the
-        flat fp32 bucket is rounded into a bf16 staging buffer, summed over ranks in bf16, and written back as fp32."""
+        flat fp32 bucket is rounded into a bf16 staging buffer, summed over ranks in bf16, and written back as fp32.
+        `always`: issue the collectives even at world size 1 (a one-GPU box then exercises the whole RCCL call path)."""
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (always and dist.is_initialized())
         groups = [list(params)] if groups is None else [list(g) for g in groups]
         self.params = [p for g in groups for p in g if p.requires_grad]
         if len(set(map(id, self.params))) != len(self.params):
@@ -77,13 +83,9 @@ class GradientAverager:
             raise ValueError("GradientAverager: comm_dtype must be None / torch.float32 / torch.bfloat16")
         self.comm_dtype = None if comm_dtype == torch.float32 else comm_dtype
         self.sync = True
-        # one communicator per stream group (see the ordering contract); the first group keeps the caller's
-        self.comms = [process_group]
-        for _ in groups[1:]:
-            self.comms.append(dist.new_group() if (dist.is_initialized() and self.world > 1) else process_group)
+        self.comm = process_group                          # the one communicator of every bucket (see the ordering contract)
         self.buckets = []                                  # [flat buffer, [params], arrivals, pending work, group, staging]
-        self._next = [0] * len(groups)                     # per group: position (in its bucket list) of the next bucket to issue
-        self._order = [[] for _ in groups]                 # per group: bucket indices in issue order
+        self._next = 0                                     # the next bucket (global construction order) to issue
         self._ready = set()                                # complete buckets waiting for a lower-numbered one
         self._issued = set()
         cap = bucket_mb * (1 << 20)
@@ -116,7 +118,6 @@ class GradientAverager:
         for p, o in zip(ps, offs):
             p.grad = flat[o:o + p.numel()].view_as(p)
         stage = torch.empty(n, dtype=self.comm_dtype, device=flat.device) if self.comm_dtype is not None else None
-        self._order[gi].append(len(self.buckets))
         self.buckets.append([flat, ps, 0, None, gi, stage])
 
     def _issue(self, bi):
@@ -126,7 +127,7 @@ class GradientAverager:
         if b[5] is not None:
             b[5].copy_(b[0])
             buf = b[5]
-        b[3] = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.comms[b[4]], async_op=True)
+        b[3] = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.comm, async_op=True)
         self._issued.add(bi)
 
     def _hook(self, p):
@@ -136,58 +137,69 @@ class GradientAverager:
         if b[2] < len(b[1]):
             return
         b[2] = 0                                           # bucket complete
-        if not (self.sync and self.world > 1):
+        if not (self.sync and self.active):
             return
         if bi in self._issued or bi in self._ready:
             raise RuntimeError("GradientAverager: a bucket completed twice in one exchange window (call finish() once per step)")
         self._ready.add(bi)
-        gi = b[4]
-        order = self._order[gi]
-        while self._next[gi] < len(order) and order[self._next[gi]] in self._ready:         # in-order issue, cascade
-            nxt = order[self._next[gi]]
-            self._ready.discard(nxt)
-            self._issue(nxt)
-            self._next[gi] += 1
+        while self._next < len(self.buckets) and self._next in self._ready:                 # in-order issue, cascade
+            self._ready.discard(self._next)
+            self._issue(self._next)
+            self._next += 1
 
     def finish(self):
         """Make the current stream wait for every outstanding exchange (call before clipping / the optimizer).
         Raises if the exchange is enabled and some bucket is incomplete: one of its parameters received no gradient in
         this step (freeze it or leave it out of the averager), so the ranks would otherwise diverge silently."""
-        if self.sync and self.world > 1:
+        if self.sync and self.active:
             bad = [bi for bi, b in enumerate(self.buckets) if bi not in self._issued]
             if bad:
                 names = []
                 for bi in bad[:4]:
                     b = self.buckets[bi]
-                    names.append(f"bucket {bi} (group {b[4]}): {b[2]}/{len(b[1])} gradients arrived")
+                    names.append(f"bucket {bi} (group {b[4]}): {b[2]}/{len(b[1])} gradients arrived" +
+                                 (" (complete, held back by a lower-numbered bucket)" if bi in self._ready else ""))
+                self._wait_all()                            # nothing stays in flight behind the exception
                 self._reset_window()
                 raise RuntimeError("GradientAverager.finish(): gradient exchange incomplete -- " + "; ".join(names) +
                                    ".  A parameter that gets no gradient (unused sub-module, e.g. a PLM pooler) must be "
-                                   "frozen (requires_grad_(False)) or excluded; nothing was stepped.")
+                                   "frozen (requires_grad_(False)) or excluded.  Nothing was stepped; the buckets that had been "
+                                   "issued hold averaged gradients, the others local ones: call zero_grad() before the next step.")
+        self._wait_all()
+        self._reset_window()
+
+    def _wait_all(self):
         for b in self.buckets:
             if b[3] is not None:
                 b[3].wait()
                 b[3] = None
                 if b[5] is not None:
                     b[0].copy_(b[5])
-        self._reset_window()
 
     def exchange_all(self):
         """Average every bucket over the ranks now, in bucket order, on the current stream (blocking semantics of the
         stream: later work on it sees the averaged gradients).  For owners without hooks; no-op at world size 1."""
-        if not (self.sync and self.world > 1):
+        self.exchange_begin()
+        self.exchange_end()
+
+    def exchange_begin(self):
+        """Issue every bucket's all-reduce (bucket order, asynchronous): the collectives run on the backend's own stream behind
+        whatever the current stream has been given so far, and beside whatever it is given next -- the graphed step calls this
+        between its two forward/backward graphs, so the exchange of the multimodal gradients overlaps the Swin backward."""
+        if not (self.sync and self.active):
             return
         for bi in range(len(self.buckets)):
             self._issue(bi)
-        for b in self.buckets:
-            b[3].wait()
-            b[3] = None
-            if b[5] is not None:
-                b[0].copy_(b[5])
+
+    def exchange_end(self):
+        """make the current stream wait for the collectives exchange_begin() issued"""
+        if not (self.sync and self.active):
+            return
+        self._wait_all()
         self._reset_window()
 
     def _reset_window(self):
-        self._next = [0] * len(self._order)
+        self._next = 0
         self._ready.clear()
         self._issued.clear()
         for b in self.buckets:

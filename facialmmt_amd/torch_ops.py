@@ -11,6 +11,13 @@ Registered (forward ops return what their backward needs as extra outputs, as cu
     fmmt::layer_norm(x, gamma, beta, eps) -> (y, mean, rstd)                              nn.LayerNorm
     fmmt::window_attention(qkv, table, index, n_img, H, W, heads, shift, scale) -> (out, lse)   W-MSA / SW-MSA core on token-order qkv
     fmmt::patch_embed_u8(img_u8, flavour, bf16) -> cols                                    input pre-step + patch gather (no gradient)
+    fmmt::layer_norm_merge(x, gamma, beta, eps, merge_hw) -> (y, mean, rstd)              PatchMerging's 2x2 gather + LayerNorm(4C)
+    fmmt::linear_splitk(x, weight, bias?) -> y                                            the 37632 -> 512 embedding head (split-K launch)
+    fmmt::batch_norm_1d(x, gamma, beta, running_mean, running_var, momentum, eps, training) -> (y, save_mean, save_invstd, running_mean', running_var')
+    fmmt::mha(q, k, v?, key_bias?, heads, scale, dropout_p, seed) -> (out, lse)           cross-modal attention core (packed k|v when v is None)
+    fmmt::posemb_scale(x, table, scale) -> y                                              sqrt(E) x + sinusoidal position embedding
+    fmmt::window_block(x, ln_w, ln_b, eps, wqkv, bqkv?, wproj, bproj?, table, index, n_img, H, W, heads, shift, scale, rowscale?)
+                       -> (y, xn, attn_out, mean, rstd, lse)                               norm1 -> (S)W-MSA -> proj -> residual in one launch (C = 96)
 
 The nn.Modules of facialmmt_amd/modules keep using ops.py (fewer dispatcher hops per launch); tests/test_gpu_torch_ops.py
 holds the two front ends bit-identical, forward and backward, and runs torch.library.opcheck on each operator."""
@@ -245,3 +252,254 @@ def patch_embed_u8(img_u8: Tensor, flavour: str, bf16: bool) -> Tensor:
 @patch_embed_u8.register_fake
 def _(img_u8, flavour, bf16):
     return img_u8.new_empty(img_u8.shape[0] * 3136, 48, dtype=torch.bfloat16 if bf16 else torch.float32)
+
+
+# ------------------------------------------------------------------------------------------------ PatchMerging gather + LayerNorm
+def _ln_call(x, gamma, beta, eps, merge_hw):
+    from . import _lib
+    lib = _lib.load()
+    x = x.contiguous()
+    if merge_hw:
+        n, L, Cq = x.shape
+        M, C = n * (merge_hw // 2) ** 2, 4 * Cq
+        y = torch.empty((n, (merge_hw // 2) ** 2, C), dtype=x.dtype, device=x.device)
+    else:
+        C = x.shape[-1]
+        M = x.numel() // C
+        y = torch.empty_like(x)
+    mean = torch.empty(M, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+    g, b = gamma.float().contiguous(), beta.float().contiguous()
+    rc = lib.fmmt_layernorm_fwd(_lib.dtype_code(x.dtype), M, C, x.data_ptr(), g.data_ptr(), b.data_ptr(), eps, y.data_ptr(), mean.data_ptr(),
+                                rstd.data_ptr(), merge_hw, ops._st())
+    _lib.check(rc, f"fmmt_layernorm_fwd(M={M},C={C},merge={merge_hw})")
+    return y, mean, rstd
+
+
+@torch.library.custom_op(f"{_LIB}::layer_norm_merge", mutates_args=(), device_types="cuda")
+def layer_norm_merge(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, merge_hw: int) -> Tuple[Tensor, Tensor, Tensor]:
+    """x (n, H*W, C/4) token grid, H = W = merge_hw -> LayerNorm over the 2x2-neighbour concat (n, H*W/4, C)  (Swin_Transformer.py:316-325)"""
+    return _ln_call(x, gamma, beta, eps, merge_hw)
+
+
+@layer_norm_merge.register_fake
+def _(x, gamma, beta, eps, merge_hw):
+    n, L, Cq = x.shape
+    m = n * (merge_hw // 2) ** 2
+    return x.new_empty(n, (merge_hw // 2) ** 2, 4 * Cq), x.new_empty(m, dtype=torch.float32), x.new_empty(m, dtype=torch.float32)
+
+
+def _lnm_setup(ctx, inputs, output):
+    x, gamma, beta, eps, merge_hw = inputs
+    _, mean, rstd = output
+    ctx.save_for_backward(x, mean, rstd, gamma)
+    ctx.merge_hw = merge_hw
+    ctx.set_materialize_grads(False)
+
+
+def _lnm_backward(ctx, dy, _dmean, _drstd):
+    from . import _lib
+    x, mean, rstd, gamma = ctx.saved_tensors
+    lib = _lib.load()
+    x = x.contiguous()
+    n, L, Cq = x.shape
+    M, C = n * (ctx.merge_hw // 2) ** 2, 4 * Cq
+    dy = dy.contiguous()
+    g = gamma.float().contiguous()
+    dx = torch.empty_like(x)
+    dg = torch.empty(C, dtype=torch.float32, device=x.device)
+    db = torch.empty(C, dtype=torch.float32, device=x.device)
+    nbytes = lib.fmmt_layernorm_bwd_workspace(C)
+    ws = ops._ws(nbytes, x.device)
+    rc = lib.fmmt_layernorm_bwd(_lib.dtype_code(x.dtype), M, C, dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), g.data_ptr(), None,
+                                dx.data_ptr(), dg.data_ptr(), db.data_ptr(), ctx.merge_hw, ws.data_ptr(), nbytes, ops._st())
+    _lib.check(rc, f"fmmt_layernorm_bwd(M={M},C={C},merge={ctx.merge_hw})")
+    return dx, dg, db, None, None
+
+
+layer_norm_merge.register_autograd(_lnm_backward, setup_context=_lnm_setup)
+
+
+# ------------------------------------------------------------------------------------------------ split-K head Linear
+@torch.library.custom_op(f"{_LIB}::linear_splitk", mutates_args=(), device_types="cuda")
+def linear_splitk(x: Tensor, weight: Tensor, bias: Optional[Tensor]) -> Tensor:
+    """y = x w^T + b for few rows and a very long K (the 49*768 -> 512 embedding head, Swin_Transformer.py:493): fmmt_linear_fwd_splitk
+    where the library says the shape is a split-K shape, fmmt_linear_fwd otherwise (ops.linear_raw makes that choice)"""
+    x2 = x.reshape(-1, x.shape[-1]).contiguous()
+    return ops.linear_raw(x2, _cast(weight, x.dtype), bias).reshape(*x.shape[:-1], weight.shape[0])
+
+
+@linear_splitk.register_fake
+def _(x, weight, bias):
+    return x.new_empty(*x.shape[:-1], weight.shape[0])
+
+
+def _lsk_setup(ctx, inputs, output):
+    x, weight, bias = inputs
+    ctx.save_for_backward(x, weight)
+    ctx.has_bias = bias is not None
+
+
+def _lsk_backward(ctx, dy):
+    x, weight = ctx.saved_tensors
+    dy2 = dy.reshape(-1, weight.shape[0]).contiguous()
+    x2 = x.reshape(-1, x.shape[-1]).contiguous()
+    dx = ops.linear_raw(dy2, _cast(weight, dy2.dtype, True), None).reshape(x.shape) if ctx.needs_input_grad[0] else None
+    dw, db = ops.wgrad_raw(dy2, x2, ctx.has_bias)
+    return dx, dw, db
+
+
+linear_splitk.register_autograd(_lsk_backward, setup_context=_lsk_setup)
+
+
+# ------------------------------------------------------------------------------------------------ BatchNorm1d of the embedding head
+@torch.library.custom_op(f"{_LIB}::batch_norm_1d", mutates_args=(), device_types="cuda")
+def batch_norm_1d(x: Tensor, gamma: Tensor, beta: Tensor, running_mean: Tensor, running_var: Tensor, momentum: float, eps: float,
+                  training: bool) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
+    """functional form (an operator with an autograd formula may not mutate its inputs): the updated running statistics are
+    returned as outputs 3 and 4 -- nn.BatchNorm1d semantics are `running_mean.copy_(out[3]); running_var.copy_(out[4])`"""
+    rm, rv = running_mean.clone(), running_var.clone()
+    y, sm, si = ops.batch_norm_1d_fwd_raw(x.contiguous(), gamma.float().contiguous(), beta.float().contiguous(), rm, rv, momentum, eps, training)
+    return y, sm, si, rm, rv
+
+
+@batch_norm_1d.register_fake
+def _(x, gamma, beta, running_mean, running_var, momentum, eps, training):
+    C = x.shape[1]
+    return (torch.empty_like(x), x.new_empty(C, dtype=torch.float32), x.new_empty(C, dtype=torch.float32),
+            torch.empty_like(running_mean), torch.empty_like(running_var))
+
+
+def _bn_setup(ctx, inputs, output):
+    x, gamma, beta, rm, rv, momentum, eps, training = inputs
+    _, sm, si, _rm, _rv = output
+    ctx.save_for_backward(x, gamma, sm, si)
+    ctx.training = bool(training)
+    ctx.set_materialize_grads(False)
+
+
+def _bn_backward(ctx, dy, _dsm, _dsi, _drm, _drv):
+    x, gamma, sm, si = ctx.saved_tensors
+    dx, dg, db = ops.batch_norm_1d_bwd_raw(dy.contiguous(), x.contiguous(), gamma.float().contiguous(), sm, si, ctx.training)
+    return dx, dg, db, None, None, None, None, None
+
+
+batch_norm_1d.register_autograd(_bn_backward, setup_context=_bn_setup)
+
+
+# ------------------------------------------------------------------------------------------------ cross-modal attention core
+@torch.library.custom_op(f"{_LIB}::mha", mutates_args=(), device_types="cuda")
+def mha(q: Tensor, k: Tensor, v: Optional[Tensor], key_bias: Optional[Tensor], num_heads: int, scale: float, dropout_p: float,
+        seed: int) -> Tuple[Tensor, Tensor]:
+    """q (Lq, B, E), k / v (Lk, B, E) time-major -- or k = the packed (Lk, B, 2E) [k | v] projection and v None; key_bias (B, Lk) fp32
+    additive logit bias; dropout mask = hash(seed, element), replayed by the backward (multihead_attention.py:85-128)"""
+    kb = key_bias.to(torch.float32).contiguous() if key_bias is not None else None
+    return ops.mha_fwd_raw(q.contiguous(), k.contiguous(), v.contiguous() if v is not None else None, num_heads, scale, dropout_p, seed, None, kb)
+
+
+@mha.register_fake
+def _(q, k, v, key_bias, num_heads, scale, dropout_p, seed):
+    Lq, B, E = q.shape
+    return torch.empty_like(q), q.new_empty(B * num_heads * Lq, dtype=torch.float32)
+
+
+def _mha_setup(ctx, inputs, output):
+    q, k, v, key_bias, num_heads, scale, dropout_p, seed = inputs
+    out, lse = output
+    ctx.save_for_backward(q, k, v, key_bias, out, lse)
+    ctx.cfg = (num_heads, scale, dropout_p, seed)
+    ctx.set_materialize_grads(False)
+
+
+def _mha_backward(ctx, dout, _dlse):
+    q, k, v, key_bias, out, lse = ctx.saved_tensors
+    num_heads, scale, dropout_p, seed = ctx.cfg
+    kb = key_bias.to(torch.float32).contiguous() if key_bias is not None else None
+    dq, dk, dv = ops.mha_bwd_raw(q.contiguous(), k.contiguous(), v.contiguous() if v is not None else None, out, dout.contiguous(), lse,
+                                 num_heads, scale, dropout_p, seed, None, kb)
+    return dq, dk, dv, None, None, None, None, None
+
+
+mha.register_autograd(_mha_backward, setup_context=_mha_setup)
+
+
+# ------------------------------------------------------------------------------------------------ cross-modal input embedding
+@torch.library.custom_op(f"{_LIB}::posemb_scale", mutates_args=(), device_types="cuda")
+def posemb_scale(x: Tensor, table: Tensor, scale: float) -> Tensor:
+    """y = scale * x + table[position], position of (t, b) = t + 1 where x[t, b, 0] != 0, else 0 (CrossmodalTransformer.py:63-66)"""
+    from . import _lib
+    x = x.contiguous()
+    L, B, E = x.shape
+    y = torch.empty_like(x)
+    _lib.check(_lib.load().fmmt_posemb_scale_fwd(_lib.dtype_code(x.dtype), L, B, E, x.data_ptr(), table.data_ptr(), scale, y.data_ptr(), ops._st()),
+               f"fmmt_posemb_scale_fwd(L={L},B={B},E={E})")
+    return y
+
+
+@posemb_scale.register_fake
+def _(x, table, scale):
+    return torch.empty_like(x)
+
+
+def _pe_setup(ctx, inputs, output):
+    ctx.scale = inputs[2]
+
+
+def _pe_backward(ctx, dy):
+    from . import _lib
+    dy = dy.contiguous()
+    dx = torch.empty_like(dy)
+    _lib.check(_lib.load().fmmt_scale(_lib.dtype_code(dy.dtype), dy.numel(), dy.data_ptr(), ctx.scale, dx.data_ptr(), ops._st()), "fmmt_scale")
+    return dx, None, None
+
+
+posemb_scale.register_autograd(_pe_backward, setup_context=_pe_setup)
+
+
+# ------------------------------------------------------------------------------------------------ fused attention half of a Swin block
+@torch.library.custom_op(f"{_LIB}::window_block", mutates_args=(), device_types="cuda")
+def window_block(x: Tensor, ln_w: Tensor, ln_b: Tensor, eps: float, wqkv: Tensor, bqkv: Optional[Tensor], wproj: Tensor, bproj: Optional[Tensor],
+                 table: Tensor, index_i32: Tensor, n_img: int, H: int, W: int, num_heads: int, shift: int, scale: float,
+                 rowscale: Optional[Tensor]) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor, Tensor]:
+    """y = x + rowscale * (proj(W-MSA(LN(x) wqkv^T + bqkv)) + bproj) in one launch (fmmt_window_block_fwd; bf16, C = 96); shift > 0 uses the
+    standard SW-MSA mask of (H, W, shift).  Also returns LN(x), the attention output, the row statistics and the log-sum-exp."""
+    C = x.shape[-1]
+    y, xn, o, mean, rstd, lse = ops.window_block_raw(
+        x.reshape(-1, C).contiguous(), n_img, H, W, num_heads, shift, ln_w.float().contiguous(), ln_b.float().contiguous(), eps, _cast(wqkv, x.dtype),
+        bqkv.float().contiguous() if bqkv is not None else None, _cast(wproj, x.dtype), bproj.float().contiguous() if bproj is not None else None,
+        table.float().contiguous(), index_i32, scale, rowscale, True)
+    return y.reshape(x.shape), xn, o, mean, rstd, lse
+
+
+@window_block.register_fake
+def _(x, ln_w, ln_b, eps, wqkv, bqkv, wproj, bproj, table, index_i32, n_img, H, W, num_heads, shift, scale, rowscale):
+    C = x.shape[-1]
+    m = x.numel() // C
+    f32 = dict(dtype=torch.float32)
+    return (torch.empty_like(x), x.new_empty(m, C), x.new_empty(m, C), x.new_empty(m, **f32), x.new_empty(m, **f32),
+            x.new_empty(n_img * (H // 7) * (W // 7) * num_heads * 49, **f32))
+
+
+def _wb_setup(ctx, inputs, output):
+    x, ln_w, ln_b, eps, wqkv, bqkv, wproj, bproj, table, index_i32, n_img, H, W, num_heads, shift, scale, rowscale = inputs
+    _, xn, o, mean, rstd, lse = output
+    ctx.save_for_backward(x, xn, o, mean, rstd, lse, ln_w, wqkv, bqkv, wproj, table, index_i32, rowscale)
+    ctx.cfg = (n_img, H, W, num_heads, shift, scale, bproj is not None)
+    ctx.set_materialize_grads(False)
+
+
+def _wb_backward(ctx, dy, *_unused):
+    x, xn, o, mean, rstd, lse, ln_w, wqkv, bqkv, wproj, table, index_i32, rowscale = ctx.saved_tensors
+    n_img, H, W, num_heads, shift, scale, has_bproj = ctx.cfg
+    mask = None
+    if shift:
+        from .modules.SwinTransformer.Swin_Transformer import build_shift_mask
+        mask = build_shift_mask(H, W, 7, shift).to(x.device)
+    C = x.shape[-1]
+    g = ops.window_block_backward(dy, x.reshape(-1, C).contiguous(), xn, o, mean, rstd, lse, ln_w.float().contiguous(), wqkv, bqkv, wproj,
+                                  table.float().contiguous(), index_i32, mask, rowscale, (n_img, H, W, C, num_heads, shift, scale, x.shape))
+    dx, dg, db, dwq, dbq, dwp, dbp, dtable = g
+    return (dx, dg, db, None, dwq, dbq, dwp, dbp if has_bproj else None, dtable.to(table.dtype), None, None, None, None, None, None, None, None)
+
+
+window_block.register_autograd(_wb_backward, setup_context=_wb_setup)

@@ -450,8 +450,59 @@ def _reset_optimizer_state(opt):
                 v.zero_()
 
 
+class HFAdamW(torch.optim.Optimizer):
+    """`transformers.AdamW` restated (the optimizer class the reference constructs, train.py:307,333; transformers 4.24
+    optimization.py, not vendored under the reference tree): defaults betas (0.9, 0.999), **eps 1e-6, weight_decay 0.0**,
+    correct_bias True; per step
+        m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p -= lr sqrt(1 - b2^t) / (1 - b1^t) * m / (sqrt(v) + eps);  p += p * (-lr wd)
+    i.e. eps is added BEFORE the bias correction and the decoupled decay is applied AFTER the update -- both differ from
+    torch.optim.AdamW (whose defaults are also eps 1e-8, weight_decay 0.01).  `lr` may be a 0-dim device tensor and the step
+    counter is a device tensor, so the eager step is capture-safe; the graphed steps hand the same hyper-parameters to
+    fmmt_adamw_batch(hf_semantics=1) through FusedClipAdamW.  One parameter group."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, correct_bias=correct_bias))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        for g in self.param_groups:
+            ps = [p for p in g["params"] if p.grad is not None]
+            if not ps:
+                continue
+            grads = [p.grad for p in ps]
+            for p in ps:
+                st = self.state[p]
+                if not st:
+                    st["exp_avg"] = torch.zeros_like(p)
+                    st["exp_avg_sq"] = torch.zeros_like(p)
+            gs = self.state[g["params"][0]]                      # the group's step counter lives with its first parameter (a device scalar)
+            if "step" not in gs:
+                gs["step"] = torch.zeros((), dtype=torch.float32, device=ps[0].device)
+            t = gs["step"]
+            t.add_(1.0)
+            b1, b2 = g["betas"]
+            m = [self.state[p]["exp_avg"] for p in ps]
+            v = [self.state[p]["exp_avg_sq"] for p in ps]
+            torch._foreach_mul_(m, b1)
+            torch._foreach_add_(m, grads, alpha=1.0 - b1)
+            torch._foreach_mul_(v, b2)
+            torch._foreach_addcmul_(v, grads, grads, value=1.0 - b2)
+            den = torch._foreach_sqrt(v)
+            torch._foreach_add_(den, g["eps"])
+            lr = g["lr"] if torch.is_tensor(g["lr"]) else torch.tensor(float(g["lr"]), dtype=torch.float32, device=ps[0].device)
+            step_size = lr * torch.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t) if g["correct_bias"] else lr
+            upd = torch._foreach_div(m, den)
+            torch._foreach_mul_(upd, step_size)
+            torch._foreach_sub_(ps, upd)
+            if g["weight_decay"] > 0.0:
+                dec = torch._foreach_mul(ps, lr * (-g["weight_decay"]))
+                torch._foreach_add_(ps, dec)
+        return loss
+
+
 class FusedClipAdamW:
-    """clip_grad_norm_ + torch.optim.AdamW.step() (+ the bf16 re-rounding of parameters stepped through fp32 masters) as one
+    """clip_grad_norm_ + AdamW.step() (torch.optim.AdamW, or HFAdamW = the reference's transformers.AdamW) (+ the bf16 re-rounding of parameters stepped through fp32 masters) as one
     multi-tensor norm and ONE kernel launch (fmmt_adamw_batch): the gradients are read once and not scaled in place, the fp32
     parameters are not read a second time for their bf16 twins.  Takes its hyper-parameters from an existing torch AdamW
     (one parameter group, tensor learning rate on the device as `capturable=True` keeps it, so a LambdaLR scheduler keeps
@@ -460,16 +511,17 @@ class FusedClipAdamW:
     @staticmethod
     def eligible(opt, params):
         import os
-        if os.environ.get("FMMT_FUSED_ADAMW", "1") == "0" or type(opt) is not torch.optim.AdamW or len(opt.param_groups) != 1:
+        if os.environ.get("FMMT_FUSED_ADAMW", "1") == "0" or type(opt) not in (torch.optim.AdamW, HFAdamW) or len(opt.param_groups) != 1:
             return False
         g = opt.param_groups[0]
         return (torch.is_tensor(g["lr"]) and g["lr"].is_cuda and not g.get("amsgrad", False) and not g.get("maximize", False)
-                and all(p.dtype == torch.float32 and p.is_cuda for p in params))
+                and g.get("correct_bias", True) and all(p.dtype == torch.float32 and p.is_cuda for p in params))
 
     def __init__(self, opt, params, grad_of, low_of, max_norm):
         import numpy as np
         g = opt.param_groups[0]
         self.lr, (self.b1, self.b2), self.eps, self.wd = g["lr"], g["betas"], g["eps"], g["weight_decay"]
+        self.hf = isinstance(opt, HFAdamW)                    # transformers.AdamW's update (the reference's class) vs torch.optim.AdamW's
         self.max_norm = float(max_norm)
         dev = params[0].device
         self.step = torch.zeros((), dtype=torch.float32, device=dev)
@@ -499,7 +551,7 @@ class FusedClipAdamW:
         from . import ops
         self.step.add_(1.0)
         self.norm.copy_(torch.nn.utils.get_total_norm(self.grads, 2.0, foreach=True))
-        ops.adamw_batch(self.n, self.blocks, self.desc, self.lr, self.step, self.norm, self.b1, self.b2, self.eps, self.wd, self.max_norm)
+        ops.adamw_batch(self.n, self.blocks, self.desc, self.lr, self.step, self.norm, self.b1, self.b2, self.eps, self.wd, self.max_norm, self.hf)
 
 
 def _pin_shadows(modules):
@@ -531,13 +583,16 @@ def _bump_versions(params):
 
 
 class GraphedTargetStep:
-    """The whole target-task step as TWO HIP graphs, replayed per step with one host call each:
+    """The whole target-task step as THREE HIP graphs, replayed per step with one host call each:
 
-      A  text encoder (forked onto a second stream) || Swin forward -> frame filter -> fusion stack -> cross-entropy ->
-         backward through everything; the multimodal gradients accumulate IN PLACE into static flat fp32 buffers
-         (parallel.GradientAverager's buckets, hooks off), Swin's gradients land in static buffers nobody reads
-         (they are discarded in the target step, train.py:20,141);
-      -- N > 1: one eager all-reduce per flat bucket between the two graphs (the only collective of the step) --
+      A1 text encoder (forked onto a second stream) || Swin forward -> frame filter -> fusion stack -> cross-entropy ->
+         backward through the fusion stack and the text encoder, down to the gradient of Swin's output; the multimodal
+         gradients land in static flat fp32 buffers (parallel.GradientAverager's buckets, hooks off);
+      -- N > 1: one asynchronous all-reduce per flat bucket is ISSUED here (the only collective of the step): the
+         collectives run on the backend's stream behind A1 and BESIDE A2 --
+      A2 Swin's backward from that gradient (a third of the step); its parameter gradients land in buffers nobody reads
+         (Swin's target-step gradients are discarded, train.py:20,141, and therefore never exchanged);
+      -- N > 1: the stream waits for the collectives --
       B  clip_grad_norm_ + optimizer.step() (capturable) + zeroing of the flat buffers.
 
     Why: issued launch by launch the step costs ~75 ms of host time (Swin's ~600 launches through Python autograd and
@@ -561,8 +616,11 @@ class GraphedTargetStep:
         self.swin, self.mm, self.opt, self.sched, self.args = swin_model, multimodal_model, optimizer, scheduler, args
         self.autocast_dtype = autocast_dtype
         self.i_batch = 0
+        self.timing = None
         dev = batch[0].device
-        self.static = [t.clone() if torch.is_tensor(t) else t for t in batch]
+        # every batch entry becomes a static device tensor: a python list / int baked into the capture would silently be reused
+        # by every replay (the reference's collate hands num_imgs and the utterance index over as lists)
+        self.static = [t.clone() if torch.is_tensor(t) else torch.as_tensor(t, device=dev) for t in batch]
         # static flat gradient buffers for the multimodal parameters (hooks off: inside a replay no autograd hook fires)
         self.masters = masters
         self.flat = averager if averager is not None else GradientAverager(step_parameters(self.mm, masters), hooks=False)
@@ -607,19 +665,29 @@ class GraphedTargetStep:
         torch.cuda.set_rng_state(rng, dev)
         # -- capture
         self.shadows = _pin_shadows([self.swin, self.mm])
-        self.graph_a, self.graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        self.graph_a, self.graph_a2, self.graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with capture_window():
             with torch.cuda.graph(self.graph_a, stream=cap):
-                self.loss, self.new_mask = self._fwd_bwd()
+                self.loss, self.new_mask, swin_out = self._fwd_bwd_multimodal()
+            with torch.cuda.graph(self.graph_a2, pool=self.graph_a.pool(), stream=cap):
+                self._bwd_swin(swin_out)
+            del swin_out
             with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), stream=cap):
                 self._update()
-        _KEEP_GRAPHS.append((self.graph_a, self.graph_b))
+        _KEEP_GRAPHS.append((self.graph_a, self.graph_a2, self.graph_b))
         self.swin.zero_grad(set_to_none=True)              # drop the references; the graph's pool keeps the buffers
         self.mm.pair_stream = None
         self.flat.zero_grad()                              # the capture itself executes nothing
 
-    # one micro-step: forward + backward (runs eagerly during warm-up, once more under capture)
+    # one micro-step: forward + backward (runs eagerly during warm-up, once more under capture), in the two pieces the graphs hold
     def _fwd_bwd(self):
+        loss, new_mask, swin_out = self._fwd_bwd_multimodal()
+        self._bwd_swin(swin_out)
+        return loss, new_mask
+
+    def _fwd_bwd_multimodal(self):
+        """forward of everything + backward of the loss down to (a) the multimodal parameters and (b) Swin's output; returns
+        (loss, kept-frame mask, (Swin output, its gradient)) -- the second piece continues from the latter"""
         (ids, attn_mask, sep_mask, audio, audio_mask, vision_inputs, vision_mask, labels, frames, num_imgs, utt_idx) = self.static
         mm, args = self.mm, self.args
         ctx = (lambda: torch.autocast("cuda", dtype=self.autocast_dtype)) if self.autocast_dtype is not None else None
@@ -644,11 +712,24 @@ class GraphedTargetStep:
                     t.record_stream(main)
             logits = mm.fusion_branch(pending[0], pending[1], audio, audio_mask, vis_concat, new_mask)
         loss = F.cross_entropy(logits.float(), labels) / args.trg_accumulation_steps
-        loss.backward()
+        # backward, first piece: every leaf the optimizer steps plus Swin's output (the autograd graph below `preds` -- Swin -- is
+        # left untouched, with its saved activations, for the second piece)
+        leaves = [l for l, _ in self.pairs if l.requires_grad]
+        got = torch.autograd.grad(loss, [preds] + leaves, allow_unused=True)
+        dpreds = got[0]
+        for l, g in zip(leaves, got[1:]):
+            l.grad = g
         # (Letting the fused update read the model's own .grad tensors instead -- no hand-over, 2.8 GB less traffic -- was
         #  tried: the ~870 gradient tensors then stay allocated across the graph and the step got 2.8 ms SLOWER; not kept.)
         _hand_over_gradients(self.pairs, self.flat_view_of, self.accumulate)
-        return loss.detach(), new_mask
+        return loss.detach(), new_mask, (preds, dpreds)
+
+    def _bwd_swin(self, swin_out):
+        """backward, second piece: Swin from the gradient of its output.  Nobody reads the result in the target step (train.py:20,141
+        zero Swin's gradients before the auxiliary task uses its optimizer); it is computed because the reference computes it."""
+        preds, dpreds = swin_out
+        if dpreds is not None:
+            torch.autograd.backward(preds, dpreds)
 
     def _update(self):
         if self.fused is not None:                           # norm + one launch: clip, AdamW, bf16 twins (FusedClipAdamW)
@@ -666,19 +747,50 @@ class GraphedTargetStep:
             l.grad = None
 
     def __call__(self, batch):
+        if len(batch) != len(self.static):
+            raise ValueError(f"GraphedTargetStep: batch of {len(batch)} entries, captured with {len(self.static)}")
         with torch.no_grad():
-            for dst, src in zip(self.static, batch):
-                if torch.is_tensor(dst) and dst is not src:
-                    dst.copy_(src, non_blocking=True)
+            for i, (dst, src) in enumerate(zip(self.static, batch)):
+                if dst is src:
+                    continue
+                src = src if torch.is_tensor(src) else torch.as_tensor(src)
+                if tuple(src.shape) != tuple(dst.shape):
+                    raise ValueError(f"GraphedTargetStep: batch entry {i} has shape {tuple(src.shape)}, the captured graphs are for {tuple(dst.shape)}")
+                dst.copy_(src, non_blocking=True)
         self.graph_a.replay()
         self.i_batch += 1
-        if self.i_batch % self.args.trg_accumulation_steps == 0:
-            self.flat.exchange_all()                       # no-op at world size 1
+        last = self.i_batch % self.args.trg_accumulation_steps == 0
+        if last:
+            self.flat.exchange_begin()                     # no-op at world size 1; the collectives run beside graph A2
+            if self.timing is not None:
+                self.timing["begin"].record()
+        self.graph_a2.replay()
+        if last:
+            if self.timing is not None:
+                self.timing["a2_done"].record()
+            self.flat.exchange_end()
+            if self.timing is not None:
+                self.timing["end"].record()
             self.graph_b.replay()
             _bump_versions(self.flat.params)                # a replay changes the parameters behind autograd's back
             if self.sched is not None:
                 self.sched.step()
         return self.loss, self.new_mask
+
+    def time_exchange(self, on: bool = True):
+        """record three events per step around the exchange (issue / Swin backward enqueued / collectives waited for):
+        `exchange_ms()` then returns (ms from issue to the end of the wait, ms of that the stream spent waiting AFTER graph A2)"""
+        self.timing = {k: torch.cuda.Event(enable_timing=True) for k in ("begin", "a2_done", "end")} if on else None
+
+    def exchange_ms(self):
+        t = self.timing
+        torch.cuda.synchronize()
+        return t["begin"].elapsed_time(t["end"]), t["a2_done"].elapsed_time(t["end"])
+
+    def start_epoch(self):
+        """a partial accumulation window does not carry into the next epoch (train.py:52,54 restart the counter per epoch)"""
+        self.i_batch = 0
+        self.flat.zero_grad()
 
 
 class GraphedAuxStep:
@@ -748,6 +860,9 @@ class GraphedAuxStep:
             p.grad = None
 
     def __call__(self, images, labels):
+        if tuple(images.shape) != tuple(self.images.shape) or tuple(labels.shape) != tuple(self.labels.shape):
+            raise ValueError(f"GraphedAuxStep: batch of shape {tuple(images.shape)} / {tuple(labels.shape)}, captured for "
+                             f"{tuple(self.images.shape)} / {tuple(self.labels.shape)}")
         with torch.no_grad():
             if images is not self.images:
                 self.images.copy_(images, non_blocking=True)
@@ -755,12 +870,17 @@ class GraphedAuxStep:
         self.graph_a.replay()
         self.i_batch += 1
         if self.i_batch % self.args.aux_accumulation_steps == 0:
-            self.flat.exchange_all()
+            self.flat.exchange_all()                         # Swin's gradients: 187 MB fp32, nothing left in the step to hide them behind
             self.graph_b.replay()
             _bump_versions(self.flat.params)
             if self.sched is not None:
                 self.sched.step()
         return self.loss
+
+    def start_epoch(self):
+        """a partial accumulation window does not carry into the next epoch (train.py:17,20 restart per epoch)"""
+        self.i_batch = 0
+        self.flat.zero_grad()
 
 
 class AuxStep:

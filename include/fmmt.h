@@ -157,6 +157,28 @@ int fmmt_window_attn_bwd(int dtype, int n_img, int H, int W, int C, int num_head
                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * The attention half of a SwinTransformerBlock in ONE launch, one wavefront per window (bf16; C = 96, head_dim 32):
+ *   y = x + rowscale[img] * ( proj( W-MSA( LayerNorm(x) . wqkv^T + bqkv ) ) + bproj )
+ * replaces norm1 -> roll -> window_partition -> WindowAttention.forward -> window_reverse -> roll -> residual + DropPath of
+ * SwinTransformerBlock.forward (Swin_Transformer.py:233-266; WindowAttention :113-144; window helpers :33-62): the
+ * normalised tokens, qkv (three times the activation) and the attention output never round-trip HBM between four launches.
+ *   x, y      : [n_img*H*W, C] token order (dtype = FMMT_BF16);   wqkv [3C, C], wproj [C, C] (bf16, nn.Linear layout)
+ *   ln_gamma/ln_beta [C], bqkv [3C] (may be NULL), bproj [C] (may be NULL), table [169, num_heads], rowscale [n_img] (may be NULL): fp32
+ *   shift > 0 : the SW-MSA mask SwinTransformerBlock builds for (H, W, shift) (:208-227), derived from window coordinates
+ *               (a caller holding any other mask tensor uses the four-launch form: fmmt_window_attn_fwd takes the tensor)
+ *   saved for the backward (what the four launches would have left behind, minus qkv):
+ *     xn [tokens, C] = LayerNorm(x) (may be NULL), attn_out [tokens, C] = attention output before proj (may be NULL),
+ *     mean / rstd [tokens] fp32 (both or neither), lse [n_img*nW*num_heads*49] fp32 (required).
+ * Operand roundings and GEMM accumulation orders are those of fmmt_layernorm_fwd -> fmmt_linear_fwd -> fmmt_window_attn_fwd ->
+ * fmmt_linear_fwd; the softmax differs in the last bits (base-2 exponentials, normalisation after the second product).
+ * Other widths / dtypes return FMMT_EINVAL (use the four-launch form). */
+int fmmt_window_block_fwd(int dtype, int n_img, int H, int W, int C, int num_heads, int shift,
+                          const void* x, const float* ln_gamma, const float* ln_beta, float eps,
+                          const void* wqkv, const float* bqkv, const void* wproj, const float* bproj,
+                          const float* table, const int32_t* index, float scale, const float* rowscale,
+                          void* y, void* xn, void* attn_out, float* mean, float* rstd, float* lse, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Multi-head attention core of the cross-modal encoder.  Replaces multihead_attention.py:85
  * (q *= scaling), :94-98 (head split), :109 (bmm), :121 (fp32 softmax), :124 (dropout), :126 (bmm),
  * :128 (head merge).  Time-major operands: q [Lq, B, E], k / v [Lk, B, ldkv] (k and v may be column
@@ -177,6 +199,13 @@ int fmmt_mha_bwd(int dtype, int Lq, int Lk, int B, int E, int num_heads,
                  const void* q, int ldq, const void* k, const void* v, int ldkv, float scale, const float* key_bias,
                  float dropout_p, uint64_t seed, const uint64_t* seed_dev, const void* out, const void* dout, int ldo,
                  const float* lse, void* dq, int lddq, void* dk, void* dv, int lddkv, void* stream);
+
+/* The second return value of MultiheadAttention.forward (multihead_attention.py:133-134): the attention probabilities AFTER dropout,
+ * averaged over the heads, weights fp32 [B, Lq, Lk].  Every caller in the reference discards it, so fmmt_mha_fwd does not form it;
+ * this entry point recomputes it on request from q, k, the log-sum-exp fmmt_mha_fwd saved and the same dropout seed. */
+int fmmt_mha_avg_weights(int dtype, int Lq, int Lk, int B, int E, int num_heads, const void* q, int ldq, const void* k, int ldkv,
+                         float scale, const float* key_bias, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
+                         const float* lse, float* weights, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * PatchEmbed.  Conv2d(3,96,k=4,s=4) + flatten + transpose (Swin_Transformer.py:407,419) has
@@ -239,13 +268,15 @@ int fmmt_cast_batch(int n_desc, int n_tiles, const void* desc, void* stream);
 
 /* Gradient clipping + AdamW + bf16 re-rounding of the parameters in one launch over every tensor of the step's optimizer.
  * Replaces `clip_grad_norm_(model.parameters(), clip)` (its scaling pass; the norm itself is the caller's, a device scalar) and
- * `optimizer.step()` with torch.optim.AdamW semantics (train.py:135-143, 336-349), and the re-rounding of bf16 parameters that
- * are stepped through fp32 masters.  desc: DEVICE array of n_desc records
+ * `optimizer.step()` (train.py:135-143), and the re-rounding of bf16 parameters that are stepped through fp32 masters.
+ * hf_semantics != 0: the update of transformers.AdamW, the class the reference constructs (train.py:307,333: eps added to
+ * sqrt(v) before the bias correction, decoupled weight decay applied after the update; its defaults are eps 1e-6, weight_decay 0);
+ * hf_semantics == 0: torch.optim.AdamW (decay first, bias-corrected denominator).  desc: DEVICE array of n_desc records
  *   { float* p; const void* g; float* m; float* v; bf16* low_or_null; int64 n; int32 blk_begin, g_is_bf16; }  (56 bytes)
  * one block per 4096 elements, blk_begin = blocks of all earlier records, n_blocks = their total.  lr, step (the 1-based
  * step count t as a float) and total_norm (may be NULL: no clipping) are DEVICE scalars, so the call can sit in a HIP graph. */
 int fmmt_adamw_batch(int n_desc, int n_blocks, const void* desc, const float* lr, const float* step, const float* total_norm,
-                     float beta1, float beta2, float eps, float weight_decay, float max_norm, void* stream);
+                     float beta1, float beta2, float eps, float weight_decay, float max_norm, int hf_semantics, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Input pre-step fused into PatchEmbed's gather.  Replaces, for one batch of square uint8 face

@@ -46,6 +46,40 @@ def test_mha_module(golden, dev):
     golden.check("crossmodal", "mha/out", o, **TOL)
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+def test_mha_need_weights_returns_head_averaged_probabilities(dev, dtype, tol):
+    """MultiheadAttention.forward(..., need_weights=True): the reference's second return value (multihead_attention.py:133-134,
+    head-averaged post-dropout probabilities, (B, Lq, Lk)) against the oracle (itself held to the reference's mha/out golden) in
+    eval mode, separate and packed k|v projections; with dropout: non-negative, reproducible per seed, and averaging to the
+    undropped weights."""
+    from facialmmt_amd.modules.multihead_attention import MultiheadAttention
+    from oracle import crossmodal as OC
+    m = MultiheadAttention(768, 12, attn_dropout=0.1).eval()
+    synth.fill_state_dict(m, seed=40, prefix="mha.")
+    sd = {"mha." + k: v.clone() for k, v in m.state_dict().items()}
+    m.to(dev)
+    q = synth.tensor("mha_q", (38, 2, 768), seed=5)
+    kv = synth.tensor("mha_kv", (128, 2, 768), seed=6)
+    v2 = synth.tensor("mha_v", (128, 2, 768), seed=7)
+    for value in (v2, kv):                                     # distinct value tensor / self-shared key = value (packed projection)
+        ro, rw = OC.mha(sd, "mha.", q, kv, value, 12)
+        with torch.no_grad():
+            o, w = m(q.to(dev).to(dtype), kv.to(dev).to(dtype), (kv if value is kv else value).to(dev).to(dtype), need_weights=True) if value is not kv else \
+                (lambda k_: m(q.to(dev).to(dtype), k_, k_, need_weights=True))(kv.to(dev).to(dtype))
+        assert w.shape == (2, 38, 128) and w.dtype == torch.float32
+        assert (w.cpu() - rw).abs().max().item() <= tol * rw.abs().max().item()
+        assert (o.float().cpu() - ro).abs().max().item() <= max(tol, 1e-4) * ro.abs().max().item()
+        assert torch.allclose(w.sum(-1), torch.ones_like(w.sum(-1)), atol=5e-3 if dtype == torch.bfloat16 else 1e-5)
+    m.train()
+    k_ = kv.to(dev).to(dtype)
+    torch.manual_seed(3)
+    _, wd = m(q.to(dev).to(dtype), k_, k_, need_weights=True)
+    torch.manual_seed(3)
+    _, wd2 = m(q.to(dev).to(dtype), k_, k_, need_weights=True)
+    assert torch.equal(wd, wd2) and (wd >= 0).all() and not torch.equal(wd, w)
+    assert abs(wd.sum(-1).mean().item() - 1.0) < 2e-2          # E[keep / (1 - p)] = 1
+
+
 @pytest.mark.parametrize("Lq,Lk", [(38, 128), (128, 38), (160, 166), (166, 160)])
 @pytest.mark.parametrize("B", [1, 4])
 def test_encoder(golden, dev, enc, Lq, Lk, B):

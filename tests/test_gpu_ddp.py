@@ -3,9 +3,14 @@ box, gloo transport -- RCCL refuses two ranks per device) each run the target-ta
 parallel.GradientAverager, and must end with the parameters a single process gets from the mean gradient of both
 utterances.  Two variants of the step:
 
-  hooks   TargetStep + hook-driven averager: two stream groups (text encoder / fusion stack, one communicator each),
-          several buckets, gradient accumulation over two micro-steps (exchange only on the second);
-  graphs  GraphedTargetStep: the step as two HIP graphs with the bucket all-reduces issued between them.
+  hooks   TargetStep + hook-driven averager: two stream groups (fusion stack / text encoder) on ONE communicator with one
+          global in-order issue sequence, several buckets, gradient accumulation over two micro-steps (exchange only on the second);
+  graphs  GraphedTargetStep: the step as three HIP graphs, the bucket all-reduces issued between the multimodal backward and
+          the Swin backward and waited for before the optimizer graph.
+
+The same two variants run on RCCL (backend nccl, one device per rank) where the box has two GPUs
+(test_two_rank_target_step_on_rccl, skipped otherwise), and the graphed step runs its whole RCCL call path at world size 1 on
+any GPU box (test_rccl_world_size_one_runs_the_exchange_path).
 
 BatchNorm1d of the Swin head stays per replica (batch statistics of the rank's own frames), as under the reference's
 single device; the single-process reference therefore runs the two utterances one after the other, never concatenated."""
@@ -61,11 +66,12 @@ def _batch(dev, cfg, rank, micro):
     return tuple(b)
 
 
-def _worker(rank, world, port, mode, out_dir):
+def _worker(rank, world, port, mode, out_dir, backend="gloo"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    dev = torch.device("cuda:0")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
     torch.cuda.set_device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": dev} if backend == "nccl" else {}))
     from facialmmt_amd.parallel import GradientAverager, broadcast_parameters
     from facialmmt_amd.train_step import GraphedTargetStep, TargetStep
     acc = 2 if mode == "hooks" else 1
@@ -98,8 +104,57 @@ def _worker(rank, world, port, mode, out_dir):
 
 @pytest.mark.parametrize("mode", ["hooks", "graphs"])
 def test_two_rank_target_step_equals_mean_gradient_step(mode, tmp_path):
+    _two_ranks(mode, tmp_path, "gloo")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one device per rank: two GPUs")
+@pytest.mark.parametrize("mode", ["hooks", "graphs"])
+def test_two_rank_target_step_on_rccl(mode, tmp_path):
+    _two_ranks(mode, tmp_path, "nccl")
+
+
+def _one_rank_rccl(rank, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    from facialmmt_amd.parallel import GradientAverager
+    from facialmmt_amd.train_step import GraphedTargetStep
+    out = {}
+    for always in (False, True):
+        cfg, swin, mm = _build(dev, 1)
+        params = [p for p in mm.parameters() if p.requires_grad]
+        opt = torch.optim.SGD(params, lr=0.05)
+        avg = GradientAverager(params, hooks=False, bucket_mb=1, comm_dtype=torch.bfloat16 if always else None, always=always)
+        assert avg.active == always
+        step = GraphedTargetStep(swin, mm, opt, None, cfg, _batch(dev, cfg, 0, 0), averager=avg)
+        step.time_exchange(True)
+        for i in range(STEPS):
+            step(_batch(dev, cfg, 0, i))
+        out[always] = ({k: v.detach().cpu() for k, v in mm.named_parameters()}, step.exchange_ms())
+    torch.save(out, os.path.join(out_dir, "one_rank.pt"))
+    dist.destroy_process_group()
+
+
+def test_rccl_world_size_one_runs_the_exchange_path(tmp_path):
+    """GraphedTargetStep with backend nccl (= RCCL) at world size 1 and GradientAverager(always=True): every bucket goes through
+    dist.all_reduce on RCCL between the graphs (bf16 wire), the stream waits for the collectives, the optimizer graph follows --
+    the parameters must equal those of the run without any collective up to the bf16 rounding of the gradients on the wire."""
+    mp.spawn(_one_rank_rccl, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    out = torch.load(os.path.join(str(tmp_path), "one_rank.pt"), weights_only=False)
+    (p0, _), (p1, (total_ms, exposed_ms)) = out[False], out[True]
+    assert total_ms >= 0 and exposed_ms >= 0
+    moved = 0
+    for k, w in p0.items():
+        assert (p1[k] - w).abs().max().item() <= 2e-3 * max(1.0, w.abs().max().item()), k
+        moved += int((p1[k] - w).abs().max() > 0)
+    assert moved > 0                                         # the bf16 wire really carried the gradients
+
+
+def _two_ranks(mode, tmp_path, backend):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), mode, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), mode, str(tmp_path), backend), nprocs=world, join=True)
     ret = [torch.load(os.path.join(str(tmp_path), f"rank{r}.pt"), weights_only=True) for r in range(world)]
     # single-process reference: SGD on the mean over ranks (and sum over micro-steps / accumulation) of the per-utterance gradients
     import torch.nn.functional as F

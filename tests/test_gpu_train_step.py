@@ -200,6 +200,61 @@ def test_fused_clip_adamw_matches_torch():
     assert float(fused.step) == 0 and all(float(m.abs().max()) == 0 for m in fused.m)
 
 
+def test_hf_adamw_formula_and_fused_launch():
+    """train_step.HFAdamW against the update transformers.AdamW performs (train.py:307,333 construct that class; its step,
+    transformers 4.24 optimization.py, restated literally here: eps added before the bias correction, weight decay applied after
+    the update, defaults eps 1e-6 / weight_decay 0), and FusedClipAdamW(HFAdamW) = fmmt_adamw_batch(hf_semantics=1) against
+    clip_grad_norm_ + HFAdamW.step(); moving learning rate, a step that clips and one that does not, a bf16 twin."""
+    import math
+    from facialmmt_amd.train_step import FusedClipAdamW, HFAdamW
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(5)
+    shapes = [(512, 300), (7,), (4097,), (33, 5)]
+    lit = [torch.randn(sh, generator=g).to(dev) for sh in shapes]                       # literal restatement, plain tensors
+    eager = [torch.nn.Parameter(p.clone()) for p in lit]
+    mine = [torch.nn.Parameter(p.clone()) for p in lit]
+    low = mine[0].detach().to(torch.bfloat16)
+    assert HFAdamW([torch.nn.Parameter(torch.zeros(1))]).defaults["eps"] == 1e-6 and HFAdamW([torch.nn.Parameter(torch.zeros(1))]).defaults["weight_decay"] == 0.0
+    b1, b2, eps, wd = 0.9, 0.999, 1e-6, 0.01
+    m_l = [torch.zeros_like(p) for p in lit]
+    v_l = [torch.zeros_like(p) for p in lit]
+    lr = torch.tensor(1e-2, device=dev)
+    opt_e = HFAdamW(eager, lr=1e-2, weight_decay=wd)
+    opt_m = HFAdamW(mine, lr=lr, weight_decay=wd)
+    grads = {p: torch.zeros_like(p) for p in mine}
+    assert FusedClipAdamW.eligible(opt_m, mine)
+    fused = FusedClipAdamW(opt_m, mine, grads, {id(mine[0]): low}, max_norm=1.0)
+    assert fused.hf
+    for step in range(4):
+        scale = 10.0 if step % 2 == 0 else 1e-3
+        cur = 1e-2 * (step + 1) / 4
+        gs = [torch.randn(sh, generator=g).to(dev) * scale for sh in shapes]
+        for pe, pm, gr in zip(eager, mine, gs):
+            pe.grad = gr.clone()
+            grads[pm].copy_(gr)
+        for grp in opt_e.param_groups:
+            grp["lr"] = cur
+        lr.fill_(cur)
+        torch.nn.utils.clip_grad_norm_(eager, 1.0)
+        # literal transformers.AdamW.step on the clipped gradients
+        t = step + 1
+        for p_, m_, v_, pe in zip(lit, m_l, v_l, eager):
+            gr = pe.grad
+            m_.mul_(b1).add_(gr, alpha=1.0 - b1)
+            v_.mul_(b2).addcmul_(gr, gr, value=1.0 - b2)
+            denom = v_.sqrt().add_(eps)
+            step_size = cur * math.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
+            p_.addcdiv_(m_, denom, value=-step_size)
+            p_.add_(p_, alpha=-cur * wd)
+        opt_e.step()
+        fused.update()
+    torch.cuda.synchronize()
+    for pl, pe, pm in zip(lit, eager, mine):
+        assert torch.allclose(pl, pe.detach(), rtol=2e-6, atol=2e-7), (pl - pe).abs().max()
+        assert torch.allclose(pe, pm, rtol=2e-6, atol=2e-7), (pe - pm).abs().max()
+    assert torch.equal(low, mine[0].detach().to(torch.bfloat16))
+
+
 @pytest.mark.parametrize("accumulation", [1, 2])
 def test_fused_optimizer_in_the_graphed_step_equals_eager_adamw(accumulation):
     """GraphedTargetStep with an AdamW optimizer: graph B is one norm + fmmt_adamw_batch (clip + AdamW on the flat gradient
