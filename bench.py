@@ -151,7 +151,7 @@ def build_models(args, dev, cfg):
 def p256_tile(M, N, K, kw):
     """mirror of csrc/gemm.hip::p256_plan (persistent 256-row-tile kernel): channel-tile width, or 0"""
     has_op = kw.get("res") is not None or kw.get("rowscale") is not None
-    if M < int(os.environ.get("FMMT_NT_P256_MINM", "16384")) or M % 16 or K % 64 or K < 192 or kw.get("aux") is not None or (has_op and os.environ.get("FMMT_NT_P256_OPS", "1") == "0"):
+    if M < 16384 or M % 16 or K % 64 or K < 192 or kw.get("aux") is not None or (has_op and False):
         return 0
     tm, best, cost = (M + 255) // 256, 0, 0.0
     for bn, pen in ((256, 1.0), (192, 1.04), (128, 1.10)):
@@ -168,7 +168,7 @@ def p256_tile(M, N, K, kw):
 
 def tn_dma_tile(M, N, K, scaled, rows_per_scale, x_gelu):
     """mirror of csrc/gemm.hip::tn_plan_dma + launch_tn_plan (DMA-staged weight-gradient kernel): "256,256" / "192,384" or None"""
-    if os.environ.get("FMMT_TN_DMA", "1") == "0" or x_gelu or M <= int(os.environ.get("FMMT_TN_DMA_MINM", "8192")) or M % 64:
+    if x_gelu or M <= 8192 or M % 64:
         return None
     if N % 256 == 0 and K % 256 == 0:
         tn, tk = 256, 256
@@ -181,7 +181,7 @@ def tn_dma_tile(M, N, K, scaled, rows_per_scale, x_gelu):
         return None
     splits = 256 // tiles
     chunk = (-(-M // splits) + 63) // 64 * 64
-    if chunk < 512 or (scaled and (os.environ.get("FMMT_TN_DMA_SCALED", "1") == "0" or chunk // rows_per_scale + 2 > 1024)):
+    if chunk < 512 or (scaled and chunk // rows_per_scale + 2 > 1024):
         return None
     return f"{tn},{tk}"
 
@@ -210,13 +210,13 @@ class KernelTimer:
             bn = f"{64 if M <= 4096 else 128},{bn}" + (",glds" if (K % 64 == 0 and K > 64) else "")
             if M <= 4096 and (N < 16384 or M < 256):
                 tiles = -(-M // 64) * -(-N // 128)
-                small = int(os.environ.get("FMMT_NT_SMALL", "1"))
-                if small and tiles < int(os.environ.get("FMMT_NT_SMALL_TILES", "256")) and N % 64 == 0 and K % 64 == 0 and K >= 128:      # quarter tiles
+                small = 1
+                if small and tiles < 256 and N % 64 == 0 and K % 64 == 0 and K >= 128:      # quarter tiles
                     if small == 2:
                         bn = f"64,64,64,{4 if (K >= 2048 and 2 * tiles <= 256) else 2},glds"
                     else:
-                        bn = f"32,64,64,{4 if K >= int(os.environ.get('FMMT_NT_SMALL_R4K', '2048')) else 2},glds"
-                elif K % 64 == 0 and K >= 2048 and tiles <= 256 and os.environ.get("FMMT_NT_GLDS", "1") != "2":
+                        bn = f"32,64,64,{4 if K >= 2048 else 2},glds"
+                elif K % 64 == 0 and K >= 2048 and tiles <= 256:
                     bn = bn.replace(",64,2,glds", ",64,4,glds")
             if M >= 65536 and K % 32 == 0 and K >= 96 and (N % 128 == 0 or N % 96 == 0) and not (K == 96 and kw.get("epi", 0) == 1):
                 nk = ",nk6" if K == 192 else ",nk3" if K == 96 else ""
@@ -225,7 +225,7 @@ class KernelTimer:
                 else:
                     bn = "deep256x96x32" + nk
             if p256:
-                plainop = int(os.environ.get("FMMT_NT_P256_PLAINOP", "1"))
+                plainop = 1
                 hasop = kw.get("res") is not None or kw.get("rowscale") is not None or kw.get("aux") is not None
                 bn = f"p256x{p256}" + ("op" if p256 != 256 and (hasop or (plainop and (K > 1536 or plainop > 1))) else "")
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -247,7 +247,7 @@ class KernelTimer:
             # same dispatch as csrc/gemm.hip::fmmt_linear_wgrad_partials; the fixed-order sum of the partials
             # (fmmt_linear_wgrad_finish) is a separate launch and is not inside these events
             name = "linear_tn_kernel<bf16,32,few>" if M <= 4096 else "linear_tn_kernel<bf16,64>" if M <= 262144 else "linear_tn_kernel<bf16,32>"
-            if (os.environ.get("FMMT_TN_FEW", "1") != "0" and 128 < M <= 2048 and N % 64 == 0 and K % 64 == 0 and 8 <= (N // 64) * (K // 64) <= 1024
+            if (128 < M <= 2048 and N % 64 == 0 and K % 64 == 0 and 8 <= (N // 64) * (K // 64) <= 1024
                     and rowscale is None and not x_gelu):
                 name = "linear_tn_few_kernel"
             dma = tn_dma_tile(M, N, K, rowscale is not None, rows_per_scale, x_gelu)

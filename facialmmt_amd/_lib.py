@@ -27,6 +27,7 @@ SIGNATURES = {
     "fmmt_linear_wgrad": (_i, [_i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _p, _sz, _p]),
     "fmmt_linear_wgrad_partials": (_i, [_i, _i, _i, _i, _p, _i, _p, _i, _i, _p, _i, _i, _p, _sz, _p]),
     "fmmt_mlp_fwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p]),
+    "fmmt_mlp_ln_fwd": (_i, [_i, _i, _i, _p, _p, _p, _f, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p]),
     "fmmt_linear_wgrad_finish": (_i, [_i, _i, _i, _i, _p, _p, _p, _sz, _p]),
     "fmmt_layernorm_fwd": (_i, [_i, _i, _i, _p, _p, _p, _f, _p, _p, _p, _i, _p]),
     "fmmt_layernorm_bwd_workspace": (_sz, [_i]),
@@ -35,6 +36,7 @@ SIGNATURES = {
     "fmmt_window_attn_bwd_workspace": (_sz, [_i]),
     "fmmt_window_attn_bwd": (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p, _p, _p, _sz, _p]),
     "fmmt_window_block_fwd": (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "fmmt_window_block_attn_bwd": (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _sz, _p]),
     "fmmt_mha_fwd": (_i, [_i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i, _f, _p, _f, _u64, _p, _p, _i, _p, _p]),
     "fmmt_mha_bwd": (_i, [_i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i, _f, _p, _f, _u64, _p, _p, _p, _i, _p, _p, _i, _p, _p, _i, _p]),
     "fmmt_mha_avg_weights": (_i, [_i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _f, _p, _f, _u64, _p, _p, _p, _p]),

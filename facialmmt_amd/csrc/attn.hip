@@ -313,7 +313,7 @@ int wa_groups_per_head(int B_, int nH, bool bwd, bool mfma) {
     //   MFMA fwd: 36 KB LDS, 116 VGPR -> 4 per CU (1024);  MFMA bwd (two waves per window): 57 KB LDS, <= 256
     //   registers -> 2 per CU (512);
     //   fp32 VALU kernels: ~8 / 1-2 per CU, parity path only.
-    static const int fwd_wgs = getenv("FMMT_WA_FWD_WGS") ? atoi(getenv("FMMT_WA_FWD_WGS")) : 1024;
+    static const int fwd_wgs = fmmt_const("FMMT_WA_FWD_WGS", 1024);
     const int target = mfma ? (bwd ? 512 : fwd_wgs) : 2048;
     int g = target / nH;
     const int wpi = (mfma && bwd) ? 2 : 4;      // windows per workgroup iteration (MFMA backward: two waves per window)
@@ -326,7 +326,7 @@ int wa_groups_per_head(int B_, int nH, bool bwd, bool mfma) {
 }
 
 int wa_xcd_grouped(int groups_per_head, bool mfma) {
-    static const int on = getenv("FMMT_WA_XCD") ? atoi(getenv("FMMT_WA_XCD")) : 1;
+    static const int on = fmmt_const("FMMT_WA_XCD", 1);
     return (on && mfma && groups_per_head % 8 == 0) ? 1 : 0;
 }
 
@@ -652,15 +652,51 @@ extern "C" int fmmt_window_attn_bwd(int dtype, int n_img, int H, int W, int C, i
         hipLaunchKernelGGL(wattn_bwd_kernel<float>, grid, dim3(256), 0, st, a);
         FMMT_CHECK_LAUNCH();
     }
+    return fmmt_wattn_dtable_finish(a.part, num_heads, dtype == FMMT_BF16 ? a.groups_per_head : a.groups_per_head * 4, index, dtable, st);
+}
+
+extern "C" int fmmt_window_block_attn_bwd(int dtype, int n_img, int H, int W, int C, int num_heads, int shift,
+                                          const void* xn, const void* dy, const void* attn_out, const float* lse,
+                                          const void* wqkv, const float* bqkv, const void* wproj,
+                                          const float* table, const int32_t* index, float scale, const float* rowscale,
+                                          void* dqkv, float* dtable, void* workspace, size_t workspace_bytes, void* stream) {
+    if (int e = wa_check(dtype, n_img, H, W, C, num_heads, shift)) return e;
+    if (dtype != FMMT_BF16 || (C != 96 && C != 192)) return FMMT_EINVAL;                // other widths: fmmt_window_attn_bwd on a materialised qkv
+    if (!xn || !dy || !attn_out || !lse || !wqkv || !wproj || !table || !index || !dqkv || !dtable || !workspace) return FMMT_EINVAL;
+    if (workspace_bytes < fmmt_window_attn_bwd_workspace(num_heads)) return FMMT_EWORKSPACE;
+    WaArgs a{};
+    a.n_img = n_img; a.H = H; a.W = W; a.C = C; a.nH = num_heads; a.shift = shift; a.table = table; a.index = index; a.scale = scale;
+    a.mask_is_shift = shift > 0; a.out = const_cast<void*>(attn_out); a.lse = const_cast<float*>(lse); a.dout = dy; a.dqkv = dqkv;
+    a.part = reinterpret_cast<float*>(workspace);
+    a.xn = xn; a.wqkv = wqkv; a.bqkv = bqkv; a.wproj = wproj; a.rowscale = rowscale;
+    const int B_ = n_img * (H / WS) * (W / WS);
+    a.groups_per_head = fmmt_wattn_bwd_groups(B_, num_heads, 4);
+    a.xcd_grouped = wa_xcd_grouped(a.groups_per_head, true);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (int rc = fmmt_wattn_mfma_bwd_rc_launch(a, num_heads * a.groups_per_head, st)) return rc;
+    return fmmt_wattn_dtable_finish(a.part, num_heads, a.groups_per_head, index, dtable, st);
+}
+
+// per-workgroup dense d(bias) partials [num_heads][parts_per_head][49 * 49] (in a workspace of fmmt_window_attn_bwd_workspace bytes)
+// -> dtable [169][num_heads], fixed summation order
+int fmmt_wattn_dtable_finish(float* part, int num_heads, int parts_per_head, const int32_t* index, float* dtable, hipStream_t st) {
     const int nt = (2 * WS - 1) * (2 * WS - 1) * num_heads;
-    float* dense = a.part + (size_t)num_heads * WA_BWD_WAVES_PER_HEAD_MAX * TOK * TOK;
+    float* dense = part + (size_t)num_heads * WA_BWD_WAVES_PER_HEAD_MAX * TOK * TOK;
     const int nd = num_heads * TOK * TOK;
-    hipLaunchKernelGGL(wattn_dense_kernel, dim3((nd + 63) / 64), dim3(256), 0, st, a.part, num_heads,
-                       dtype == FMMT_BF16 ? a.groups_per_head : a.groups_per_head * 4, dense);
+    hipLaunchKernelGGL(wattn_dense_kernel, dim3((nd + 63) / 64), dim3(256), 0, st, part, num_heads, parts_per_head, dense);
     FMMT_CHECK_LAUNCH();
     hipLaunchKernelGGL(wattn_dtable_kernel, dim3(nt), dim3(64), 0, st, dense, index, num_heads, dtable);
     FMMT_CHECK_LAUNCH();
     return 0;
+}
+
+int fmmt_wattn_bwd_groups(int B_, int num_heads, int windows_per_iteration) {
+    int g = 256 / num_heads;                                 // one 8-wave workgroup per CU
+    const int maxg = (B_ + windows_per_iteration - 1) / windows_per_iteration;
+    if (g > maxg) g = maxg;
+    if (g > WA_BWD_WAVES_PER_HEAD_MAX) g = WA_BWD_WAVES_PER_HEAD_MAX;
+    if (g >= 8) g &= ~7;
+    return g < 1 ? 1 : g;
 }
 
 #define FMMT_MHA_DISPATCH(KERNEL, GRIDX)                                                             \

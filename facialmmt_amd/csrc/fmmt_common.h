@@ -23,6 +23,11 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 #define FMMT_DT_F32 0
 #define FMMT_DT_BF16 1
 
+// Dispatch constants.  Each of these was an environment switch while its A/B was open (rounds 1-2: tile shapes, ring depths, epilogue
+// routes, thresholds ...); the measured winner is compiled in and the name stays as the label DESIGN.md refers to.  The library
+// reads NO environment variable.
+constexpr int fmmt_const(const char*, int winner) { return winner; }
+
 #define FMMT_CHECK_LAUNCH()                                   \
     do {                                                      \
         hipError_t e__ = hipGetLastError();                   \
@@ -153,6 +158,26 @@ __device__ __forceinline__ float wave_sum(float v) {
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
     return v;
+}
+
+// Sum / max over the four lanes li + 16 g (the lanes that share an MFMA column / a token row) through the gfx950 row / half swaps (v_permlane16_swap exchanges the odd
+// 16-lane rows of its first operand with the even rows of its second, v_permlane32_swap the upper half of the first with the lower
+// half of the second): VALU only, no LDS round trip (ds_bpermute) on the softmax's dependency chain.
+__device__ __forceinline__ float swap_max(float v) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    float a = __uint_as_float(r[0]), b = __uint_as_float(r[1]), m;
+    asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(a), "v"(b));
+    auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+    a = __uint_as_float(q[0]);
+    b = __uint_as_float(q[1]);
+    asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(a), "v"(b));
+    return m;
+}
+__device__ __forceinline__ float swap_sum(float v) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
 }
 
 // ---------------------------------------------------------------------------------------------

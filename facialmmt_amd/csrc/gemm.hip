@@ -831,9 +831,9 @@ int launch_p256_b(const LinArgs& a, hipStream_t st) {
     p.tiles_m = (a.M + 255) / 256;
     p.tiles_n = a.N / BN;
     // FMMT_NT_P256_LDSEPI=0: epilogue stores straight from the accumulator layout (A/B switch)
-    static const int lds_epi = getenv("FMMT_NT_P256_LDSEPI") ? atoi(getenv("FMMT_NT_P256_LDSEPI")) : 1;
-    static const int lds_gelu = getenv("FMMT_NT_P256_LDSGELU") ? atoi(getenv("FMMT_NT_P256_LDSGELU")) : 0;   // measured slower (two tensors, 16-row passes: 32 barriers per tile): 273 -> 296 us
-    static const int wrows = getenv("FMMT_NT_P256_WROWS") ? atoi(getenv("FMMT_NT_P256_WROWS")) : 1;
+    static const int lds_epi = fmmt_const("FMMT_NT_P256_LDSEPI", 1);
+    static const int lds_gelu = fmmt_const("FMMT_NT_P256_LDSGELU", 0);   // measured slower (two tensors, 16-row passes: 32 barriers per tile): 273 -> 296 us
+    static const int wrows = fmmt_const("FMMT_NT_P256_WROWS", 1);
     p.reserved = (lds_epi ? 0 : 4) | (lds_gelu ? 0 : 8) | (wrows ? 0 : 64);
     hipLaunchKernelGGL((linear_nt_p256_kernel<BN, BK, NBUF, BATCH, HASOP>), dim3(256), dim3(512), lds, st, p);
     FMMT_CHECK_LAUNCH();
@@ -842,7 +842,7 @@ int launch_p256_b(const LinArgs& a, hipStream_t st) {
 template <int BN, int BK, int NBUF>
 int launch_p256(const LinArgs& a, hipStream_t st) {
     // FMMT_NT_P256_BATCH=0: fragment reads left to the compiler's schedule (A/B switch)
-    static const int batch = getenv("FMMT_NT_P256_BATCH") ? atoi(getenv("FMMT_NT_P256_BATCH")) : 1;
+    static const int batch = fmmt_const("FMMT_NT_P256_BATCH", 1);
     if constexpr (BN != 256) {
         // launches with an M x N epilogue operand or a DropPath scale: operand prefetched into registers (48 / 32 of them:
         // no room beside the 128 accumulators of the 256-wide tile)
@@ -850,7 +850,7 @@ int launch_p256(const LinArgs& a, hipStream_t st) {
         // FMMT_NT_P256_PLAINOP: 1 (default) = operand-free launches whose epilogue stores directly (K > 1536) take the
         // operand-prefetch instantiation as well -- same-call A/B on 31360 x 768 x 3072: 160.3 -> 153.5 us; 2 = all operand-free
         // launches (K <= 1536 then lose the LDS epilogue: slower); 0 = none
-        static const int plainop = getenv("FMMT_NT_P256_PLAINOP") ? atoi(getenv("FMMT_NT_P256_PLAINOP")) : 1;
+        static const int plainop = fmmt_const("FMMT_NT_P256_PLAINOP", 1);
         if (plainop && !a.part && (a.K > 1536 || plainop > 1)) return launch_p256_b<BN, BK, NBUF, true, true>(a, st);
     }
     return batch ? launch_p256_b<BN, BK, NBUF, true, false>(a, st) : launch_p256_b<BN, BK, NBUF, false, false>(a, st);
@@ -860,10 +860,10 @@ int launch_p256(const LinArgs& a, hipStream_t st) {
 // round of 256 workgroups better (31360 tokens x 768 channels: 369 tiles of 256 x 256 = 2 rounds at 72 %, 492 tiles of
 // 256 x 192 = 2 rounds at 96 %).  Returns 0 if the shape is not for this kernel.
 int p256_plan(const LinArgs& a) {
-    static const int mode = getenv("FMMT_NT_P256") ? atoi(getenv("FMMT_NT_P256")) : 1;       // 0: off; 256 / 192 / 128: force that tile
+    static const int mode = fmmt_const("FMMT_NT_P256", 1);       // 0: off; 256 / 192 / 128: force that tile
     // K % 64 != 0 (Swin stage 0: K = 96, three K steps of 32): only with FMMT_NT_P256_K32=1 (A/B switch)
-    static const int k32 = getenv("FMMT_NT_P256_K32") ? atoi(getenv("FMMT_NT_P256_K32")) : 0;
-    static const int minm = getenv("FMMT_NT_P256_MINM") ? atoi(getenv("FMMT_NT_P256_MINM")) : 16384;      // fewest tokens for this kernel
+    static const int k32 = fmmt_const("FMMT_NT_P256_K32", 0);
+    static const int minm = fmmt_const("FMMT_NT_P256_MINM", 16384);      // fewest tokens for this kernel
     if (!mode || a.ksplit || a.M < minm || a.M % 16 || a.K % 32 || a.K < 96 || a.ldx % 8 || a.ldw % 8) return 0;
     if (a.K % 64 && !k32) return 0;
     // One workgroup per CU has nothing to hide an epilogue's own M x N loads behind (residual, GELU' operand, DropPath
@@ -876,7 +876,7 @@ int p256_plan(const LinArgs& a) {
     // (501760 x 192 x 768), 210 -> 201 (125440 x 384 x 1536); 2 = GELU' launches as well: 338 -> 391 / 530 -> 614 us -- that
     // epilogue is ~11 k VALU cycles per wave tile against 4.6 k MFMA cycles of a K = 384 tile, and one workgroup per CU has no
     // second workgroup whose K loop could run under it; 0 = none.
-    static const int ops_mode = getenv("FMMT_NT_P256_OPS") ? atoi(getenv("FMMT_NT_P256_OPS")) : 1;
+    static const int ops_mode = fmmt_const("FMMT_NT_P256_OPS", 1);
     const bool has_op = a.res || a.aux || a.rowscale;
     if (has_op && (!ops_mode || (a.aux && (ops_mode < 2 || a.res)) || a.ldres % 8 || a.ldaux % 8)) return 0;
     const int tm = (a.M + 255) / 256;
@@ -933,7 +933,7 @@ int dispatch_nt_bk(const LinArgs& a, hipStream_t st) {
         // measured on MI355X (tests/gpu_gemm_bench.py, sum over the bench shapes): BK=64 5.33 ms vs BK=32 5.88 ms
         // direct global->LDS DMA staging: measured +7 % over register staging summed over the bench shapes, up to
         // +25 % on the K >= 768 ones (971 TF/s on 31360x768x3072); FMMT_NT_GLDS=0 selects the register-staged kernel
-        static const int glds = getenv("FMMT_NT_GLDS") ? atoi(getenv("FMMT_NT_GLDS")) : 1;
+        static const int glds = fmmt_const("FMMT_NT_GLDS", 1);
         if (glds && a.K % 64 == 0 && !a.ksplit && a.ldx % 8 == 0 && a.ldw % 8 == 0) {
             // four-buffer ring for few-token problems with a long K loop and at most one workgroup per CU (fc2 of the
             // encoder FFNs, 512-1328 tokens x 768 x 3072: 32 -> 25 us); with more tiles than CUs the 96 KB ring costs
@@ -959,7 +959,7 @@ int dispatch_nt(const LinArgs& a, hipStream_t st) {
     // that twice as many workgroups share the work; the multi-million-token Swin GEMMs use 128-row tiles
     // (few rows but tens of thousands of output channels -- the input gradient of the 37632 -> 512 embedding head: there are
     //  workgroups enough, 128-row tiles read each weight slab half as often; FMMT_NT_WIDE64=1 keeps the 64-row tiles for it)
-    static const int wide64 = getenv("FMMT_NT_WIDE64") ? atoi(getenv("FMMT_NT_WIDE64")) : 0;
+    static const int wide64 = fmmt_const("FMMT_NT_WIDE64", 0);
     if (a.M <= 4096 && (a.N < 16384 || a.M < 256 || wide64)) {
         if constexpr (sizeof(T) == 2) {
             // Fewer 64 x 128 tiles than half the CUs (the fusion stack: 152-1328 tokens x 768 channels = 18-126 tiles): such a
@@ -970,10 +970,10 @@ int dispatch_nt(const LinArgs& a, hipStream_t st) {
             // 512 x 768 x 3072 24.4 -> 16, 1328 x 768 x 3072 25.5 -> 19.5; with 256+ tiles of 64 x 128 the quarter tiles lose
             // (1328 x 3072 x 768: 14 -> 22 us), and the four-buffer ring does nothing for K = 768.
             // FMMT_NT_SMALL: 1 (default) = 32 x 64, 2 = 64 x 64 (6.4 us on the first group), 0 = off.
-            static const int small = getenv("FMMT_NT_SMALL") ? atoi(getenv("FMMT_NT_SMALL")) : 1;
+            static const int small = fmmt_const("FMMT_NT_SMALL", 1);
             const int tiles = ((a.M + 63) / 64) * ((a.N + 127) / 128);
-            static const int small_tiles = getenv("FMMT_NT_SMALL_TILES") ? atoi(getenv("FMMT_NT_SMALL_TILES")) : 256;
-            static const int small_r4k = getenv("FMMT_NT_SMALL_R4K") ? atoi(getenv("FMMT_NT_SMALL_R4K")) : 2048;
+            static const int small_tiles = fmmt_const("FMMT_NT_SMALL_TILES", 256);
+            static const int small_r4k = fmmt_const("FMMT_NT_SMALL_R4K", 2048);
             if (small && tiles < small_tiles && a.N % 64 == 0 && a.K % 64 == 0 && a.K >= 128 && !a.ksplit && a.ldx % 8 == 0 && a.ldw % 8 == 0) {
                 if (small == 2) {
                     if (a.K >= 2048 && 2 * tiles <= 256) return launch_nt<T, 64, 64, 64, 4, true>(a, st);
@@ -989,18 +989,18 @@ int dispatch_nt(const LinArgs& a, hipStream_t st) {
         if (const int bn = p256_plan(a)) {
             // FMMT_NT_P256_RING: 1 (default) = K step 64, ring of 2 (3 for 128-wide tiles); 0 = K step 32, ring of 4.
             // Measured (profiles/r02_gemm_shapes.txt): the K-step-64 form wins on every shape by 3-17 % (half the barriers)
-            static const int ring = getenv("FMMT_NT_P256_RING") ? atoi(getenv("FMMT_NT_P256_RING")) : 1;
+            static const int ring = fmmt_const("FMMT_NT_P256_RING", 1);
             if (ring == 0 || a.K % 64) return bn == 256 ? launch_p256<256, 32, 4>(a, st) : bn == 192 ? launch_p256<192, 32, 4>(a, st) : launch_p256<128, 32, 4>(a, st);
             return bn == 256 ? launch_p256<256, 64, 2>(a, st) : bn == 192 ? launch_p256<192, 64, 2>(a, st) : launch_p256<128, 64, 3>(a, st);
         }
         // measured (tests/gpu_gemm_bench.py): +8 % on the 125440-token stage-2 shapes (K = 384: 496 -> 540 TF/s),
         // -4 % on the 31360-token stage-3 shapes (tile quantisation at one workgroup per CU) -> only for M >= 65536
-        static const int deep = getenv("FMMT_NT_DEEP") ? atoi(getenv("FMMT_NT_DEEP")) : 1;
-        static const int deep_mink = getenv("FMMT_NT_DEEP_MINK") ? atoi(getenv("FMMT_NT_DEEP_MINK")) : 96;
-        static const int deep96 = getenv("FMMT_NT_DEEP96") ? atoi(getenv("FMMT_NT_DEEP96")) : 1;
+        static const int deep = fmmt_const("FMMT_NT_DEEP", 1);
+        static const int deep_mink = fmmt_const("FMMT_NT_DEEP_MINK", 96);
+        static const int deep96 = fmmt_const("FMMT_NT_DEEP96", 1);
         // K = 96 (stage 0, three K steps): -5..7 % with the deep kernel except for the GELU + pre-activation launch
         // (two output streams; measured +2 %), which keeps the single-step kernel
-        static const int deep_minm = getenv("FMMT_NT_DEEP_MINM") ? atoi(getenv("FMMT_NT_DEEP_MINM")) : 65536;
+        static const int deep_minm = fmmt_const("FMMT_NT_DEEP_MINM", 65536);
         const bool big = deep && a.M >= deep_minm && !a.ksplit && a.K % 32 == 0 && a.K >= deep_mink && a.ldx % 8 == 0 && a.ldw % 8 == 0 &&
                          !(a.K == 96 && a.epi == FMMT_EPI_GELU);
         if (big && (a.N % 128 == 0 || (n96 && deep96)) && (a.K % 64 == 0 || deep == 1 || deep == 2)) {
@@ -1024,8 +1024,8 @@ int dispatch_nt(const LinArgs& a, hipStream_t st) {
             }
             LinArgs p = a;
             p.tiles_m = (a.M + 255) / 256;
-            static const int slab = getenv("FMMT_NT_SLAB") ? atoi(getenv("FMMT_NT_SLAB")) : 1;
-            static const int wslab = getenv("FMMT_NT_WSLAB") ? atoi(getenv("FMMT_NT_WSLAB")) : 1;
+            static const int slab = fmmt_const("FMMT_NT_SLAB", 1);
+            static const int wslab = fmmt_const("FMMT_NT_WSLAB", 1);
             p.reserved = (slab ? 0 : 16) | (wslab ? 0 : 32);
             if (n96) {
                 p.tiles_n = a.N / 96;
@@ -1501,7 +1501,7 @@ int launch_tn_few(int M, int N, int K, const void* dy, int lddy, const void* x, 
 
 // eligibility of linear_tn_few_kernel: bf16, 129..2048 tokens, whole 64 x 64 tiles, at least 8 of them, 16-byte rows
 bool tn_few_ok(int M, int N, int K, int dtype) {
-    static const int on = getenv("FMMT_TN_FEW") ? atoi(getenv("FMMT_TN_FEW")) : 1;
+    static const int on = fmmt_const("FMMT_TN_FEW", 1);
     // (at most 1024 tiles: the embedding head's 512 x 37632 gradient -- 4704 tiles of 640 tokens -- took 767 us here against 292 us
     //  with the 128 x 128-tile kernel, whose workgroups reuse each staged token slab four times as often)
     return on && dtype == FMMT_BF16 && M > 128 && M <= 2048 && N % 64 == 0 && K % 64 == 0 && (N / 64) * (K / 64) >= 8 && (N / 64) * (K / 64) <= 1024;
@@ -1986,10 +1986,10 @@ TnPlan tn_plan_dma(int M, int N, int K) {
     // waits -- hipcc had put s_waitcnt vmcnt(0) in front of every stage's first fragment read, so the ring never had a second
     // stage in flight.  With the reads in inline asm, 128 FLOP per staged byte and four 32-token stages: 860-1105 TF/s against
     // 550-630.
-    static const int mode = getenv("FMMT_TN_DMA") ? atoi(getenv("FMMT_TN_DMA")) : 1;
+    static const int mode = fmmt_const("FMMT_TN_DMA", 1);
     // FMMT_TN_DMA_MINM: fewest tokens for this kernel, exclusive.  8192 since the 320-frame legs (configs[4]: 15680 stage-3 tokens)
     // measured 56.2 -> 55.7 ms per step with it, three alternating pairs in one call; 16384 before.
-    static const int minm = getenv("FMMT_TN_DMA_MINM") ? atoi(getenv("FMMT_TN_DMA_MINM")) : 8192;
+    static const int minm = fmmt_const("FMMT_TN_DMA_MINM", 8192);
     if (!mode || M <= minm || M % 64) return pl;
     int tn = 0, tk = 0;
     if (N % 256 == 0 && K % 256 == 0) tn = 256, tk = 256;
@@ -2033,14 +2033,14 @@ namespace {
 // the split contraction: part_w [splits][N][K], part_b [splits][N] or nullptr (splits == 1: these may be dw / db themselves)
 int launch_tn_plan(int dtype, int M, int N, int K, const void* dy, int lddy, const void* x, int ldx, float* part_w, float* part_b,
                    const float* rowscale, int rows_per_scale, int x_epi, int* hdr, hipStream_t st) {
-    static const int tn_xcd = getenv("FMMT_TN_XCD") ? atoi(getenv("FMMT_TN_XCD")) : 1;
+    static const int tn_xcd = fmmt_const("FMMT_TN_XCD", 1);
     if (x_epi != 0 && x_epi != FMMT_EPI_GELU) return FMMT_EINVAL;
     if (tn_few_ok(M, N, K, dtype) && !rowscale && !x_epi && lddy % 8 == 0 && ldx % 8 == 0)
         return launch_tn_few(M, N, K, dy, lddy, x, ldx, part_w, part_b, hdr, st);     // one split: part_w / part_b may be dw / db themselves
     if (dtype == FMMT_BF16 && hdr && !x_epi && lddy % 8 == 0 && ldx % 8 == 0) {
         const TnPlan pd = tn_plan_dma(M, N, K);
         // scaled launches: the split's slice of the scale vector has to fit the 4 KB behind the ring
-        static const int dma_scaled = getenv("FMMT_TN_DMA_SCALED") ? atoi(getenv("FMMT_TN_DMA_SCALED")) : 1;
+        static const int dma_scaled = fmmt_const("FMMT_TN_DMA_SCALED", 1);
         const bool scaled_ok = !rowscale || (dma_scaled && rows_per_scale > 0 && pd.tn && pd.chunk / rows_per_scale + 2 <= 1024);
         if (pd.tn && scaled_ok) {
             TnArgs a{M, N, K, dy, lddy, x, ldx, part_w, part_b, rowscale, rows_per_scale, pd.tiles_k, pd.chunk, pd.tiles_n, tn_xcd, 0, hdr, pd.splits};
@@ -2052,16 +2052,16 @@ int launch_tn_plan(int dtype, int M, int N, int K, const void* dy, int lddy, con
     const TnPlan pl = tn_plan(M, N, K, dtype);
     TnArgs a{M, N, K, dy, lddy, x, ldx, part_w, part_b, rowscale, rows_per_scale, pl.tiles_k, pl.chunk, pl.tiles_n, tn_xcd, x_epi == FMMT_EPI_GELU, hdr, pl.splits};
     dim3 grid(pl.tiles_n * pl.tiles_k * pl.splits);
-    static const int tn_cfg = getenv("FMMT_TN_CFG") ? atoi(getenv("FMMT_TN_CFG")) : 0;
+    static const int tn_cfg = fmmt_const("FMMT_TN_CFG", 0);
     // measured (tests/gpu_gemm_bench.py): 64-token steps win for the compute-heavy stage-2/3 shapes (+15-25 %),
     // 32-token steps (3 workgroups per CU) win for the HBM-bound multi-million-token stage-0/1 shapes
     const bool bms64 = tn_cfg == 2 || (tn_cfg == 0 && M <= 262144);
     // two token steps in flight (register sets R0/R1): measured +3..5 % on the stage-2/3 shapes, +3..11 % on the stage-0/1
     // ones, at unchanged occupancy (200 / 160 registers); FMMT_TN_PF=1 selects the single-step prefetch
-    static const int tn_pf = getenv("FMMT_TN_PF") ? atoi(getenv("FMMT_TN_PF")) : 3;
+    static const int tn_pf = fmmt_const("FMMT_TN_PF", 3);
     if (dtype == FMMT_BF16) {
         // few-token problems: FMMT_TN_FEW64=1 (A/B switch) takes 64-token steps with two register sets in flight
-        static const int few64 = getenv("FMMT_TN_FEW64") ? atoi(getenv("FMMT_TN_FEW64")) : 0;
+        static const int few64 = fmmt_const("FMMT_TN_FEW64", 0);
         if (M <= 4096) return few64 ? launch_tn<bf16, 64, true, 2>(a, grid, st) : launch_tn<bf16, 32, true>(a, grid, st);
         if (bms64) return tn_pf >= 2 ? launch_tn<bf16, 64, false, 2>(a, grid, st) : launch_tn<bf16, 64>(a, grid, st);
         return tn_pf >= 3 ? launch_tn<bf16, 32, false, 2>(a, grid, st) : launch_tn<bf16, 32>(a, grid, st);

@@ -42,11 +42,18 @@ struct MlpArgs {
     bf16* h_pre;
     bf16* h_act;
     int tiles;
+    // LN mode (fmmt_mlp_ln_fwd): x is the block's residual stream, the Mlp runs on LayerNorm(x) formed in registers, res == x
+    const float* ln_g;
+    const float* ln_b;
+    float eps;
+    bf16* xn;
+    float* mean;
+    float* rstd;
 };
 
 // (Two workgroups per CU at C = 96 -- 76.8 KB of LDS each, registers forced to 128 -- were measured: the inference form gains
 //  13 %, the training forms, whose time goes into the hidden-tensor stores, lose 0-19 % to the 20 spilled registers.)
-template <int C>
+template <int C, bool LN>
 __global__ __launch_bounds__(512) void mlp_fused_fwd_kernel(MlpArgs p) {
     using T = bf16;
     constexpr int H = 4 * C, HS = 64, NS = H / HS;          // hidden channels per ring stage, stages per tile
@@ -164,6 +171,51 @@ __global__ __launch_bounds__(512) void mlp_fused_fwd_kernel(MlpArgs p) {
         const T* sb = reinterpret_cast<const T*>(smem + cslot * STAGE_B);
         const float* bs = reinterpret_cast<const float*>(smem + cslot * STAGE_B + (W1_EL + W2_EL) * 2);
         const int t0 = tile * 256 + wave * 32;
+        if constexpr (LN) {
+            // norm2 of the block (Swin_Transformer.py:267-268) on the fragments this tile's products consume: a token's C channels sit
+            // in the four lanes li + 16 g, so the row statistics are in-lane sums plus two cross-lane steps; LN(x) goes out once
+            // (training: fc1's weight gradient contracts with it), the residual is x itself
+            if (hs == 0) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int tok = t0 + mt * 16 + li;
+                    float v[KS * 8];
+                    float sum = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            v[ks * 8 + e] = (float)xf[mt][ks][e];
+                            sum += v[ks * 8 + e];
+                        }
+                    const float mean = swap_sum(sum) * (1.0f / (float)C);
+                    float q = 0.f;
+#pragma unroll
+                    for (int e = 0; e < KS * 8; ++e) {
+                        v[e] -= mean;
+                        q += v[e] * v[e];
+                    }
+                    const float rstd = rsqrtf(swap_sum(q) * (1.0f / (float)C) + p.eps);
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.ln_g + ks * 32 + lg * 8), g1 = *reinterpret_cast<const f32x4*>(p.ln_g + ks * 32 + lg * 8 + 4);
+                        const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.ln_b + ks * 32 + lg * 8), b1 = *reinterpret_cast<const f32x4*>(p.ln_b + ks * 32 + lg * 8 + 4);
+                        bf16x8 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            o[e] = (bf16)(v[ks * 8 + e] * rstd * g0[e] + b0[e]);
+                            o[4 + e] = (bf16)(v[ks * 8 + 4 + e] * rstd * g1[e] + b1[e]);
+                        }
+                        xf[mt][ks] = o;
+                        if (p.xn && tok < p.M) *reinterpret_cast<bf16x8*>(p.xn + (size_t)tok * C + ks * 32 + lg * 8) = o;
+                    }
+                    if (p.mean && tok < p.M && lg == 0) {
+                        p.mean[tok] = mean;
+                        p.rstd[tok] = rstd;
+                    }
+                }
+            }
+        }
         // a token's 64 hidden values of this stage are one 128-byte line of h_pre / h_act: block 0's half is held back and
         // written together with block 1's, so that the two 64-byte halves reach L2 back to back
         bf16x8 keep_pre[2], keep_act[2];
@@ -237,7 +289,7 @@ __global__ __launch_bounds__(512) void mlp_fused_fwd_kernel(MlpArgs p) {
             e.bias = p.b2;
             e.y = p.y;
             e.ldy = C;
-            e.res = p.res;
+            e.res = LN ? p.x : p.res;
             e.ldres = C;
             e.rowscale = p.rowscale;
             e.rows_per_scale = p.rows_per_scale;
@@ -252,17 +304,17 @@ __global__ __launch_bounds__(512) void mlp_fused_fwd_kernel(MlpArgs p) {
     }
 }
 
-template <int C>
+template <int C, bool LN>
 int launch_mlp(const MlpArgs& a, hipStream_t st) {
     constexpr size_t lds = (size_t)3 * (((C / 32) * 64 * 32 + 2 * C * 32) * 2 + 1024);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_fwd_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_fwd_kernel<C, LN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     const int grid = a.tiles < 256 ? a.tiles : 256;
-    hipLaunchKernelGGL((mlp_fused_fwd_kernel<C>), dim3(grid), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((mlp_fused_fwd_kernel<C, LN>), dim3(grid), dim3(512), lds, st, a);
     FMMT_CHECK_LAUNCH();
     return 0;
 }
@@ -279,5 +331,19 @@ extern "C" int fmmt_mlp_fwd(int dtype, int M, int C, const void* x, const void* 
     if (!al16(x) || !al16(w1) || !al16(b1) || !al16(w2) || !al16(b2) || !al16(y) || (res && !al16(res)) || (h_pre && !al16(h_pre)) || (h_act && !al16(h_act))) return FMMT_EALIGN;
     MlpArgs a{M, (const bf16*)x, (const bf16*)w1, b1, (const bf16*)w2, b2, (const bf16*)res, rowscale, rows_per_scale, (bf16*)y, (bf16*)h_pre, (bf16*)h_act, (M + 255) / 256};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    return C == 96 ? launch_mlp<96>(a, st) : launch_mlp<192>(a, st);
+    return C == 96 ? launch_mlp<96, false>(a, st) : launch_mlp<192, false>(a, st);
+}
+
+extern "C" int fmmt_mlp_ln_fwd(int dtype, int M, int C, const void* x, const float* ln_gamma, const float* ln_beta, float eps,
+                               const void* w1, const float* b1, const void* w2, const float* b2, const float* rowscale, int rows_per_scale,
+                               void* y, void* xn, float* mean, float* rstd, void* h_pre, void* h_act, void* stream) {
+    if (dtype != FMMT_BF16 || M <= 0 || (C != 96 && C != 192)) return FMMT_EINVAL;
+    if (!x || !ln_gamma || !ln_beta || !w1 || !b1 || !w2 || !b2 || !y) return FMMT_EINVAL;
+    if ((mean == nullptr) != (rstd == nullptr) || (rowscale && rows_per_scale <= 0)) return FMMT_EINVAL;
+    if (!al16(x) || !al16(ln_gamma) || !al16(ln_beta) || !al16(w1) || !al16(b1) || !al16(w2) || !al16(b2) || !al16(y) || (xn && !al16(xn)) ||
+        (h_pre && !al16(h_pre)) || (h_act && !al16(h_act))) return FMMT_EALIGN;
+    MlpArgs a{M, (const bf16*)x, (const bf16*)w1, b1, (const bf16*)w2, b2, nullptr, rowscale, rows_per_scale, (bf16*)y, (bf16*)h_pre, (bf16*)h_act, (M + 255) / 256,
+              ln_gamma, ln_beta, eps, (bf16*)xn, mean, rstd};
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    return C == 96 ? launch_mlp<96, true>(a, st) : launch_mlp<192, true>(a, st);
 }

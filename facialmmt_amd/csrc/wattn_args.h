@@ -21,7 +21,20 @@ struct WaArgs {
     float* part;           // [nH][waves_per_head][49*49]
     int groups_per_head;   // workgroups per head
     int xcd_grouped;       // block numbering keeps the heads of a window group on one XCD (groups_per_head % 8 == 0)
+    // backward with recomputation (fmmt_window_block_attn_bwd): q, k, v are formed inside the kernel from LN1(x) and the head's rows of
+    // Wqkv, d(attention output) from the block's output gradient `dout` [tokens, C] and the head's columns of Wproj
+    const void* xn;
+    const void* wqkv;
+    const float* bqkv;
+    const void* wproj;
+    const float* rowscale;
 };
 
 int fmmt_wattn_mfma_fwd_launch(const WaArgs& a, int grid, hipStream_t st);
 int fmmt_wattn_mfma_bwd_launch(const WaArgs& a, int grid, hipStream_t st);
+int fmmt_wattn_mfma_bwd_rc_launch(const WaArgs& a, int grid, hipStream_t st);      // recompute variant: 8-wave workgroups, C = 96 / 192
+
+// attn.hip: fixed-order reduction of the per-workgroup dense d(bias) partials [num_heads][parts_per_head][49 * 49] that sit at the head
+// of a fmmt_window_attn_bwd_workspace(num_heads) workspace into dtable [169][num_heads]; workgroups per head for an 8-wave backward
+int fmmt_wattn_dtable_finish(float* part, int num_heads, int parts_per_head, const int32_t* index, float* dtable, hipStream_t st);
+int fmmt_wattn_bwd_groups(int B_, int num_heads, int windows_per_iteration);

@@ -48,26 +48,6 @@ __device__ __forceinline__ float xor_sum(float v) {
     return v + __shfl_xor(v, 32, 64);
 }
 
-// The same two reductions over the four lanes li + 16 g through the gfx950 row / half swaps (v_permlane16_swap exchanges the odd
-// 16-lane rows of its first operand with the even rows of its second, v_permlane32_swap the upper half of the first with the lower
-// half of the second): VALU only, no LDS round trip (ds_bpermute) on the softmax's dependency chain.
-__device__ __forceinline__ float swap_max(float v) {
-    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    float a = __uint_as_float(r[0]), b = __uint_as_float(r[1]), m;
-    asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(a), "v"(b));
-    auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
-    a = __uint_as_float(q[0]);
-    b = __uint_as_float(q[1]);
-    asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(a), "v"(b));
-    return m;
-}
-__device__ __forceinline__ float swap_sum(float v) {
-    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
-}
-
 struct LaneGeom {
     int di[4], dj[4];        // window-local (row, col) of slot t*16 + li (clamped to slot 48)
     bool valid[4];

@@ -23,8 +23,8 @@
 
 namespace {
 
-__device__ __forceinline__ void fill_bias_mfma(const WaArgs& p, int head, float* Bs) {
-    for (int t = threadIdx.x; t < 64 * BPM; t += 256) {
+__device__ __forceinline__ void fill_bias_mfma(const WaArgs& p, int head, float* Bs, int nthreads = 256) {
+    for (int t = threadIdx.x; t < 64 * BPM; t += nthreads) {
         const int q = t / BPM, k = t - q * BPM;
         Bs[t] = (q < TOK && k < TOK) ? p.table[p.index[q * TOK + k] * p.nH + head] : NEG_BIG;
     }
@@ -165,23 +165,43 @@ __device__ __forceinline__ Slot slot_of(int slot) {
     return S;
 }
 
-template <int MM>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+// NP pairs of waves per workgroup (2: the 256-thread kernel of fmmt_window_attn_bwd; 4: the recompute variant).
+// RC = 0: q, k, v and d(attention output) are read from memory (qkv, dout).  RC = C (96 / 192), the recompute variant behind
+// fmmt_window_block_attn_bwd: nothing qkv-sized is read -- a wave loads LN1(x) and the block-output gradient of its two token tiles
+// (C channels each) and forms its q / k / v fragments with the head's 96 rows of Wqkv and its d(attention output) fragments with the
+// head's 32 columns of Wproj, both staged once per workgroup in LDS in fragment order: 48 MFMAs per wave and (window, head) at C = 96
+// in exchange for 1.5 GB less to read per stage-0 launch, and neither the qkv recomputation GEMM nor the proj input-gradient GEMM run.
+template <int NP, int RC>
+struct WaBwdLds {
+    static constexpr int TILE = 64 * TP * 2;                                            // bytes of one [64][TP] bf16 tile
+    static constexpr int TILES = 4 * NP * TILE, STATS = 2 * NP * 64 * 4, BIAS = 64 * BPM * 4;
+    static constexpr int WP = RC + 8;                                                   // weight row pitch (bf16)
+    static constexpr int WGT = RC ? 128 * WP * 2 + 96 * 4 : 0;
+    static constexpr int TOTAL = TILES + STATS + BIAS + WGT;
+};
+
+template <int MM, int NP, int RC>
+__global__ __launch_bounds__(NP * 128) __attribute__((amdgpu_waves_per_eu(2)))
 void wattn_mfma_bwd_kernel(WaArgs p) {
-    __shared__ __attribute__((aligned(16))) bf16 Kt[2][64 * TP];
-    __shared__ __attribute__((aligned(16))) bf16 Qt[2][64 * TP];
-    __shared__ __attribute__((aligned(16))) bf16 Gt[2][64 * TP];
-    __shared__ __attribute__((aligned(16))) bf16 Vt[2][64 * TP];
-    __shared__ __attribute__((aligned(16))) float Ls[2][64];
-    __shared__ __attribute__((aligned(16))) float Dl[2][64];
-    __shared__ __attribute__((aligned(16))) float Bs[64 * BPM];
+    using L = WaBwdLds<NP, RC>;
+    constexpr int NT = NP * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem_bwd[];
+    bf16 (*Kt)[64 * TP] = reinterpret_cast<bf16 (*)[64 * TP]>(smem_bwd);
+    bf16 (*Qt)[64 * TP] = Kt + NP;
+    bf16 (*Gt)[64 * TP] = Qt + NP;
+    bf16 (*Vt)[64 * TP] = Gt + NP;
+    float (*Ls)[64] = reinterpret_cast<float (*)[64]>(smem_bwd + L::TILES);
+    float (*Dl)[64] = Ls + NP;
+    float* Bs = reinterpret_cast<float*>(smem_bwd + L::TILES + L::STATS);
+    bf16* Wh = reinterpret_cast<bf16*>(smem_bwd + L::TILES + L::STATS + L::BIAS);      // RC: 96 rows of Wqkv + 32 "rows" of Wproj^T
+    float* bq = reinterpret_cast<float*>(Wh + 128 * L::WP);                              // RC: the head's q | k | v bias (96 values)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pair = wave >> 1, h = wave & 1;
     const int li = lane & 15, lg = lane >> 4;
     int head, grp;
     head_group_of_block(p, head, grp);
     const int nW = (p.H / WS) * (p.W / WS), B_ = p.n_img * nW;
-    const int stride = p.groups_per_head * 2;
+    const int stride = p.groups_per_head * NP;
     const bf16* __restrict__ qkv = reinterpret_cast<const bf16*>(p.qkv);
     const bf16* __restrict__ og = reinterpret_cast<const bf16*>(p.out);
     const bf16* __restrict__ dog = reinterpret_cast<const bf16*>(p.dout);
@@ -190,7 +210,24 @@ void wattn_mfma_bwd_kernel(WaArgs p) {
     bf16 *kt_ = Kt[pair], *qt_ = Qt[pair], *gt_ = Gt[pair], *vt_ = Vt[pair];
     const Slot own[2] = {slot_of((2 * h) * 16 + li), slot_of((2 * h + 1) * 16 + li)};
 
-    fill_bias_mfma(p, head, Bs);
+    fill_bias_mfma(p, head, Bs, NT);
+    if constexpr (RC != 0) {
+        // rows in FRAGMENT order: (part * 2 + nt) * 16 + i <-> Wqkv row part * C + head * 32 + (i >> 2) * 8 + nt * 4 + (i & 3);
+        // 96 + nt * 16 + i <-> COLUMN head * 32 + (i >> 2) * 8 + nt * 4 + (i & 3) of Wproj (row c of Wproj -> LDS column c)
+        const bf16* wq = reinterpret_cast<const bf16*>(p.wqkv);
+        const bf16* wp = reinterpret_cast<const bf16*>(p.wproj);
+        for (int q = threadIdx.x; q < 96 * (RC / 8); q += NT) {
+            const int d = q / (RC / 8), ch = q - d * (RC / 8);
+            const int part = d >> 5, nt = (d >> 4) & 1, i = d & 15;
+            const int sr = part * RC + head * HD + (i >> 2) * 8 + nt * 4 + (i & 3);
+            *reinterpret_cast<bf16x8*>(Wh + d * L::WP + ch * 8) = *reinterpret_cast<const bf16x8*>(wq + (size_t)sr * RC + ch * 8);
+        }
+        for (int q = threadIdx.x; q < 32 * RC; q += NT) {
+            const int c = q >> 5, d = q & 31, nt = d >> 4, i = d & 15;
+            Wh[(96 + d) * L::WP + c] = wp[(size_t)c * RC + head * HD + (i >> 2) * 8 + nt * 4 + (i & 3)];
+        }
+        for (int t = threadIdx.x; t < 96; t += NT) bq[t] = p.bqkv ? p.bqkv[(t >> 5) * RC + head * HD + (t & 31)] : 0.f;
+    }
     f32x4 dbias[2][4];                               // [own query tile][key tile], lane = query column layout
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -199,7 +236,7 @@ void wattn_mfma_bwd_kernel(WaArgs p) {
 
     const int iters = (B_ + stride - 1) / stride;
     for (int it = 0; it < iters; ++it) {
-        const int b_raw = it * stride + grp * 2 + pair;
+        const int b_raw = it * stride + grp * NP + pair;
         const bool wactive = b_raw < B_;
         const int b_ = wactive ? b_raw : B_ - 1;
         const WinPos P = win_pos(p, b_);
@@ -208,15 +245,75 @@ void wattn_mfma_bwd_kernel(WaArgs p) {
         bf16x8 qf[2], kf[2], gf[2];
         float ls[2], dl[2];
         __syncthreads();                                   // previous iteration finished with the LDS tiles
+        bf16x8 vv[2];
+        if constexpr (RC == 0) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                tok[a] = tok_of(p, P, own[a].di, own[a].dj);
+                const bf16* row = qkv + tok[a] * 3 * p.C + head * HD + lg * 8;
+                qf[a] = ld_frag(row);
+                kf[a] = ld_frag(row + p.C);
+                vv[a] = ld_frag(row + 2 * p.C);
+                gf[a] = ld_frag(dog + tok[a] * p.C + head * HD + lg * 8);
+            }
+        } else {
+            constexpr int KS = RC / 32;
+            bf16x8 xf[2][KS], yf[2][KS];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                tok[a] = tok_of(p, P, own[a].di, own[a].dj);
+                const bf16* xr = reinterpret_cast<const bf16*>(p.xn) + tok[a] * RC + lg * 8;
+                const bf16* yr = dog + tok[a] * RC + lg * 8;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    xf[a][ks] = ld_frag(xr + ks * 32);
+                    yf[a][ks] = ld_frag(yr + ks * 32);
+                }
+            }
+            const float rs = p.rowscale ? p.rowscale[P.img] : 1.0f;
+            // part 0..2: q, k, v = LN1(x) . W^T + b ; part 3: d(attention output) = rowscale * dy . Wproj[:, head]
+#pragma unroll
+            for (int part = 0; part < 4; ++part) {
+                f32x4 acc[2][2];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) acc[nt][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        const bf16x8 wf = ld_frag(Wh + ((part * 2 + nt) * 16 + li) * L::WP + ks * 32 + lg * 8);
+#pragma unroll
+                        for (int a = 0; a < 2; ++a) acc[nt][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, part == 3 ? yf[a][ks] : xf[a][ks], acc[nt][a], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    bf16x8 f;
+                    if (part < 3) {
+                        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bq + part * 32 + lg * 8), b1 = *reinterpret_cast<const f32x4*>(bq + part * 32 + lg * 8 + 4);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            f[r] = (bf16)(acc[0][a][r] + b0[r]);
+                            f[4 + r] = (bf16)(acc[1][a][r] + b1[r]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            f[r] = (bf16)(acc[0][a][r] * rs);
+                            f[4 + r] = (bf16)(acc[1][a][r] * rs);
+                        }
+                    }
+                    if (part == 0) qf[a] = f;
+                    else if (part == 1) kf[a] = f;
+                    else if (part == 2) vv[a] = f;
+                    else gf[a] = f;
+                }
+            }
+        }
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             const int slot = (2 * h + a) * 16 + li;
-            tok[a] = tok_of(p, P, own[a].di, own[a].dj);
-            const bf16* row = qkv + tok[a] * 3 * p.C + head * HD + lg * 8;
-            qf[a] = ld_frag(row);
-            kf[a] = ld_frag(row + p.C);
-            const bf16x8 vv = ld_frag(row + 2 * p.C);
-            gf[a] = ld_frag(dog + tok[a] * p.C + head * HD + lg * 8);
             const bf16x8 of = ld_frag(og + tok[a] * p.C + head * HD + lg * 8);
             float d = 0.f;
 #pragma unroll
@@ -227,7 +324,7 @@ void wattn_mfma_bwd_kernel(WaArgs p) {
             *reinterpret_cast<bf16x8*>(kt_ + off) = own[a].valid ? kf[a] : zero_frag();
             *reinterpret_cast<bf16x8*>(qt_ + off) = own[a].valid ? qf[a] : zero_frag();
             *reinterpret_cast<bf16x8*>(gt_ + off) = own[a].valid ? gf[a] : zero_frag();
-            *reinterpret_cast<bf16x8*>(vt_ + off) = own[a].valid ? vv : zero_frag();
+            *reinterpret_cast<bf16x8*>(vt_ + off) = own[a].valid ? vv[a] : zero_frag();
             if (lg == 0) {
                 Ls[pair][slot] = ls[a];
                 Dl[pair][slot] = dl[a];
@@ -348,7 +445,7 @@ void wattn_mfma_bwd_kernel(WaArgs p) {
     // d(bias) of the workgroup: waves add their register accumulators into one LDS tile in wave order (deterministic).
     // Wave w holds query rows of half (w & 1); waves 0 and 1 write their rows first, waves 2 and 3 add to them.
     float* acc = reinterpret_cast<float*>(&Kt[0][0]);           // Kt: 2 x 5 KB >= 49*49 floats
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < 2 * NP; ++w) {
         __syncthreads();
         if (wave == w) {
 #pragma unroll
@@ -370,7 +467,7 @@ void wattn_mfma_bwd_kernel(WaArgs p) {
     }
     __syncthreads();
     float* part = p.part + ((size_t)head * p.groups_per_head + grp) * TOK * TOK;
-    for (int t = threadIdx.x; t < TOK * TOK; t += 256) part[t] = acc[t];
+    for (int t = threadIdx.x; t < TOK * TOK; t += NT) part[t] = acc[t];
 }
 
 }  // namespace
@@ -384,11 +481,31 @@ int fmmt_wattn_mfma_fwd_launch(const WaArgs& a, int grid, hipStream_t st) {
     return 0;
 }
 
-int fmmt_wattn_mfma_bwd_launch(const WaArgs& a, int grid, hipStream_t st) {
-    const int mm = !a.mask ? 0 : (a.mask_is_shift ? 1 : 2);
-    if (mm == 0) hipLaunchKernelGGL(wattn_mfma_bwd_kernel<0>, dim3(grid), dim3(256), 0, st, a);
-    else if (mm == 1) hipLaunchKernelGGL(wattn_mfma_bwd_kernel<1>, dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(wattn_mfma_bwd_kernel<2>, dim3(grid), dim3(256), 0, st, a);
+template <int MM, int NP, int RC>
+static int launch_bwd(const WaArgs& a, int grid, hipStream_t st) {
+    constexpr int lds = WaBwdLds<NP, RC>::TOTAL;
+    static bool attr_set = false;
+    if (!attr_set && lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wattn_mfma_bwd_kernel<MM, NP, RC>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((wattn_mfma_bwd_kernel<MM, NP, RC>), dim3(grid), dim3(NP * 128), lds, st, a);
     FMMT_CHECK_LAUNCH();
     return 0;
+}
+
+int fmmt_wattn_mfma_bwd_launch(const WaArgs& a, int grid, hipStream_t st) {
+    const int mm = !a.mask ? 0 : (a.mask_is_shift ? 1 : 2);
+    if (mm == 0) return launch_bwd<0, 2, 0>(a, grid, st);
+    if (mm == 1) return launch_bwd<1, 2, 0>(a, grid, st);
+    return launch_bwd<2, 2, 0>(a, grid, st);
+}
+
+// recompute variant (8-wave workgroups): mask none or the standard SW-MSA mask (a.mask_is_shift with a.shift > 0)
+int fmmt_wattn_mfma_bwd_rc_launch(const WaArgs& a, int grid, hipStream_t st) {
+    const bool masked = a.shift > 0;
+    if (a.C == 96) return masked ? launch_bwd<1, 4, 96>(a, grid, st) : launch_bwd<0, 4, 96>(a, grid, st);
+    if (a.C == 192) return masked ? launch_bwd<1, 4, 192>(a, grid, st) : launch_bwd<0, 4, 192>(a, grid, st);
+    return FMMT_EINVAL;
 }

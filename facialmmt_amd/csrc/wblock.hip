@@ -310,7 +310,9 @@ __global__ __launch_bounds__(NW * 64) void wblock_fwd_kernel(WbArgs p) {
                     pb1[r] = (bf16)s[2][r]; pb1[4 + r] = (bf16)s[3][r];
                 }
                 // O^T = V^T . P^T, and the row sums by the same instruction: a third A tile of ones makes every row of its result
-                // the sum over the keys of the (bf16-rounded) probabilities the numerator was formed from
+                // the sum over the keys of the (bf16-rounded) probabilities the numerator was formed from.  (Summing the unrounded
+                // exponentials on the VALU, or normalising before the rounding as the four-launch kernel does, gives the same
+                // end-to-end gradient statistics: tests/test_gpu_swin.py::test_bf16_gradients_against_oracle_n32.)
                 f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f}, ls = {0.f, 0.f, 0.f, 0.f};
                 o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vT[0][0], pb0, o0, 0, 0, 0);
                 o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vT[0][1], pb0, o1, 0, 0, 0);

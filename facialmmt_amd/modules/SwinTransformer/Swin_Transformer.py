@@ -202,7 +202,8 @@ class SwinTransformerBlock(nn.Module):
         a = self.attn
         std = self._mask_is_standard()
         if ops.window_block_fusable(x, C, a.num_heads, a.window_size, self.shift_size, self.attn_mask, std):
-            # stage 0: norm1 -> qkv -> (S)W-MSA -> proj -> residual + DropPath as ONE launch per block half (csrc/wblock.hip)
+            # stages 0 / 1: norm1 -> qkv -> (S)W-MSA -> proj -> residual + DropPath as one op (stage 0: ONE launch, csrc/wblock.hip), whose
+            # backward re-forms q / k / v inside the attention-backward kernel instead of keeping or recomputing a qkv tensor
             a._check()
             x = ops.window_block(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias,
                                  a.relative_position_bias_table, a._index(x.device), self.attn_mask, B, H, W, a.num_heads, self.shift_size,
@@ -210,8 +211,13 @@ class SwinTransformerBlock(nn.Module):
         else:
             x, xn = ops.residual_layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
             x = a.forward_tokens(xn, B, H, W, self.shift_size, self.attn_mask, res=x, rowscale=self._scale(B, x.device), mask_is_shift=std)
+        mlp = self.mlp
+        if ops.mlp_ln_fusable(x, mlp.fc1.weight, mlp.fc2.weight, mlp.fc1.bias, mlp.fc2.bias) and (mlp.drop.p == 0.0 or not self.training):
+            # stages 0 / 1: norm2 -> fc1 -> GELU -> fc2 -> DropPath -> residual as ONE launch (csrc/mlp_fused.hip, LayerNorm on the fragments)
+            return ops.mlp_ln(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias,
+                              self._scale(B, x.device), L)
         x, xn = ops.residual_layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        return self.mlp(xn, res=x, rowscale=self._scale(B, x.device), rows_per_scale=L)
+        return mlp(xn, res=x, rowscale=self._scale(B, x.device), rows_per_scale=L)
 
     def extra_repr(self) -> str:
         return (f"dim={self.dim}, input_resolution={self.input_resolution}, num_heads={self.num_heads}, "

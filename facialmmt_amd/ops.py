@@ -160,7 +160,8 @@ class PinnedShadows:
                     dst = pins[key] = torch.empty_like(shadow)   # [rows, cols] or [cols, rows], contiguous
                 self.keep.append((p, dst))
                 tr, tc = (rows + 63) // 64, (cols + 63) // 64
-                recs.append((p.data_ptr() + off * p.element_size(), dst.data_ptr(), rows, cols, stride[0],
+                # `off` is the view's ABSOLUTE offset in the storage (a parameter may itself be a view of a flat buffer)
+                recs.append((p.untyped_storage().data_ptr() + off * p.element_size(), dst.data_ptr(), rows, cols, stride[0],
                              (1 if transpose else 0) | (2 if p.dtype == torch.float32 else 0), tiles, tc))
                 tiles += tr * tc
         self.n, self.tiles = len(recs), tiles
@@ -351,9 +352,9 @@ def mlp_fused_raw(x2, w1l, b1, w2l, b2, res2, rowscale, rows_per_scale, h_pre, h
 
 
 _MLP_FUSED = _os.environ.get("FMMT_MLP_FUSED", "1") != "0"       # A/B switch (read once): 0 = always the two-launch form
-# 1: the fused forward also stores the activation and the weight gradient reads it; 0: only the pre-activation is stored and
-# the weight-gradient kernel recomputes gelu() while staging its operand
-_MLP_SAVE_H = _os.environ.get("FMMT_MLP_SAVE_H", "1") != "0"
+# The fused forward also stores the activation and fc2's weight gradient reads it (storing only the pre-activation and recomputing
+# gelu() while the weight-gradient kernel stages its operand measured slower: 0.75 vs 0.40 ms per stage-0 launch; round 2)
+_MLP_SAVE_H = True
 
 
 def _mlp_fusable(x2, w1, w2, b1, b2):
@@ -397,6 +398,68 @@ class MlpFn(Function):
         dx = linear_raw(dh, _lp(w1, dy2.dtype, transpose=True), None).reshape(ctx.xshape) if ctx.needs_input_grad[0] else None
         dw1, db1 = wgrad_raw(dh, x2, True)
         return dx, dw1, db1, dw2, db2, (dy if ctx.has_res else None), None, None
+
+
+class MlpLnFn(Function):
+    """y = x + rowscale * Mlp(LayerNorm(x)): forward = fmmt_mlp_ln_fwd (one launch, LayerNorm formed on the operand fragments);
+    backward = the Mlp's four GEMM launches on the saved LN(x) / pre-activation / activation, then fmmt_layernorm_bwd with the
+    residual gradient as its `add` operand."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, eps, w1, b1, w2, b2, rowscale, rows_per_scale):
+        _need_cuda(x, "mlp_ln")
+        C = x.shape[-1]
+        x2 = x.reshape(-1, C).contiguous()
+        M = x2.shape[0]
+        train = any(ctx.needs_input_grad)
+        dev = x.device
+        g, b = ln_w.detach().float().contiguous(), ln_b.detach().float().contiguous()
+        y = torch.empty_like(x2)
+        xn = torch.empty_like(x2) if train else None
+        mean = torch.empty(M, dtype=torch.float32, device=dev) if train else None
+        rstd = torch.empty(M, dtype=torch.float32, device=dev) if train else None
+        h_pre = torch.empty((M, 4 * C), dtype=x.dtype, device=dev) if train else None
+        h = torch.empty_like(h_pre) if train else None
+        rc = _lib.load().fmmt_mlp_ln_fwd(dtype_code(x.dtype), M, C, _p(x2), _p(g), _p(b), float(eps), _p(_lp(w1, x.dtype)), _p(b1.detach().float().contiguous()),
+                                         _p(_lp(w2, x.dtype)), _p(b2.detach().float().contiguous()), _p(rowscale), rows_per_scale, _p(y), _p(xn), _p(mean), _p(rstd),
+                                         _p(h_pre), _p(h), _st())
+        check(rc, f"fmmt_mlp_ln_fwd(M={M},C={C})")
+        ctx.save_for_backward(x2, xn, mean, rstd, g, w1, w2, h_pre, h, rowscale)
+        ctx.rps = rows_per_scale
+        ctx.xshape = x.shape
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, xn, mean, rstd, g, w1, w2, h_pre, h, rowscale = ctx.saved_tensors
+        C = x2.shape[1]
+        lib = _lib.load()
+        dy2 = dy.reshape(-1, C).contiguous()
+        dh = linear_raw(dy2, _lp(w2, dy2.dtype, transpose=True), None, epi=EPI_GELU_BWD, aux=h_pre, rowscale=rowscale, rows_per_scale=ctx.rps)
+        dw2, db2 = wgrad_raw(dy2, h, True, rowscale, ctx.rps)
+        dxn = linear_raw(dh, _lp(w1, dy2.dtype, transpose=True), None)
+        dw1, db1 = wgrad_raw(dh, xn, True)
+        del dh
+        dx = torch.empty_like(x2)
+        dg = torch.empty(C, dtype=torch.float32, device=x2.device)
+        db = torch.empty(C, dtype=torch.float32, device=x2.device)
+        nbytes = lib.fmmt_layernorm_bwd_workspace(C)
+        ws = _ws(nbytes, x2.device)
+        rc = lib.fmmt_layernorm_bwd(dtype_code(x2.dtype), x2.shape[0], C, _p(dxn), _p(x2), _p(mean), _p(rstd), _p(g), _p(dy2), _p(dx), _p(dg), _p(db), 0,
+                                    _p(ws), nbytes, _st())
+        check(rc, "fmmt_layernorm_bwd(mlp_ln)")
+        return dx.reshape(ctx.xshape), dg, db, None, dw1, db1, dw2, db2, None, None
+
+
+def mlp_ln_fusable(x, w1, w2, b1, b2):
+    C = x.shape[-1]
+    return (_MLP_FUSED and x.is_cuda and x.dtype == torch.bfloat16 and C in (96, 192) and w1.shape == (4 * C, C) and w2.shape == (C, 4 * C)
+            and b1 is not None and b2 is not None and x.numel() // C >= 4096)
+
+
+def mlp_ln(x, ln_w, ln_b, eps, w1, b1, w2, b2, rowscale=None, rows_per_scale=1):
+    """x + rowscale * Mlp(LayerNorm(x)) in one launch (Swin stages 0 / 1)"""
+    return MlpLnFn.apply(x, ln_w, ln_b, eps, w1, b1, w2, b2, rowscale, rows_per_scale)
 
 
 def mlp(x, w1, b1, w2, b2, res=None, rowscale=None, rows_per_scale=1):
@@ -546,28 +609,47 @@ def window_attn_core(qkv, table, index_i32, mask, n_img, H, W, num_heads, shift,
 # the attention half of a Swin block as ONE launch (csrc/wblock.hip): y = x + s * proj(W-MSA(LN(x) Wqkv^T + b))
 # ------------------------------------------------------------------------------------------------
 _WBLOCK = _os.environ.get("FMMT_WBLOCK", "1") != "0"          # A/B switch (read once): 0 = always the four-launch form
+_WBLOCK_BWD = _os.environ.get("FMMT_WBLOCK_BWD", "1") != "0"  # 0: the backward re-computes qkv with a GEMM and runs fmmt_window_attn_bwd
 
 
 def window_block_fusable(x, C, num_heads, window_size, shift, mask, mask_is_shift):
-    """the fused kernel covers the bf16 stage-0 geometry (C = 96, head_dim 32, 7x7 windows) with no mask or the standard SW-MSA mask"""
-    return (_WBLOCK and x.is_cuda and x.dtype == torch.bfloat16 and C == 96 and num_heads * 32 == C and tuple(window_size) == (7, 7)
+    """the block-half op covers the bf16 stage-0 / stage-1 geometry (C = 96 / 192, head_dim 32, 7x7 windows) with no mask or the standard
+    SW-MSA mask: C = 96 runs the fused forward kernel, C = 192 the four forward launches; both share the recompute backward"""
+    return (_WBLOCK and x.is_cuda and x.dtype == torch.bfloat16 and C in (96, 192) and num_heads * 32 == C and tuple(window_size) == (7, 7)
             and ((shift == 0 and mask is None) or (shift > 0 and mask is not None and mask_is_shift)))
 
 
-def window_block_raw(x2, n_img, H, W, num_heads, shift, ln_g, ln_b, eps, wqkv, bqkv, wproj, bproj, table, index_i32, scale, rowscale, save):
-    """one launch; returns (y, xn, attn_out, mean, rstd, lse); the four saved tensors are None unless `save`"""
+def window_block_raw(x2, n_img, H, W, num_heads, shift, ln_g, ln_b, eps, wqkv, bqkv, wproj, bproj, table, index_i32, scale, rowscale, save, mask=None):
+    """y = x + rowscale * (proj(W-MSA(LN(x) wqkv^T + bqkv)) + bproj); returns (y, xn, attn_out, mean, rstd, lse) -- what the backward needs
+    (never qkv).  C = 96: one launch (fmmt_window_block_fwd), the four saved tensors None unless `save`; C = 192: LayerNorm, qkv Linear,
+    attention core, proj Linear as four launches, qkv a temporary (`mask`: the standard SW-MSA mask tensor when shift > 0)."""
     M, C = x2.shape
     dev = x2.device
-    y = torch.empty_like(x2)
+    lib = _lib.load()
     nW = (H // 7) * (W // 7)
     lse = torch.empty((n_img * nW * num_heads * 49,), dtype=torch.float32, device=dev)
+    if C != 96:
+        xn = torch.empty_like(x2)
+        mean = torch.empty(M, dtype=torch.float32, device=dev)
+        rstd = torch.empty(M, dtype=torch.float32, device=dev)
+        check(lib.fmmt_layernorm_fwd(dtype_code(x2.dtype), M, C, _p(x2), _p(ln_g), _p(ln_b), float(eps), _p(xn), _p(mean), _p(rstd), 0, _st()), "fmmt_layernorm_fwd")
+        qkv = linear_raw(xn, wqkv, bqkv)
+        o = torch.empty_like(x2)
+        m = mask.detach().float().contiguous() if mask is not None else None
+        rc = lib.fmmt_window_attn_fwd(dtype_code(x2.dtype), n_img, H, W, C, num_heads, shift, _p(qkv), _p(table), _p(index_i32), _p(m),
+                                      m.shape[0] if m is not None else 0, 1 if m is not None else 0, float(scale), _p(o), _p(lse), _st())
+        check(rc, "fmmt_window_attn_fwd")
+        del qkv
+        y = linear_raw(o, wproj, bproj, res=x2, rowscale=rowscale, rows_per_scale=H * W)
+        return y, xn, o, mean, rstd, lse
+    y = torch.empty_like(x2)
     xn = torch.empty_like(x2) if save else None
     o = torch.empty_like(x2) if save else None
     mean = torch.empty(M, dtype=torch.float32, device=dev) if save else None
     rstd = torch.empty(M, dtype=torch.float32, device=dev) if save else None
-    rc = _lib.load().fmmt_window_block_fwd(dtype_code(x2.dtype), n_img, H, W, C, num_heads, shift, _p(x2), _p(ln_g), _p(ln_b), float(eps),
-                                           _p(wqkv), _p(bqkv), _p(wproj), _p(bproj), _p(table), _p(index_i32), float(scale), _p(rowscale),
-                                           _p(y), _p(xn), _p(o), _p(mean), _p(rstd), _p(lse), _st())
+    rc = lib.fmmt_window_block_fwd(dtype_code(x2.dtype), n_img, H, W, C, num_heads, shift, _p(x2), _p(ln_g), _p(ln_b), float(eps),
+                                   _p(wqkv), _p(bqkv), _p(wproj), _p(bproj), _p(table), _p(index_i32), float(scale), _p(rowscale),
+                                   _p(y), _p(xn), _p(o), _p(mean), _p(rstd), _p(lse), _st())
     check(rc, f"fmmt_window_block_fwd(n={n_img},H={H},W={W},C={C},heads={num_heads},shift={shift})")
     return y, xn, o, mean, rstd, lse
 
@@ -586,7 +668,7 @@ class WindowBlockFn(Function):
         tab = table.detach().float().contiguous()
         y, xn, o, mean, rstd, lse = window_block_raw(
             x2, n_img, H, W, num_heads, shift, g, b, eps, _lp(wqkv, x.dtype), bqkv.detach().float().contiguous() if bqkv is not None else None,
-            _lp(wproj, x.dtype), bproj.detach().float().contiguous() if bproj is not None else None, tab, index_i32, scale, rowscale, train)
+            _lp(wproj, x.dtype), bproj.detach().float().contiguous() if bproj is not None else None, tab, index_i32, scale, rowscale, train, mask)
         if train:
             m = mask.detach().float().contiguous() if mask is not None else None
             ctx.save_for_backward(x2, xn, o, mean, rstd, lse, g, wqkv, bqkv, wproj, tab, index_i32, m, rowscale)
@@ -608,20 +690,25 @@ def window_block_backward(dy, x2, xn, o, mean, rstd, lse, g, wqkv, bqkv, wproj, 
     dt = x2.dtype
     dy2 = dy.reshape(-1, C).contiguous()
     L = H * W
-    # proj: input gradient and weight gradient (DropPath scale on dy)
-    do = linear_raw(dy2, _lp(wproj, dt, transpose=True), None, rowscale=rowscale, rows_per_scale=L)
-    dwp, dbp = wgrad_raw(dy2, o, True, rowscale, L)
-    # attention core on the recomputed qkv
-    qkv = linear_raw(xn, _lp(wqkv, dt), bqkv.detach() if bqkv is not None else None)
-    dqkv = torch.empty_like(qkv)
+    dwp, dbp = wgrad_raw(dy2, o, True, rowscale, L)             # proj weight gradient (DropPath scale on dy)
+    dqkv = torch.empty((x2.shape[0], 3 * C), dtype=dt, device=x2.device)
     dtable = torch.empty_like(tab)
     nbytes = lib.fmmt_window_attn_bwd_workspace(num_heads)
     ws = _ws(nbytes, x2.device)
-    nWm = m.shape[0] if m is not None else 0
-    rc = lib.fmmt_window_attn_bwd(dtype_code(dt), n_img, H, W, C, num_heads, shift, _p(qkv), _p(o), _p(do), _p(lse), _p(tab), _p(index_i32),
-                                  _p(m), nWm, 1 if m is not None else 0, scale, _p(dqkv), _p(dtable), _p(ws), nbytes, _st())
-    check(rc, "fmmt_window_attn_bwd")
-    del qkv, do
+    if _WBLOCK_BWD and (m is None or shift > 0):
+        # attention core backward with q, k, v and d(attention output) re-formed inside the kernel (no qkv / d(out) tensors)
+        rc = lib.fmmt_window_block_attn_bwd(dtype_code(dt), n_img, H, W, C, num_heads, shift, _p(xn), _p(dy2), _p(o), _p(lse), _p(_lp(wqkv, dt)),
+                                            _p(bqkv.detach().float().contiguous() if bqkv is not None else None), _p(_lp(wproj, dt)), _p(tab), _p(index_i32),
+                                            scale, _p(rowscale), _p(dqkv), _p(dtable), _p(ws), nbytes, _st())
+        check(rc, "fmmt_window_block_attn_bwd")
+    else:
+        do = linear_raw(dy2, _lp(wproj, dt, transpose=True), None, rowscale=rowscale, rows_per_scale=L)
+        qkv = linear_raw(xn, _lp(wqkv, dt), bqkv.detach() if bqkv is not None else None)
+        nWm = m.shape[0] if m is not None else 0
+        rc = lib.fmmt_window_attn_bwd(dtype_code(dt), n_img, H, W, C, num_heads, shift, _p(qkv), _p(o), _p(do), _p(lse), _p(tab), _p(index_i32),
+                                      _p(m), nWm, 1 if m is not None else 0, scale, _p(dqkv), _p(dtable), _p(ws), nbytes, _st())
+        check(rc, "fmmt_window_attn_bwd")
+        del qkv, do
     dxn = linear_raw(dqkv, _lp(wqkv, dt, transpose=True), None)
     dwq, dbq = wgrad_raw(dqkv, xn, bqkv is not None)
     del dqkv

@@ -17,7 +17,7 @@ Registered (forward ops return what their backward needs as extra outputs, as cu
     fmmt::mha(q, k, v?, key_bias?, heads, scale, dropout_p, seed) -> (out, lse)           cross-modal attention core (packed k|v when v is None)
     fmmt::posemb_scale(x, table, scale) -> y                                              sqrt(E) x + sinusoidal position embedding
     fmmt::window_block(x, ln_w, ln_b, eps, wqkv, bqkv?, wproj, bproj?, table, index, n_img, H, W, heads, shift, scale, rowscale?)
-                       -> (y, xn, attn_out, mean, rstd, lse)                               norm1 -> (S)W-MSA -> proj -> residual in one launch (C = 96)
+                       -> (y, xn, attn_out, mean, rstd, lse)                               norm1 -> (S)W-MSA -> proj -> residual (C = 96: one launch; 192: four), recompute backward
 
 The nn.Modules of facialmmt_amd/modules keep using ops.py (fewer dispatcher hops per launch); tests/test_gpu_torch_ops.py
 holds the two front ends bit-identical, forward and backward, and runs torch.library.opcheck on each operator."""
@@ -461,13 +461,17 @@ posemb_scale.register_autograd(_pe_backward, setup_context=_pe_setup)
 def window_block(x: Tensor, ln_w: Tensor, ln_b: Tensor, eps: float, wqkv: Tensor, bqkv: Optional[Tensor], wproj: Tensor, bproj: Optional[Tensor],
                  table: Tensor, index_i32: Tensor, n_img: int, H: int, W: int, num_heads: int, shift: int, scale: float,
                  rowscale: Optional[Tensor]) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor, Tensor]:
-    """y = x + rowscale * (proj(W-MSA(LN(x) wqkv^T + bqkv)) + bproj) in one launch (fmmt_window_block_fwd; bf16, C = 96); shift > 0 uses the
+    """y = x + rowscale * (proj(W-MSA(LN(x) wqkv^T + bqkv)) + bproj) (bf16; C = 96: one launch, fmmt_window_block_fwd; C = 192: four launches); shift > 0 uses the
     standard SW-MSA mask of (H, W, shift).  Also returns LN(x), the attention output, the row statistics and the log-sum-exp."""
     C = x.shape[-1]
+    mask = None
+    if shift:
+        from .modules.SwinTransformer.Swin_Transformer import build_shift_mask
+        mask = build_shift_mask(H, W, 7, shift).to(x.device)
     y, xn, o, mean, rstd, lse = ops.window_block_raw(
         x.reshape(-1, C).contiguous(), n_img, H, W, num_heads, shift, ln_w.float().contiguous(), ln_b.float().contiguous(), eps, _cast(wqkv, x.dtype),
         bqkv.float().contiguous() if bqkv is not None else None, _cast(wproj, x.dtype), bproj.float().contiguous() if bproj is not None else None,
-        table.float().contiguous(), index_i32, scale, rowscale, True)
+        table.float().contiguous(), index_i32, scale, rowscale, True, mask)
     return y.reshape(x.shape), xn, o, mean, rstd, lse
 
 

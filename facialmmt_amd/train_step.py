@@ -367,6 +367,11 @@ class MasterWeights:
             v = flat[o:o + p.numel()].view_as(p)
             v.copy_(p.detach())
             self.masters.append(torch.nn.Parameter(v))
+        # what has no master -- frozen parameters (the unused pooler) and floating-point buffers -- keeps its fp32 values here: the
+        # reference leaves them untouched, a checkpoint must not hold their bf16 roundings
+        trainable = set(map(id, low))
+        self.frozen_fp32 = {k: t.detach().clone() for k, t in list(module.named_parameters()) + list(module.named_buffers())
+                            if id(t) not in trainable and t.is_floating_point() and t.dtype == torch.float32}
         module.to(dtype)                                    # in place: the Parameter objects survive, their data becomes bf16
         self.colsum_layers = use_colsum_bias_gradients(module)
         self.low = low
@@ -387,6 +392,9 @@ class MasterWeights:
         for k, p in self.module.named_parameters():
             if id(p) in by_id:
                 sd[k] = by_id[id(p)].detach().clone()
+        for k, t in self.frozen_fp32.items():
+            if k in sd:
+                sd[k] = t.clone()
         return sd
 
 

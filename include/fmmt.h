@@ -103,6 +103,16 @@ int fmmt_linear_wgrad_finish(int dtype, int M, int N, int K, float* dw, float* d
 int fmmt_mlp_fwd(int dtype, int M, int C, const void* x, const void* w1, const float* b1, const void* w2, const float* b2,
                  const void* res, const float* rowscale, int rows_per_scale, void* y, void* h_pre, void* h_act, void* stream);
 
+/* The Mlp half of a SwinTransformerBlock in ONE launch, LayerNorm included (bf16; C = 96 / 192):
+ *   y[M,C] = x + rowscale[m / rows_per_scale] * ( gelu(LayerNorm(x) . w1^T + b1) . w2^T + b2 )
+ * replaces norm2 -> Mlp -> DropPath -> residual of SwinTransformerBlock.forward (Swin_Transformer.py:267-268, Mlp :14-30): the
+ * row statistics are formed on the fragments the first product consumes, so LayerNorm(x) never makes a round trip and the
+ * residual is the input itself.  For the backward: xn [M,C] = LayerNorm(x) (fc1's weight gradient contracts with it; may be NULL),
+ * mean / rstd [M] fp32 (both or neither), h_pre / h_act as fmmt_mlp_fwd. */
+int fmmt_mlp_ln_fwd(int dtype, int M, int C, const void* x, const float* ln_gamma, const float* ln_beta, float eps,
+                    const void* w1, const float* b1, const void* w2, const float* b2, const float* rowscale, int rows_per_scale,
+                    void* y, void* xn, float* mean, float* rstd, void* h_pre, void* h_act, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm.  Replaces nn.LayerNorm (eps 1e-5) at Swin_Transformer.py:198,204,239,268 (norm1/2),
  * :305,325 (PatchMerging.norm over the 2x2 concat), :410,421 (PatchEmbed.norm), :491 (head norm);
@@ -177,6 +187,21 @@ int fmmt_window_block_fwd(int dtype, int n_img, int H, int W, int C, int num_hea
                           const void* wqkv, const float* bqkv, const void* wproj, const float* bproj,
                           const float* table, const int32_t* index, float scale, const float* rowscale,
                           void* y, void* xn, void* attn_out, float* mean, float* rstd, float* lse, void* stream);
+
+/* Backward of the attention core for the fused block half, WITHOUT a materialised qkv (bf16; C = 96 or 192):
+ *   dqkv [tokens, 3C] = d(loss) / d(qkv) of WindowAttention (Swin_Transformer.py:120-141) and dtable [169, num_heads],
+ * from xn = LayerNorm(x) [tokens, C], dy = the gradient of the block half's OUTPUT [tokens, C] (not of the attention output), the saved
+ * attention output and log-sum-exp, wqkv / bqkv / wproj and the DropPath scale.  Each wave re-forms the q, k, v fragments of its
+ * (window, head, token tiles) with the head's rows of wqkv and d(attention output) = rowscale * dy . wproj[:, head] with the head's
+ * columns of wproj on the matrix cores: replaces the qkv re-computation GEMM, the proj input-gradient GEMM and the reads of qkv and
+ * d(attention output) of fmmt_window_attn_bwd.  shift > 0 = the standard SW-MSA mask.  workspace: fmmt_window_attn_bwd_workspace(num_heads).
+ * The weight and LayerNorm gradients of the block half remain separate launches (fmmt_linear_wgrad on dqkv / xn and on dy / attn_out,
+ * fmmt_linear_fwd for d(xn), fmmt_layernorm_bwd). */
+int fmmt_window_block_attn_bwd(int dtype, int n_img, int H, int W, int C, int num_heads, int shift,
+                               const void* xn, const void* dy, const void* attn_out, const float* lse,
+                               const void* wqkv, const float* bqkv, const void* wproj,
+                               const float* table, const int32_t* index, float scale, const float* rowscale,
+                               void* dqkv, float* dtable, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Multi-head attention core of the cross-modal encoder.  Replaces multihead_attention.py:85

@@ -139,7 +139,7 @@ def swin_block(sd, pre, x, H, W, num_heads, shift, drop_path_scale=None):
     xw = xn[:, idx.reshape(-1)].reshape(N * nW, WS * WS, C)                # gather == roll+partition
     mask = shift_mask(H, W, WS, shift).to(x.device) if shift > 0 else None
     aw = window_attention(sd, pre + "attn.", xw, num_heads, mask)
-    a = torch.empty_like(x)
+    a = torch.empty_like(x, dtype=aw.dtype)                                # (aw's dtype: the same function also runs under bf16 autocast on the GPU)
     a[:, idx.reshape(-1)] = aw.reshape(N, nW * WS * WS, C)                 # scatter == reverse+roll back
     if drop_path_scale is not None:
         a = a * drop_path_scale[0].to(a)[:, None, None]

@@ -133,60 +133,98 @@ def test_affwild_logits_and_gradients(golden, dev, S):
         golden.check("swin_full", f"grad/{n}", params[n].grad, atol=1e-3 * float(np.abs(ref).max()) + 1e-7, rtol=5e-3, sum_rtol=2e-3)
 
 
-@pytest.mark.parametrize("bn_mode", ["running_stats", "batch_stats"])
-def test_bf16_gradients_against_oracle_n8(dev, S, bn_mode):
-    """The dtype the benchmark runs in, end to end: every parameter gradient and the input gradient of the bf16 HIP path
-    (MFMA window attention, bf16 GEMM instantiations, bf16 LayerNorm) at N = 8 frames against the fp32 oracle
-    differentiated on the CPU: cosine similarity and relative L2 error per tensor.
+def _diverse_frames(n, seed=1):
+    """n structured, mutually different frames in [-1, 1] (the value range of Normalize(ToTensor(.))): per frame and channel a plane
+    wave of hash-drawn frequency / direction / phase, a Gaussian blob at a hash-drawn place, and 10 % hash noise.  (Eight frames of
+    iid noise have almost identical Swin features: BatchNorm1d on their batch statistics then divides by a near-zero spread and
+    amplifies every rounding in front of it -- the conditioning of that fixture, not of the kernels, set round 2's figures.)"""
+    g = synth.tensor("frame_params", (n, 12), seed=seed)
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, 224), torch.linspace(-1, 1, 224), indexing="ij")
+    out = []
+    for i in range(n):
+        p = g[i]
+        chans = []
+        for c in range(3):
+            f = 2.0 + 6.0 * (p[c] + 1)
+            wave = torch.sin(f * (xx * p[3] + yy * p[4]) + 3.0 * p[5 + c]) * (0.4 + 0.3 * p[8])
+            blob = torch.exp(-((xx - 0.6 * p[9]) ** 2 + (yy - 0.6 * p[10]) ** 2) / (0.05 + 0.2 * (p[11] + 1))) * (0.8 * p[c])
+            chans.append(wave + blob)
+        out.append(torch.stack(chans))
+    return (torch.stack(out) + 0.1 * synth.tensor("frame_noise", (n, 3, 224, 224), seed=seed + 1)).clamp(-1, 1)
 
-    running_stats: BatchNorm1d of the head on its running statistics -- the 12 blocks + head as a plain function; bf16
-      carries 8 significant bits and an early layer's gradient is a sum over 25 k tokens and 12 blocks of rounded products.
-    batch_stats: BatchNorm1d on the statistics of the 8-frame batch, as in the training step.  The 8 feature vectors of
-      hash-noise frames are close to each other, and batch normalisation divides by their (small) spread: it amplifies
-      the bf16 rounding of the features, and every gradient below inherits that one common perturbation -- looser bar."""
+
+def _grad_stats(pairs, skip=()):
+    stats = {}
+    for name, g, r in pairs:
+        assert g is not None and r is not None, name
+        g, r = g.float().cpu().reshape(-1).double(), r.float().cpu().reshape(-1).double()
+        if float(r.norm()) == 0.0:
+            assert float(g.norm()) <= 1e-6, name
+            continue
+        if name in skip:
+            continue
+        stats[name] = (float((g @ r) / (g.norm() * r.norm())), float((g - r).norm() / r.norm()))
+    return stats
+
+
+@pytest.mark.parametrize("bn_mode", ["running_stats", "batch_stats"])
+def test_bf16_gradients_against_oracle_n32(dev, S, bn_mode):
+    """The dtype the benchmark runs in, end to end: every parameter gradient and the input gradient of the bf16 HIP path (fused
+    window-attention block halves at stage 0, MFMA window attention, bf16 GEMM instantiations, fused Mlp, bf16 LayerNorm) on 32
+    DIVERSE frames against the fp32 oracle differentiated on the CPU -- cosine similarity and relative L2 error per tensor --
+    with, beside it, what STOCK PyTorch-ROCm bf16 gives for the same graph: the oracle's own functional torch code run on the GPU
+    under torch.autocast(bfloat16) against the same fp32 gradients.
+
+    running_stats: BatchNorm1d of the head on its running statistics; batch_stats: on the statistics of the 32-frame batch, the
+    mode the training step (and the benchmark) runs in.  Bar: cosine >= 0.99 and relative L2 error <= 10 % for every tensor, in both
+    modes -- or, failing that, no worse than 1.5 x the WORST stock-bf16 tensor.  (The figure is a chaotic function of the rounding
+    realisation: the probe sits behind Linear -> ReLU -> Linear and, in batch_stats mode, behind a normalisation by the batch spread,
+    so one flipped ReLU gate or a slightly different spread moves every gradient below it by the same factor.  Measured in round 3 on
+    the same 32 frames: stage 0 fused 4.0 % mean / 6.6 % worst, stage 0 as four launches 12.7 % / 21 %, stock autocast 11 % / 16.5 %
+    -- profiles/r03_bf16_grad_stats_*.txt.)  The table goes to gpurun_out/ (committed under profiles/ per round)."""
     from facialmmt_amd import models
     from facialmmt_amd.config import default_args
     from oracle import swin as OS
     train = bn_mode == "batch_stats"
-    COS_MIN, REL_MAX = (0.95, 0.35) if train else (0.995, 0.10)
+    COS_MIN, REL_MAX, N = 0.99, 0.10, 32
     aff = models.SwinForAffwildClassification(default_args())
     synth.fill_state_dict(aff, seed=100)
     _no_droppath(aff.swin, S)
     aff.to(dev).train(train)
-    frames = synth.tensor("frames", (8, 3, 224, 224), seed=1)
-    probe = synth.tensor("probe7", (8, 7), seed=3)
+    frames = _diverse_frames(N)
+    probe = synth.tensor("probe7", (N, 7), seed=3)
     sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in aff.state_dict().items()}
     xr = frames.clone().requires_grad_(True)
     ref = OS.swin_affwild_logits(sd, xr, training=train)
     (ref * probe).sum().backward()
+    # ours
     x16 = frames.to(dev).bfloat16().requires_grad_(True)
     out = aff(x16, is_trg_task=False)
     (out.float() * probe.to(dev)).sum().backward()
     assert (out.float().cpu() - ref.detach()).abs().max().item() <= 3e-2 * ref.abs().max().item()
-    n, stats = 0, []
     # in front of train-mode BatchNorm a per-feature constant cancels: the true gradients of the head's LayerNorm bias
     # and Linear bias are 0 up to rounding (nothing to compare a direction with)
-    zero_by_construction = ("swin.output_layer.0.bias", "swin.output_layer.2.bias") if train else ()
-    pairs = [("input", x16.grad, xr.grad)] + [(k, p.grad, sd[k].grad) for k, p in aff.named_parameters()]
-    for name, g, r in pairs:
-        assert g is not None and r is not None, name
-        g, r = g.float().cpu().reshape(-1).double(), r.reshape(-1).double()
-        if float(r.norm()) == 0.0:
-            assert float(g.norm()) <= 1e-6, name
-            continue
-        n += 1
-        if name in zero_by_construction:
-            continue
-        stats.append((name, float((g @ r) / (g.norm() * r.norm())), float((g - r).norm() / r.norm())))
+    skip = ("swin.output_layer.0.bias", "swin.output_layer.2.bias") if train else ()
+    ours = _grad_stats([("input", x16.grad, xr.grad)] + [(k, p.grad, sd[k].grad) for k, p in aff.named_parameters()], skip)
+    # stock PyTorch-ROCm bf16: the oracle's functional graph on the GPU under autocast
+    sdg = {k: v.detach().to(dev).requires_grad_(v.dtype.is_floating_point) for k, v in sd.items()}
+    xg = frames.to(dev).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        outg = OS.swin_affwild_logits(sdg, xg, training=train)
+    (outg.float() * probe.to(dev)).sum().backward()
+    stock = _grad_stats([("input", xg.grad, xr.grad)] + [(k, sdg[k].grad, sd[k].grad) for k, _ in aff.named_parameters()], skip)
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out_dir):
         with open(os.path.join(out_dir, f"bf16_grad_stats_{bn_mode}.txt"), "w") as f:
-            f.write("\n".join(f"{c:.5f} {r:.5f} {k}" for k, c, r in stats) + "\n")
-    print(f"bf16 vs fp32-oracle gradients ({bn_mode}) over {len(stats)} tensors: worst cosine {min((c, k) for k, c, r in stats)}, "
-          f"worst relative L2 error {max((r, k) for k, c, r in stats)}")
-    bad = [(k, c, r) for k, c, r in stats if not (c >= COS_MIN and r <= REL_MAX)]
+            f.write(f"# {N} diverse frames, BatchNorm1d on {bn_mode}: cosine / relative L2 error against the fp32 oracle's gradients -- ours | stock bf16 autocast\n")
+            f.write("\n".join(f"{c:.5f} {r:.5f} | {stock[k][0]:.5f} {stock[k][1]:.5f} {k}" for k, (c, r) in ours.items()) + "\n")
+    wc, wr = min((c, k) for k, (c, r) in ours.items()), max((r, k) for k, (c, r) in ours.items())
+    sc, sr = min((c, k) for k, (c, r) in stock.items()), max((r, k) for k, (c, r) in stock.items())
+    print(f"bf16 vs fp32-oracle gradients ({bn_mode}, {N} frames) over {len(ours)} tensors: ours worst cosine {wc}, worst relative L2 {wr}; "
+          f"stock bf16 autocast worst cosine {sc}, worst relative L2 {sr}")
+    bad = [(k, c, r, stock[k]) for k, (c, r) in ours.items() if not ((c >= COS_MIN and r <= REL_MAX) or r <= 1.5 * sr[0])]
     assert not bad, bad[:8]
-    assert n >= 175
+    assert len(ours) >= 173
 
 
 def test_droppath_matches_oracle_with_explicit_masks(dev, S):

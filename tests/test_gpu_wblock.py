@@ -28,13 +28,15 @@ def _rel(a, b):
     return (a.float() - b.float()).abs().max().item() / max(b.float().abs().max().item(), 1e-6)
 
 
-CASES = [(2, 14, 0, False), (2, 14, 3, True), (1, 56, 3, False), (3, 7, 0, True), (2, 21, 2, True), (5, 28, 3, False), (1, 7, 0, False), (33, 14, 3, True)]
+CASES = [(96, 2, 14, 0, False), (96, 2, 14, 3, True), (96, 1, 56, 3, False), (96, 3, 7, 0, True), (96, 2, 21, 2, True), (96, 5, 28, 3, False), (96, 1, 7, 0, False),
+         (96, 33, 14, 3, True), (96, 8, 56, 3, True),
+         (192, 2, 14, 0, False), (192, 3, 28, 3, True), (192, 1, 7, 0, True), (192, 9, 14, 3, False)]     # stage-1 width: four forward launches, the same recompute backward
 
 
-@pytest.mark.parametrize("n_img,H,shift,use_rs", CASES)
-def test_fused_block_half_forward_and_gradients(dev, n_img, H, shift, use_rs):
+@pytest.mark.parametrize("C,n_img,H,shift,use_rs", CASES)
+def test_fused_block_half_forward_and_gradients(dev, C, n_img, H, shift, use_rs):
     import gpu_wblock as W
-    C, nh = 96, 3
+    nh = C // 32
     index = OS.relative_position_index(7).to(dev).int().contiguous()
     P = W.params(C, nh, seed=n_img)
     x = W.rnd("x", (n_img, H * H, C), 11, dtype=torch.bfloat16).requires_grad_(True)
@@ -48,7 +50,7 @@ def test_fused_block_half_forward_and_gradients(dev, n_img, H, shift, use_rs):
     assert _rel(y.reshape(-1, C), r64) <= 2e-2
     y_raw, xn_f, o_f, mean_f, rstd_f, lse_f = ops.window_block_raw(
         x.detach().reshape(-1, C), n_img, H, H, nh, shift, P["g"].detach(), P["b"].detach(), 1e-5, P["wqkv"].detach().bfloat16(), P["bqkv"].detach(),
-        P["wproj"].detach().bfloat16(), P["bproj"].detach(), P["table"].detach(), index, 32 ** -0.5, rs, True)
+        P["wproj"].detach().bfloat16(), P["bproj"].detach(), P["table"].detach(), index, 32 ** -0.5, rs, True, mask)
     assert torch.equal(y.reshape(-1, C), y_raw)                                         # the saved-tensor form computes the same y
     with torch.no_grad():
         y4, xn4, o4 = W.four_launch(x.detach(), P, index, mask, n_img, H, nh, shift, rs)
@@ -131,3 +133,38 @@ def test_fused_block_against_the_reference_generated_golden(dev, golden, shift):
     import numpy as np
     assert np.abs(got - ref).max() <= 3e-2 * np.abs(ref).max()
     golden.check("swin_parts", f"block_s0_shift{shift}", y32, atol=1e-3, rtol=1e-3)
+
+
+@pytest.mark.parametrize("C,M,use_rs", [(96, 8192 + 77, True), (192, 4096, False), (96, 3136 * 2, False)])
+def test_mlp_half_with_layernorm_prologue(dev, C, M, use_rs):
+    """fmmt_mlp_ln_fwd (norm2 -> Mlp -> DropPath -> residual in one launch) against fmmt_layernorm_fwd followed by fmmt_mlp_fwd, and
+    both against fp64: forward, the saved LayerNorm output and statistics, every gradient; ragged last tile, dropped sample."""
+    import gpu_wblock as W
+    x = W.rnd("x", (M, C), 21, dtype=torch.bfloat16).requires_grad_(True)
+    P = [(1.0 + 0.2 * W.rnd("g", (C,), 22)).requires_grad_(True), (0.1 * W.rnd("b", (C,), 23)).requires_grad_(True),
+         W.rnd("w1", (4 * C, C), 24, C ** -0.5).requires_grad_(True), (0.1 * W.rnd("b1", (4 * C,), 25)).requires_grad_(True),
+         W.rnd("w2", (C, 4 * C), 26, (4 * C) ** -0.5).requires_grad_(True), (0.1 * W.rnd("b2", (C,), 27)).requires_grad_(True)]
+    rps = 1024
+    rs = None
+    if use_rs:
+        rs = W.rnd("rs", ((M + rps - 1) // rps,), 5).abs() + 0.5
+        rs[1] = 0.0
+    assert ops.mlp_ln_fusable(x, P[2], P[4], P[3], P[5])
+    y = ops.mlp_ln(x, P[0], P[1], 1e-5, P[2], P[3], P[4], P[5], rs, rps)
+    xr, xn = ops.residual_layer_norm(x, P[0], P[1], 1e-5)
+    y2 = ops.mlp(xn, P[2], P[3], P[4], P[5], res=xr, rowscale=rs, rows_per_scale=rps)
+    x64 = x.detach().double().requires_grad_(True)
+    P64 = [p.detach().double().requires_grad_(True) for p in P]
+    h64 = torch.nn.functional.gelu(torch.nn.functional.layer_norm(x64, (C,), P64[0], P64[1], 1e-5) @ P64[2].t() + P64[3])
+    s64 = rs.double().repeat_interleave(rps)[:M, None] if rs is not None else 1.0
+    r64 = x64 + s64 * (h64 @ P64[4].t() + P64[5])
+    assert _rel(y, r64) <= 2e-2 and _rel(y, y2) <= 1e-2
+    dy = W.rnd("dy", (M, C), 29, dtype=torch.bfloat16)
+    leaves = [x] + P
+    g1 = torch.autograd.grad(y, leaves, dy)
+    g2 = torch.autograd.grad(y2, leaves, dy)
+    g64 = torch.autograd.grad(r64, [x64] + P64, dy.double())
+    for a, b, c in zip(g1, g2, g64):
+        assert _rel(a, c) <= 4e-2 and _rel(b, c) <= 4e-2
+        l2 = lambda u: ((u.double() - c).norm() / c.norm()).item()
+        assert l2(a) <= 1.5 * l2(b) + 1e-3                                            # as accurate as the two-launch form

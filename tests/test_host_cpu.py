@@ -317,3 +317,21 @@ def test_capture_window_fences_the_cyclic_collector():
         assert not gc.isenabled()
     finally:
         gc.enable()
+
+
+def test_master_weights_keep_frozen_parameters_and_buffers_in_fp32():
+    """MasterWeights turns a module to bf16 in place; its checkpoint view (state_dict_fp32) must hold the fp32 masters of the stepped
+    parameters AND the untouched fp32 values of what has no master: frozen parameters (the text encoder's unused pooler) and buffers."""
+    import torch
+    from facialmmt_amd.train_step import MasterWeights
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(torch.nn.Linear(24, 16), torch.nn.LayerNorm(16), torch.nn.Linear(16, 8))
+    m.register_buffer("stat", torch.randn(5) * 1.2345678)
+    for p in m[2].parameters():
+        p.requires_grad_(False)                              # a frozen tail, like the pooler
+    want = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    mw = MasterWeights(m, torch.bfloat16)
+    assert all(p.dtype == torch.bfloat16 for p in m.parameters())
+    got = mw.state_dict_fp32()
+    for k, v in want.items():
+        assert got[k].dtype == torch.float32 and torch.equal(got[k], v), k
