@@ -740,7 +740,7 @@ def main():
                        "parallelism": f"dp{world}", "kept_frame_fraction": round(float(kept.mean().item()), 3),
                        "model_tflops_per_s_per_gpu": round(flops_step / (ms * 1e-3) / 1e12, 1),
                        "host_enqueue_ms_per_step": round(issue_s / args.steps * 1e3, 1), "host_issue_ms_into_idle_queue": round(idle_issue_ms, 1),
-                       "hip_graphs": {2: "whole step: 3 graphs (fwd + multimodal bwd | Swin bwd | clip+optimizer)", 1: "multimodal model only (Swin eager)", 0: "none"}[args.graphs],
+                       "hip_graphs": {2: ("whole step: 3 graphs (fwd + multimodal bwd | Swin bwd | clip+optimizer), gradient exchange beside the second" if ddp else "whole step: 2 graphs (fwd+bwd | clip+optimizer)"), 1: "multimodal model only (Swin eager)", 0: "none"}[args.graphs],
                        "text_encoder_concurrent_with_swin": bool(args.graphs and args.overlap_text),
                        "text_encoder_parameters": "bf16 with fp32 master weights in the optimizer" if (args.graphs == 2 and args.plm_dtype == "bf16" and args.dtype == "bf16") else "fp32 under bf16 autocast",
                        "gradient_allreduce": None if not ddp else f"{args.grad_comm}, {'issued between the multimodal backward and the Swin backward (graphs A1 | A2), waited for before the optimizer graph' if args.graphs == 2 else 'hook-driven, overlapped with backward'}",

@@ -304,6 +304,234 @@ __global__ __launch_bounds__(512) void mlp_fused_fwd_kernel(MlpArgs p) {
     }
 }
 
+// =============================================================================================
+// Backward of the same Mlp with respect to its input, one launch:
+//     dh = rowscale * (dy . W2) * gelu'(h_pre)          [M, 4C]   (stored: the two weight-gradient launches contract with it)
+//     dx = dh . W1                                       [M, C]
+// i.e. the forward kernel with the roles turned: product 1 contracts dy (in registers for the tile) with 64-row stages of W2^T,
+// epilogue 1 multiplies by GELU' of the saved pre-activation and the DropPath scale, and its accumulator tiles are the B operand of
+// product 2 against W1^T.  As two launches (fmmt_linear_fwd with FMMT_EPI_GELU_BWD, fmmt_linear_fwd) dh is written and read back:
+// 1.5 GB of the 3.9 GB the pair moves at stage 0.
+//
+// The pre-activation tile of a stage (a token's 64 values = one 128-byte line, four 16-byte loads per lane) is the one operand that is
+// neither DMA-able into the shared ring (32 KB per stage) nor free to be an ordinary load: beside LDS-DMA the compiler waits vmcnt(0)
+// for every ordinary load, which would drain the ring once per stage.  It is therefore loaded by inline assembly one stage ahead and
+// counted by hand: per wave and step the memory operations are, in program order,
+//     [wait stage s] [barrier] DMA(s+2): CNT   AUX(s+1): 4   ... dh stores of step s: 0..4   (+ the tile end's loads and stores)
+// so stage s has landed when at most CNT + 8 younger operations are outstanding (AUX(s-1), DMA(s+1), AUX(s); step 0: CNT + 4), and
+// AUX(s) has landed when at most CNT + 4 are (DMA(s+2), AUX(s+1); fewer at the tail, where the waits fall back to vmcnt(0)).
+// Lower bounds only: stores and tile-end operations make a wait stricter, never wrong.  The two register sets of the AUX loads
+// alternate statically (the step loop is unrolled by two: a register copy of data still in flight would copy garbage).
+__device__ __forceinline__ void gload16_asm(bf16x8& dst, const void* ptr) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
+}
+
+template <int C>
+__global__ __launch_bounds__(512) void mlp_fused_bwd_kernel(MlpArgs p) {
+    using T = bf16;
+    constexpr int H = 4 * C, HS = 64, NS = H / HS;
+    constexpr int KS = C / 32;
+    constexpr int NT2 = C / 16, CW2 = 4 * NT2;
+    constexpr int W1_EL = KS * HS * 32, W2_EL = 2 * C * 32;
+    constexpr int STAGE_B = (W1_EL + W2_EL) * 2;
+    constexpr int NBUF = 3;
+    constexpr int NI = KS * (HS / 16) + 2 * (C / 16);
+    static_assert(NI % 8 == 0 && NS % 2 == 0, "uniform DMA count per wave; an even number of steps per tile");
+    constexpr int CNT = NI / 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    auto swz = [](int row) { return ((row >> 3) ^ (row >> 2)) & 3; };
+    const int r16 = lane >> 2, c4 = lane & 3;
+
+    // p.w1 = W2^T [4C][C] (rows: hidden), p.w2 = W1^T [C][4C] (rows: input channels): the stage layout of the forward kernel
+    auto issue = [&](int slot, int hs) {
+        char* base = smem + slot * STAGE_B;
+#pragma unroll
+        for (int i = 0; i < CNT; ++i) {
+            const int j = i * 8 + wave;
+            const T* src;
+            T* dst;
+            if (j < KS * 4) {
+                const int ks = j >> 2, r0 = (j & 3) * 16, r = r0 + r16;
+                src = p.w1 + (size_t)(hs * HS + r) * C + ks * 32 + ((c4 ^ swz(r)) << 3);
+                dst = reinterpret_cast<T*>(base) + ks * (HS * 32) + r0 * 32;
+            } else {
+                const int q = j - KS * 4, b = q / (C / 16), r0 = (q % (C / 16)) * 16, r = r0 + r16;
+                src = p.w2 + (size_t)r * H + hs * HS + b * 32 + ((c4 ^ swz(r)) << 3);
+                dst = reinterpret_cast<T*>(base) + W1_EL + b * (C * 32) + r0 * 32;
+            }
+            __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)dst, 16, 0, 0);
+        }
+    };
+
+    int w1off[2], w2off[NT2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int r = chan_of<8>(nt, li >> 2, li & 3);
+        w1off[nt] = r * 32 + ((lg ^ swz(r)) << 3);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt) {
+        const int r = chan_of<CW2>(nt, li >> 2, li & 3);
+        w2off[nt] = W1_EL + r * 32 + ((lg ^ swz(r)) << 3);
+    }
+
+    const int G = gridDim.x;
+    const int ntile = (int)blockIdx.x < p.tiles ? (p.tiles - (int)blockIdx.x + G - 1) / G : 0;
+    const int nsteps = ntile * NS;
+    int ihs = 0, islot = 0;
+    auto issue_next = [&]() {
+        issue(islot, ihs);
+        islot = islot + 1 == NBUF ? 0 : islot + 1;
+        ihs = ihs + 1 == NS ? 0 : ihs + 1;
+    };
+    // the saved pre-activation of (tile, stage hs): lane = token li of m-tile mt, hidden channels hs * 64 + blk * 32 + lg * 8 ..
+    auto issue_aux = [&](int tile, int hs, bf16x8 (&dst)[4]) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int tok = min(tile * 256 + wave * 32 + mt * 16 + li, p.M - 1);
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) gload16_asm(dst[mt * 2 + blk], p.h_pre + (size_t)tok * H + hs * HS + blk * 32 + lg * 8);
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < NBUF - 1; ++s)
+        if (s < nsteps) issue_next();
+
+    bf16x8 xf[2][KS];
+    float rsv[2];
+    auto load_x = [&](int tile) {
+        const int t0 = tile * 256 + wave * 32;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int tok = min(t0 + mt * 16 + li, p.M - 1);
+            rsv[mt] = row_scale(p.rowscale, tok, p.rows_per_scale);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) xf[mt][ks] = *reinterpret_cast<const bf16x8*>(p.x + (size_t)tok * C + ks * 32 + lg * 8);
+        }
+    };
+    f32x4 acc2[2][NT2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) acc2[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int tile = blockIdx.x, hs = 0, cslot = 0, s = 0;
+    bf16x8 auxA[4], auxB[4];
+    if (ntile > 0) {
+        issue_aux(tile, 0, auxA);                            // AUX(0), behind DMA(0) and DMA(1)
+        load_x(tile);
+    }
+    auto step = [&](bf16x8 (&cur)[4], bf16x8 (&nxt)[4]) {
+        // -- stage s landed?
+        if (s + 1 >= nsteps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (s == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT + 4) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT + 8) : "memory");
+        __builtin_amdgcn_s_barrier();
+        if (s + NBUF - 1 < nsteps) issue_next();
+        if (s + 1 < nsteps) {
+            const int nhs = hs + 1 == NS ? 0 : hs + 1;
+            issue_aux(hs + 1 == NS ? tile + G : tile, nhs, nxt);
+        }
+        const T* sb = reinterpret_cast<const T*>(smem + cslot * STAGE_B);
+        const int t0 = tile * 256 + wave * 32;
+        bf16x8 keep[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            f32x4 acc1[2][2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) acc1[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                bf16x8 wf[2];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) wf[nt] = *reinterpret_cast<const bf16x8*>(sb + ks * (HS * 32) + blk * (32 * 32) + w1off[nt]);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) acc1[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt][ks], acc1[mt][nt], 0, 0, 0);
+            }
+            if (blk == 0) {
+                // -- AUX(s) landed?  (younger: DMA(s+2), AUX(s+1), where issued)
+                if (s + NBUF - 1 < nsteps) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]) : "n"(CNT + 4) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3])::"memory");
+            }
+            bf16x8 hf[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                float v[8], ax[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = acc1[mt][0][r];
+                    v[4 + r] = acc1[mt][1][r];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ax[e] = (float)cur[mt * 2 + blk][e];
+                gelu_grad_mul_inplace<T>(v, ax, 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hf[mt][e] = (bf16)(v[e] * rsv[mt]);
+                const int tok = t0 + mt * 16 + li;
+                if (blk == 0) keep[mt] = hf[mt];
+                else if (tok < p.M) {
+                    const size_t off = (size_t)tok * H + hs * HS + lg * 8;
+                    *reinterpret_cast<bf16x8*>(p.h_act + off) = keep[mt];
+                    *reinterpret_cast<bf16x8*>(p.h_act + off + 32) = hf[mt];
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT2; ++nt) {
+                const bf16x8 wf2 = *reinterpret_cast<const bf16x8*>(sb + blk * (C * 32) + w2off[nt]);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) acc2[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf2, hf[mt], acc2[mt][nt], 0, 0, 0);
+            }
+        }
+        cslot = cslot + 1 == NBUF ? 0 : cslot + 1;
+        ++s;
+        if (++hs == NS) {
+            const int next = tile + G;
+            if (next < p.tiles) load_x(next);
+            LinArgs e{};
+            e.M = p.M;
+            e.N = C;
+            e.y = p.y;
+            e.ldy = C;
+            nt_epilogue<T, 2, NT2>(e, acc2, t0, 0, li, lg);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT2; ++nt) acc2[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            hs = 0;
+            tile = next;
+        }
+    };
+    while (s < nsteps) {                                     // nsteps is even (NS is)
+        step(auxA, auxB);
+        step(auxB, auxA);
+    }
+}
+
+template <int C>
+int launch_mlp_bwd(const MlpArgs& a, hipStream_t st) {
+    constexpr size_t lds = (size_t)3 * (((C / 32) * 64 * 32 + 2 * C * 32) * 2);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_bwd_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int grid = a.tiles < 256 ? a.tiles : 256;
+    hipLaunchKernelGGL((mlp_fused_bwd_kernel<C>), dim3(grid), dim3(512), lds, st, a);
+    FMMT_CHECK_LAUNCH();
+    return 0;
+}
+
 template <int C, bool LN>
 int launch_mlp(const MlpArgs& a, hipStream_t st) {
     constexpr size_t lds = (size_t)3 * (((C / 32) * 64 * 32 + 2 * C * 32) * 2 + 1024);
@@ -346,4 +574,16 @@ extern "C" int fmmt_mlp_ln_fwd(int dtype, int M, int C, const void* x, const flo
               ln_gamma, ln_beta, eps, (bf16*)xn, mean, rstd};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     return C == 96 ? launch_mlp<96, true>(a, st) : launch_mlp<192, true>(a, st);
+}
+
+extern "C" int fmmt_mlp_bwd_input(int dtype, int M, int C, const void* dy, const void* h_pre, const void* w2t, const void* w1t,
+                                  const float* rowscale, int rows_per_scale, void* dh, void* dx, void* stream) {
+    if (dtype != FMMT_BF16 || M <= 0 || (C != 96 && C != 192)) return FMMT_EINVAL;
+    if (!dy || !h_pre || !w2t || !w1t || !dh || !dx || (rowscale && rows_per_scale <= 0)) return FMMT_EINVAL;
+    if (!al16(dy) || !al16(h_pre) || !al16(w2t) || !al16(w1t) || !al16(dh) || !al16(dx)) return FMMT_EALIGN;
+    MlpArgs a{};
+    a.M = M; a.x = (const bf16*)dy; a.w1 = (const bf16*)w2t; a.w2 = (const bf16*)w1t; a.rowscale = rowscale; a.rows_per_scale = rows_per_scale;
+    a.y = (bf16*)dx; a.h_pre = (bf16*)const_cast<void*>(h_pre); a.h_act = (bf16*)dh; a.tiles = (M + 255) / 256;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    return C == 96 ? launch_mlp_bwd<96>(a, st) : launch_mlp_bwd<192>(a, st);
 }

@@ -400,6 +400,25 @@ class MlpFn(Function):
         return dx, dw1, db1, dw2, db2, (dy if ctx.has_res else None), None, None
 
 
+_MLP_BWD_FUSED = _os.environ.get("FMMT_MLP_BWD_FUSED", "1") != "0"   # A/B switch (read once): 0 = GELU' GEMM + input-gradient GEMM as two launches
+_MLP_BWD_WIDTHS = (96, 192) if _os.environ.get("FMMT_MLP_BWD_FUSED", "1") == "192" else (96,)
+
+
+def mlp_bwd_input_raw(dy2, h_pre, w1, w2, rowscale, rows_per_scale):
+    """(dh, dx) of the Mlp: one launch where the fused kernel applies (bf16, C = 96), the two GEMM launches otherwise"""
+    M, C = dy2.shape
+    dt = dy2.dtype
+    if _MLP_BWD_FUSED and dt == torch.bfloat16 and C in _MLP_BWD_WIDTHS and w1.shape == (4 * C, C) and M >= 4096:
+        dh = torch.empty((M, 4 * C), dtype=dt, device=dy2.device)
+        dx = torch.empty_like(dy2)
+        rc = _lib.load().fmmt_mlp_bwd_input(dtype_code(dt), M, C, _p(dy2), _p(h_pre), _p(_lp(w2, dt, transpose=True)), _p(_lp(w1, dt, transpose=True)),
+                                            _p(rowscale), rows_per_scale, _p(dh), _p(dx), _st())
+        check(rc, f"fmmt_mlp_bwd_input(M={M},C={C})")
+        return dh, dx
+    dh = linear_raw(dy2, _lp(w2, dt, transpose=True), None, epi=EPI_GELU_BWD, aux=h_pre, rowscale=rowscale, rows_per_scale=rows_per_scale)
+    return dh, linear_raw(dh, _lp(w1, dt, transpose=True), None)
+
+
 class MlpLnFn(Function):
     """y = x + rowscale * Mlp(LayerNorm(x)): forward = fmmt_mlp_ln_fwd (one launch, LayerNorm formed on the operand fragments);
     backward = the Mlp's four GEMM launches on the saved LN(x) / pre-activation / activation, then fmmt_layernorm_bwd with the
@@ -435,9 +454,8 @@ class MlpLnFn(Function):
         C = x2.shape[1]
         lib = _lib.load()
         dy2 = dy.reshape(-1, C).contiguous()
-        dh = linear_raw(dy2, _lp(w2, dy2.dtype, transpose=True), None, epi=EPI_GELU_BWD, aux=h_pre, rowscale=rowscale, rows_per_scale=ctx.rps)
+        dh, dxn = mlp_bwd_input_raw(dy2, h_pre, w1, w2, rowscale, ctx.rps)
         dw2, db2 = wgrad_raw(dy2, h, True, rowscale, ctx.rps)
-        dxn = linear_raw(dh, _lp(w1, dy2.dtype, transpose=True), None)
         dw1, db1 = wgrad_raw(dh, xn, True)
         del dh
         dx = torch.empty_like(x2)
@@ -608,14 +626,18 @@ def window_attn_core(qkv, table, index_i32, mask, n_img, H, W, num_heads, shift,
 # ------------------------------------------------------------------------------------------------
 # the attention half of a Swin block as ONE launch (csrc/wblock.hip): y = x + s * proj(W-MSA(LN(x) Wqkv^T + b))
 # ------------------------------------------------------------------------------------------------
-_WBLOCK = _os.environ.get("FMMT_WBLOCK", "1") != "0"          # A/B switch (read once): 0 = always the four-launch form
+_WBLOCK = _os.environ.get("FMMT_WBLOCK", "1") != "0"          # A/B switch (read once): 0 = always the four-launch form; 192 = also at stage 1
+_WBLOCK_WIDTHS = (96, 192) if _os.environ.get("FMMT_WBLOCK", "1") == "192" else (96,)
 _WBLOCK_BWD = _os.environ.get("FMMT_WBLOCK_BWD", "1") != "0"  # 0: the backward re-computes qkv with a GEMM and runs fmmt_window_attn_bwd
 
 
 def window_block_fusable(x, C, num_heads, window_size, shift, mask, mask_is_shift):
-    """the block-half op covers the bf16 stage-0 / stage-1 geometry (C = 96 / 192, head_dim 32, 7x7 windows) with no mask or the standard
-    SW-MSA mask: C = 96 runs the fused forward kernel, C = 192 the four forward launches; both share the recompute backward"""
-    return (_WBLOCK and x.is_cuda and x.dtype == torch.bfloat16 and C in (96, 192) and num_heads * 32 == C and tuple(window_size) == (7, 7)
+    """the block-half op runs where it pays: the bf16 stage-0 geometry (C = 96, head_dim 32, 7x7 windows) with no mask or the standard
+    SW-MSA mask -- fused forward kernel + recompute backward.  (C = 192 is implemented -- four forward launches, the same recompute
+    backward, tests/test_gpu_wblock.py -- and reachable with FMMT_WBLOCK=192, but at stage 1 the recompute backward loses: six heads
+    re-read LN(x) / dy and redo 96 MFMAs per wave, 835 us per launch against 480 + 130 for the attention backward and the proj input
+    gradient it replaces.)"""
+    return (_WBLOCK and x.is_cuda and x.dtype == torch.bfloat16 and C in _WBLOCK_WIDTHS and num_heads * 32 == C and tuple(window_size) == (7, 7)
             and ((shift == 0 and mask is None) or (shift > 0 and mask is not None and mask_is_shift)))
 
 

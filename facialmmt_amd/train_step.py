@@ -591,7 +591,8 @@ def _bump_versions(params):
 
 
 class GraphedTargetStep:
-    """The whole target-task step as THREE HIP graphs, replayed per step with one host call each:
+    """The whole target-task step as HIP graphs, replayed per step with one host call each -- two graphs (A = A1 + A2 as one, then B) on
+    a single GPU, three when a gradient exchange has to be hidden (N > 1):
 
       A1 text encoder (forked onto a second stream) || Swin forward -> frame filter -> fusion stack -> cross-entropy ->
          backward through the fusion stack and the text encoder, down to the gradient of Swin's output; the multimodal
@@ -673,13 +674,21 @@ class GraphedTargetStep:
         torch.cuda.set_rng_state(rng, dev)
         # -- capture
         self.shadows = _pin_shadows([self.swin, self.mm])
-        self.graph_a, self.graph_a2, self.graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        # With an exchange to hide (N > 1) the forward/backward is TWO graphs, cut where the multimodal gradients are complete; alone on
+        # the GPU it stays ONE graph: inside it the text encoder's backward runs as a branch beside Swin's backward, which a cut in
+        # front of Swin's backward would serialise (measured at N = 1: 72.1 ms per step cut, 69 ms uncut).
+        self.split = bool(getattr(self.flat, "active", False))
+        self.graph_a, self.graph_a2, self.graph_b = torch.cuda.CUDAGraph(), (torch.cuda.CUDAGraph() if self.split else None), torch.cuda.CUDAGraph()
         with capture_window():
-            with torch.cuda.graph(self.graph_a, stream=cap):
-                self.loss, self.new_mask, swin_out = self._fwd_bwd_multimodal()
-            with torch.cuda.graph(self.graph_a2, pool=self.graph_a.pool(), stream=cap):
-                self._bwd_swin(swin_out)
-            del swin_out
+            if self.split:
+                with torch.cuda.graph(self.graph_a, stream=cap):
+                    self.loss, self.new_mask, swin_out = self._fwd_bwd_multimodal()
+                with torch.cuda.graph(self.graph_a2, pool=self.graph_a.pool(), stream=cap):
+                    self._bwd_swin(swin_out)
+                del swin_out
+            else:
+                with torch.cuda.graph(self.graph_a, stream=cap):
+                    self.loss, self.new_mask = self._fwd_bwd()
             with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), stream=cap):
                 self._update()
         _KEEP_GRAPHS.append((self.graph_a, self.graph_a2, self.graph_b))
@@ -689,11 +698,10 @@ class GraphedTargetStep:
 
     # one micro-step: forward + backward (runs eagerly during warm-up, once more under capture), in the two pieces the graphs hold
     def _fwd_bwd(self):
-        loss, new_mask, swin_out = self._fwd_bwd_multimodal()
-        self._bwd_swin(swin_out)
+        loss, new_mask, _ = self._fwd_bwd_multimodal(whole=True)
         return loss, new_mask
 
-    def _fwd_bwd_multimodal(self):
+    def _fwd_bwd_multimodal(self, whole=False):
         """forward of everything + backward of the loss down to (a) the multimodal parameters and (b) Swin's output; returns
         (loss, kept-frame mask, (Swin output, its gradient)) -- the second piece continues from the latter"""
         (ids, attn_mask, sep_mask, audio, audio_mask, vision_inputs, vision_mask, labels, frames, num_imgs, utt_idx) = self.static
@@ -720,6 +728,10 @@ class GraphedTargetStep:
                     t.record_stream(main)
             logits = mm.fusion_branch(pending[0], pending[1], audio, audio_mask, vis_concat, new_mask)
         loss = F.cross_entropy(logits.float(), labels) / args.trg_accumulation_steps
+        if whole:                                            # one piece: autograd runs the text branch's backward beside Swin's
+            loss.backward()
+            _hand_over_gradients(self.pairs, self.flat_view_of, self.accumulate)
+            return loss.detach(), new_mask, None
         # backward, first piece: every leaf the optimizer steps plus Swin's output (the autograd graph below `preds` -- Swin -- is
         # left untouched, with its saved activations, for the second piece)
         leaves = [l for l, _ in self.pairs if l.requires_grad]
@@ -772,7 +784,8 @@ class GraphedTargetStep:
             self.flat.exchange_begin()                     # no-op at world size 1; the collectives run beside graph A2
             if self.timing is not None:
                 self.timing["begin"].record()
-        self.graph_a2.replay()
+        if self.graph_a2 is not None:
+            self.graph_a2.replay()
         if last:
             if self.timing is not None:
                 self.timing["a2_done"].record()

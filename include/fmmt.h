@@ -113,6 +113,14 @@ int fmmt_mlp_ln_fwd(int dtype, int M, int C, const void* x, const float* ln_gamm
                     const void* w1, const float* b1, const void* w2, const float* b2, const float* rowscale, int rows_per_scale,
                     void* y, void* xn, float* mean, float* rstd, void* h_pre, void* h_act, void* stream);
 
+/* Input gradient of the same Mlp in ONE launch (bf16; C = 96 / 192), autograd of Swin_Transformer.py:14-30 with respect to x:
+ *   dh[M,4C] = rowscale[m / rows_per_scale] * (dy[M,C] . w2) * gelu'(h_pre)      (stored: both weight gradients contract with it)
+ *   dx[M,C]  = dh . w1
+ * w2t = w2^T [4C, C] and w1t = w1^T [C, 4C] (the transposed bf16 copies the two-launch form also reads).  Replaces
+ * fmmt_linear_fwd(FMMT_EPI_GELU_BWD) followed by fmmt_linear_fwd: dh is written once and never read back by this pair. */
+int fmmt_mlp_bwd_input(int dtype, int M, int C, const void* dy, const void* h_pre, const void* w2t, const void* w1t,
+                       const float* rowscale, int rows_per_scale, void* dh, void* dx, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm.  Replaces nn.LayerNorm (eps 1e-5) at Swin_Transformer.py:198,204,239,268 (norm1/2),
  * :305,325 (PatchMerging.norm over the 2x2 concat), :410,421 (PatchEmbed.norm), :491 (head norm);

@@ -34,9 +34,10 @@ CASES = [(96, 2, 14, 0, False), (96, 2, 14, 3, True), (96, 1, 56, 3, False), (96
 
 
 @pytest.mark.parametrize("C,n_img,H,shift,use_rs", CASES)
-def test_fused_block_half_forward_and_gradients(dev, C, n_img, H, shift, use_rs):
+def test_fused_block_half_forward_and_gradients(dev, C, n_img, H, shift, use_rs, monkeypatch):
     import gpu_wblock as W
     nh = C // 32
+    monkeypatch.setattr(ops, "_WBLOCK_WIDTHS", (96, 192))
     index = OS.relative_position_index(7).to(dev).int().contiguous()
     P = W.params(C, nh, seed=n_img)
     x = W.rnd("x", (n_img, H * H, C), 11, dtype=torch.bfloat16).requires_grad_(True)
@@ -168,3 +169,32 @@ def test_mlp_half_with_layernorm_prologue(dev, C, M, use_rs):
         assert _rel(a, c) <= 4e-2 and _rel(b, c) <= 4e-2
         l2 = lambda u: ((u.double() - c).norm() / c.norm()).item()
         assert l2(a) <= 1.5 * l2(b) + 1e-3                                            # as accurate as the two-launch form
+    # the fused input-gradient launch hand-counts its in-flight loads: the same backward five more times, bit for bit
+    for _ in range(5):
+        y3 = ops.mlp_ln(x, P[0], P[1], 1e-5, P[2], P[3], P[4], P[5], rs, rps)
+        g3 = torch.autograd.grad(y3, leaves, dy)
+        for a, b in zip(g1, g3):
+            assert torch.equal(a, b)
+
+
+def test_fused_mlp_input_gradient_launch(dev):
+    """fmmt_mlp_bwd_input (dh and dx of the Mlp in one launch, C = 96) against the two GEMM launches it replaces (GELU' epilogue, then
+    the input gradient): dh bit-identical (same products, same rounding), dx bit-identical; ragged token counts, a dropped sample;
+    at the bench size (2 M tokens) a checksum comparison."""
+    import gpu_wblock as W
+    from facialmmt_amd._lib import EPI_GELU_BWD
+    C = int(os.environ.get("MLP_BWD_TEST_C", "96"))
+    for M, rps in ((4096 + 33, 1000), (256 * 40, 3136), (3136 * 640 * 96 // C, 3136 * 96 // C)):
+        g = torch.Generator(device=dev).manual_seed(M)
+        dy = torch.randn(M, C, device=dev, generator=g).bfloat16()
+        hp = torch.randn(M, 4 * C, device=dev, generator=g).bfloat16()
+        w1 = (torch.randn(4 * C, C, device=dev, generator=g) * C ** -0.5).bfloat16()
+        w2 = (torch.randn(C, 4 * C, device=dev, generator=g) * (4 * C) ** -0.5).bfloat16()
+        rs = torch.rand((M + rps - 1) // rps, device=dev, generator=g) + 0.5
+        rs[0] = 0.0
+        dh, dx = ops.mlp_bwd_input_raw(dy, hp, w1, w2, rs, rps)
+        dh2 = ops.linear_raw(dy, w2.t().contiguous(), None, epi=EPI_GELU_BWD, aux=hp, rowscale=rs, rows_per_scale=rps)
+        dx2 = ops.linear_raw(dh2, w1.t().contiguous(), None)
+        assert torch.equal(dh, dh2), (M, (dh.float() - dh2.float()).abs().max().item())
+        assert torch.equal(dx, dx2), (M, (dx.float() - dx2.float()).abs().max().item())
+        del dh, dx, dh2, dx2
