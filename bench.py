@@ -227,7 +227,8 @@ class KernelTimer:
             if p256:
                 plainop = 1
                 hasop = kw.get("res") is not None or kw.get("rowscale") is not None or kw.get("aux") is not None
-                bn = f"p256x{p256}" + ("op" if p256 != 256 and (hasop or (plainop and (K > 1536 or plainop > 1))) else "")
+                isop = p256 != 256 and (hasop or (plainop and (K > 1536 or plainop > 1)))
+                bn = f"p256x{p256}" + ("op" if isop else "pipe" if K >= 384 else "")      # launch_p256: pipelined K loop from K = 384
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             y = raw(x2, w, bias, **kw)
@@ -804,9 +805,9 @@ def kernel_symbol(bn):
                  "fmmt_window_attn_bwd": "wattn_mfma_bwd_kernel", "fmmt_mlp_fwd": "mlp_fused_fwd_kernel", "fmmt_window_block_fwd": "wblock_fwd_kernel"}
         return names.get(base, base) + ("<" + rest if rest else "")
     if bn.startswith("p256x"):
-        op = bn.endswith("op")
-        w = bn[5:-2] if op else bn[5:]
-        return f"linear_nt_p256_kernel<{w},64,{3 if w == '128' else 2},true,{'true' if op else 'false'}>"
+        op, pipe = bn.endswith("op"), bn.endswith("pipe")
+        w = bn[5:-2] if op else bn[5:-4] if pipe else bn[5:]
+        return f"linear_nt_p256_kernel<{w},64,{3 if w == '128' else 2},true,{'true' if op else 'false'},{'true' if pipe else 'false'}>"
     if bn.startswith("deep256") and bn != "deep256x128x64":         # deep256x{128,96}x32[,nkN]
         width = "128" if bn.startswith("deep256x128") else "96"
         return f"linear_nt_deep32_kernel<{bn[-1] if ',nk' in bn else '0'},{width}>"

@@ -36,7 +36,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def cc(job):
         src, obj = job
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + os.environ.get("FMMT_CFLAGS", "").split() + ["-c", src, "-o", obj]      # FMMT_CFLAGS: development builds (e.g. -DFMMT_P256_TRACE)
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

@@ -514,8 +514,9 @@ __device__ __forceinline__ void nt_read_frags(bf16x8 (&o)[NF], const unsigned (&
     }
 }
 
-template <int BN, int BK, int NBUF, bool BATCH = true, bool HASOP = false>
+template <int BN, int BK, int NBUF, bool BATCH = true, bool HASOP = false, bool PIPE = false>
 __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
+
     using T = bf16;
     constexpr int BM = 256, PITCH = BK, MT = 8, NT = BN / 64, WN = BN / 4, CW = 4 * NT;
     constexpr int RPI = BK == 64 ? 8 : 16;                 // tile rows per DMA instruction (64 lanes x 16 B = 1 KB)
@@ -554,28 +555,39 @@ __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
     // DMA instructions this wave issues per stage (wave 7 carries the bias slab on top)
     const int my_cnt = (NI - wave + 7) / 8 + (wave == 7 ? 1 : 0);
     const bool cnt_hi = my_cnt > CNT_LO;                                            // CNT_LO or CNT_LO + 1 (+ 2 never: see below)
-    auto issue = [&](int slot, int m0, int n0, int k0, int par) {
-        T* base = S + slot * STAGE;
+    // Addresses of the DMA pieces.  A piece's global address is (uniform base) + (32-bit byte offset of this lane's 16 bytes at
+    // k = 0, recomputed when the issue cursor enters a tile) + (k offset): one VALU add per piece and K step, the SGPR-base form
+    // of the instruction.  (Formed from scratch per piece -- row, channel permutation, 64-bit row x pitch product -- the address
+    // arithmetic was ~12 VALU instructions per piece, and the issue phase 1370 cycles of a 4100-cycle K step, s_memtime stamps.)
+    constexpr int NP = (NI + 7) / 8;                       // pieces per wave and stage (the last may be absent: j >= NI)
+    unsigned poff[NP], boff = 0;
+    auto tile_offsets = [&](int m0, int n0) {
 #pragma unroll
-        for (int i = 0; i < (NI + 7) / 8; ++i) {
-            const int j = i * 8 + wave;                                             // wave-uniform
-            if (j < NI) {
-                const int row0 = j * RPI;
-                const T* src;
-                if (row0 < BN) {
-                    const int r = row0 + rl;
-                    src = wg + (size_t)(n0 + wchan(r)) * p.ldw + k0 + ((cl ^ key(r)) << 3);
-                } else {
-                    const int rx = row0 - BN;
-                    const int rb = min(m0 + rx, p.M - RPI);                         // ragged last panel: re-read valid rows (never stored)
-                    src = xg + (size_t)(rb + rl) * p.ldx + k0 + ((cl ^ key(rx + rl)) << 3);
-                }
-                __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(base + row0 * PITCH), 16, 0, 0);
+        for (int i = 0; i < NP; ++i) {
+            const int row0 = (i * 8 + wave) * RPI;                                    // wave-uniform
+            if (row0 < BN) {
+                const int r = row0 + rl;
+                poff[i] = ((unsigned)(n0 + wchan(r)) * (unsigned)p.ldw + (unsigned)((cl ^ key(r)) << 3)) * 2u;
+            } else {
+                const int rx = row0 - BN;
+                const int rb = min(m0 + rx, p.M - RPI);                             // ragged last panel: re-read valid rows (never stored)
+                poff[i] = ((unsigned)(rb + rl) * (unsigned)p.ldx + (unsigned)((cl ^ key(rx + rl)) << 3)) * 2u;
             }
         }
+        boff = p.bias ? (unsigned)(n0 + min(lane * 4, BN - 4)) * 4u : (unsigned)lane * 16u;
+    };
+    auto issue_piece = [&](int i, int slot, unsigned kbyte) {
+        const int j = i * 8 + wave;
+        if (j < NI) {
+            const int row0 = j * RPI;
+            const char* b = row0 < BN ? reinterpret_cast<const char*>(wg) : reinterpret_cast<const char*>(xg);
+            __builtin_amdgcn_global_load_lds((gptr_t*)(b + (size_t)(poff[i] + kbyte)), (lptr_t*)(S + slot * STAGE + row0 * PITCH), 16, 0, 0);
+        }
+    };
+    auto issue_bias = [&](int par) {
         if (wave == 7) {
-            const float* bsrc = p.bias ? p.bias + n0 + min(lane * 4, BN - 4) : reinterpret_cast<const float*>(wg) + lane * 4;
-            __builtin_amdgcn_global_load_lds((gptr_t*)bsrc, (lptr_t*)(bias_s + par * 256), 16, 0, 0);
+            const char* b = p.bias ? reinterpret_cast<const char*>(p.bias) : reinterpret_cast<const char*>(wg);
+            __builtin_amdgcn_global_load_lds((gptr_t*)(b + (size_t)boff), (lptr_t*)(bias_s + par * 256), 16, 0, 0);
         }
     };
     // The oldest stage in flight has landed when at most `ahead` younger stages -- and the `stores` store instructions this wave
@@ -648,22 +660,31 @@ __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
     };
 
     const int G = gridDim.x;                               // multiple of 8
-    const int first = ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3);
     const int total = p.tiles_m * p.tiles_n;
+    // (Tile order: a contiguous run of tiles per workgroup -- a token panel fetched from HBM by its first tile, re-read from L2 /
+    //  MALL by the same workgroup's next tiles_n - 1 -- was measured against this round-robin order: 0-10 % slower, every shape.)
+    const int first = ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3);
+    const int tstep = G;
     const int ntile = first < total ? (total - first + G - 1) / G : 0;
     const int nsteps = ntile * nk;
     // issue-side cursor
-    int it = first, ik = 0, im0 = (first / p.tiles_n) * BM, in0 = (first % p.tiles_n) * BN, ipar = 0, islot = 0;
-    auto issue_next = [&]() {
-        issue(islot, im0, in0, ik * BK, ipar);
+    int it = first, ik = 0, ipar = 0, islot = 0;
+    tile_offsets((first / p.tiles_n) * BM, (first % p.tiles_n) * BN);
+    auto issue_advance = [&]() {
         islot = islot + 1 == NBUF ? 0 : islot + 1;
         if (++ik == nk) {
             ik = 0;
-            it += G;
-            im0 = (it / p.tiles_n) * BM;
-            in0 = (it % p.tiles_n) * BN;
+            it += tstep;
             ipar ^= 1;
+            tile_offsets((it / p.tiles_n) * BM, (it % p.tiles_n) * BN);
         }
+    };
+    auto issue_next = [&]() {
+        const unsigned kbyte = (unsigned)ik * (BK * 2);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) issue_piece(i, islot, kbyte);
+        issue_bias(ipar);
+        issue_advance();
     };
 #pragma unroll
     for (int s = 0; s < NBUF - 1; ++s)
@@ -689,17 +710,121 @@ __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
     const bool lds_gelu = p.epi == FMMT_EPI_GELU && !(p.reserved & 8);      // GELU (+ pre-activation): two tensors through the slab
     const bool lds_epi = !HASOP && (p.epi == 0 || lds_gelu) && (!p.y_pre || lds_gelu) && !p.part && !(p.reserved & 4) && p.K <= 1536;
     T* __restrict__ yg = reinterpret_cast<T*>(p.y);
-    for (int s = 0; s < nsteps; ++s) {
-        wait_landed(min(nsteps - 1 - s, NBUF - 2), st_prev);
-        st_prev = 0;
-        __builtin_amdgcn_s_barrier();                      // every wave's part of stage s is in LDS; stage s - 1 is free
-        if constexpr (HASOP) {
-            // residual / GELU' operand / DropPath scale of THIS tile: loaded now, in front of this step's DMA, used after the
-            // step's MFMAs
-            if (ck == nk - 1) nt_epilogue_prefetch<MT, NT>(p, pre, (ct / p.tiles_n) * BM + wm * 128, (ct % p.tiles_n) * BN + wn * WN, li, lg);
+    // PIPE: fragment reads software-pipelined against the MFMAs.  The eight waves of the workgroup pass the K step's barrier
+    // together, so with "read a K block's fragments, wait, issue its MFMAs" they all queue on the LDS at once (88 KB per K block
+    // at 128 B per cycle: ~700 cycles) and then all on the matrix cores (2 waves x 24 MFMAs x 16 cycles per SIMD): the two
+    // phases alternate instead of overlapping, and a K step takes ~4100 cycles for 1536 cycles of MFMA work.  Here a K step is
+    // cut into micro-batches of XB token fragments (+ the weight fragments at the head of a K block); the reads of micro-batch
+    // u + 1 are issued in front of the MFMAs of micro-batch u and waited for behind them, two register buffers alternating.
+    // The step's barrier moves in front of the LAST micro-batch's MFMAs: by then every read of stage s has returned (the slot
+    // is free for the DMA of stage s + NBUF) and the first reads of stage s + 1 can go out under those MFMAs.
+    constexpr int XB = NT >= 4 ? 2 : 4;                    // token fragments per micro-batch (register budget: 128 accumulators at NT = 4)
+    constexpr int UB = MT / XB, U = (BK / 32) * UB;        // micro-batches per 32-deep K block / per K step
+    bf16x8 pw[2][NT], px[2][XB];
+    auto request = [&](int slot, int u) {                  // issue (do not wait for) the fragment reads of micro-batch u
+        const unsigned sbase = lds0 + (unsigned)slot * (unsigned)(STAGE * 2);
+        const int kk = u / UB, h = u % UB;
+        const unsigned flip = kk ? 64u : 0u;
+        if (h == 0) {
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+                asm volatile("ds_read_b128 %0, %1" : "=v"(pw[kk & 1][b]) : "v"((((unsigned)woff[b] * 2u) ^ flip) + sbase) : "memory");
         }
-        if (s + NBUF - 1 < nsteps) issue_next();
-        compute(cslot);
+#pragma unroll
+        for (int a = 0; a < XB; ++a)
+            asm volatile("ds_read_b128 %0, %1" : "=v"(px[u & 1][a]) : "v"((((unsigned)xoff[h * XB + a] * 2u) ^ flip) + sbase) : "memory");
+    };
+    auto landed = [&](int u) {                             // the reads request(.., u) issued have returned
+        const int kk = u / UB, h = u % UB;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int a = 0; a < XB; ++a) asm volatile("" : "+v"(px[u & 1][a]));
+        if (h == 0) {
+#pragma unroll
+            for (int b = 0; b < NT; ++b) asm volatile("" : "+v"(pw[kk & 1][b]));
+        }
+    };
+    bool pend = false;
+    // sync point of stage k: its DMA has landed for every wave, and every wave is done reading the stage before it
+    auto sync_stage = [&](int k, int ck_k, int ct_k) {
+        wait_landed(min(nsteps - 1 - k, NBUF - 2), st_prev);
+        st_prev = 0;
+        __builtin_amdgcn_s_barrier();
+        if constexpr (HASOP) {
+            // residual / GELU' operand / DropPath scale of the tile that step k completes: loaded now, in front of the DMA, used
+            // after the step's MFMAs
+            if (ck_k == nk - 1) nt_epilogue_prefetch<MT, NT>(p, pre, (ct_k / p.tiles_n) * BM + wm * 128, (ct_k % p.tiles_n) * BN + wn * WN, li, lg);
+        }
+        if constexpr (PIPE) {
+            pend = k + NBUF - 1 < nsteps;                  // the stage at the issue cursor goes out piecewise: issue_group
+        } else {
+            if (k + NBUF - 1 < nsteps) issue_next();
+        }
+    };
+    // PIPE: the DMA pieces of the stage that sync point P(k) releases a slot for go out in NG groups, one in front of the MFMAs
+    // of each of the next NG micro-batches (the one P(k) sits in, then the first ones of step k).  What the s_memtime stamps say
+    // about a K step of the plain loop (256 x 192 tile, cycles per wave): DMA issue 940-1370, fragment reads + MFMAs 1040-1300,
+    // barrier + DMA wait 950-1150 -- and the issue phase is not address arithmetic (12 -> 2 VALU instructions per piece took it
+    // from 1370 to 940): a piece occupies the CU's one vector-memory path for ~16 cycles (64 B per cycle), the eight waves issue
+    // their 7 pieces together, each piece queues behind the other waves' (~125 cycles per piece).  The path's 900 cycles, the
+    // LDS's ~1150 and the matrix cores' 1630 per K step add up instead of overlapping because the barrier keeps all waves in the
+    // same phase.  Moving groups of pieces under later micro-batches trades issue-phase cycles for DMA-wait cycles (a stage has
+    // one K step to land): worth 5-10 % at K >= 768, nothing at K = 384, a loss at K = 192; turns taken by wave class within a
+    // micro-batch (SIMD partners in different classes): 0-5 % slower.
+    constexpr int NG = BN == 256 ? 1 : 2;                  // same-call A/B of 1 / 2 / 3 groups, see launch_p256
+    auto issue_group = [&](int g) {
+        if (!pend) return;
+        const unsigned kbyte = (unsigned)ik * (BK * 2);
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+            if ((i * NG) / NP == g) issue_piece(i, islot, kbyte);
+        if (g == NG - 1) {
+            issue_bias(ipar);
+            issue_advance();
+        }
+    };
+    if constexpr (PIPE) {
+        static_assert(BK == 64 && BATCH, "pipelined reads: 64-deep K steps (the weight buffers alternate by K block)");
+        if (nsteps > 0) {
+            sync_stage(0, 0, first);
+            issue_group(0);
+            request(0, 0);
+            landed(0);
+        }
+    }
+    for (int s = 0; s < nsteps; ++s) {
+        if constexpr (PIPE) {
+            const int nslot = cslot + 1 == NBUF ? 0 : cslot + 1;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                int grp_now = -1;                          // the DMA group that goes out under this micro-batch's MFMAs
+                if (u + 1 < U) {
+                    request(cslot, u + 1);
+                    if (u + 1 < NG) grp_now = u + 1;
+                } else if (s + 1 < nsteps) {
+                    const bool wrap = ck + 1 == nk;
+                    sync_stage(s + 1, wrap ? 0 : ck + 1, wrap ? ct + tstep : ct);
+                    request(nslot, 0);
+                    grp_now = 0;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (grp_now >= 0) issue_group(grp_now);
+                {
+                    const int kk = u / UB, h = u % UB;
+#pragma unroll
+                    for (int a = 0; a < XB; ++a)
+#pragma unroll
+                        for (int b = 0; b < NT; ++b)
+                            acc[h * XB + a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pw[kk & 1][b], px[u & 1][a], acc[h * XB + a][b], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (u + 1 < U) landed(u + 1);
+                else if (s + 1 < nsteps) landed(0);
+            }
+        } else {
+            sync_stage(s, ck, ct);
+            compute(cslot);
+        }
         cslot = cslot + 1 == NBUF ? 0 : cslot + 1;
         if (++ck == nk) {
             const int m0 = (ct / p.tiles_n) * BM, n0 = (ct % p.tiles_n) * BN;
@@ -745,7 +870,7 @@ __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
                         if (two) emit(a, ypre, false);
                         emit(a, yg, p.epi == FMMT_EPI_GELU);
                     }
-                    if (mw + 128 <= p.M) st_prev = MT * 2 * (two ? 2 : 1);
+                    if (!PIPE && mw + 128 <= p.M) st_prev = MT * 2 * (two ? 2 : 1);   // (PIPE: DMA pieces follow the stores, see issue_group)
                 }
             } else if (lds_epi) {
                 const int rows_left = p.M - (m0 + wm * 128);             // token rows of this wave group that exist
@@ -799,7 +924,7 @@ __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
                     round(pass, yg, lds_gelu);
                 }
                 // a wave group with all its 128 rows inside M issued exactly this many stores per wave (ragged panel: unknown -> 0)
-                if (rows_left >= 128) st_prev = (128 / PR) * NSL * (two ? 2 : 1);
+                if (!PIPE && rows_left >= 128) st_prev = (128 / PR) * NSL * (two ? 2 : 1);
             } else if constexpr (HASOP) {
                 nt_epilogue<T, MT, NT, true, true>(p, acc, m0 + wm * 128, n0 + wn * WN, li, lg, &pre);
             } else {
@@ -810,19 +935,19 @@ __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
 #pragma unroll
                 for (int b = 0; b < NT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
             ck = 0;
-            ct += G;
+            ct += tstep;
             cpar ^= 1;
         }
     }
 }
 
-template <int BN, int BK, int NBUF, bool BATCH, bool HASOP>
+template <int BN, int BK, int NBUF, bool BATCH, bool HASOP, bool PIPE = false>
 int launch_p256_b(const LinArgs& a, hipStream_t st) {
     constexpr size_t lds = (size_t)NBUF * (BN + 256) * BK * 2 + 2 * 256 * sizeof(float) + (BN == 256 ? 8 * 16 * 144 : 2 * (BN == 192 ? 32 : 16) * (BN * 2 + 16));   // ring, bias slabs, epilogue scratch (BN = 256: wave-private slabs)
     static_assert(lds <= 160 * 1024, "LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_nt_p256_kernel<BN, BK, NBUF, BATCH, HASOP>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_nt_p256_kernel<BN, BK, NBUF, BATCH, HASOP, PIPE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -835,7 +960,7 @@ int launch_p256_b(const LinArgs& a, hipStream_t st) {
     static const int lds_gelu = fmmt_const("FMMT_NT_P256_LDSGELU", 0);   // measured slower (two tensors, 16-row passes: 32 barriers per tile): 273 -> 296 us
     static const int wrows = fmmt_const("FMMT_NT_P256_WROWS", 1);
     p.reserved = (lds_epi ? 0 : 4) | (lds_gelu ? 0 : 8) | (wrows ? 0 : 64);
-    hipLaunchKernelGGL((linear_nt_p256_kernel<BN, BK, NBUF, BATCH, HASOP>), dim3(256), dim3(512), lds, st, p);
+    hipLaunchKernelGGL((linear_nt_p256_kernel<BN, BK, NBUF, BATCH, HASOP, PIPE>), dim3(256), dim3(512), lds, st, p);
     FMMT_CHECK_LAUNCH();
     return 0;
 }
@@ -853,6 +978,14 @@ int launch_p256(const LinArgs& a, hipStream_t st) {
         static const int plainop = fmmt_const("FMMT_NT_P256_PLAINOP", 1);
         if (plainop && !a.part && (a.K > 1536 || plainop > 1)) return launch_p256_b<BN, BK, NBUF, true, true>(a, st);
     }
+    if constexpr (BK == 64) {
+        // Pipelined fragment reads + DMA pieces in groups (PIPE), for K >= 384.  Same-call A/B against the plain loop, us per
+        // launch: 31360 x 2304 x 768 124 -> 115, 31360 x 3072 x 768 150 -> 141, 31360 x 768 x 768 44.4 -> 41.2, 125440 x 1536 x 384
+        // (256-wide tile, one group) 190 -> 178, 125440 x 384 x 384 52.7 -> 50.2, 125440 x 1152 x 384 / 384 x 1536 / 384 x 1152 +-1 %;
+        // K = 192 (three K steps per tile: the late pieces are waited for) 210 -> 220, stays on the plain loop.
+        static const int pipe = fmmt_const("FMMT_NT_P256_PIPE", 1);
+        if (pipe && a.K >= 384) return launch_p256_b<BN, BK, NBUF, true, false, true>(a, st);
+    }
     return batch ? launch_p256_b<BN, BK, NBUF, true, false>(a, st) : launch_p256_b<BN, BK, NBUF, false, false>(a, st);
 }
 
@@ -866,6 +999,7 @@ int p256_plan(const LinArgs& a) {
     static const int minm = fmmt_const("FMMT_NT_P256_MINM", 16384);      // fewest tokens for this kernel
     if (!mode || a.ksplit || a.M < minm || a.M % 16 || a.K % 32 || a.K < 96 || a.ldx % 8 || a.ldw % 8) return 0;
     if (a.K % 64 && !k32) return 0;
+    if ((unsigned long long)a.M * a.ldx >= (1ull << 31) || (unsigned long long)a.N * a.ldw >= (1ull << 31)) return 0;   // 32-bit byte offsets of the DMA pieces
     // One workgroup per CU has nothing to hide an epilogue's own M x N loads behind (residual, GELU' operand, DropPath
     // scale: the in-order vmcnt also makes them wait for the DMA stages in flight).  Measured on MI355X
     // (profiles/r02_gemm_shapes.txt): plain / bias / GELU + pre-activation launches gain 5-50 % over the two-workgroup

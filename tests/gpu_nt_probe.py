@@ -3,6 +3,9 @@ process per setting, same gpurun call); --vendor adds hipBLASLt (torch.nn.functi
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from facialmmt_amd import _lib
+if os.environ.get("PROBE_LIB"):                                # A/B of two builds in one gpurun call
+    _lib.LIB_PATH = os.environ["PROBE_LIB"]
 from facialmmt_amd import ops
 from facialmmt_amd._lib import EPI_GELU, EPI_GELU_BWD
 dev = torch.device("cuda:0")
