@@ -18,10 +18,13 @@ Other BASELINE.json configs (each run prints its own line naming its configs[i])
     --config 4    320-frame face sequence, 1 utterance/GPU, 150 auxiliary images per step          (configs[4], per-GPU leg)
 
 Rank 0 prints ONE JSON line: metric utterances/s (whole job), plus
-  roofline     -- the dominant kernel family of the Linear layers (largest total time), timed with HIP events on the launch
-                  stream in eager steps issued right after the timed region (the timed steps themselves are two HIP-graph
-                  replays each, inside which nothing can be bracketed): achieved = sum(2*M*N*K) / sum(duration) against the
-                  2.5 PFLOP/s dense bf16 MFMA peak; `traffic` from the committed PMC pass (profiles/traffic.json);
+  roofline     -- the dominant kernel family (largest total GPU time among the bracketed many-token launches), timed with HIP
+                  events on the launch stream in eager steps issued right after the timed region (the timed steps themselves
+                  are HIP-graph replays, inside which nothing can be bracketed).  Its bound follows from its algorithmic
+                  intensity: above 312 FLOP/B (2.5 PFLOP/s / 8 TB/s) achieved = sum(2*M*N*K) / sum(duration) against the dense
+                  bf16 MFMA peak, below it achieved = algorithmic bytes / duration against 8 TB/s; `traffic` from the committed
+                  PMC pass (profiles/traffic.json); `families` lists every bracketed family, `roofline_mfma` / `roofline_hbm`
+                  the largest family on either side of the ridge;
   cpu_baseline -- the oracle (CPU restatement, fp32) timed on the host cores of this box on a bounded sample of the same
                   workload (N=1 only): forward+backward (value) and forward-only, with a thread sweep."""
 from __future__ import annotations
@@ -225,7 +228,7 @@ class KernelTimer:
                 else:
                     bn = "deep256x96x32" + nk
             if p256:
-                plainop = 1
+                plainop = 0
                 hasop = kw.get("res") is not None or kw.get("rowscale") is not None or kw.get("aux") is not None
                 isop = p256 != 256 and (hasop or (plainop and (K > 1536 or plainop > 1)))
                 bn = f"p256x{p256}" + ("op" if isop else "pipe" if K >= 384 else "")      # launch_p256: pipelined K loop from K = 384
@@ -674,7 +677,7 @@ def main():
         if args.shape_report:
             with open(args.shape_report, "w") as f:
                 f.write(timer.shape_report(args.steps) + "\n")
-        roof = roof_hbm = None
+        roof = roof_hbm = roof_mfma = None
         if fams:
             # the dominant kernel = the family with the most GPU time among the many-token launches (the few-token GEMMs of the
             # fusion stack are launch-bound 10-25 us kernels: many of them, no roofline to speak of)
@@ -687,7 +690,7 @@ def main():
                     tj = json.load(f)
                 t = tj.get(kname)
                 if t:
-                    traffic = (2 * t["fetch_size_kb"] + t["write_size_kb"]) * 1024
+                    traffic = (2 * t["fetch_size_kb"] + (t["write_size_kb"] or 0)) * 1024
                     traffic_src = f"profiles/traffic.json ({tj.get('_source', 'committed rocprofv3 --pmc pass')}): 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE per launch; not measured in this run"
             except OSError:
                 pass
@@ -695,8 +698,16 @@ def main():
             def rate(c, f, b, t):
                 return {"achieved": round(f / t / 1e12, 1), "frac": round(f / t / 1e12 / PEAK_BF16_TFLOPS, 4),
                         "avg_launch_us": round(t / c * 1e6, 1), "algorithmic_GB_per_s": round(b / t / 1e9, 0)}
-            roof = {"bound": "mfma", "kernel": kname, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s"}
-            roof.update(rate(cnt, fl, by, sec))
+            # bound of the dominant kernel from its algorithmic intensity: below the ridge (2.5 PFLOP/s / 8 TB/s = 312 FLOP/B) the HBM
+            # roofline is the lower one and `achieved` / `peak` are bytes per second
+            ridge = PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+            if fl / max(by, 1.0) < ridge:
+                roof = {"bound": "hbm", "kernel": kname, "peak": PEAK_HBM_GBS, "unit": "GB/s", "achieved": round(by / sec / 1e9, 0),
+                        "frac": round(by / sec / 1e9 / PEAK_HBM_GBS, 4), "avg_launch_us": round(sec / cnt * 1e6, 1),
+                        "TFLOP_per_s": round(fl / sec / 1e12, 1), "flop_per_byte": round(fl / max(by, 1.0), 1)}
+            else:
+                roof = {"bound": "mfma", "kernel": kname, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s"}
+                roof.update(rate(cnt, fl, by, sec))
             roof.update({"traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": round(by / cnt), "launches_per_step": cnt // 2,
                          "share_of_step": round(sec / 2 / (ms * 1e-3), 3),
@@ -705,6 +716,13 @@ def main():
             if live:
                 roof["in_timed_region_with_text_stream"] = rate(*live)
                 roof["frac_in_timed_region"] = roof["in_timed_region_with_text_stream"]["frac"]
+            # the largest family above the ridge as well (the dominant kernel by time may be an HBM-bound one)
+            mf = [(k, v) for k, v in big.items() if v[1] / max(v[2], 1.0) >= ridge]
+            if mf:
+                k, v = max(mf, key=lambda kv: kv[1][3])
+                roof_mfma = {"bound": "mfma", "kernel": kernel_symbol(k), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "launches_per_step": v[0] // 2,
+                             "ms_per_step": round(v[3] / 2 * 1e3, 3)}
+                roof_mfma.update(rate(*v))
             # every bracketed family, Linear or not: time per step, TFLOP/s and algorithmic GB/s; bound = "hbm" where the algorithmic
             # intensity is below the ridge (2.5 PFLOP/s / 8 TB/s = 312 FLOP/B)
             def fam(v):
@@ -749,6 +767,7 @@ def main():
                        "exchange_ms_exposed": (xchg or {}).get("ms_exposed_after_swin_backward"), "exchange": xchg},
             "roofline": roof,
             "roofline_hbm": roof_hbm,
+            "roofline_mfma": roof_mfma,
             "cpu_baseline": None,
             "pcie_inclusive": pcie,
         }
@@ -788,7 +807,8 @@ def other_configs(args):
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
             j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
             out[f"configs[{c}]"] = {"ms_per_step": j["ms_per_step"], "value": j["value"], "unit": j["unit"], "steps": j["steps"], "workload": j["config"]["workload"],
-                                    "dominant_kernel": (j.get("roofline") or {}).get("kernel"), "frac": (j.get("roofline") or {}).get("frac"),
+                                    "dominant_kernel": (j.get("roofline") or {}).get("kernel"), "bound": (j.get("roofline") or {}).get("bound"),
+                                    "frac": (j.get("roofline") or {}).get("frac"),
                                     "traffic": (j.get("roofline") or {}).get("traffic")}
         except Exception as e:                               # a reported leg only
             out[f"configs[{c}]"] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}

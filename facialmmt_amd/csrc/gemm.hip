@@ -972,10 +972,10 @@ int launch_p256(const LinArgs& a, hipStream_t st) {
         // launches with an M x N epilogue operand or a DropPath scale: operand prefetched into registers (48 / 32 of them:
         // no room beside the 128 accumulators of the 256-wide tile)
         if (a.res || a.aux || a.rowscale) return launch_p256_b<BN, BK, NBUF, true, true>(a, st);
-        // FMMT_NT_P256_PLAINOP: 1 (default) = operand-free launches whose epilogue stores directly (K > 1536) take the
-        // operand-prefetch instantiation as well -- same-call A/B on 31360 x 768 x 3072: 160.3 -> 153.5 us; 2 = all operand-free
-        // launches (K <= 1536 then lose the LDS epilogue: slower); 0 = none
-        static const int plainop = fmmt_const("FMMT_NT_P256_PLAINOP", 1);
+        // FMMT_NT_P256_PLAINOP: 1 = operand-free launches whose epilogue stores directly (K > 1536) take the operand-prefetch
+        // instantiation as well (round 2: 31360 x 768 x 3072 160 -> 153 us); against the pipelined loop below it loses (135 -> 127 us,
+        // same call): 0
+        static const int plainop = fmmt_const("FMMT_NT_P256_PLAINOP", 0);
         if (plainop && !a.part && (a.K > 1536 || plainop > 1)) return launch_p256_b<BN, BK, NBUF, true, true>(a, st);
     }
     if constexpr (BK == 64) {

@@ -39,5 +39,9 @@ rm -rf $O/prof_$TAG $O/profiso_$TAG $O/pmc_FETCH_SIZE_$TAG $O/pmc_WRITE_SIZE_$TA
 GEMM_BENCH_VENDOR=1 timeout 600 python tests/gpu_gemm_bench.py > $S/gemm_shapes.txt 2>&1
 timeout 300 python tests/gpu_nt_probe.py --vendor > $S/nt_shapes.txt 2>&1
 timeout 300 python tests/gpu_tn_probe.py > $S/tn_shapes.txt 2>&1
-{ FMMT_NT_SMALL=0 timeout 200 python tests/gpu_few_probe.py; timeout 200 python tests/gpu_few_probe.py; } > $S/few_shapes.txt 2>&1
+timeout 200 python tests/gpu_few_probe.py > $S/few_shapes.txt 2>&1
+# Swin forward + backward alone (640 frames) with its own per-kernel table, and the fused stage-0 launches one by one
+timeout 300 python tests/gpu_time_swin.py 640 > $S/swin_time.txt 2>&1
+bash tools/prof_swin.sh > /dev/null 2>&1; cp $O/swin_kernel_stats.md $S/swin_kernel_stats.md
+timeout 300 python tests/gpu_wblock.py --speed > $S/wblock_speed.txt 2>&1
 cut -c1-300 $S/bench.json

@@ -43,7 +43,7 @@ def pmc(d):
     print("# rocprofv3 --pmc (own pass): per-kernel counter sums and per-dispatch averages\n")
     print("| kernel | counter | dispatches | sum | avg / dispatch |\n|---|---|---:|---:|---:|")
     order = sorted(agg.items(), key=lambda kv: -max(v[1] for v in kv[1].values()))
-    for k, cs in order[:30]:
+    for k, cs in order[:int(os.environ.get("PMC_ROWS", "60"))]:
         for c, (n, s) in sorted(cs.items()):
             print(f"| `{k[:90]}` | {c} | {n} | {s:.4g} | {s / n:.4g} |")
 
