@@ -11,6 +11,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "gelu_lut_data.h"
 
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -115,6 +116,31 @@ __device__ __forceinline__ f32x2 gelu_grad_fast2(f32x2 x) {
     gelu_parts2(x, cdf, g);
     return x * g * 0.3989422804014327f + cdf;
 }
+// Table form for the bf16 kernels whose epilogue is VALU-bound (fused Mlp: 32 activations per lane and 64-channel stage against 36 MFMAs;
+// GELU / GELU' epilogues of the GEMMs): the polynomial above is ~20 issue slots per element with its two quarter-rate transcendentals
+// (57 % of the fused Mlp's cycles).  Phi(x) -- or gelu'(x) = Phi(x) + x phi(x) -- tabulated on [-8, 8) in steps of 1/64 as
+// (value, difference to the next entry) pairs (gelu_lut_data.h, generated in double precision by tools/gen_gelu_lut.py), copied into
+// LDS (8 KB) by the kernel, linear interpolation: fma, med3, cvt, fract, address, ds_read_b64, fma = 6 VALU + 1 LDS read.
+// Interpolation error h^2/8 |f''|: <= 8e-6 absolute for Phi (relative <= 2e-3 out to x = -8: the curvature decays with the function),
+// <= 3e-5 for gelu' -- below the bf16 rounding of what is stored.  The fp32 (parity) kernels keep erff.
+constexpr int GELU_LUT_N = 1024;
+constexpr int GELU_LUT_BYTES = GELU_LUT_N * 8;
+typedef __attribute__((ext_vector_type(2))) float lut2_t;
+// copy a table into LDS: 512 chunks of 16 bytes; the caller makes it visible (barrier) before the first gelu_lut()
+__device__ __forceinline__ void gelu_lut_copy(lut2_t* tab, const float* src, int tid, int nthreads) {
+    for (int i = tid; i < GELU_LUT_BYTES / 16; i += nthreads)
+        reinterpret_cast<f32x4*>(tab)[i] = reinterpret_cast<const f32x4*>(src)[i];
+}
+__device__ __forceinline__ float gelu_lut(const lut2_t* tab, float x) {
+    float t = __builtin_fmaf(x, 64.0f, (float)(GELU_LUT_N / 2));
+    t = __builtin_amdgcn_fmed3f(t, 0.0f, (float)GELU_LUT_N - 0.001f);
+    const lut2_t e = tab[(int)t];
+    return __builtin_fmaf(__builtin_amdgcn_fractf(t), e.y, e.x);
+}
+// v[e] <- gelu(v[e]) / v[e] <- v[e] * gelu'(pre[e]) through a table in LDS (nullptr: the polynomial)
+template <typename T> __device__ __forceinline__ void gelu_inplace_lut(const lut2_t* tab, float* v, int n);
+template <typename T> __device__ __forceinline__ void gelu_grad_mul_inplace_lut(const lut2_t* tab, float* v, const float* pre, int n);
+
 // element-type dispatch used by the GEMM epilogue: exact for float, packed-fast for bf16
 template <typename T> __device__ __forceinline__ void gelu_inplace(float* v, int n) {
     if constexpr (sizeof(T) == 4) {
@@ -141,6 +167,16 @@ template <typename T> __device__ __forceinline__ void gelu_grad_mul_inplace(floa
             v[e + 1] *= r.y;
         }
     }
+}
+template <typename T> __device__ __forceinline__ void gelu_inplace_lut(const lut2_t* tab, float* v, int n) {
+    if (sizeof(T) == 4 || !tab) return gelu_inplace<T>(v, n);
+#pragma unroll
+    for (int e = 0; e < n; ++e) v[e] *= gelu_lut(tab, v[e]);
+}
+template <typename T> __device__ __forceinline__ void gelu_grad_mul_inplace_lut(const lut2_t* tab, float* v, const float* pre, int n) {
+    if (sizeof(T) == 4 || !tab) return gelu_grad_mul_inplace<T>(v, pre, n);
+#pragma unroll
+    for (int e = 0; e < n; ++e) v[e] *= gelu_lut(tab, pre[e]);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -327,7 +327,8 @@ __global__ __launch_bounds__(512) void linear_nt_deep_kernel(LinArgs p) {
     } else {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                      // every wave is done with the K loop's stages
-        nt_epilogue_wslab<T>(p, acc, smem + wave * (16 * 272), lane, li, lg, m0 + wm * 64, n0 + wn * 64);
+        const lut2_t* lut = wslab_stage_lut<3 * STAGE * 2>(p, smem, tid, 512);
+        nt_epilogue_wslab<T>(p, acc, smem + wave * (16 * 272), lane, li, lg, m0 + wm * 64, n0 + wn * 64, lut);
     }
 }
 
@@ -447,7 +448,8 @@ void linear_nt_deep32_kernel(LinArgs p) {
         if constexpr (BN == 128) {                         // operand / GELU epilogues: wave-private slab, whole 128-byte lines
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                  // every wave is done with the K loop's stages
-            nt_epilogue_wslab<T>(p, acc, smem + wave * (16 * 272), lane, li, lg, m0 + wm * 64, n0 + wn * WN);
+            const lut2_t* lut = wslab_stage_lut<3 * STAGE * 2>(p, smem, tid, 512);
+            nt_epilogue_wslab<T>(p, acc, smem + wave * (16 * 272), lane, li, lg, m0 + wm * 64, n0 + wn * WN, lut);
         }
     }
 }
@@ -686,6 +688,18 @@ __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
         issue_bias(ipar);
         issue_advance();
     };
+    // GELU epilogue of the 256-wide tile (fc1 forward of stages 2 / 3): Phi table in LDS behind the wave slabs (fmmt_common.h), copied
+    // before the first DMA goes out (the copy's own loads are ordinary ones: waited for with vmcnt(0)); the first K step's barrier
+    // publishes it
+    const lut2_t* lut = nullptr;
+    if constexpr (BN == 256 && !HASOP) {
+        if (p.epi == FMMT_EPI_GELU) {
+            lut2_t* l = reinterpret_cast<lut2_t*>(smem + (size_t)NBUF * STAGE * sizeof(T) + 2 * 256 * sizeof(float) + 8 * (16 * 144));
+            gelu_lut_copy(l, fmmt_gelu_lut_phi, tid, 512);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            lut = l;
+        }
+    }
 #pragma unroll
     for (int s = 0; s < NBUF - 1; ++s)
         if (s < nsteps) issue_next();
@@ -851,7 +865,7 @@ __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
                             float t[8];
 #pragma unroll
                             for (int e = 0; e < 8; ++e) t[e] = acc[a][2 * c + (e >> 2)][e & 3];
-                            if (gelu) gelu_inplace<T>(t, 8);
+                            if (gelu) gelu_inplace_lut<T>(lut, t, 8);
                             bf16x8 v;
 #pragma unroll
                             for (int e = 0; e < 8; ++e) v[e] = (bf16)t[e];
@@ -943,7 +957,7 @@ __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
 
 template <int BN, int BK, int NBUF, bool BATCH, bool HASOP, bool PIPE = false>
 int launch_p256_b(const LinArgs& a, hipStream_t st) {
-    constexpr size_t lds = (size_t)NBUF * (BN + 256) * BK * 2 + 2 * 256 * sizeof(float) + (BN == 256 ? 8 * 16 * 144 : 2 * (BN == 192 ? 32 : 16) * (BN * 2 + 16));   // ring, bias slabs, epilogue scratch (BN = 256: wave-private slabs)
+    constexpr size_t lds = (size_t)NBUF * (BN + 256) * BK * 2 + 2 * 256 * sizeof(float) + (BN == 256 ? 8 * 16 * 144 + GELU_LUT_BYTES : 2 * (BN == 192 ? 32 : 16) * (BN * 2 + 16));   // ring, bias slabs, epilogue scratch (BN = 256: wave-private slabs + the GELU table)
     static_assert(lds <= 160 * 1024, "LDS");
     static bool attr_set = false;
     if (!attr_set) {

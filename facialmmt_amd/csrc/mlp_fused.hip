@@ -72,6 +72,9 @@ __global__ __launch_bounds__(512) void mlp_fused_fwd_kernel(MlpArgs p) {
     const int li = lane & 15, lg = lane >> 4;
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
+    lut2_t* lut = reinterpret_cast<lut2_t*>(smem + NBUF * STAGE_B);          // Phi(x) table (fmmt_common.h), behind the ring
+    gelu_lut_copy(lut, fmmt_gelu_lut_phi, tid, 512);
+    __syncthreads();
     auto swz = [](int row) { return ((row >> 3) ^ (row >> 2)) & 3; };       // 16-byte chunk swizzle of 64-byte rows (as linear_nt_deep32)
     const int r16 = lane >> 2, c4 = lane & 3;
 
@@ -252,7 +255,8 @@ __global__ __launch_bounds__(512) void mlp_fused_fwd_kernel(MlpArgs p) {
                 bf16x8 pre8;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) pre8[e] = (bf16)v[e];
-                gelu_inplace<T>(v, 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= gelu_lut(lut, v[e]);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) hf[mt][e] = (bf16)v[e];
                 if (blk == 0) {
@@ -345,6 +349,9 @@ __global__ __launch_bounds__(512) void mlp_fused_bwd_kernel(MlpArgs p) {
     const int li = lane & 15, lg = lane >> 4;
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
+    lut2_t* lut = reinterpret_cast<lut2_t*>(smem + NBUF * STAGE_B);          // gelu'(x) table (fmmt_common.h), behind the ring
+    gelu_lut_copy(lut, fmmt_gelu_lut_grad, tid, 512);
+    __syncthreads();
     auto swz = [](int row) { return ((row >> 3) ^ (row >> 2)) & 3; };
     const int r16 = lane >> 2, c4 = lane & 3;
 
@@ -474,9 +481,8 @@ __global__ __launch_bounds__(512) void mlp_fused_bwd_kernel(MlpArgs p) {
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) ax[e] = (float)cur[mt * 2 + blk][e];
-                gelu_grad_mul_inplace<T>(v, ax, 8);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) hf[mt][e] = (bf16)(v[e] * rsv[mt]);
+                for (int e = 0; e < 8; ++e) hf[mt][e] = (bf16)(v[e] * gelu_lut(lut, ax[e]) * rsv[mt]);
                 const int tok = t0 + mt * 16 + li;
                 if (blk == 0) keep[mt] = hf[mt];
                 else if (tok < p.M) {
@@ -519,7 +525,7 @@ __global__ __launch_bounds__(512) void mlp_fused_bwd_kernel(MlpArgs p) {
 
 template <int C>
 int launch_mlp_bwd(const MlpArgs& a, hipStream_t st) {
-    constexpr size_t lds = (size_t)3 * (((C / 32) * 64 * 32 + 2 * C * 32) * 2);
+    constexpr size_t lds = (size_t)3 * (((C / 32) * 64 * 32 + 2 * C * 32) * 2) + GELU_LUT_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_bwd_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -534,7 +540,7 @@ int launch_mlp_bwd(const MlpArgs& a, hipStream_t st) {
 
 template <int C, bool LN>
 int launch_mlp(const MlpArgs& a, hipStream_t st) {
-    constexpr size_t lds = (size_t)3 * (((C / 32) * 64 * 32 + 2 * C * 32) * 2 + 1024);
+    constexpr size_t lds = (size_t)3 * (((C / 32) * 64 * 32 + 2 * C * 32) * 2 + 1024) + GELU_LUT_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_fwd_kernel<C, LN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

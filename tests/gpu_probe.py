@@ -22,6 +22,11 @@ def rnd(name, shape, seed=0, scale=1.0, dtype=torch.float32):
     return (synth.tensor(name, shape, seed=seed) * scale).to(dev).to(dtype)
 
 
+def one_ulp(a, b):
+    """bf16 tensors equal to within one rounding step at the largest magnitude"""
+    return bool((a.float() - b.float()).abs().max() <= b.float().abs().max() * 2.0 ** -7)
+
+
 def report(name, got, ref, tol):
     got, ref = got.float(), ref.float()
     err = (got - ref).abs().max().item()
@@ -168,7 +173,9 @@ def t_mlp_fused():
             hp_u = torch.empty((M, 4 * C), dtype=dt, device=dev)
             h_u = ops.linear_raw(x, w1, b1, epi=EPI_GELU, y_pre=hp_u)
             y_u = ops.linear_raw(h_u, w2, b2, res=r_, rowscale=s_, rows_per_scale=49)
-            RES.append((f"mlp fused == two launches {variant} {M}x{C}", bool(torch.equal(y_f, y_u)) and bool(torch.equal(hp_f, hp_u))))
+            # pre-activation: same products, same rounding -> bit-identical; y: the fused kernel's GELU is the LDS table, the GEMM epilogue's
+            # the table or the polynomial depending on the kernel -> equal to within one bf16 rounding of the hidden activation
+            RES.append((f"mlp fused == two launches {variant} {M}x{C}", one_ulp(y_f, y_u) and bool(torch.equal(hp_f, hp_u))))
             if not RES[-1][1]:
                 print(f"FAIL mlp fused vs two launches {variant} {M}x{C}: y {(y_f.float() - y_u.float()).abs().max().item():.3e} "
                       f"pre {(hp_f.float() - hp_u.float()).abs().max().item():.3e}", flush=True)
@@ -176,7 +183,7 @@ def t_mlp_fused():
             RES.append((f"mlp fused no-pre identical {variant} {M}x{C}", bool(torch.equal(y_n, y_f))))
             ha = torch.empty((M, 4 * C), dtype=dt, device=dev)
             y_a = ops.mlp_fused_raw(x, w1, b1, w2, b2, r_, s_, 49, hp_f, ha)         # both hidden tensors stored
-            RES.append((f"mlp fused + activation identical {variant} {M}x{C}", bool(torch.equal(y_a, y_f)) and bool(torch.equal(ha, h_u))))
+            RES.append((f"mlp fused + activation identical {variant} {M}x{C}", bool(torch.equal(y_a, y_f)) and one_ulp(ha, h_u)))
             del ha, y_a
             pre = x.float() @ w1.float().t() + b1
             ref = torch.nn.functional.gelu(pre).to(dt).float() @ w2.float().t() + b2

@@ -179,8 +179,9 @@ def test_mlp_half_with_layernorm_prologue(dev, C, M, use_rs):
 
 def test_fused_mlp_input_gradient_launch(dev):
     """fmmt_mlp_bwd_input (dh and dx of the Mlp in one launch, C = 96) against the two GEMM launches it replaces (GELU' epilogue, then
-    the input gradient): dh bit-identical (same products, same rounding), dx bit-identical; ragged token counts, a dropped sample;
-    at the bench size (2 M tokens) a checksum comparison."""
+    the input gradient): same products, same rounding points; gelu' comes from the LDS table in the fused kernel and from the table or
+    the polynomial in the GEMM epilogue (by kernel), so dh agrees to one bf16 rounding step and dx to the accumulation of those;
+    ragged token counts, a dropped sample, the bench size (2 M tokens).  Against fp64: test_mlp_half_* below."""
     import gpu_wblock as W
     from facialmmt_amd._lib import EPI_GELU_BWD
     C = int(os.environ.get("MLP_BWD_TEST_C", "96"))
@@ -195,6 +196,8 @@ def test_fused_mlp_input_gradient_launch(dev):
         dh, dx = ops.mlp_bwd_input_raw(dy, hp, w1, w2, rs, rps)
         dh2 = ops.linear_raw(dy, w2.t().contiguous(), None, epi=EPI_GELU_BWD, aux=hp, rowscale=rs, rows_per_scale=rps)
         dx2 = ops.linear_raw(dh2, w1.t().contiguous(), None)
-        assert torch.equal(dh, dh2), (M, (dh.float() - dh2.float()).abs().max().item())
-        assert torch.equal(dx, dx2), (M, (dx.float() - dx2.float()).abs().max().item())
+        for got, want, ulps in ((dh, dh2, 1.0), (dx, dx2, 2.0)):
+            err, scale = (got.float() - want.float()).abs().max().item(), want.float().abs().max().item()
+            assert err <= ulps * scale * 2.0 ** -7, (M, err, scale)
+        assert (dh[:rps] == 0).all() and (dx[:rps] == 0).all()                                  # the dropped sample
         del dh, dx, dh2, dx2
