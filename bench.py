@@ -704,7 +704,8 @@ def main():
             if fl / max(by, 1.0) < ridge:
                 roof = {"bound": "hbm", "kernel": kname, "peak": PEAK_HBM_GBS, "unit": "GB/s", "achieved": round(by / sec / 1e9, 0),
                         "frac": round(by / sec / 1e9 / PEAK_HBM_GBS, 4), "avg_launch_us": round(sec / cnt * 1e6, 1),
-                        "TFLOP_per_s": round(fl / sec / 1e12, 1), "flop_per_byte": round(fl / max(by, 1.0), 1)}
+                        "TFLOP_per_s": round(fl / sec / 1e12, 1), "flop_per_byte": round(fl / max(by, 1.0), 1),
+                        "frac_of_mfma_peak": round(fl / sec / 1e12 / PEAK_BF16_TFLOPS, 4)}     # for a GEMM family near the ridge: both views
             else:
                 roof = {"bound": "mfma", "kernel": kname, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s"}
                 roof.update(rate(cnt, fl, by, sec))
