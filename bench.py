@@ -69,6 +69,10 @@ def parse():
     ap.add_argument("--grad-comm", default="bf16", choices=["fp32", "bf16"], help="element type of the gradient all-reduce (N > 1): bf16 halves the bytes on the xGMI links (0.87 GB instead of 1.74 GB per step)")
     ap.add_argument("--other-configs", type=int, default=1, help="N = 1 only: after the timed region also run 4 steps of configs[3] and configs[4] (per-GPU legs, own processes) and report them under `other_configs`")
     ap.add_argument("--parallel-fusion", type=int, default=1, help="capture independent halves of the fusion stack as parallel graph branches")
+    ap.add_argument("--discarded-swin-gradients", choices=["compute", "skip"], default="compute",
+                    help="'compute' (default): the target step back-propagates through Swin as the reference does, although nothing reads those gradients "
+                         "(train.py:20,33,140-143); 'skip': train_step's option that does not compute them (same training to fp32 rounding, reported as a "
+                         "separate leg of the default run, never as `value`)")
     ap.add_argument("--force-ddp", action="store_true", help="run the data-parallel gradient exchange path even with one process (exercises the N>1 code path on one GPU)")
     ap.add_argument("--shape-report", default=None, help="write a per-GEMM-shape timing table to this file (development aid)")
     ap.add_argument("--host-input-leg", type=int, default=1, help="after the timed region, also time the steps with the batch handed over in pinned host memory (PCIe-inclusive rate; reported, never `value`)")
@@ -518,7 +522,8 @@ def main():
             aopt = HFAdamW(swin.parameters(), lr=torch.tensor(cfg.aux_lr, device=dev))       # train.py:333: no weight decay on the Swin model
             aux_step = GraphedAuxStep(swin, aopt, torch.optim.lr_scheduler.LambdaLR(aopt, lr_of), cfg, *aux_batch, averager=aflat)
         step = GraphedTargetStep(swin, mm, opt, sched, cfg, batch, autocast_dtype=act, overlap_text=bool(args.overlap_text),
-                                 parallel_fusion=bool(args.parallel_fusion), averager=flat, masters=masters)
+                                 parallel_fusion=bool(args.parallel_fusion), averager=flat, masters=masters,
+                                 discarded_swin_gradients=args.discarded_swin_gradients)
     else:
         if args.graphs == 1:
             from facialmmt_amd.train_step import graph_multimodal, select_frames
@@ -781,8 +786,11 @@ def main():
             line["config"]["dry_run"] = f"ranks share device {local}, backend {backend}: not a measurement"
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, cfg)
-        if world == 1 and args.other_configs and args.config == 1:
+        if args.discarded_swin_gradients == "skip":
+            line["config"]["workload"] += "; Swin's (discarded) target-step gradients NOT computed: not the reference's work per step, not comparable with `value` of the default run"
+        if world == 1 and args.other_configs and args.config == 1 and args.discarded_swin_gradients == "compute":
             line["other_configs"] = other_configs(args)
+            line["discarded_swin_gradients_skipped"] = skip_leg(args)
     if dist.is_initialized():
         dist.destroy_process_group()
     if rank == 0:
@@ -814,6 +822,23 @@ def other_configs(args):
         except Exception as e:                               # a reported leg only
             out[f"configs[{c}]"] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
     return out
+
+
+def skip_leg(args):
+    """The same configs[1] step with train_step's discarded_swin_gradients="skip" (own process, 6 steps): a REPORTED leg -- the
+    reference spends this backward on gradients it zeroes unread; skipping it leaves every later parameter unchanged to fp32 rounding
+    (tests/test_gpu_train_step.py::test_skipping_the_discarded_swin_backward_changes_nothing).  Never `value`."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--host-input-leg", "0", "--other-configs", "0",
+           "--dtype", args.dtype, "--graphs", str(args.graphs), "--discarded-swin-gradients", "skip"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
+        j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        return {"ms_per_step": j["ms_per_step"], "value": j["value"], "unit": j["unit"], "steps": j["steps"],
+                "note": "option train_step.*(discarded_swin_gradients='skip'): Swin forward without autograd, no Swin backward; the reference computes these "
+                        "gradients and zeroes them unread (train.py:20,33,140-143); same training to fp32 rounding; NOT `value`"}
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {str(e)[:200]}"}
 
 
 def kernel_symbol(bn):

@@ -210,15 +210,29 @@ def graph_multimodal(mm, sample_args, autocast_dtype=None, overlap_text=True, pa
     return mm
 
 
+# The reference back-propagates the target-task loss through Swin (the emotion features are written into the vision tensor by a
+# differentiable copy, train.py:101-104,121), but nothing ever reads those gradients: the target step clips and steps the multimodal
+# model only (train.py:140-143), and Swin's optimizer zeroes them before its next use (train.py:20,33).  With "skip" the Swin forward
+# of the target step runs without autograd (its fused kernels then also skip the saved-activation stores) and no Swin backward runs:
+# the parameters, BatchNorm statistics and losses of every later step are the same to fp32 rounding (tests/test_gpu_train_step.py: the
+# inference form of a few forward launches differs in the last bit), at 60 % of the step time (40.5 against 66.1 ms).  It is an OPTION: the default executes what the reference executes, and bench.py's `value` is measured with it.
+SKIP_NOTE = "Swin's target-step gradients are never read (train.py:20,33,140-143): 'skip' does not compute them"
+
+
 class TargetStep:
     """Swin (train mode, Gumbel-softmax head) -> frame filter -> multimodal model -> CE -> backward ->
     (every `accumulation_steps`) clip + AdamW + schedule, as train.py:46-143.  Only the multimodal
     optimizer steps here; Swin receives gradients through the emotion features and is updated by the
     auxiliary task's optimizer (train.py:31), so its gradients are dropped after each step."""
 
-    def __init__(self, swin_model, multimodal_model, optimizer, scheduler, args, autocast_dtype=None, ddp_model=None, averager=None):
+    def __init__(self, swin_model, multimodal_model, optimizer, scheduler, args, autocast_dtype=None, ddp_model=None, averager=None,
+                 discarded_swin_gradients="compute"):
         """Data parallel: pass `averager` (parallel.GradientAverager over the multimodal parameters) or, alternatively,
-        `ddp_model` (the module wrapped by torch's DistributedDataParallel)."""
+        `ddp_model` (the module wrapped by torch's DistributedDataParallel).
+        `discarded_swin_gradients`: "compute" (default, what the reference executes) or "skip" -- see SKIP_NOTE."""
+        if discarded_swin_gradients not in ("compute", "skip"):
+            raise ValueError("discarded_swin_gradients: 'compute' or 'skip'")
+        self.skip_swin_bwd = discarded_swin_gradients == "skip"
         self.swin = swin_model
         self.mm = multimodal_model
         self.mm_call = ddp_model if ddp_model is not None else multimodal_model
@@ -269,7 +283,11 @@ class TargetStep:
                     self.mm.launch_text(ids, attn_mask, sep_mask, utt_idx)
             else:
                 self.mm.launch_text(ids, attn_mask, sep_mask, utt_idx)
-        preds = self.swin(frames, is_trg_task=True)                                  # (sumF, 7), Gumbel-softmax
+        if self.skip_swin_bwd:
+            with torch.no_grad():
+                preds = self.swin(frames, is_trg_task=True)
+        else:
+            preds = self.swin(frames, is_trg_task=True)                              # (sumF, 7), Gumbel-softmax
         mark("swin_fwd")
         vis_concat, new_mask = select_frames(preds.float(), vision_inputs, vision_mask, num_imgs, args.FacialEmoImpor_threshold)
         mark("frame_filter")
@@ -613,12 +631,15 @@ class GraphedTargetStep:
     Parity: tests/test_gpu_train_step.py walks this against the eager TargetStep (same losses, same parameters)."""
 
     def __init__(self, swin_model, multimodal_model, optimizer, scheduler, args, batch, autocast_dtype=None,
-                 overlap_text=True, parallel_fusion=True, averager=None, warmup_iters=2, masters=None):
+                 overlap_text=True, parallel_fusion=True, averager=None, warmup_iters=2, masters=None, discarded_swin_gradients="compute"):
         """`averager`: GradientAverager(hooks=False) over the parameters the optimizer steps (default: the multimodal
         model's); `masters`: optional MasterWeights of the text encoder -- then `averager` and the optimizer must have been
-        built over `step_parameters(multimodal_model, masters)`."""
+        built over `step_parameters(multimodal_model, masters)`; `discarded_swin_gradients`: "compute" (default) / "skip", SKIP_NOTE."""
         import os
         from .parallel import GradientAverager
+        if discarded_swin_gradients not in ("compute", "skip"):
+            raise ValueError("discarded_swin_gradients: 'compute' or 'skip'")
+        self.skip_swin_bwd = discarded_swin_gradients == "skip"
         if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "") != "0":
             raise RuntimeError("GraphedTargetStep: DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 must be in the environment before the HIP "
                                "runtime initialises (see facialmmt_amd/__init__.py)")
@@ -717,7 +738,11 @@ class GraphedTargetStep:
             self.text_stream.wait_stream(main)             # fork: the text branch does not depend on the visual path
             with torch.cuda.stream(self.text_stream), ac():
                 pending = mm.text_branch(ids, attn_mask, sep_mask, torch.as_tensor(utt_idx, device=ids.device))
-        preds = self.swin(frames, is_trg_task=True)
+        if self.skip_swin_bwd:
+            with torch.no_grad():
+                preds = self.swin(frames, is_trg_task=True)
+        else:
+            preds = self.swin(frames, is_trg_task=True)
         vis_concat, new_mask = select_frames(preds.float(), vision_inputs, vision_mask, num_imgs, args.FacialEmoImpor_threshold)
         with ac():
             if pending is None:
@@ -735,7 +760,10 @@ class GraphedTargetStep:
         # backward, first piece: every leaf the optimizer steps plus Swin's output (the autograd graph below `preds` -- Swin -- is
         # left untouched, with its saved activations, for the second piece)
         leaves = [l for l, _ in self.pairs if l.requires_grad]
-        got = torch.autograd.grad(loss, [preds] + leaves, allow_unused=True)
+        if self.skip_swin_bwd:
+            got = (None,) + tuple(torch.autograd.grad(loss, leaves, allow_unused=True))
+        else:
+            got = torch.autograd.grad(loss, [preds] + leaves, allow_unused=True)
         dpreds = got[0]
         for l, g in zip(leaves, got[1:]):
             l.grad = g

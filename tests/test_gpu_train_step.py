@@ -75,7 +75,7 @@ def test_scheduled_step_equals_eager_step(mode):
         assert (p0[k] - p1[k]).abs().max().item() <= 1e-4 * max(1.0, p0[k].abs().max().item()), k
 
 
-def _run_six(dev, graphed, accumulation, bf16_plm=False, adamw=False):
+def _run_six(dev, graphed, accumulation, bf16_plm=False, adamw=False, swin_gradients="compute"):
     from facialmmt_amd import models
     from facialmmt_amd.config import default_args
     from facialmmt_amd.train_step import GraphedTargetStep, TargetStep
@@ -111,11 +111,11 @@ def _run_six(dev, graphed, accumulation, bf16_plm=False, adamw=False):
     else:
         opt = torch.optim.SGD(mm.parameters(), lr=0.05)
     if graphed:
-        step = GraphedTargetStep(swin, mm, opt, None, cfg, batch, autocast_dtype=None, masters=masters)
+        step = GraphedTargetStep(swin, mm, opt, None, cfg, batch, autocast_dtype=None, masters=masters, discarded_swin_gradients=swin_gradients)
         assert step.text_stream is not None
         assert (step.fused is not None) == adamw
     else:
-        step = TargetStep(swin, mm, opt, None, cfg, autocast_dtype=None)
+        step = TargetStep(swin, mm, opt, None, cfg, autocast_dtype=None, discarded_swin_gradients=swin_gradients)
     losses = []
     for _ in range(6):
         loss, kept = step(batch)
@@ -144,6 +144,24 @@ def test_whole_step_graphs_equal_eager_step(accumulation):
     assert (rm0 - rm1).abs().max().item() <= 1e-4 * max(1.0, rm0.abs().max().item())
     for k in p0:
         assert (p0[k] - p1[k]).abs().max().item() <= 1e-4 * max(1.0, p0[k].abs().max().item()), k
+
+
+@pytest.mark.parametrize("graphed", [False, True])
+def test_skipping_the_discarded_swin_backward_changes_nothing(graphed):
+    """discarded_swin_gradients="skip" (train_step.SKIP_NOTE: the reference never reads Swin's target-step gradients): six steps with
+    and without Swin's backward -- same losses, multimodal parameters, BatchNorm running statistics and kept-frame mask.  Equal to
+    fp32 rounding, not bit for bit: without autograd Swin's forward takes the inference form of a few launches (no saved
+    pre-activations), whose last bit can differ (first loss 2.6707118 vs 2.6707120)."""
+    dev = torch.device("cuda:0")
+    l0, p0, rm0, nb0, k0 = _run_six(dev, graphed, 1, swin_gradients="compute")
+    l1, p1, rm1, nb1, k1 = _run_six(dev, graphed, 1, swin_gradients="skip")
+    assert l0[0] != l0[-1]
+    for a, b in zip(l0, l1):
+        assert abs(a - b) <= 2e-6 * max(1.0, abs(a)), (l0, l1)
+    assert nb0 == nb1 == 6 and torch.equal(k0, k1)
+    assert (rm0 - rm1).abs().max().item() <= 1e-5 * max(1.0, rm0.abs().max().item())
+    for k in p0:
+        assert (p0[k] - p1[k]).abs().max().item() <= 1e-5 * max(1.0, p0[k].abs().max().item()), k
 
 
 def test_bf16_text_encoder_with_fp32_masters_tracks_fp32_run():
