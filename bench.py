@@ -36,6 +36,7 @@ import sys
 import time
 
 os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # before the HIP runtime initialises: see facialmmt_amd/__init__.py
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # multi-process GPU work on this driver: dmabuf IPC only (RCCL's hipIpcGetMemHandle fails otherwise)
 
 import torch
 import torch.distributed as dist
