@@ -327,8 +327,7 @@ __global__ __launch_bounds__(512) void linear_nt_deep_kernel(LinArgs p) {
     } else {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                      // every wave is done with the K loop's stages
-        const lut2_t* lut = wslab_stage_lut<3 * STAGE * 2>(p, smem, tid, 512);
-        nt_epilogue_wslab<T>(p, acc, smem + wave * (16 * 272), lane, li, lg, m0 + wm * 64, n0 + wn * 64, lut);
+        nt_epilogue_wslab<T>(p, acc, smem + wave * (16 * 272), lane, li, lg, m0 + wm * 64, n0 + wn * 64);
     }
 }
 
@@ -448,8 +447,10 @@ void linear_nt_deep32_kernel(LinArgs p) {
         if constexpr (BN == 128) {                         // operand / GELU epilogues: wave-private slab, whole 128-byte lines
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                  // every wave is done with the K loop's stages
-            const lut2_t* lut = wslab_stage_lut<3 * STAGE * 2>(p, smem, tid, 512);
-            nt_epilogue_wslab<T>(p, acc, smem + wave * (16 * 272), lane, li, lg, m0 + wm * 64, n0 + wn * WN, lut);
+            // (The GELU' table of fmmt_common.h staged in the freed stages was tried here: 532 -> 501 us at stage 1 -- and one launch in
+            //  ~40 wrote a garbage 16 x 64 fragment, always a wave of the third token quarter, wherever the table sat; staging it without
+            //  using it was clean.  Not understood, not kept: this epilogue stays on the polynomial.)
+            nt_epilogue_wslab<T>(p, acc, smem + wave * (16 * 272), lane, li, lg, m0 + wm * 64, n0 + wn * WN);
         }
     }
 }

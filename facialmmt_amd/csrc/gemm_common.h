@@ -225,30 +225,13 @@ __device__ __forceinline__ void nt_epilogue_slab(const LinArgs& p, f32x4 (&acc)[
     }
 }
 
-// The table of a GELU / GELU' epilogue, staged in the K loop's freed LDS behind the eight wave slabs (bytes 36864 .. 45055); call between
-// the barrier that ends the K loop and nt_epilogue_wslab, with LDS_BYTES = the kernel's dynamic LDS size.  Returns nullptr (polynomial)
-// where there is no such epilogue or no room.
-constexpr int WSLAB_LUT_OFF = 36864;
-template <int LDS_BYTES>
-__device__ __forceinline__ const lut2_t* wslab_stage_lut(const LinArgs& p, char* smem, int tid, int nthreads) {
-    if constexpr (LDS_BYTES < WSLAB_LUT_OFF + GELU_LUT_BYTES) return nullptr;
-    if (p.epi != FMMT_EPI_GELU && p.epi != FMMT_EPI_GELU_BWD) return nullptr;
-    lut2_t* lut = reinterpret_cast<lut2_t*>(smem + WSLAB_LUT_OFF);
-    gelu_lut_copy(lut, p.epi == FMMT_EPI_GELU ? fmmt_gelu_lut_phi : fmmt_gelu_lut_grad, tid, nthreads);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    return lut;
-}
-
 // Every epilogue (GELU + pre-activation, GELU', DropPath scale, residual) of a 64 x 64 WAVE tile through a wave-private fp32
 // slab, one 16-row fragment at a time: 64 channels of bf16 are exactly one 128-byte line, so after the transposition every store
 // AND every load of the residual / GELU' operand is eight complete lines per instruction instead of sixteen 64-byte pieces.
 // No barrier (a wave's LDS operations execute in order), so two co-resident workgroups keep hiding one another's epilogue.
 // Same fp32 arithmetic in the same order as nt_epilogue.  wslab: this wave's 16 x 272 bytes.
-// lut: the Phi / gelu' table in LDS (fmmt_common.h) for the GELU / GELU' epilogues, nullptr = the polynomial
 template <typename T>
-__device__ __forceinline__ void nt_epilogue_wslab(const LinArgs& p, f32x4 (&acc)[4][4], char* wslab, int lane, int li, int lg, int mbase, int nbase,
-                                                  const lut2_t* lut = nullptr) {
+__device__ __forceinline__ void nt_epilogue_wslab(const LinArgs& p, f32x4 (&acc)[4][4], char* wslab, int lane, int li, int lg, int mbase, int nbase) {
     static_assert(sizeof(T) == 2, "bf16 path");
     constexpr int PITCH = 64 * 4 + 16;
     T* __restrict__ yg = reinterpret_cast<T*>(p.y);
@@ -283,13 +266,13 @@ __device__ __forceinline__ void nt_epilogue_wslab(const LinArgs& p, f32x4 (&acc)
                 };
                 if (p.epi == FMMT_EPI_GELU) {
                     if (ypre) put(ypre, p.ldy);
-                    gelu_inplace_lut<T>(lut, v, 8);
+                    gelu_inplace<T>(v, 8);
                 } else if (p.epi == FMMT_EPI_GELU_BWD) {
                     const Vec<T> t = ldvec<T>(auxg + (size_t)m * p.ldaux + n);
                     float ax[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) ax[e] = t.get(e);
-                    gelu_grad_mul_inplace_lut<T>(lut, v, ax, 8);
+                    gelu_grad_mul_inplace<T>(v, ax, 8);
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] *= rs;

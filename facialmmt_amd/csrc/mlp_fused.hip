@@ -49,6 +49,9 @@ struct MlpArgs {
     bf16* xn;
     float* mean;
     float* rstd;
+    // LN-backward epilogue of the input-gradient kernel (fmmt_mlp_ln_bwd_input): the LayerNorm's input, and per-workgroup partial sums
+    const bf16* ln_x;
+    float* ln_part;
 };
 
 // (Two workgroups per CU at C = 96 -- 76.8 KB of LDS each, registers forced to 128 -- were measured: the inference form gains
@@ -330,7 +333,27 @@ __device__ __forceinline__ void gload16_asm(bf16x8& dst, const void* ptr) {
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
 }
 
-template <int C>
+__device__ __forceinline__ void gload4_asm(float& dst, const void* ptr) {
+    asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
+}
+// sum over the 16 lanes of a DPP row (= the 16 tokens li of one lane group lg), result in every lane; fixed order
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));   // row_ror:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));   // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));   // row_ror:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));   // row_ror:1
+    return v;
+}
+
+// LNB (fmmt_mlp_ln_bwd_input, C = 96): the backward of the block's norm2 as this kernel's tile epilogue.  Product 2's accumulator tile
+// IS d(LN out) of the wave's 32 tokens in the layout of the LayerNorm input's fragments (token li; channels c * 32 + lg * 8 + e), the
+// whole 96-channel row in the four lanes li + 16 g: the two row sums are in-lane sums + two swaps, dx = rstd (g - mean(g) - xhat
+// mean(g xhat)) + dy is stored instead of d(LN out) -- the separate LayerNorm-backward launch (read d(LN out), x, dy; write dx: 1.5 GB
+// at stage 0) is gone.  x / mean / rstd of the tile are requested by inline assembly at the END of the tile's last-but-one step: the
+// last step's AUX wait (vmcnt(CNT + 4), or 0 at the tail) then covers them, they are older than everything it lets fly.
+// d(gamma) / d(beta): in-lane products, summed over the row's 16 tokens by DPP (fixed order), each of the 48 values kept by the lane
+// li == v % 16 (3 registers); per-wave slots -> fixed-order sum over the waves -> one row of partial sums per workgroup.
+template <int C, bool LNB = false>
 __global__ __launch_bounds__(512) void mlp_fused_bwd_kernel(MlpArgs p) {
     using T = bf16;
     constexpr int H = 4 * C, HS = 64, NS = H / HS;
@@ -351,6 +374,11 @@ __global__ __launch_bounds__(512) void mlp_fused_bwd_kernel(MlpArgs p) {
     typedef __attribute__((address_space(3))) void lptr_t;
     lut2_t* lut = reinterpret_cast<lut2_t*>(smem + NBUF * STAGE_B);          // gelu'(x) table (fmmt_common.h), behind the ring
     gelu_lut_copy(lut, fmmt_gelu_lut_grad, tid, 512);
+    float* gam_s = reinterpret_cast<float*>(smem + NBUF * STAGE_B + GELU_LUT_BYTES);                 // LNB: gamma [C]
+    float* slot_s = gam_s + C;                                                                       // LNB: [8 waves][4 lg][48]
+    if constexpr (LNB) {
+        if (tid < C) gam_s[tid] = p.ln_g[tid];
+    }
     __syncthreads();
     auto swz = [](int row) { return ((row >> 3) ^ (row >> 2)) & 3; };
     const int r16 = lane >> 2, c4 = lane & 3;
@@ -404,6 +432,19 @@ __global__ __launch_bounds__(512) void mlp_fused_bwd_kernel(MlpArgs p) {
             const int tok = min(tile * 256 + wave * 32 + mt * 16 + li, p.M - 1);
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) gload16_asm(dst[mt * 2 + blk], p.h_pre + (size_t)tok * H + hs * HS + blk * 32 + lg * 8);
+        }
+    };
+    // LNB: the LayerNorm input and statistics of this wave's 32 tokens (see the kernel's header)
+    bf16x8 lx[2][LNB ? KS : 1];
+    float lmean[2], lrstd[2], own[3] = {0.f, 0.f, 0.f};
+    auto issue_ln = [&](int tile) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int tok = min(tile * 256 + wave * 32 + mt * 16 + li, p.M - 1);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) gload16_asm(lx[mt][ks], p.ln_x + (size_t)tok * C + ks * 32 + lg * 8);
+            gload4_asm(lmean[mt], p.mean + tok);
+            gload4_asm(lrstd[mt], p.rstd + tok);
         }
     };
 #pragma unroll
@@ -498,10 +539,70 @@ __global__ __launch_bounds__(512) void mlp_fused_bwd_kernel(MlpArgs p) {
                 for (int mt = 0; mt < 2; ++mt) acc2[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf2, hf[mt], acc2[mt][nt], 0, 0, 0);
             }
         }
+        if constexpr (LNB) {
+            if (hs == NS - 2) issue_ln(tile);
+        }
         cslot = cslot + 1 == NBUF ? 0 : cslot + 1;
         ++s;
         if (++hs == NS) {
             const int next = tile + G;
+            if constexpr (LNB) {
+                float dgl[KS * 8], dbl[KS * 8];
+#pragma unroll
+                for (int v = 0; v < KS * 8; ++v) dgl[v] = dbl[v] = 0.f;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    // one token tile at a time, the row's values formed twice (sums, then outputs) rather than kept: registers
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(lx[mt][ks]));
+                    asm volatile("" : "+v"(lmean[mt]), "+v"(lrstd[mt]));
+                    const int tok = t0 + mt * 16 + li;
+                    const bool valid = tok < p.M;
+                    const float mean = lmean[mt], rstd = lrstd[mt];
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int c = 0; c < KS; ++c) {
+                        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gam_s + c * 32 + lg * 8), g1 = *reinterpret_cast<const f32x4*>(gam_s + c * 32 + lg * 8 + 4);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float d = acc2[mt][2 * c + (e >> 2)][e & 3];
+                            const float xh = ((float)lx[mt][c][e] - mean) * rstd;
+                            const float gm = d * (e < 4 ? g0[e & 3] : g1[e & 3]);
+                            s1 += gm;
+                            s2 += gm * xh;
+                        }
+                    }
+                    s1 = swap_sum(s1) * (1.0f / (float)C);
+                    s2 = swap_sum(s2) * (1.0f / (float)C);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int c = 0; c < KS; ++c) {
+                        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gam_s + c * 32 + lg * 8), g1 = *reinterpret_cast<const f32x4*>(gam_s + c * 32 + lg * 8 + 4);
+                        bf16x8 o;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const int v = c * 8 + e;
+                            const float d = acc2[mt][2 * c + (e >> 2)][e & 3];
+                            const float xh = ((float)lx[mt][c][e] - mean) * rstd;
+                            const float gm = d * (e < 4 ? g0[e & 3] : g1[e & 3]);
+                            o[e] = (bf16)(rstd * (gm - s1 - xh * s2) + (float)xf[mt][c][e]);
+                            const float dv = valid ? d : 0.f;
+                            dgl[v] += dv * xh;
+                            dbl[v] += dv;
+                        }
+                        if (valid) *reinterpret_cast<bf16x8*>(p.y + (size_t)tok * C + c * 32 + lg * 8) = o;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int v = 0; v < KS * 8; ++v) {
+                    const float a = row16_sum(dgl[v]), b = row16_sum(dbl[v]);
+                    if (li == (v & 15)) own[v >> 4] += a;
+                    if (li == ((v + KS * 8) & 15)) own[(v + KS * 8) >> 4] += b;
+                }
+                if (next < p.tiles) load_x(next);
+            } else {
             if (next < p.tiles) load_x(next);
             LinArgs e{};
             e.M = p.M;
@@ -509,6 +610,7 @@ __global__ __launch_bounds__(512) void mlp_fused_bwd_kernel(MlpArgs p) {
             e.y = p.y;
             e.ldy = C;
             nt_epilogue<T, 2, NT2>(e, acc2, t0, 0, li, lg);
+            }
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -521,19 +623,43 @@ __global__ __launch_bounds__(512) void mlp_fused_bwd_kernel(MlpArgs p) {
         step(auxA, auxB);
         step(auxB, auxA);
     }
+    if constexpr (LNB) {
+        static_assert(C == 96, "48 partial sums per lane group: 3 per lane");
+#pragma unroll
+        for (int k = 0; k < 3; ++k) slot_s[(wave * 4 + lg) * 48 + k * 16 + li] = own[k];
+        __syncthreads();
+        if (tid < 2 * C) {
+            const int kind = tid / C, ch = tid % C;
+            const int v = kind * 24 + (ch >> 5) * 8 + (ch & 7), lgc = (ch >> 3) & 3;
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) a += slot_s[(w * 4 + lgc) * 48 + v];
+            p.ln_part[(size_t)blockIdx.x * 2 * C + tid] = a;
+        }
+    }
 }
 
-template <int C>
+// rows of per-workgroup partial sums [nblocks][2 C] -> d(gamma) [C], d(beta) [C]; fixed order
+__global__ void mlp_ln_part_reduce_kernel(const float* __restrict__ part, int nblocks, int C, float* dgamma, float* dbeta) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * C) return;
+    float a = 0.f;
+    for (int b = 0; b < nblocks; ++b) a += part[(size_t)b * 2 * C + i];
+    if (i < C) dgamma[i] = a;
+    else dbeta[i - C] = a;
+}
+
+template <int C, bool LNB = false>
 int launch_mlp_bwd(const MlpArgs& a, hipStream_t st) {
-    constexpr size_t lds = (size_t)3 * (((C / 32) * 64 * 32 + 2 * C * 32) * 2) + GELU_LUT_BYTES;
+    constexpr size_t lds = (size_t)3 * (((C / 32) * 64 * 32 + 2 * C * 32) * 2) + GELU_LUT_BYTES + (LNB ? (C + 8 * 4 * 48) * sizeof(float) : 0);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_bwd_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_bwd_kernel<C, LNB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     const int grid = a.tiles < 256 ? a.tiles : 256;
-    hipLaunchKernelGGL((mlp_fused_bwd_kernel<C>), dim3(grid), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((mlp_fused_bwd_kernel<C, LNB>), dim3(grid), dim3(512), lds, st, a);
     FMMT_CHECK_LAUNCH();
     return 0;
 }
@@ -592,4 +718,27 @@ extern "C" int fmmt_mlp_bwd_input(int dtype, int M, int C, const void* dy, const
     a.y = (bf16*)dx; a.h_pre = (bf16*)const_cast<void*>(h_pre); a.h_act = (bf16*)dh; a.tiles = (M + 255) / 256;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     return C == 96 ? launch_mlp_bwd<96>(a, st) : launch_mlp_bwd<192>(a, st);
+}
+
+extern "C" size_t fmmt_mlp_ln_bwd_input_workspace(int C) { return (size_t)256 * 2 * C * sizeof(float); }
+
+extern "C" int fmmt_mlp_ln_bwd_input(int dtype, int M, int C, const void* dy, const void* h_pre, const void* w2t, const void* w1t,
+                                     const float* rowscale, int rows_per_scale, const void* x, const float* mean, const float* rstd,
+                                     const float* ln_gamma, void* dh, void* dx, float* dgamma, float* dbeta, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+    if (dtype != FMMT_BF16 || M <= 0 || C != 96) return FMMT_EINVAL;                     // other widths: fmmt_mlp_bwd_input + fmmt_layernorm_bwd
+    if (!dy || !h_pre || !w2t || !w1t || !dh || !dx || !x || !mean || !rstd || !ln_gamma || !dgamma || !dbeta || !workspace) return FMMT_EINVAL;
+    if (rowscale && rows_per_scale <= 0) return FMMT_EINVAL;
+    if (workspace_bytes < fmmt_mlp_ln_bwd_input_workspace(C)) return FMMT_EWORKSPACE;
+    if (!al16(dy) || !al16(h_pre) || !al16(w2t) || !al16(w1t) || !al16(dh) || !al16(dx) || !al16(x) || !al16(workspace)) return FMMT_EALIGN;
+    MlpArgs a{};
+    a.M = M; a.x = (const bf16*)dy; a.w1 = (const bf16*)w2t; a.w2 = (const bf16*)w1t; a.rowscale = rowscale; a.rows_per_scale = rows_per_scale;
+    a.y = (bf16*)dx; a.h_pre = (bf16*)const_cast<void*>(h_pre); a.h_act = (bf16*)dh; a.tiles = (M + 255) / 256;
+    a.ln_g = ln_gamma; a.mean = const_cast<float*>(mean); a.rstd = const_cast<float*>(rstd); a.ln_x = (const bf16*)x; a.ln_part = (float*)workspace;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (int rc = launch_mlp_bwd<96, true>(a, st)) return rc;
+    const int grid = a.tiles < 256 ? a.tiles : 256;
+    hipLaunchKernelGGL(mlp_ln_part_reduce_kernel, dim3((2 * C + 63) / 64), dim3(64), 0, st, (const float*)workspace, grid, C, dgamma, dbeta);
+    FMMT_CHECK_LAUNCH();
+    return 0;
 }

@@ -402,6 +402,7 @@ class MlpFn(Function):
 
 _MLP_BWD_FUSED = _os.environ.get("FMMT_MLP_BWD_FUSED", "1") != "0"   # A/B switch (read once): 0 = GELU' GEMM + input-gradient GEMM as two launches
 _MLP_BWD_WIDTHS = (96, 192) if _os.environ.get("FMMT_MLP_BWD_FUSED", "1") == "192" else (96,)
+_MLP_BWD_LN = _os.environ.get("FMMT_MLP_BWD_LN", "1") != "0"     # A/B switch (read once): 0 = fmmt_mlp_bwd_input + fmmt_layernorm_bwd
 
 
 def mlp_bwd_input_raw(dy2, h_pre, w1, w2, rowscale, rows_per_scale):
@@ -454,6 +455,21 @@ class MlpLnFn(Function):
         C = x2.shape[1]
         lib = _lib.load()
         dy2 = dy.reshape(-1, C).contiguous()
+        M, dt = x2.shape[0], x2.dtype
+        if _MLP_BWD_FUSED and _MLP_BWD_LN and dt == torch.bfloat16 and C == 96 and M >= 4096:
+            # input gradient of the Mlp AND the LayerNorm backward in one launch (fmmt_mlp_ln_bwd_input)
+            dh = torch.empty((M, 4 * C), dtype=dt, device=x2.device)
+            dx = torch.empty_like(x2)
+            dg = torch.empty(C, dtype=torch.float32, device=x2.device)
+            db = torch.empty(C, dtype=torch.float32, device=x2.device)
+            nbytes = lib.fmmt_mlp_ln_bwd_input_workspace(C)
+            ws = _ws(nbytes, x2.device)
+            rc = lib.fmmt_mlp_ln_bwd_input(dtype_code(dt), M, C, _p(dy2), _p(h_pre), _p(_lp(w2, dt, transpose=True)), _p(_lp(w1, dt, transpose=True)),
+                                           _p(rowscale), ctx.rps, _p(x2), _p(mean), _p(rstd), _p(g), _p(dh), _p(dx), _p(dg), _p(db), _p(ws), nbytes, _st())
+            check(rc, f"fmmt_mlp_ln_bwd_input(M={M},C={C})")
+            dw2, db2 = wgrad_raw(dy2, h, True, rowscale, ctx.rps)
+            dw1, db1 = wgrad_raw(dh, xn, True)
+            return dx.reshape(ctx.xshape), dg, db, None, dw1, db1, dw2, db2, None, None
         dh, dxn = mlp_bwd_input_raw(dy2, h_pre, w1, w2, rowscale, ctx.rps)
         dw2, db2 = wgrad_raw(dy2, h, True, rowscale, ctx.rps)
         dw1, db1 = wgrad_raw(dh, xn, True)

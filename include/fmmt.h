@@ -121,6 +121,17 @@ int fmmt_mlp_ln_fwd(int dtype, int M, int C, const void* x, const float* ln_gamm
 int fmmt_mlp_bwd_input(int dtype, int M, int C, const void* dy, const void* h_pre, const void* w2t, const void* w1t,
                        const float* rowscale, int rows_per_scale, void* dh, void* dx, void* stream);
 
+/* The same launch with the backward of the block's norm2 (Swin_Transformer.py:267-268: x = x + drop_path(mlp(norm2(x)))) as its tile
+ * epilogue: instead of d(LN out) it writes dx = LayerNorm'(d(LN out); x, mean, rstd, gamma) + dy, the gradient of the block's residual
+ * stream below the Mlp half, and d(gamma) / d(beta) of norm2 (per-workgroup partial sums in `workspace`, summed in fixed order by a
+ * second small launch).  x: the LayerNorm's input (M, C); mean / rstd: the statistics fmmt_mlp_ln_fwd saved.  bf16, C = 96
+ * (FMMT_EINVAL otherwise: fmmt_mlp_bwd_input + fmmt_layernorm_bwd).  Replaces autograd through nn.LayerNorm + Mlp. */
+size_t fmmt_mlp_ln_bwd_input_workspace(int C);
+int fmmt_mlp_ln_bwd_input(int dtype, int M, int C, const void* dy, const void* h_pre, const void* w2t, const void* w1t,
+                          const float* rowscale, int rows_per_scale, const void* x, const float* mean, const float* rstd,
+                          const float* ln_gamma, void* dh, void* dx, float* dgamma, float* dbeta, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm.  Replaces nn.LayerNorm (eps 1e-5) at Swin_Transformer.py:198,204,239,268 (norm1/2),
  * :305,325 (PatchMerging.norm over the 2x2 concat), :410,421 (PatchEmbed.norm), :491 (head norm);
