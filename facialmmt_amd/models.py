@@ -26,6 +26,24 @@ from .modules.CrossmodalTransformer import CrossModalTransformerEncoder
 from .modules.SwinTransformer.backbone_def import BackboneFactory
 from .modules.Transformer import AdditiveAttention, MELDTransEncoder
 
+
+class InputProjection(nn.Linear):
+    """nn.Linear (same parameters, same state_dict keys) for the audio / vision input projections (src/models.py:66-67): vendor GEMMs as
+    autograd would call them, the bias gradient through fmmt_colsum (ops.VendorLinearFn).  Why not the stock module: inside the replayed
+    multi-stream HIP graph of train_step.GraphedTargetStep torch's own bias-gradient reduction of these two layers was not reproducible
+    (16-48 of 768 sums off by up to 3 % of the largest in most replays, the gradient that reaches the layer bit-identical:
+    tests/gpu_race_step.py); the column-sum launch is."""
+
+    def forward(self, x):
+        if self.bias is None or not x.is_cuda or not torch.is_grad_enabled() or self.weight.shape[0] % 8:
+            return super().forward(x)
+        from . import ops
+        dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
+        if dt not in (torch.bfloat16, torch.float32):
+            return super().forward(x)
+        with torch.autocast("cuda", enabled=False):          # the casts autocast would insert, spelled out (differentiable)
+            return ops.VendorLinearFn.apply(x.to(dt), self.weight.to(dt), self.bias.to(dt))
+
 DEFAULT_SWIN_CONF = os.path.join(os.path.dirname(os.path.abspath(__file__)), "modules", "SwinTransformer", "swin_conf.yaml")
 
 
@@ -111,10 +129,10 @@ class MultiModalTransformerForClassification(nn.Module):
             self.roberta = plm
         else:
             self.bert = plm
-        self.text_linear = nn.Linear(plm.config.hidden_size, self.hidden_size)
-        self.audio_linear = nn.Linear(self.audio_emb_dim, self.hidden_size)
+        self.text_linear = InputProjection(plm.config.hidden_size, self.hidden_size)
+        self.audio_linear = InputProjection(self.audio_emb_dim, self.hidden_size)
         self.audio_utt_transformer = MELDTransEncoder(config, self.audio_utt_Transformernum, self.get_audio_utt_max_lens, self.hidden_size)
-        self.vision_linear = nn.Linear(self.vision_emb_dim, self.hidden_size)
+        self.vision_linear = InputProjection(self.vision_emb_dim, self.hidden_size)
         self.vision_utt_transformer = MELDTransEncoder(config, self.vision_utt_Transformernum, self.get_vision_utt_max_lens, self.hidden_size)
         self.attention = AdditiveAttention(self.hidden_size, self.hidden_size)
         self.CrossModalTrans_TA = CrossModalTransformerEncoder(self.hidden_size, self.crossmodal_num_heads_TA,

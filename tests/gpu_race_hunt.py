@@ -21,6 +21,8 @@ reps = int(os.environ.get("REPS", "30"))
 first = None
 nbad = 0
 for it in range(reps):
+    torch.manual_seed(1234)                                  # --train: the same DropPath masks in every pass
+    torch.cuda.manual_seed_all(1234)
     out = swin(frames)
     grads = torch.autograd.grad((out.float() * w).sum(), [frames] + [p for _, p in named], allow_unused=True)
     cur = [("out", out.detach())] + [("d_frames", grads[0])] + [(n, gr) for (n, _), gr in zip(named, grads[1:]) if gr is not None]
