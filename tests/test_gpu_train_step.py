@@ -3,6 +3,7 @@ as two HIP graphs and the text branch on a second HIP stream, (c) the same plus 
 bucketed gradients, world size 1) must walk the same trajectory -- same losses, same updated parameters -- over six
 optimisation steps (a ROCm 7.0 HIP-graph defect that corrupts replayed gradients from the third replay on is what this test
 first caught; facialmmt_amd/__init__.py carries the workaround).  Dropout inside the multimodal model is off; Swin's DropPath / Gumbel noise replay from the seed."""
+import os
 import types
 
 import pytest
@@ -290,3 +291,14 @@ def test_fused_optimizer_in_the_graphed_step_equals_eager_adamw(accumulation):
     # losses above are the end-to-end check.
     for k in p0:
         assert (p0[k] - p1[k]).abs().max().item() <= 2 * 2e-3 * 6 + 1e-4, k
+
+
+def test_replayed_benchmark_step_is_reproducible():
+    """Consistency at the bench size (configs[1], bf16, text branch and parallel fusion on their own streams): the captured forward +
+    backward graph replayed 12 times on the same inputs and generator state gives the same loss, kept-frame mask and flat gradient
+    buckets bit for bit (tests/gpu_race_step.py; round 3 found the stock input projections' bias gradients failing this)."""
+    import subprocess, sys
+    env = dict(os.environ, REPS="12")
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpu_race_step.py")], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "12 replays, 0 with differences" in r.stdout, r.stdout[-2000:]
