@@ -358,6 +358,9 @@ __global__ __launch_bounds__(512) void mlp_fused_bwd_kernel(MlpArgs p) {
     using T = bf16;
     constexpr int H = 4 * C, HS = 64, NS = H / HS;
     constexpr int KS = C / 32;
+    // token tiles (16 tokens) per wave: two at C = 96; one at C = 192, where two would need 96 + 48 + 32 registers for product 2's
+    // accumulators, the dy fragments and the pre-activation tiles alone (it spilled 23 registers under loads counted by hand)
+    constexpr int MTW = C == 96 ? 2 : 1, TW = 16 * MTW, TT = 8 * TW;
     constexpr int NT2 = C / 16, CW2 = 4 * NT2;
     constexpr int W1_EL = KS * HS * 32, W2_EL = 2 * C * 32;
     constexpr int STAGE_B = (W1_EL + W2_EL) * 2;
@@ -375,7 +378,7 @@ __global__ __launch_bounds__(512) void mlp_fused_bwd_kernel(MlpArgs p) {
     lut2_t* lut = reinterpret_cast<lut2_t*>(smem + NBUF * STAGE_B);          // gelu'(x) table (fmmt_common.h), behind the ring
     gelu_lut_copy(lut, fmmt_gelu_lut_grad, tid, 512);
     float* gam_s = reinterpret_cast<float*>(smem + NBUF * STAGE_B + GELU_LUT_BYTES);                 // LNB: gamma [C]
-    float* slot_s = gam_s + C;                                                                       // LNB: [8 waves][4 lg][48]
+    float* slot_s = reinterpret_cast<float*>(smem);                                                  // LNB, after the last step: [8 waves][4 lg][2 NV] over the ring
     if constexpr (LNB) {
         if (tid < C) gam_s[tid] = p.ln_g[tid];
     }
@@ -426,21 +429,24 @@ __global__ __launch_bounds__(512) void mlp_fused_bwd_kernel(MlpArgs p) {
         ihs = ihs + 1 == NS ? 0 : ihs + 1;
     };
     // the saved pre-activation of (tile, stage hs): lane = token li of m-tile mt, hidden channels hs * 64 + blk * 32 + lg * 8 ..
-    auto issue_aux = [&](int tile, int hs, bf16x8 (&dst)[4]) {
+    auto issue_aux = [&](int tile, int hs, bf16x8 (&dst)[2 * MTW]) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int tok = min(tile * 256 + wave * 32 + mt * 16 + li, p.M - 1);
+        for (int mt = 0; mt < MTW; ++mt) {
+            const int tok = min(tile * TT + wave * TW + mt * 16 + li, p.M - 1);
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) gload16_asm(dst[mt * 2 + blk], p.h_pre + (size_t)tok * H + hs * HS + blk * 32 + lg * 8);
         }
     };
     // LNB: the LayerNorm input and statistics of this wave's 32 tokens (see the kernel's header)
-    bf16x8 lx[2][LNB ? KS : 1];
-    float lmean[2], lrstd[2], own[3] = {0.f, 0.f, 0.f};
+    bf16x8 lx[MTW][LNB ? KS : 1];
+    constexpr int NV = KS * 8, NOWN = 2 * NV / 16;          // LNB: d(gamma) | d(beta) values per lane group, kept per lane
+    float lmean[MTW], lrstd[MTW], own[NOWN];
+#pragma unroll
+    for (int i = 0; i < NOWN; ++i) own[i] = 0.f;
     auto issue_ln = [&](int tile) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int tok = min(tile * 256 + wave * 32 + mt * 16 + li, p.M - 1);
+        for (int mt = 0; mt < MTW; ++mt) {
+            const int tok = min(tile * TT + wave * TW + mt * 16 + li, p.M - 1);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) gload16_asm(lx[mt][ks], p.ln_x + (size_t)tok * C + ks * 32 + lg * 8);
             gload4_asm(lmean[mt], p.mean + tok);
@@ -451,35 +457,35 @@ __global__ __launch_bounds__(512) void mlp_fused_bwd_kernel(MlpArgs p) {
     for (int s = 0; s < NBUF - 1; ++s)
         if (s < nsteps) issue_next();
 
-    bf16x8 xf[2][KS];
-    float rsv[2];
+    bf16x8 xf[MTW][KS];
+    float rsv[MTW];
     auto load_x = [&](int tile) {
-        const int t0 = tile * 256 + wave * 32;
+        const int t0 = tile * TT + wave * TW;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < MTW; ++mt) {
             const int tok = min(t0 + mt * 16 + li, p.M - 1);
             rsv[mt] = row_scale(p.rowscale, tok, p.rows_per_scale);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) xf[mt][ks] = *reinterpret_cast<const bf16x8*>(p.x + (size_t)tok * C + ks * 32 + lg * 8);
         }
     };
-    f32x4 acc2[2][NT2];
+    f32x4 acc2[MTW][NT2];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt) acc2[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     int tile = blockIdx.x, hs = 0, cslot = 0, s = 0;
-    bf16x8 auxA[4], auxB[4];
+    bf16x8 auxA[2 * MTW], auxB[2 * MTW];
     if (ntile > 0) {
         issue_aux(tile, 0, auxA);                            // AUX(0), behind DMA(0) and DMA(1)
         load_x(tile);
     }
-    auto step = [&](bf16x8 (&cur)[4], bf16x8 (&nxt)[4]) {
+    auto step = [&](bf16x8 (&cur)[2 * MTW], bf16x8 (&nxt)[2 * MTW]) {
         // -- stage s landed?
         if (s + 1 >= nsteps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (s == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT + 4) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT + 8) : "memory");
+        else if (s == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT + 2 * MTW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT + 4 * MTW) : "memory");
         __builtin_amdgcn_s_barrier();
         if (s + NBUF - 1 < nsteps) issue_next();
         if (s + 1 < nsteps) {
@@ -487,13 +493,13 @@ __global__ __launch_bounds__(512) void mlp_fused_bwd_kernel(MlpArgs p) {
             issue_aux(hs + 1 == NS ? tile + G : tile, nhs, nxt);
         }
         const T* sb = reinterpret_cast<const T*>(smem + cslot * STAGE_B);
-        const int t0 = tile * 256 + wave * 32;
-        bf16x8 keep[2];
+        const int t0 = tile * TT + wave * TW;
+        bf16x8 keep[MTW];
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
-            f32x4 acc1[2][2];
+            f32x4 acc1[MTW][2];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) acc1[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -502,18 +508,20 @@ __global__ __launch_bounds__(512) void mlp_fused_bwd_kernel(MlpArgs p) {
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) wf[nt] = *reinterpret_cast<const bf16x8*>(sb + ks * (HS * 32) + blk * (32 * 32) + w1off[nt]);
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
+                for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt) acc1[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt][ks], acc1[mt][nt], 0, 0, 0);
             }
             if (blk == 0) {
                 // -- AUX(s) landed?  (younger: DMA(s+2), AUX(s+1), where issued)
-                if (s + NBUF - 1 < nsteps) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]) : "n"(CNT + 4) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3])::"memory");
-            }
-            bf16x8 hf[2];
+                if (s + NBUF - 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT + 2 * MTW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
+                for (int i = 0; i < 2 * MTW; ++i) asm volatile("" : "+v"(cur[i]));
+            }
+            bf16x8 hf[MTW];
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) {
                 float v[8], ax[8];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -536,7 +544,7 @@ __global__ __launch_bounds__(512) void mlp_fused_bwd_kernel(MlpArgs p) {
             for (int nt = 0; nt < NT2; ++nt) {
                 const bf16x8 wf2 = *reinterpret_cast<const bf16x8*>(sb + blk * (C * 32) + w2off[nt]);
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) acc2[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf2, hf[mt], acc2[mt][nt], 0, 0, 0);
+                for (int mt = 0; mt < MTW; ++mt) acc2[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf2, hf[mt], acc2[mt][nt], 0, 0, 0);
             }
         }
         if constexpr (LNB) {
@@ -547,11 +555,8 @@ __global__ __launch_bounds__(512) void mlp_fused_bwd_kernel(MlpArgs p) {
         if (++hs == NS) {
             const int next = tile + G;
             if constexpr (LNB) {
-                float dgl[KS * 8], dbl[KS * 8];
 #pragma unroll
-                for (int v = 0; v < KS * 8; ++v) dgl[v] = dbl[v] = 0.f;
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
+                for (int mt = 0; mt < MTW; ++mt) {
                     // one token tile at a time, the row's values formed twice (sums, then outputs) rather than kept: registers
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -587,20 +592,16 @@ __global__ __launch_bounds__(512) void mlp_fused_bwd_kernel(MlpArgs p) {
                             const float xh = ((float)lx[mt][c][e] - mean) * rstd;
                             const float gm = d * (e < 4 ? g0[e & 3] : g1[e & 3]);
                             o[e] = (bf16)(rstd * (gm - s1 - xh * s2) + (float)xf[mt][c][e]);
+                            // d(gamma), d(beta): summed over the row's 16 tokens now (DPP, fixed order), kept by lane li == v % 16
                             const float dv = valid ? d : 0.f;
-                            dgl[v] += dv * xh;
-                            dbl[v] += dv;
+                            const float sg = row16_sum(dv * xh), sb = row16_sum(dv);
+                            if (li == (v & 15)) own[v >> 4] += sg;
+                            if (li == ((v + NV) & 15)) own[(v + NV) >> 4] += sb;
                         }
                         if (valid) *reinterpret_cast<bf16x8*>(p.y + (size_t)tok * C + c * 32 + lg * 8) = o;
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int v = 0; v < KS * 8; ++v) {
-                    const float a = row16_sum(dgl[v]), b = row16_sum(dbl[v]);
-                    if (li == (v & 15)) own[v >> 4] += a;
-                    if (li == ((v + KS * 8) & 15)) own[(v + KS * 8) >> 4] += b;
-                }
                 if (next < p.tiles) load_x(next);
             } else {
             if (next < p.tiles) load_x(next);
@@ -609,10 +610,10 @@ __global__ __launch_bounds__(512) void mlp_fused_bwd_kernel(MlpArgs p) {
             e.N = C;
             e.y = p.y;
             e.ldy = C;
-            nt_epilogue<T, 2, NT2>(e, acc2, t0, 0, li, lg);
+            nt_epilogue<T, MTW, NT2>(e, acc2, t0, 0, li, lg);
             }
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT2; ++nt) acc2[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
             hs = 0;
@@ -624,16 +625,16 @@ __global__ __launch_bounds__(512) void mlp_fused_bwd_kernel(MlpArgs p) {
         step(auxB, auxA);
     }
     if constexpr (LNB) {
-        static_assert(C == 96, "48 partial sums per lane group: 3 per lane");
+        __syncthreads();                                     // every wave is done with the ring: the slots alias its first bytes
 #pragma unroll
-        for (int k = 0; k < 3; ++k) slot_s[(wave * 4 + lg) * 48 + k * 16 + li] = own[k];
+        for (int k = 0; k < NOWN; ++k) slot_s[(wave * 4 + lg) * (2 * NV) + k * 16 + li] = own[k];
         __syncthreads();
         if (tid < 2 * C) {
             const int kind = tid / C, ch = tid % C;
-            const int v = kind * 24 + (ch >> 5) * 8 + (ch & 7), lgc = (ch >> 3) & 3;
+            const int v = kind * NV + (ch >> 5) * 8 + (ch & 7), lgc = (ch >> 3) & 3;
             float a = 0.f;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) a += slot_s[(w * 4 + lgc) * 48 + v];
+            for (int w = 0; w < 8; ++w) a += slot_s[(w * 4 + lgc) * (2 * NV) + v];
             p.ln_part[(size_t)blockIdx.x * 2 * C + tid] = a;
         }
     }
@@ -650,14 +651,18 @@ __global__ void mlp_ln_part_reduce_kernel(const float* __restrict__ part, int nb
 }
 
 template <int C, bool LNB = false>
-int launch_mlp_bwd(const MlpArgs& a, hipStream_t st) {
-    constexpr size_t lds = (size_t)3 * (((C / 32) * 64 * 32 + 2 * C * 32) * 2) + GELU_LUT_BYTES + (LNB ? (C + 8 * 4 * 48) * sizeof(float) : 0);
+int launch_mlp_bwd(const MlpArgs& a0, hipStream_t st) {
+    constexpr size_t lds = (size_t)3 * (((C / 32) * 64 * 32 + 2 * C * 32) * 2) + GELU_LUT_BYTES + (LNB ? C * sizeof(float) : 0);
+    static_assert(lds <= 160 * 1024, "LDS");
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_bwd_kernel<C, LNB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
+    MlpArgs a = a0;
+    constexpr int TT = C == 96 ? 256 : 128;                  // tokens per tile (the kernel's MTW)
+    a.tiles = (a.M + TT - 1) / TT;
     const int grid = a.tiles < 256 ? a.tiles : 256;
     hipLaunchKernelGGL((mlp_fused_bwd_kernel<C, LNB>), dim3(grid), dim3(512), lds, st, a);
     FMMT_CHECK_LAUNCH();
@@ -726,7 +731,7 @@ extern "C" int fmmt_mlp_ln_bwd_input(int dtype, int M, int C, const void* dy, co
                                      const float* rowscale, int rows_per_scale, const void* x, const float* mean, const float* rstd,
                                      const float* ln_gamma, void* dh, void* dx, float* dgamma, float* dbeta, void* workspace,
                                      size_t workspace_bytes, void* stream) {
-    if (dtype != FMMT_BF16 || M <= 0 || C != 96) return FMMT_EINVAL;                     // other widths: fmmt_mlp_bwd_input + fmmt_layernorm_bwd
+    if (dtype != FMMT_BF16 || M <= 0 || (C != 96 && C != 192)) return FMMT_EINVAL;       // other widths: fmmt_mlp_bwd_input + fmmt_layernorm_bwd
     if (!dy || !h_pre || !w2t || !w1t || !dh || !dx || !x || !mean || !rstd || !ln_gamma || !dgamma || !dbeta || !workspace) return FMMT_EINVAL;
     if (rowscale && rows_per_scale <= 0) return FMMT_EINVAL;
     if (workspace_bytes < fmmt_mlp_ln_bwd_input_workspace(C)) return FMMT_EWORKSPACE;
@@ -736,8 +741,8 @@ extern "C" int fmmt_mlp_ln_bwd_input(int dtype, int M, int C, const void* dy, co
     a.y = (bf16*)dx; a.h_pre = (bf16*)const_cast<void*>(h_pre); a.h_act = (bf16*)dh; a.tiles = (M + 255) / 256;
     a.ln_g = ln_gamma; a.mean = const_cast<float*>(mean); a.rstd = const_cast<float*>(rstd); a.ln_x = (const bf16*)x; a.ln_part = (float*)workspace;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (int rc = launch_mlp_bwd<96, true>(a, st)) return rc;
-    const int grid = a.tiles < 256 ? a.tiles : 256;
+    if (int rc = C == 96 ? launch_mlp_bwd<96, true>(a, st) : launch_mlp_bwd<192, true>(a, st)) return rc;
+    const int tiles = (M + (C == 96 ? 256 : 128) - 1) / (C == 96 ? 256 : 128), grid = tiles < 256 ? tiles : 256;
     hipLaunchKernelGGL(mlp_ln_part_reduce_kernel, dim3((2 * C + 63) / 64), dim3(64), 0, st, (const float*)workspace, grid, C, dgamma, dbeta);
     FMMT_CHECK_LAUNCH();
     return 0;

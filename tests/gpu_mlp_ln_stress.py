@@ -7,8 +7,7 @@ from facialmmt_amd import ops
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 bad = 0
-for M in (2007040, 8192 + 77, 256 * 300 + 5):
-    C = 96
+for M, C in ((2007040, 96), (8192 + 77, 96), (256 * 300 + 5, 96), (501760, 192), (128 * 300 + 9, 192)):
     x = torch.randn(M, C, device=dev).bfloat16().requires_grad_(True)
     g = (1 + 0.2 * torch.randn(C, device=dev)).requires_grad_(True); b = (0.1 * torch.randn(C, device=dev)).requires_grad_(True)
     w1 = (torch.randn(4 * C, C, device=dev) * C ** -0.5).requires_grad_(True); b1 = (0.1 * torch.randn(4 * C, device=dev)).requires_grad_(True)
@@ -18,7 +17,7 @@ for M in (2007040, 8192 + 77, 256 * 300 + 5):
     side = torch.cuda.Stream()
     junk = torch.randn(8192, 8192, device=dev)
     first = None
-    n = 40 if M > 1000000 else 200
+    n = 40 if M > 400000 else 200
     for it in range(n):
         if it % 3 == 1:
             with torch.cuda.stream(side):
@@ -32,7 +31,7 @@ for M in (2007040, 8192 + 77, 256 * 300 + 5):
             for k, (a, c) in enumerate(zip(first, gr)):
                 if not torch.equal(a, c):
                     bad += 1
-                    print(f"M={M} iteration {it}: gradient {k} differs, max |diff| {(a.float() - c.float()).abs().max().item():.3e}", flush=True)
+                    print(f"M={M} C={C} iteration {it}: gradient {k} differs, max |diff| {(a.float() - c.float()).abs().max().item():.3e}", flush=True)
     torch.cuda.synchronize()
-    print(f"M={M}: {n} repetitions done, mismatches so far {bad}", flush=True)
+    print(f"M={M} C={C}: {n} repetitions done, mismatches so far {bad}", flush=True)
 sys.exit(1 if bad else 0)
