@@ -106,7 +106,7 @@ def _lp(w: torch.Tensor, dtype, transpose: bool = False) -> torch.Tensor:
         return wd.contiguous()
     capturing = wd.is_cuda and torch.cuda.is_current_stream_capturing()
     key = (w.storage_offset(), tuple(w.shape), tuple(w.stride()), dtype, transpose)
-    if capturing:
+    if capturing and _PIN_SCOPE:                            # only inside the capture of a step that refreshes them (pinned_scope)
         pin = _PINNED.get(id(base))
         if pin is not None and key in pin:
             return pin[key]                                  # refreshed by PinnedShadows.refresh() at the head of the graph
@@ -127,6 +127,26 @@ def _lp(w: torch.Tensor, dtype, transpose: bool = False) -> torch.Tensor:
 
 
 _PINNED: dict = {}              # id(parameter) -> {key: static shadow}: consulted only while a graph is being captured
+_PIN_SCOPE: list = []           # PinnedShadows objects whose owners are capturing right now (pinned_scope)
+
+
+class pinned_scope:
+    """`with pinned_scope(shadows):` around the capture of a step whose graph starts with shadows.refresh().  Only inside it does
+    `_lp` hand out the static shadows: any other capture (graph_multimodal, a user's own graph) would otherwise bake in shadows that
+    nothing in ITS graph refreshes -- stale weights after the first optimizer step."""
+
+    def __init__(self, shadows):
+        self.shadows = shadows
+
+    def __enter__(self):
+        if self.shadows is not None:
+            _PIN_SCOPE.append(self.shadows)
+        return self
+
+    def __exit__(self, *exc):
+        if self.shadows is not None:
+            _PIN_SCOPE.remove(self.shadows)
+        return False
 
 
 class PinnedShadows:

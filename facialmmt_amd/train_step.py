@@ -580,6 +580,11 @@ class FusedClipAdamW:
         ops.adamw_batch(self.n, self.blocks, self.desc, self.lr, self.step, self.norm, self.b1, self.b2, self.eps, self.wd, self.max_norm, self.hf)
 
 
+def _ops_pinned_scope(shadows):
+    from . import ops
+    return ops.pinned_scope(shadows)
+
+
 def _pin_shadows(modules):
     """ops.PinnedShadows over the parameters of `modules` (FMMT_PIN_SHADOWS=0: per-weight casts inside the graph, as before)"""
     import os
@@ -700,7 +705,7 @@ class GraphedTargetStep:
         # front of Swin's backward would serialise (measured at N = 1: 72.1 ms per step cut, 69 ms uncut).
         self.split = bool(getattr(self.flat, "active", False))
         self.graph_a, self.graph_a2, self.graph_b = torch.cuda.CUDAGraph(), (torch.cuda.CUDAGraph() if self.split else None), torch.cuda.CUDAGraph()
-        with capture_window():
+        with capture_window(), _ops_pinned_scope(self.shadows):
             if self.split:
                 with torch.cuda.graph(self.graph_a, stream=cap):
                     self.loss, self.new_mask, swin_out = self._fwd_bwd_multimodal()
@@ -879,7 +884,7 @@ class GraphedAuxStep:
         torch.cuda.set_rng_state(rng, dev)
         self.shadows = _pin_shadows([self.swin])
         self.graph_a, self.graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with capture_window():
+        with capture_window(), _ops_pinned_scope(self.shadows):
             with torch.cuda.graph(self.graph_a, stream=cap):
                 self.loss = self._fwd_bwd()
             with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), stream=cap):
