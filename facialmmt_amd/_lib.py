@@ -57,6 +57,7 @@ SIGNATURES = {
     "fmmt_resize_table": (_i, [_i, _i, _i, _p, _p]),
     "fmmt_resize_band_rows": (_i, [_p, _i]),
     "fmmt_patch_embed_u8": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p]),
+    "fmmt_patch_embed_ln_fwd": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p]),
 }
 
 _ERR = {-1: "FMMT_EINVAL (bad shape / unsupported size)", -2: "FMMT_EALIGN (pointer or leading dimension not 16-byte aligned)",

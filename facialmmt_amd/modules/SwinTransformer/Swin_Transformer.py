@@ -317,7 +317,10 @@ class PatchEmbed(nn.Module):
                  "PatchEmbed kernel is built for 3x224x224 images and 4x4 patches")
         B = x.shape[0]
         cols = ops.patch_embed_u8(x, resize, dtype or self.proj.weight.dtype)
-        y = ops.linear(cols, self.proj.weight.view(self.embed_dim, -1), self.proj.bias).view(B, self.num_patches, self.embed_dim)
+        w2d = self.proj.weight.view(self.embed_dim, -1)
+        if ops.patch_proj_ln_fusable(cols, w2d, self.norm):    # projection + bias + LayerNorm: one launch
+            return ops.patch_proj_ln(cols, w2d, self.proj.bias, self.norm.weight, self.norm.bias, self.norm.eps).view(B, self.num_patches, self.embed_dim)
+        y = ops.linear(cols, w2d, self.proj.bias).view(B, self.num_patches, self.embed_dim)
         if self.norm is not None:
             y = ops.layer_norm(y, self.norm.weight, self.norm.bias, self.norm.eps)
         return y
@@ -329,7 +332,10 @@ class PatchEmbed(nn.Module):
         _require(tuple(self.img_size) == (224, 224) and tuple(self.patch_size) == (4, 4) and C == 3,
                  "PatchEmbed kernel is built for 3x224x224 images and 4x4 patches")
         cols = ops.patch_im2col(x)                                                   # (B*3136, 48)
-        y = ops.linear(cols, self.proj.weight.view(self.embed_dim, -1), self.proj.bias).view(B, self.num_patches, self.embed_dim)
+        w2d = self.proj.weight.view(self.embed_dim, -1)
+        if ops.patch_proj_ln_fusable(cols, w2d, self.norm):
+            return ops.patch_proj_ln(cols, w2d, self.proj.bias, self.norm.weight, self.norm.bias, self.norm.eps).view(B, self.num_patches, self.embed_dim)
+        y = ops.linear(cols, w2d, self.proj.bias).view(B, self.num_patches, self.embed_dim)
         if self.norm is not None:
             y = ops.layer_norm(y, self.norm.weight, self.norm.bias, self.norm.eps)
         return y

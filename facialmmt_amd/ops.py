@@ -572,6 +572,59 @@ def layer_norm(x, gamma, beta, eps=1e-5, merge_hw=0):
     return LayerNormFn.apply(x, gamma, beta, eps, merge_hw)
 
 
+_PATCH_LN = _os.environ.get("FMMT_PATCH_LN", "1") != "0"    # A/B switch (read once): 0 = projection and LayerNorm as two launches
+
+
+class PatchProjLnFn(Function):
+    """LayerNorm(cols W^T + b) of PatchEmbed in one launch (fmmt_patch_embed_ln_fwd); backward = fmmt_layernorm_bwd on the saved
+    pre-LayerNorm rows, then the projection's weight / bias / input gradients as for any Linear."""
+
+    @staticmethod
+    def forward(ctx, cols, weight, bias, gamma, beta, eps):
+        _need_cuda(cols, "patch_proj_ln")
+        M, K = cols.shape
+        C = weight.shape[0]
+        train = any(ctx.needs_input_grad)
+        dev, dt = cols.device, cols.dtype
+        g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        y = torch.empty((M, C), dtype=dt, device=dev)
+        x_pre = torch.empty_like(y) if train else None
+        mean = torch.empty(M, dtype=torch.float32, device=dev) if train else None
+        rstd = torch.empty(M, dtype=torch.float32, device=dev) if train else None
+        rc = _lib.load().fmmt_patch_embed_ln_fwd(dtype_code(dt), M, C, K, _p(cols), _p(_lp(weight, dt)), _p(bias.detach().float().contiguous() if bias is not None else None),
+                                                 _p(g), _p(b), float(eps), _p(x_pre), _p(y), _p(mean), _p(rstd), _st())
+        check(rc, f"fmmt_patch_embed_ln_fwd(M={M})")
+        ctx.save_for_backward(cols, weight, x_pre, mean, rstd, g)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        cols, weight, x_pre, mean, rstd, g = ctx.saved_tensors
+        M, C = x_pre.shape
+        lib = _lib.load()
+        dy = dy.contiguous()
+        dxp = torch.empty_like(x_pre)
+        dg = torch.empty(C, dtype=torch.float32, device=dy.device)
+        db = torch.empty(C, dtype=torch.float32, device=dy.device)
+        nbytes = lib.fmmt_layernorm_bwd_workspace(C)
+        ws = _ws(nbytes, dy.device)
+        check(lib.fmmt_layernorm_bwd(dtype_code(dy.dtype), M, C, _p(dy), _p(x_pre), _p(mean), _p(rstd), _p(g), None, _p(dxp), _p(dg), _p(db), 0,
+                                     _p(ws), nbytes, _st()), f"fmmt_layernorm_bwd(patch embed, M={M})")
+        dw, dbias = wgrad_raw(dxp, cols, ctx.has_bias)
+        dcols = linear_raw(dxp, _lp(weight, dy.dtype, transpose=True), None) if ctx.needs_input_grad[0] else None
+        return dcols, dw.view_as(weight), dbias, dg, db, None
+
+
+def patch_proj_ln_fusable(cols, weight, norm):
+    return (_PATCH_LN and norm is not None and cols.is_cuda and cols.dtype == torch.bfloat16 and tuple(weight.shape) == (96, 48)
+            and tuple(norm.weight.shape) == (96,))
+
+
+def patch_proj_ln(cols, weight, bias, gamma, beta, eps):
+    return PatchProjLnFn.apply(cols, weight, bias, gamma, beta, eps)
+
+
 class ResidualLayerNormFn(Function):
     """(x, LN(x)) for pre-norm residual blocks `x + f(LN(x))`: the residual branch takes the first output,
     f the second.  Backward receives both incoming gradients at once, so the residual-gradient add is the

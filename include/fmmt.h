@@ -347,6 +347,13 @@ int fmmt_resize_band_rows(const int32_t* table, int out_size);
 int fmmt_patch_embed_u8(int dtype, int mode, int n_img, int in_size, const void* img_u8, const int32_t* table_dev,
                         const float* lut_dev, void* cols, void* stream);
 
+/* PatchEmbed's projection + bias + LayerNorm in one launch (Swin_Transformer.py:392-422: proj, flatten, norm) on the patch matrix
+ * fmmt_patch_embed_u8 / fmmt_patch_im2col produced: cols (M, K = 48) bf16, w (C = 96, 48) bf16 (Conv2d weight viewed as a matrix), bias /
+ * ln_gamma / ln_beta fp32.  y (M, 96) = LayerNorm(x_pre), x_pre = bf16(cols . w^T + bias); x_pre, mean, rstd (or NULL at inference) are
+ * what fmmt_layernorm_bwd needs.  bf16, C = 96, K = 48 only (FMMT_EINVAL otherwise: fmmt_linear_fwd + fmmt_layernorm_fwd). */
+int fmmt_patch_embed_ln_fwd(int dtype, int M, int C, int K, const void* cols, const void* w, const float* bias, const float* ln_gamma,
+                            const float* ln_beta, float eps, void* x_pre, void* y, float* mean, float* rstd, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -201,3 +201,39 @@ def test_fused_mlp_input_gradient_launch(dev):
             assert err <= ulps * scale * 2.0 ** -7, (M, err, scale)
         assert (dh[:rps] == 0).all() and (dx[:rps] == 0).all()                                  # the dropped sample
         del dh, dx, dh2, dx2
+
+
+@pytest.mark.parametrize("n", [2, 5])
+def test_patch_embed_projection_and_layernorm_in_one_launch(dev, monkeypatch, golden, n):
+    """fmmt_patch_embed_ln_fwd (PatchEmbed: proj + bias + LayerNorm, Swin_Transformer.py:392-422) in bf16: against the reference-generated
+    golden (n = 2), against the two-launch form, and forward / every gradient against an fp64 restatement; ragged last tile (n = 5:
+    15680 patches)."""
+    from facialmmt_amd import synth
+    from facialmmt_amd.modules.SwinTransformer import Swin_Transformer as S
+    pe = S.PatchEmbed(224, 4, 3, 96, torch.nn.LayerNorm)
+    synth.fill_state_dict(pe, seed=30, prefix="pe.")
+    pe.to(dev)
+    frames = synth.tensor("frames", (n, 3, 224, 224), seed=1).to(dev).bfloat16().requires_grad_(True)
+    params = list(pe.parameters())
+    assert ops.patch_proj_ln_fusable(ops.patch_im2col(frames.detach()), pe.proj.weight.view(96, -1), pe.norm)
+    y = pe(frames)
+    if n == 2:
+        import numpy as np
+        ref, stride = golden.expected("swin_parts", "patch_embed")
+        got = y.detach().float().cpu().numpy()
+        got = got if stride is None else got.reshape(-1)[::stride]
+        assert np.abs(got - ref).max() <= 3e-2 * np.abs(ref).max()
+    w = torch.randn(y.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(3)).bfloat16()
+    g1 = torch.autograd.grad(y, [frames] + params, w)
+    monkeypatch.setattr(ops, "_PATCH_LN", False)
+    y2 = pe(frames)
+    g2 = torch.autograd.grad(y2, [frames] + params, w)
+    f64 = frames.detach().double().requires_grad_(True)
+    p64 = [p.detach().double().requires_grad_(True) for p in params]
+    named = dict(zip([k for k, _ in pe.named_parameters()], p64))
+    x64 = torch.nn.functional.conv2d(f64, named["proj.weight"], named["proj.bias"], stride=4).flatten(2).transpose(1, 2)
+    r64 = torch.nn.functional.layer_norm(x64, (96,), named["norm.weight"], named["norm.bias"], 1e-5)
+    g64 = torch.autograd.grad(r64, [f64] + p64, w.double())
+    assert _rel(y, r64) <= 2e-2 and _rel(y, y2) <= 1e-2
+    for a, b, c in zip(g1, g2, g64):
+        assert _rel(a, c) <= 4e-2 and _rel(b, c) <= 4e-2
