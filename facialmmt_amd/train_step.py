@@ -618,11 +618,11 @@ class GraphedTargetStep:
     a single GPU, three when a gradient exchange has to be hidden (N > 1):
 
       A1 text encoder (forked onto a second stream) || Swin forward -> frame filter -> fusion stack -> cross-entropy ->
-         backward through the fusion stack and the text encoder, down to the gradient of Swin's output; the multimodal
-         gradients land in static flat fp32 buffers (parallel.GradientAverager's buckets, hooks off);
+         backward through the fusion stack, the text encoder and Swin's head / stages 3-1, down to the gradient of Swin's stage-0
+         output (SWIN_CUT); the multimodal gradients land in static flat fp32 buffers (parallel.GradientAverager's buckets, hooks off);
       -- N > 1: one asynchronous all-reduce per flat bucket is ISSUED here (the only collective of the step): the
          collectives run on the backend's stream behind A1 and BESIDE A2 --
-      A2 Swin's backward from that gradient (a third of the step); its parameter gradients land in buffers nobody reads
+      A2 the rest of Swin's backward from that gradient (stage 0: ~10 ms); Swin's parameter gradients land in buffers nobody reads
          (Swin's target-step gradients are discarded, train.py:20,141, and therefore never exchanged);
       -- N > 1: the stream waits for the collectives --
       B  clip_grad_norm_ + optimizer.step() (capturable) + zeroing of the flat buffers.
@@ -743,11 +743,22 @@ class GraphedTargetStep:
             self.text_stream.wait_stream(main)             # fork: the text branch does not depend on the visual path
             with torch.cuda.stream(self.text_stream), ac():
                 pending = mm.text_branch(ids, attn_mask, sep_mask, torch.as_tensor(utt_idx, device=ids.device))
+        cut, hook = {}, None
         if self.skip_swin_bwd:
             with torch.no_grad():
                 preds = self.swin(frames, is_trg_task=True)
         else:
+            if not whole:
+                # two-piece backward: the cut goes INSIDE Swin, behind stage SWIN_CUT (below): the first piece then holds the text
+                # encoder's backward beside Swin's head / stage-3 / -2 / -1 backward -- as the single graph does --, the second piece
+                # Swin's stage-0 backward beside the gradient exchange.  (Cut at Swin's output, the text backward ran alone in front
+                # of all of Swin's backward: 71.6 against 66.8 ms per step at one rank.)
+                layers = getattr(getattr(self.swin, "swin", None), "layers", None)
+                if layers is not None and len(layers) > self.SWIN_CUT + 1:
+                    hook = layers[self.SWIN_CUT].register_forward_hook(lambda m, i, o: cut.__setitem__("x", o))
             preds = self.swin(frames, is_trg_task=True)
+            if hook is not None:
+                hook.remove()
         vis_concat, new_mask = select_frames(preds.float(), vision_inputs, vision_mask, num_imgs, args.FacialEmoImpor_threshold)
         with ac():
             if pending is None:
@@ -765,17 +776,37 @@ class GraphedTargetStep:
         # backward, first piece: every leaf the optimizer steps plus Swin's output (the autograd graph below `preds` -- Swin -- is
         # left untouched, with its saved activations, for the second piece)
         leaves = [l for l, _ in self.pairs if l.requires_grad]
+        x_cut = cut.get("x") if torch.is_tensor(cut.get("x")) and cut["x"].requires_grad else None
+        late = []
         if self.skip_swin_bwd:
             got = (None,) + tuple(torch.autograd.grad(loss, leaves, allow_unused=True))
+        elif x_cut is not None:
+            # Swin's parameters ABOVE the cut get their gradients in this piece (requested explicitly: autograd.grad computes nothing it is
+            # not asked for, and the reference computes them)
+            early = {id(q) for q in self.swin.swin.patch_embed.parameters()}
+            for lyr in list(self.swin.swin.layers)[:self.SWIN_CUT + 1]:
+                early |= {id(q) for q in lyr.parameters()}
+            if getattr(self.swin.swin, "absolute_pos_embed", None) is not None:
+                early.add(id(self.swin.swin.absolute_pos_embed))
+            late = [q for q in self.swin.parameters() if q.requires_grad and id(q) not in early]
+            got = torch.autograd.grad(loss, [x_cut] + leaves + late, allow_unused=True)
         else:
+            x_cut = preds
             got = torch.autograd.grad(loss, [preds] + leaves, allow_unused=True)
         dpreds = got[0]
-        for l, g in zip(leaves, got[1:]):
+        for l, g in zip(leaves, got[1:1 + len(leaves)]):
             l.grad = g
+        for q, g in zip(late, got[1 + len(leaves):]):        # discarded like all of Swin's target-step gradients (train.py:20,33)
+            q.grad = g
         # (Letting the fused update read the model's own .grad tensors instead -- no hand-over, 2.8 GB less traffic -- was
         #  tried: the ~870 gradient tensors then stay allocated across the graph and the step got 2.8 ms SLOWER; not kept.)
         _hand_over_gradients(self.pairs, self.flat_view_of, self.accumulate)
-        return loss.detach(), new_mask, (preds, dpreds)
+        return loss.detach(), new_mask, (x_cut, dpreds)
+
+    # two-piece backward: cut behind Swin stage SWIN_CUT.  Measured at one rank with the exchange forced (ms per step, same call; the
+    # single graph: 66.9): cut at Swin's output 71.6, behind stage 2: 72.3, stage 1: 70.9-71.0, stage 0: 69.7-69.9 -- the second piece
+    # (stage 0's backward, ~10 ms) is the window the bucketed all-reduce of 0.87 GB has to fit into
+    SWIN_CUT = 0
 
     def _bwd_swin(self, swin_out):
         """backward, second piece: Swin from the gradient of its output.  Nobody reads the result in the target step (train.py:20,141
