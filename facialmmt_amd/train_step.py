@@ -704,6 +704,11 @@ class GraphedTargetStep:
         # the GPU it stays ONE graph: inside it the text encoder's backward runs as a branch beside Swin's backward, which a cut in
         # front of Swin's backward would serialise (measured at N = 1: 72.1 ms per step cut, 69 ms uncut).
         self.split = bool(getattr(self.flat, "active", False))
+        # the exchange has to fit beside the second piece: two ranks share ONE xGMI link (0.87 GB each way at ~64 GB/s: ~14 ms, an
+        # estimate -- no two-GPU box was available), so there the cut moves up one stage (second piece ~17 ms); from four ranks on the
+        # all-reduce spreads over 3-7 links (~3.5-7 ms) and fits beside stage 0's backward
+        if getattr(self.flat, "world", 1) == 2:
+            self.SWIN_CUT = 1
         self.graph_a, self.graph_a2, self.graph_b = torch.cuda.CUDAGraph(), (torch.cuda.CUDAGraph() if self.split else None), torch.cuda.CUDAGraph()
         with capture_window(), _ops_pinned_scope(self.shadows):
             if self.split:
