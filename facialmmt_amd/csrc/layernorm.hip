@@ -125,14 +125,32 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnArgs p) {
 
     for (int row = blockIdx.x * ROWS + rib; row < p.M; row += gridDim.x * ROWS) {
         const float mean = p.mean[row], rstd = p.rstd[row];
-        Vec<T> xv[NCH], gv[NCH];
+        // the residual gradient is requested with the row's other loads where that measured faster (us per launch, one profile: three
+        // chunks per lane 87 -> 75, the PatchMerging forms 395 -> 247 / 255 -> 191 / 109 -> 72) and behind the row sums, as before,
+        // where it did not (one and two chunks per lane)
+        constexpr bool EARLY_ADD = MERGE || NCH >= 3;
+        Vec<T> xv[NCH], gv[NCH], avp[EARLY_ADD ? NCH : 1];
         float s1 = 0.f, s2 = 0.f;
+        if constexpr (EARLY_ADD) {                          // ... and all of the row's loads in front of the arithmetic
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int c = sub + i * G;
+                if (c < chunks) {
+                    const size_t off = src_offset<MERGE>(row, c * VEC, p.C, p.merge_hw);
+                    xv[i] = ldvec<T>(xg + off);
+                    gv[i] = ldvec<T>(dyg + (size_t)row * p.C + c * VEC);
+                    if (addg) avp[i] = ldvec<T>(addg + off);
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = sub + i * G;
             if (c < chunks) {
-                xv[i] = ldvec<T>(xg + src_offset<MERGE>(row, c * VEC, p.C, p.merge_hw));
-                gv[i] = ldvec<T>(dyg + (size_t)row * p.C + c * VEC);
+                if constexpr (!EARLY_ADD) {
+                    xv[i] = ldvec<T>(xg + src_offset<MERGE>(row, c * VEC, p.C, p.merge_hw));
+                    gv[i] = ldvec<T>(dyg + (size_t)row * p.C + c * VEC);
+                }
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
                     const float xh = (xv[i].get(e) - mean) * rstd;
@@ -153,7 +171,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnArgs p) {
             if (c < chunks) {
                 const size_t off = src_offset<MERGE>(row, c * VEC, p.C, p.merge_hw);
                 Vec<T> o, av;
-                if (addg) av = ldvec<T>(addg + off);
+                if constexpr (EARLY_ADD) {
+                    if (addg) av = avp[i];
+                } else {
+                    if (addg) av = ldvec<T>(addg + off);
+                }
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
                     const float xh = (xv[i].get(e) - mean) * rstd;
