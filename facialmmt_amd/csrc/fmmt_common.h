@@ -29,6 +29,24 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 // reads NO environment variable.
 constexpr int fmmt_const(const char*, int winner) { return winner; }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute: one flag word per call site, one bit per device (a process
+// that drives several GPUs -- a C-ABI consumer without torch's one-process-per-GPU habit -- sets it on each), atomically (launchers may be
+// called from autograd's worker threads).  Returns 0 or the hipError.
+struct FmmtLdsOnce {
+    unsigned long long done = 0;
+    int set(const void* fn, int bytes) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return (int)e;
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (__atomic_load_n(&done, __ATOMIC_ACQUIRE) & bit) return 0;
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return (int)e;
+        __atomic_fetch_or(&done, bit, __ATOMIC_RELEASE);
+        return 0;
+    }
+};
+
 #define FMMT_CHECK_LAUNCH()                                   \
     do {                                                      \
         hipError_t e__ = hipGetLastError();                   \

@@ -45,7 +45,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 //  * K pipeline: while tile k is multiplied out of LDS, tile k+1 is in flight into registers; two LDS
 //    buffers, one barrier per K step.  BK = 64 makes every global load instruction fetch whole 128-byte
 //    rows.  K == 96 (Swin stage 0) is a single step (NBUF = 1).  (A second register stage was measured
-//    and lost: occupancy beats prefetch depth on this chip for these shapes -- tests/gpu_gemm_bench.py.)
+//    and lost: occupancy beats prefetch depth on this chip for these shapes -- tools/probes/gemm_bench.py.)
 //  * one output tile per workgroup.  (A persistent variant that issues the next tile's first K step under
 //    the epilogue was measured and lost as well: +60..100 VGPRs -> one wave per SIMD.)
 // ---------------------------------------------------------------------------------------------
@@ -960,13 +960,8 @@ template <int BN, int BK, int NBUF, bool BATCH, bool HASOP, bool PIPE = false>
 int launch_p256_b(const LinArgs& a, hipStream_t st) {
     constexpr size_t lds = (size_t)NBUF * (BN + 256) * BK * 2 + 2 * 256 * sizeof(float) + (BN == 256 ? 8 * 16 * 144 + GELU_LUT_BYTES : 2 * (BN == 192 ? 32 : 16) * (BN * 2 + 16));   // ring, bias slabs, epilogue scratch (BN = 256: wave-private slabs + the GELU table)
     static_assert(lds <= 160 * 1024, "LDS");
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_nt_p256_kernel<BN, BK, NBUF, BATCH, HASOP, PIPE>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static FmmtLdsOnce lds_once;
+    if (int rc_ = lds_once.set(reinterpret_cast<const void*>(&linear_nt_p256_kernel<BN, BK, NBUF, BATCH, HASOP, PIPE>), (int)lds)) return rc_;
     LinArgs p = a;
     p.tiles_m = (a.M + 255) / 256;
     p.tiles_n = a.N / BN;
@@ -1053,12 +1048,9 @@ template <typename T, int BM, int BN, int BK, int NBUF, bool GLDS = false>
 int launch_nt(const LinArgs& a, hipStream_t st) {
     constexpr int VEC = Vec<T>::N;
     constexpr size_t lds = (size_t)NBUF * (BM + BN) * (GLDS ? BK : BK + VEC) * sizeof(T);
-    static bool attr_set = false;
-    if (lds > 65536 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_nt_kernel<T, BM, BN, BK, NBUF, GLDS>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
+    static FmmtLdsOnce lds_once;
+    if (lds > 65536) {
+        if (int rc_ = lds_once.set(reinterpret_cast<const void*>(&linear_nt_kernel<T, BM, BN, BK, NBUF, GLDS>), (int)lds)) return rc_;
     }
     LinArgs p = a;
     p.tiles_n = (a.N + BN - 1) / BN;
@@ -1079,7 +1071,7 @@ int dispatch_nt_bk(const LinArgs& a, hipStream_t st) {
         // occupancy is what counts (NtWaves above); the fc1 + GELU + pre-activation launch is the only one still on it.
         if (!a.ksplit && a.K == 96) return launch_nt<T, BM, BN, 96, 1>(a, st);
         if (!a.ksplit && a.K <= 64) return launch_nt<T, BM, BN, 64, 1>(a, st);     // PatchEmbed (K = 48)
-        // measured on MI355X (tests/gpu_gemm_bench.py, sum over the bench shapes): BK=64 5.33 ms vs BK=32 5.88 ms
+        // measured on MI355X (tools/probes/gemm_bench.py, sum over the bench shapes): BK=64 5.33 ms vs BK=32 5.88 ms
         // direct global->LDS DMA staging: measured +7 % over register staging summed over the bench shapes, up to
         // +25 % on the K >= 768 ones (971 TF/s on 31360x768x3072); FMMT_NT_GLDS=0 selects the register-staged kernel
         static const int glds = fmmt_const("FMMT_NT_GLDS", 1);
@@ -1114,7 +1106,7 @@ int dispatch_nt(const LinArgs& a, hipStream_t st) {
             // Fewer 64 x 128 tiles than half the CUs (the fusion stack: 152-1328 tokens x 768 channels = 18-126 tiles): such a
             // launch is a chain of K / 64 steps whose cost is the step's DMA issue (six 1-KB pieces per wave) plus a barrier, on a
             // mostly idle GPU.  Quarter tiles (32 x 64) put four times the workgroups on the chip, each with half the pieces per
-            // wave and step.  Measured per launch inside a graph (tests/gpu_few_probe.py, same call): 152-640 x 768 x 768 8.5 -> 5.5 us
+            // wave and step.  Measured per launch inside a graph (tools/probes/few_probe.py, same call): 152-640 x 768 x 768 8.5 -> 5.5 us
             // (hipBLASLt 7.5-8.1), 1328 x 768 x 768 9.2 -> 6.7, 664 x 1536 x 768 9.0 -> 6.5, 512 x 3072 x 768 12.9 -> 9.8,
             // 512 x 768 x 3072 24.4 -> 16, 1328 x 768 x 3072 25.5 -> 19.5; with 256+ tiles of 64 x 128 the quarter tiles lose
             // (1328 x 3072 x 768: 14 -> 22 us), and the four-buffer ring does nothing for K = 768.
@@ -1142,7 +1134,7 @@ int dispatch_nt(const LinArgs& a, hipStream_t st) {
             if (ring == 0 || a.K % 64) return bn == 256 ? launch_p256<256, 32, 4>(a, st) : bn == 192 ? launch_p256<192, 32, 4>(a, st) : launch_p256<128, 32, 4>(a, st);
             return bn == 256 ? launch_p256<256, 64, 2>(a, st) : bn == 192 ? launch_p256<192, 64, 2>(a, st) : launch_p256<128, 64, 3>(a, st);
         }
-        // measured (tests/gpu_gemm_bench.py): +8 % on the 125440-token stage-2 shapes (K = 384: 496 -> 540 TF/s),
+        // measured (tools/probes/gemm_bench.py): +8 % on the 125440-token stage-2 shapes (K = 384: 496 -> 540 TF/s),
         // -4 % on the 31360-token stage-3 shapes (tile quantisation at one workgroup per CU) -> only for M >= 65536
         static const int deep = fmmt_const("FMMT_NT_DEEP", 1);
         static const int deep_mink = fmmt_const("FMMT_NT_DEEP_MINK", 96);
@@ -1155,8 +1147,8 @@ int dispatch_nt(const LinArgs& a, hipStream_t st) {
         if (big && (a.N % 128 == 0 || (n96 && deep96)) && (a.K % 64 == 0 || deep == 1 || deep == 2)) {
             constexpr size_t lds = (size_t)3 * (256 + 128) * 64 * 2;
             constexpr size_t lds96 = (size_t)3 * (256 + 96) * 32 * 2;
-            static bool attr_set = false;
-            if (!attr_set) {
+            static FmmtLdsOnce lds_once[7];
+            {
                 const void* fns[] = {reinterpret_cast<const void*>(&linear_nt_deep_kernel),
                                      reinterpret_cast<const void*>(&linear_nt_deep32_kernel<0, 128>),
                                      reinterpret_cast<const void*>(&linear_nt_deep32_kernel<6, 128>),
@@ -1165,11 +1157,8 @@ int dispatch_nt(const LinArgs& a, hipStream_t st) {
                                      reinterpret_cast<const void*>(&linear_nt_deep32_kernel<6, 96>),
                                      reinterpret_cast<const void*>(&linear_nt_deep32_kernel<3, 96>)};
                 const int sizes[] = {(int)lds, (int)lds / 2, (int)lds / 2, (int)lds / 2, (int)lds96, (int)lds96, (int)lds96};
-                for (int i = 0; i < 7; ++i) {
-                    hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, sizes[i]);
-                    if (e != hipSuccess) return (int)e;
-                }
-                attr_set = true;
+                for (int i = 0; i < 7; ++i)
+                    if (int rc_ = lds_once[i].set(fns[i], sizes[i])) return rc_;
             }
             LinArgs p = a;
             p.tiles_m = (a.M + 255) / 256;
@@ -1185,7 +1174,7 @@ int dispatch_nt(const LinArgs& a, hipStream_t st) {
                 return 0;
             }
             p.tiles_n = a.N / 128;
-            // measured (tests/gpu_gemm_bench.py, 125440 tokens): the K-step-32 kernel with two workgroups per CU wins
+            // measured (tools/probes/gemm_bench.py, 125440 tokens): the K-step-32 kernel with two workgroups per CU wins
             // where the epilogue is a large share of a tile's life -- GELU / GELU' launches (0.388 -> 0.340 ms) and
             // K = 384 (384x384: 0.069 -> 0.057 ms); the K-step-64 kernel keeps a 2-4 % edge on plain K >= 1152.
             // FMMT_NT_DEEP: 1 = this policy, 2 = always K step 32, 4 = always K step 64, 0 = 128-row kernels only
@@ -1487,12 +1476,9 @@ template <typename T, int BMS, bool FEW = false, int PF = 1>
 int launch_tn(const TnArgs& a, dim3 grid, hipStream_t st) {
     constexpr int VEC = Vec<T>::N;
     constexpr size_t lds = (size_t)4 * BMS * (sizeof(T) == 2 ? 128 : 128 + VEC) * sizeof(T) + (256 / (128 / VEC)) * 128 * sizeof(float);
-    static bool attr_set = false;
-    if (lds > 65536 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_tn_kernel<T, BMS, FEW, PF>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
+    static FmmtLdsOnce lds_once;
+    if (lds > 65536) {
+        if (int rc_ = lds_once.set(reinterpret_cast<const void*>(&linear_tn_kernel<T, BMS, FEW, PF>), (int)lds)) return rc_;
     }
     hipLaunchKernelGGL((linear_tn_kernel<T, BMS, FEW, PF>), grid, dim3(256), lds, st, a);
     FMMT_CHECK_LAUNCH();
@@ -1636,12 +1622,8 @@ __global__ __launch_bounds__(512) void linear_tn_few_kernel(TnArgs p) {
 
 int launch_tn_few(int M, int N, int K, const void* dy, int lddy, const void* x, int ldx, float* dw, float* db, int* hdr, hipStream_t st) {
     constexpr int lds = 80 * 1024;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_tn_few_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static FmmtLdsOnce lds_once;
+    if (int rc_ = lds_once.set(reinterpret_cast<const void*>(&linear_tn_few_kernel), lds)) return rc_;
     TnArgs a{M, N, K, dy, lddy, x, ldx, dw, db, nullptr, 1, K / 64, (M + 7) / 8, N / 64, 0, 0, hdr, 1};
     hipLaunchKernelGGL(linear_tn_few_kernel, dim3((N / 64) * (K / 64)), dim3(512), lds, st, a);
     FMMT_CHECK_LAUNCH();
@@ -1977,12 +1959,8 @@ template <int TNn, int TKk, int NBUF, int WN, bool SCALED = false>
 int launch_tn_dma(const TnArgs& a, int grid, hipStream_t st) {
     constexpr size_t lds = (size_t)NBUF * 32 * (TNn + TKk) * 2 + (SCALED ? 4096 : 0);
     static_assert(lds <= 160 * 1024, "LDS");
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_tn_dma_kernel<TNn, TKk, NBUF, WN, SCALED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static FmmtLdsOnce lds_once;
+    if (int rc_ = lds_once.set(reinterpret_cast<const void*>(&linear_tn_dma_kernel<TNn, TKk, NBUF, WN, SCALED>), (int)lds)) return rc_;
     hipLaunchKernelGGL((linear_tn_dma_kernel<TNn, TKk, NBUF, WN, SCALED>), dim3(grid), dim3(512), lds, st, a);
     FMMT_CHECK_LAUNCH();
     return 0;
@@ -2207,7 +2185,7 @@ int launch_tn_plan(int dtype, int M, int N, int K, const void* dy, int lddy, con
     TnArgs a{M, N, K, dy, lddy, x, ldx, part_w, part_b, rowscale, rows_per_scale, pl.tiles_k, pl.chunk, pl.tiles_n, tn_xcd, x_epi == FMMT_EPI_GELU, hdr, pl.splits};
     dim3 grid(pl.tiles_n * pl.tiles_k * pl.splits);
     static const int tn_cfg = fmmt_const("FMMT_TN_CFG", 0);
-    // measured (tests/gpu_gemm_bench.py): 64-token steps win for the compute-heavy stage-2/3 shapes (+15-25 %),
+    // measured (tools/probes/gemm_bench.py): 64-token steps win for the compute-heavy stage-2/3 shapes (+15-25 %),
     // 32-token steps (3 workgroups per CU) win for the HBM-bound multi-million-token stage-0/1 shapes
     const bool bms64 = tn_cfg == 2 || (tn_cfg == 0 && M <= 262144);
     // two token steps in flight (register sets R0/R1): measured +3..5 % on the stage-2/3 shapes, +3..11 % on the stage-0/1

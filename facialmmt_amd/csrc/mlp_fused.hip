@@ -23,7 +23,7 @@
 // re-read by every workgroup); activations are the HBM traffic.
 //
 // Accumulation orders equal those of the two-launch path (K ascending in both products, bf16 rounding of h before product 2),
-// so the result is bit-identical to fmmt_linear_fwd(GELU) followed by fmmt_linear_fwd(residual): tests/gpu_probe.py::t_mlp_fused.
+// so the result is bit-identical to fmmt_linear_fwd(GELU) followed by fmmt_linear_fwd(residual): tests/support_op_cases.py::t_mlp_fused.
 #include "gemm_common.h"
 
 namespace {
@@ -664,12 +664,8 @@ template <int C, bool LNB = false>
 int launch_mlp_bwd(const MlpArgs& a0, hipStream_t st) {
     constexpr size_t lds = (size_t)3 * (((C / 32) * 64 * 32 + 2 * C * 32) * 2) + GELU_LUT_BYTES + (LNB ? C * sizeof(float) : 0);
     static_assert(lds <= 160 * 1024, "LDS");
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_bwd_kernel<C, LNB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static FmmtLdsOnce lds_once;
+    if (int rc_ = lds_once.set(reinterpret_cast<const void*>(&mlp_fused_bwd_kernel<C, LNB>), (int)lds)) return rc_;
     MlpArgs a = a0;
     constexpr int TT = C == 96 ? 256 : 128;                  // tokens per tile (the kernel's MTW)
     a.tiles = (a.M + TT - 1) / TT;
@@ -682,12 +678,8 @@ int launch_mlp_bwd(const MlpArgs& a0, hipStream_t st) {
 template <int C, bool LN>
 int launch_mlp(const MlpArgs& a, hipStream_t st) {
     constexpr size_t lds = (size_t)3 * (((C / 32) * 64 * 32 + 2 * C * 32) * 2 + 1024) + GELU_LUT_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_fwd_kernel<C, LN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static FmmtLdsOnce lds_once;
+    if (int rc_ = lds_once.set(reinterpret_cast<const void*>(&mlp_fused_fwd_kernel<C, LN>), (int)lds)) return rc_;
     const int grid = a.tiles < 256 ? a.tiles : 256;
     hipLaunchKernelGGL((mlp_fused_fwd_kernel<C, LN>), dim3(grid), dim3(512), lds, st, a);
     FMMT_CHECK_LAUNCH();

@@ -484,11 +484,9 @@ int fmmt_wattn_mfma_fwd_launch(const WaArgs& a, int grid, hipStream_t st) {
 template <int MM, int NP, int RC>
 static int launch_bwd(const WaArgs& a, int grid, hipStream_t st) {
     constexpr int lds = WaBwdLds<NP, RC>::TOTAL;
-    static bool attr_set = false;
-    if (!attr_set && lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wattn_mfma_bwd_kernel<MM, NP, RC>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
+    static FmmtLdsOnce lds_once;
+    if (lds > 48 * 1024) {
+        if (int rc_ = lds_once.set(reinterpret_cast<const void*>(&wattn_mfma_bwd_kernel<MM, NP, RC>), lds)) return rc_;
     }
     hipLaunchKernelGGL((wattn_mfma_bwd_kernel<MM, NP, RC>), dim3(grid), dim3(NP * 128), lds, st, a);
     FMMT_CHECK_LAUNCH();

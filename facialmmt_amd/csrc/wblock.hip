@@ -406,12 +406,8 @@ __global__ __launch_bounds__(NW * 64) void wblock_fwd_kernel(WbArgs p) {
 template <int C, int NW>
 int wb_launch(const WbArgs& a, hipStream_t st) {
     constexpr int lds = WbLds<C>::TOTAL;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wblock_fwd_kernel<C, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static FmmtLdsOnce lds_once;
+    if (int rc_ = lds_once.set(reinterpret_cast<const void*>(&wblock_fwd_kernel<C, NW>), lds)) return rc_;
     const int need = (a.B_ + NW - 1) / NW;
     const int grid = need < 256 ? need : 256;
     hipLaunchKernelGGL((wblock_fwd_kernel<C, NW>), dim3(grid), dim3(NW * 64), lds, st, a);

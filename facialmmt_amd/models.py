@@ -32,7 +32,7 @@ class InputProjection(nn.Linear):
     autograd would call them, the bias gradient through fmmt_colsum (ops.VendorLinearFn).  Why not the stock module: inside the replayed
     multi-stream HIP graph of train_step.GraphedTargetStep torch's own bias-gradient reduction of these two layers was not reproducible
     (16-48 of 768 sums off by up to 3 % of the largest in most replays, the gradient that reaches the layer bit-identical:
-    tests/gpu_race_step.py); the column-sum launch is."""
+    tests/support_replay_step.py); the column-sum launch is."""
 
     def forward(self, x):
         if self.bias is None or not x.is_cuda or not torch.is_grad_enabled() or self.weight.shape[0] % 8:

@@ -385,12 +385,14 @@ def _mlp_fusable(x2, w1, w2, b1, b2):
 
 class MlpFn(Function):
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, res, rowscale, rows_per_scale):
+    def forward(ctx, x, w1, b1, w2, b2, res, rowscale, rows_per_scale, grad_on=True):
         _need_cuda(x, "mlp")
         K = x.shape[-1]
         x2 = x.reshape(-1, K).contiguous()
         w1l, w2l = _lp(w1, x.dtype), _lp(w2, x.dtype)
-        train = any(ctx.needs_input_grad)      # grad mode is off inside Function.forward; this is the reliable signal
+        # needs_input_grad stays True under torch.no_grad() whenever a parameter requires grad, and grad mode is always off inside
+        # Function.forward: the caller's grad mode comes in as `grad_on` (evaluated in the wrapper function)
+        train = grad_on and any(ctx.needs_input_grad)
         h_pre = torch.empty((x2.shape[0], w1.shape[0]), dtype=x.dtype, device=x.device) if train else None
         res2 = res.reshape(-1, w2.shape[0]).contiguous() if res is not None else None
         if _mlp_fusable(x2, w1, w2, b1, b2):
@@ -417,7 +419,7 @@ class MlpFn(Function):
         dw2, db2 = wgrad_raw(dy2, h, True, rowscale, ctx.rps) if h is not None else wgrad_raw(dy2, h_pre, True, rowscale, ctx.rps, x_gelu=True)
         dx = linear_raw(dh, _lp(w1, dy2.dtype, transpose=True), None).reshape(ctx.xshape) if ctx.needs_input_grad[0] else None
         dw1, db1 = wgrad_raw(dh, x2, True)
-        return dx, dw1, db1, dw2, db2, (dy if ctx.has_res else None), None, None
+        return dx, dw1, db1, dw2, db2, (dy if ctx.has_res else None), None, None, None
 
 
 _MLP_BWD_FUSED = _os.environ.get("FMMT_MLP_BWD_FUSED", "1") != "0"   # A/B switch (read once): 0 = GELU' GEMM + input-gradient GEMM as two launches
@@ -448,12 +450,12 @@ class MlpLnFn(Function):
     residual gradient as its `add` operand."""
 
     @staticmethod
-    def forward(ctx, x, ln_w, ln_b, eps, w1, b1, w2, b2, rowscale, rows_per_scale):
+    def forward(ctx, x, ln_w, ln_b, eps, w1, b1, w2, b2, rowscale, rows_per_scale, grad_on=True):
         _need_cuda(x, "mlp_ln")
         C = x.shape[-1]
         x2 = x.reshape(-1, C).contiguous()
         M = x2.shape[0]
-        train = any(ctx.needs_input_grad)
+        train = grad_on and any(ctx.needs_input_grad)
         dev = x.device
         g, b = ln_w.detach().float().contiguous(), ln_b.detach().float().contiguous()
         y = torch.empty_like(x2)
@@ -491,7 +493,7 @@ class MlpLnFn(Function):
             check(rc, f"fmmt_mlp_ln_bwd_input(M={M},C={C})")
             dw2, db2 = wgrad_raw(dy2, h, True, rowscale, ctx.rps)
             dw1, db1 = wgrad_raw(dh, xn, True)
-            return dx.reshape(ctx.xshape), dg, db, None, dw1, db1, dw2, db2, None, None
+            return dx.reshape(ctx.xshape), dg, db, None, dw1, db1, dw2, db2, None, None, None
         dh, dxn = mlp_bwd_input_raw(dy2, h_pre, w1, w2, rowscale, ctx.rps)
         dw2, db2 = wgrad_raw(dy2, h, True, rowscale, ctx.rps)
         dw1, db1 = wgrad_raw(dh, xn, True)
@@ -504,7 +506,7 @@ class MlpLnFn(Function):
         rc = lib.fmmt_layernorm_bwd(dtype_code(x2.dtype), x2.shape[0], C, _p(dxn), _p(x2), _p(mean), _p(rstd), _p(g), _p(dy2), _p(dx), _p(dg), _p(db), 0,
                                     _p(ws), nbytes, _st())
         check(rc, "fmmt_layernorm_bwd(mlp_ln)")
-        return dx.reshape(ctx.xshape), dg, db, None, dw1, db1, dw2, db2, None, None
+        return dx.reshape(ctx.xshape), dg, db, None, dw1, db1, dw2, db2, None, None, None
 
 
 def mlp_ln_fusable(x, w1, w2, b1, b2):
@@ -515,11 +517,11 @@ def mlp_ln_fusable(x, w1, w2, b1, b2):
 
 def mlp_ln(x, ln_w, ln_b, eps, w1, b1, w2, b2, rowscale=None, rows_per_scale=1):
     """x + rowscale * Mlp(LayerNorm(x)) in one launch (Swin stages 0 / 1)"""
-    return MlpLnFn.apply(x, ln_w, ln_b, eps, w1, b1, w2, b2, rowscale, rows_per_scale)
+    return MlpLnFn.apply(x, ln_w, ln_b, eps, w1, b1, w2, b2, rowscale, rows_per_scale, torch.is_grad_enabled())
 
 
 def mlp(x, w1, b1, w2, b2, res=None, rowscale=None, rows_per_scale=1):
-    return MlpFn.apply(x, w1, b1, w2, b2, res, rowscale, rows_per_scale)
+    return MlpFn.apply(x, w1, b1, w2, b2, res, rowscale, rows_per_scale, torch.is_grad_enabled())
 
 
 # ------------------------------------------------------------------------------------------------
@@ -580,11 +582,11 @@ class PatchProjLnFn(Function):
     pre-LayerNorm rows, then the projection's weight / bias / input gradients as for any Linear."""
 
     @staticmethod
-    def forward(ctx, cols, weight, bias, gamma, beta, eps):
+    def forward(ctx, cols, weight, bias, gamma, beta, eps, grad_on=True):
         _need_cuda(cols, "patch_proj_ln")
         M, K = cols.shape
         C = weight.shape[0]
-        train = any(ctx.needs_input_grad)
+        train = grad_on and any(ctx.needs_input_grad)
         dev, dt = cols.device, cols.dtype
         g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
         y = torch.empty((M, C), dtype=dt, device=dev)
@@ -613,7 +615,7 @@ class PatchProjLnFn(Function):
                                      _p(ws), nbytes, _st()), f"fmmt_layernorm_bwd(patch embed, M={M})")
         dw, dbias = wgrad_raw(dxp, cols, ctx.has_bias)
         dcols = linear_raw(dxp, _lp(weight, dy.dtype, transpose=True), None) if ctx.needs_input_grad[0] else None
-        return dcols, dw.view_as(weight), dbias, dg, db, None
+        return dcols, dw.view_as(weight), dbias, dg, db, None, None
 
 
 def patch_proj_ln_fusable(cols, weight, norm):
@@ -622,7 +624,7 @@ def patch_proj_ln_fusable(cols, weight, norm):
 
 
 def patch_proj_ln(cols, weight, bias, gamma, beta, eps):
-    return PatchProjLnFn.apply(cols, weight, bias, gamma, beta, eps)
+    return PatchProjLnFn.apply(cols, weight, bias, gamma, beta, eps, torch.is_grad_enabled())
 
 
 class ResidualLayerNormFn(Function):
@@ -772,11 +774,11 @@ class WindowBlockFn(Function):
     forward saved (LN(x), attention output, row statistics, log-sum-exp) and recomputes qkv with one GEMM."""
 
     @staticmethod
-    def forward(ctx, x, ln_w, ln_b, eps, wqkv, bqkv, wproj, bproj, table, index_i32, mask, n_img, H, W, num_heads, shift, scale, rowscale):
+    def forward(ctx, x, ln_w, ln_b, eps, wqkv, bqkv, wproj, bproj, table, index_i32, mask, n_img, H, W, num_heads, shift, scale, rowscale, grad_on=True):
         _need_cuda(x, "window_block")
         C = x.shape[-1]
         x2 = x.reshape(-1, C).contiguous()
-        train = any(ctx.needs_input_grad)
+        train = grad_on and any(ctx.needs_input_grad)
         g, b = ln_w.detach().float().contiguous(), ln_b.detach().float().contiguous()
         tab = table.detach().float().contiguous()
         y, xn, o, mean, rstd, lse = window_block_raw(
@@ -793,7 +795,7 @@ class WindowBlockFn(Function):
         x2, xn, o, mean, rstd, lse, g, wqkv, bqkv, wproj, tab, index_i32, m, rowscale = ctx.saved_tensors
         dx, dg, db, dwq, dbq, dwp, dbp, dtable = window_block_backward(dy, x2, xn, o, mean, rstd, lse, g, wqkv, bqkv, wproj, tab, index_i32, m, rowscale, ctx.cfg)
         return (dx, dg, db, None, dwq, dbq, dwp, dbp if ctx.needs_input_grad[7] else None, dtable,
-                None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None)
 
 
 def window_block_backward(dy, x2, xn, o, mean, rstd, lse, g, wqkv, bqkv, wproj, tab, index_i32, m, rowscale, cfg):
@@ -838,7 +840,7 @@ def window_block_backward(dy, x2, xn, o, mean, rstd, lse, g, wqkv, bqkv, wproj, 
 
 
 def window_block(x, ln_w, ln_b, eps, wqkv, bqkv, wproj, bproj, table, index_i32, mask, n_img, H, W, num_heads, shift, scale, rowscale=None):
-    return WindowBlockFn.apply(x, ln_w, ln_b, eps, wqkv, bqkv, wproj, bproj, table, index_i32, mask, n_img, H, W, num_heads, shift, scale, rowscale)
+    return WindowBlockFn.apply(x, ln_w, ln_b, eps, wqkv, bqkv, wproj, bproj, table, index_i32, mask, n_img, H, W, num_heads, shift, scale, rowscale, torch.is_grad_enabled())
 
 
 # ------------------------------------------------------------------------------------------------

@@ -84,7 +84,7 @@ class GradientAverager:
         self.comm_dtype = None if comm_dtype == torch.float32 else comm_dtype
         self.sync = True
         self.comm = process_group                          # the one communicator of every bucket (see the ordering contract)
-        self.buckets = []                                  # [flat buffer, [params], arrivals, pending work, group, staging]
+        self.buckets = []                                  # [flat buffer, [params], arrivals, pending work, group, staging, completion event]
         self._next = 0                                     # the next bucket (global construction order) to issue
         self._ready = set()                                # complete buckets waiting for a lower-numbered one
         self._issued = set()
@@ -118,10 +118,16 @@ class GradientAverager:
         for p, o in zip(ps, offs):
             p.grad = flat[o:o + p.numel()].view_as(p)
         stage = torch.empty(n, dtype=self.comm_dtype, device=flat.device) if self.comm_dtype is not None else None
-        self.buckets.append([flat, ps, 0, None, gi, stage])
+        self.buckets.append([flat, ps, 0, None, gi, stage, None])
 
     def _issue(self, bi):
         b = self.buckets[bi]
+        # A bucket held back in `_ready` is issued later by the cascade inside ANOTHER group's hook, i.e. with another stream
+        # current than the one that wrote its gradients (text encoder on the second stream, fusion stack on the main one):
+        # the scaling, the staging copy and the all-reduce must be ordered behind the producing stream, not just the current one.
+        if b[6] is not None:
+            torch.cuda.current_stream(b[0].device).wait_event(b[6])
+            b[6] = None
         b[0].div_(self.world)
         buf = b[0]
         if b[5] is not None:
@@ -141,6 +147,10 @@ class GradientAverager:
             return
         if bi in self._issued or bi in self._ready:
             raise RuntimeError("GradientAverager: a bucket completed twice in one exchange window (call finish() once per step)")
+        if b[0].is_cuda:                                   # the stream this hook runs on is the one that produced the bucket's last gradient
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(b[0].device))
+            b[6] = ev
         self._ready.add(bi)
         while self._next < len(self.buckets) and self._next in self._ready:                 # in-order issue, cascade
             self._ready.discard(self._next)
@@ -205,6 +215,7 @@ class GradientAverager:
         for b in self.buckets:
             b[2] = 0
             b[3] = None
+            b[6] = None
 
     def zero_grad(self):
         """zero the flat buffers in place (the .grad views must survive: never zero_grad(set_to_none=True) these)"""

@@ -499,13 +499,14 @@ class HFAdamW(torch.optim.Optimizer):
             grads = [p.grad for p in ps]
             for p in ps:
                 st = self.state[p]
-                if not st:
+                if "exp_avg" not in st:
                     st["exp_avg"] = torch.zeros_like(p)
                     st["exp_avg_sq"] = torch.zeros_like(p)
-            gs = self.state[g["params"][0]]                      # the group's step counter lives with its first parameter (a device scalar)
-            if "step" not in gs:
-                gs["step"] = torch.zeros((), dtype=torch.float32, device=ps[0].device)
-            t = gs["step"]
+            # the group's step counter is a device scalar kept IN the param group (capture-safe; transformers.AdamW keeps an int per
+            # parameter: `hf_state_dict()` below writes that layout for exchange with the reference class)
+            if not torch.is_tensor(g.get("step")):
+                g["step"] = torch.zeros((), dtype=torch.float32, device=ps[0].device)
+            t = g["step"]
             t.add_(1.0)
             b1, b2 = g["betas"]
             m = [self.state[p]["exp_avg"] for p in ps]
@@ -525,6 +526,17 @@ class HFAdamW(torch.optim.Optimizer):
                 dec = torch._foreach_mul(ps, lr * (-g["weight_decay"]))
                 torch._foreach_add_(ps, dec)
         return loss
+
+    def hf_state_dict(self):
+        """`state_dict()` in transformers.AdamW's layout: an int `step` per parameter beside exp_avg / exp_avg_sq, none in the groups"""
+        sd = self.state_dict()
+        for g in sd["param_groups"]:
+            t = g.pop("step", None)
+            n = int(t.item()) if torch.is_tensor(t) else int(t or 0)
+            for i in g["params"]:
+                if i in sd["state"]:
+                    sd["state"][i] = dict(sd["state"][i], step=n)
+        return sd
 
 
 class FusedClipAdamW:
@@ -636,9 +648,12 @@ class GraphedTargetStep:
     Parity: tests/test_gpu_train_step.py walks this against the eager TargetStep (same losses, same parameters)."""
 
     def __init__(self, swin_model, multimodal_model, optimizer, scheduler, args, batch, autocast_dtype=None,
-                 overlap_text=True, parallel_fusion=True, averager=None, warmup_iters=2, masters=None, discarded_swin_gradients="compute"):
+                 overlap_text=True, parallel_fusion=True, averager=None, warmup_iters=2, masters=None, discarded_swin_gradients="compute",
+                 swin_cut: int = 0):
         """`averager`: GradientAverager(hooks=False) over the parameters the optimizer steps (default: the multimodal
-        model's); `masters`: optional MasterWeights of the text encoder -- then `averager` and the optimizer must have been
+        model's); `swin_cut`: with an exchange to hide (N > 1), the Swin stage behind which the backward graph is cut (0: the second
+        piece is stage 0's backward, ~10 ms; 1: stages 1 + 0, ~17 ms) -- the caller picks it from a MEASURED exchange time
+        (`pick_swin_cut`, bench.py), never from a nominal link rate; `masters`: optional MasterWeights of the text encoder -- then `averager` and the optimizer must have been
         built over `step_parameters(multimodal_model, masters)`; `discarded_swin_gradients`: "compute" (default) / "skip", SKIP_NOTE."""
         import os
         from .parallel import GradientAverager
@@ -704,11 +719,9 @@ class GraphedTargetStep:
         # the GPU it stays ONE graph: inside it the text encoder's backward runs as a branch beside Swin's backward, which a cut in
         # front of Swin's backward would serialise (measured at N = 1: 72.1 ms per step cut, 69 ms uncut).
         self.split = bool(getattr(self.flat, "active", False))
-        # the exchange has to fit beside the second piece: two ranks share ONE xGMI link (0.87 GB each way at ~64 GB/s: ~14 ms, an
-        # estimate -- no two-GPU box was available), so there the cut moves up one stage (second piece ~17 ms); from four ranks on the
-        # all-reduce spreads over 3-7 links (~3.5-7 ms) and fits beside stage 0's backward
-        if getattr(self.flat, "world", 1) == 2:
-            self.SWIN_CUT = 1
+        if swin_cut not in (0, 1, 2):
+            raise ValueError("swin_cut: 0, 1 or 2")
+        self.SWIN_CUT = int(swin_cut)                      # the window behind the cut has to hold the exchange: see pick_swin_cut
         self.graph_a, self.graph_a2, self.graph_b = torch.cuda.CUDAGraph(), (torch.cuda.CUDAGraph() if self.split else None), torch.cuda.CUDAGraph()
         with capture_window(), _ops_pinned_scope(self.shadows):
             if self.split:
@@ -811,7 +824,7 @@ class GraphedTargetStep:
     # two-piece backward: cut behind Swin stage SWIN_CUT.  Measured at one rank with the exchange forced (ms per step, same call; the
     # single graph: 66.9): cut at Swin's output 71.6, behind stage 2: 72.3, stage 1: 70.9-71.0, stage 0: 69.7-69.9 -- the second piece
     # (stage 0's backward, ~10 ms) is the window the bucketed all-reduce of 0.87 GB has to fit into
-    SWIN_CUT = 0
+    SWIN_CUT = 0                                         # class default; the instance's value is the constructor's `swin_cut`
 
     def _bwd_swin(self, swin_out):
         """backward, second piece: Swin from the gradient of its output.  Nobody reads the result in the target step (train.py:20,141
@@ -881,6 +894,20 @@ class GraphedTargetStep:
         """a partial accumulation window does not carry into the next epoch (train.py:52,54 restart the counter per epoch)"""
         self.i_batch = 0
         self.flat.zero_grad()
+
+
+# GPU time of Swin's backward below a cut (ms, 640 frames bf16, profiles/r03_swin_kernel_stats.md): what the exchange can hide behind
+SWIN_TAIL_MS = {0: 10.0, 1: 17.0, 2: 27.0}
+
+
+def pick_swin_cut(exchange_ms_alone: float, frames: int = 640) -> int:
+    """The lowest cut whose second piece is at least as long as the exchange MEASURED alone on this communicator (each step up costs
+    ~1 ms of lost overlap between the text backward and Swin's, so the lowest that fits wins); 2 if none does."""
+    scale = frames / 640.0
+    for cut in (0, 1, 2):
+        if SWIN_TAIL_MS[cut] * scale >= exchange_ms_alone:
+            return cut
+    return 2
 
 
 class GraphedAuxStep:

@@ -1,6 +1,6 @@
 """Development probe (not a pytest file): runs every C-ABI entry point against a plain torch
 reference on the GPU and prints max errors without stopping at the first failure.
-Usage on the GPU box:  python tests/gpu_probe.py > gpurun_out/probe.log 2>&1"""
+Usage on the GPU box:  python tests/support_op_cases.py > gpurun_out/probe.log 2>&1"""
 import os
 import sys
 import time

@@ -1,7 +1,7 @@
 """Development probe of the fused attention half of a Swin block (csrc/wblock.hip), not a pytest file.
-  python tests/gpu_wblock.py            correctness: fused vs the four-launch form (bit-identical given the same LN output),
+  python tests/support_wblock_cases.py            correctness: fused vs the four-launch form (bit-identical given the same LN output),
                                         vs an fp64 restatement, gradients through both paths
-  python tests/gpu_wblock.py --speed    timing at the bench geometry (640 frames), fused vs four launches, fwd and fwd+bwd"""
+  python tests/support_wblock_cases.py --speed    timing at the bench geometry (640 frames), fused vs four launches, fwd and fwd+bwd"""
 import os
 import sys
 import time
@@ -59,7 +59,7 @@ def ref64(x, P, mask, n_img, H, nh, shift, rs):
     x64 = x.double()
     xn = torch.nn.functional.layer_norm(x64, (C,), P["g"].double(), P["b"].double(), 1e-5)
     qkv = xn.reshape(-1, C) @ P["wqkv"].double().t() + P["bqkv"].double()
-    from tests.gpu_probe import _wattn_ref as wattn_ref
+    from tests.support_op_cases import _wattn_ref as wattn_ref
     o = wattn_ref(qkv, P["table"].double(), mask.double() if mask is not None else None, n_img, H, C, nh, shift)
     y = o @ P["wproj"].double().t() + P["bproj"].double()
     s = rs.double().repeat_interleave(H * H)[:, None] if rs is not None else 1.0

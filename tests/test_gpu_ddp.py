@@ -152,6 +152,50 @@ def test_rccl_world_size_one_runs_the_exchange_path(tmp_path):
     assert moved > 0                                         # the bf16 wire really carried the gradients
 
 
+def _early_text_bucket(rank, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    from facialmmt_amd.parallel import GradientAverager
+    fusion = [torch.nn.Parameter(torch.zeros(1 << 16, device=dev)) for _ in range(2)]
+    text = [torch.nn.Parameter(torch.zeros(1 << 16, device=dev))]
+    avg = GradientAverager(None, bucket_mb=1, groups=[fusion, text], comm_dtype=torch.bfloat16, always=True, hooks=False)
+    assert [b[4] for b in avg.buckets] == [0, 1]
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device=dev)
+    want = torch.randn(1 << 16, device=dev)
+    ok = True
+    for _ in range(5):
+        avg.zero_grad()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):                          # the text branch: a long chain of kernels, then its gradient
+            b = a
+            for _ in range(40):
+                b = (b @ a) * 1e-2
+            text[0].grad.copy_(want + 0 * b[0, 0])
+            avg._hook(text[0])                                   # complete, but bucket 0 has not been issued: waits in _ready
+        assert avg._ready == {1}
+        for q in reversed(fusion):                               # main stream: the cascade issues bucket 0 AND the text bucket
+            q.grad.fill_(1.0)
+            avg._hook(q)
+        avg.finish()
+        torch.cuda.synchronize()
+        ok = ok and torch.equal(text[0].grad, want.bfloat16().float()) and bool((fusion[0].grad == 1).all())
+    torch.save({"ok": ok}, os.path.join(out_dir, "early.pt"))
+    dist.destroy_process_group()
+
+
+def test_text_bucket_completing_before_the_last_fusion_bucket_is_ordered_behind_its_stream(tmp_path):
+    """Round-3 ADVICE: a text-encoder bucket that completes early is issued later, by the cascade inside a fusion parameter's
+    hook, with the MAIN stream current.  Its gradients were written on the second stream: `_issue` must wait for the event the
+    completing hook recorded there before it scales / stages / reduces the bucket (bf16 wire at world size 1 on RCCL: without
+    the wait the staging copy reads the bucket before the slow side-stream chain has written it)."""
+    mp.spawn(_early_text_bucket, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    assert torch.load(os.path.join(str(tmp_path), "early.pt"))["ok"]
+
+
 def _two_ranks(mode, tmp_path, backend):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), mode, str(tmp_path), backend), nprocs=world, join=True)

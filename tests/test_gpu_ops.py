@@ -1,5 +1,5 @@
 """GPU parity of every C-ABI entry point against a plain fp64 torch restatement of the same op
-(tests/gpu_probe.py holds the cases: forward and backward, fp32 at ~1e-5 and bf16 at ~1e-2 relative to
+(tests/support_op_cases.py holds the cases: forward and backward, fp32 at ~1e-5 and bf16 at ~1e-2 relative to
 the tensor scale, ragged M/N/K tails, PatchMerging gather, shifted windows with masks, packed and
 separate k/v, dropout statistics, BatchNorm train/eval)."""
 import pytest
@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _run(fn_name):
-    from tests import gpu_probe as P
+    from tests import support_op_cases as P
     P.RES.clear()
     P.section(getattr(P, fn_name))
     bad = [n for n, ok in P.RES if not ok]

@@ -98,7 +98,7 @@ def test_swin_train_batchnorm_and_running_stats(golden, dev, swin, S):
     bn = swin.output_layer[3]
     rm0, rv0, nb0 = bn.running_mean.clone(), bn.running_var.clone(), int(bn.num_batches_tracked)
     with torch.no_grad():
-        golden.check("swin_full", "swin_train_n4", swin(frames[:4]), atol=2e-3, rtol=2e-3)
+        golden.check("swin_full", "swin_train_n4", swin(frames[:4]), **TOL)
     golden.check("swin_full", "bn_running_mean_after", bn.running_mean, **TOL)
     golden.check("swin_full", "bn_running_var_after", bn.running_var, **TOL)
     assert int(bn.num_batches_tracked) == nb0 + 1
@@ -177,7 +177,7 @@ def test_bf16_gradients_against_oracle_n32(dev, S, bn_mode):
 
     running_stats: BatchNorm1d of the head on its running statistics; batch_stats: on the statistics of the 32-frame batch, the
     mode the training step (and the benchmark) runs in.  Bar: cosine >= 0.99 and relative L2 error <= 10 % for every tensor, in both
-    modes -- or, failing that, no worse than 1.5 x the WORST stock-bf16 tensor.  (The figure is a chaotic function of the rounding
+    modes (round-3 VERDICT: the "or within 1.5 x stock's worst tensor" escape is gone).  (The figure is a chaotic function of the rounding
     realisation: the probe sits behind Linear -> ReLU -> Linear and, in batch_stats mode, behind a normalisation by the batch spread,
     so one flipped ReLU gate or a slightly different spread moves every gradient below it by the same factor.  Measured in round 3 on
     the same 32 frames: stage 0 fused 4.0 % mean / 6.6 % worst, stage 0 as four launches 12.7 % / 21 %, stock autocast 11 % / 16.5 %
@@ -222,7 +222,7 @@ def test_bf16_gradients_against_oracle_n32(dev, S, bn_mode):
     sc, sr = min((c, k) for k, (c, r) in stock.items()), max((r, k) for k, (c, r) in stock.items())
     print(f"bf16 vs fp32-oracle gradients ({bn_mode}, {N} frames) over {len(ours)} tensors: ours worst cosine {wc}, worst relative L2 {wr}; "
           f"stock bf16 autocast worst cosine {sc}, worst relative L2 {sr}")
-    bad = [(k, c, r, stock[k]) for k, (c, r) in ours.items() if not ((c >= COS_MIN and r <= REL_MAX) or r <= 1.5 * sr[0])]
+    bad = [(k, c, r, stock[k]) for k, (c, r) in ours.items() if not (c >= COS_MIN and r <= REL_MAX)]
     assert not bad, bad[:8]
     assert len(ours) >= 173
 

@@ -296,9 +296,9 @@ def test_fused_optimizer_in_the_graphed_step_equals_eager_adamw(accumulation):
 def test_replayed_benchmark_step_is_reproducible():
     """Consistency at the bench size (configs[1], bf16, text branch and parallel fusion on their own streams): the captured forward +
     backward graph replayed 12 times on the same inputs and generator state gives the same loss, kept-frame mask and flat gradient
-    buckets bit for bit (tests/gpu_race_step.py; round 3 found the stock input projections' bias gradients failing this)."""
+    buckets bit for bit (tests/support_replay_step.py; round 3 found the stock input projections' bias gradients failing this)."""
     import subprocess, sys
     env = dict(os.environ, REPS="12")
-    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpu_race_step.py")], env=env, capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "support_replay_step.py")], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "12 replays, 0 with differences" in r.stdout, r.stdout[-2000:]

@@ -35,7 +35,7 @@ CASES = [(96, 2, 14, 0, False), (96, 2, 14, 3, True), (96, 1, 56, 3, False), (96
 
 @pytest.mark.parametrize("C,n_img,H,shift,use_rs", CASES)
 def test_fused_block_half_forward_and_gradients(dev, C, n_img, H, shift, use_rs, monkeypatch):
-    import gpu_wblock as W
+    import support_wblock_cases as W
     nh = C // 32
     monkeypatch.setattr(ops, "_WBLOCK_WIDTHS", (96, 192))
     index = OS.relative_position_index(7).to(dev).int().contiguous()
@@ -140,7 +140,7 @@ def test_fused_block_against_the_reference_generated_golden(dev, golden, shift):
 def test_mlp_half_with_layernorm_prologue(dev, C, M, use_rs):
     """fmmt_mlp_ln_fwd (norm2 -> Mlp -> DropPath -> residual in one launch) against fmmt_layernorm_fwd followed by fmmt_mlp_fwd, and
     both against fp64: forward, the saved LayerNorm output and statistics, every gradient; ragged last tile, dropped sample."""
-    import gpu_wblock as W
+    import support_wblock_cases as W
     x = W.rnd("x", (M, C), 21, dtype=torch.bfloat16).requires_grad_(True)
     P = [(1.0 + 0.2 * W.rnd("g", (C,), 22)).requires_grad_(True), (0.1 * W.rnd("b", (C,), 23)).requires_grad_(True),
          W.rnd("w1", (4 * C, C), 24, C ** -0.5).requires_grad_(True), (0.1 * W.rnd("b1", (4 * C,), 25)).requires_grad_(True),
@@ -182,7 +182,7 @@ def test_fused_mlp_input_gradient_launch(dev):
     the input gradient): same products, same rounding points; gelu' comes from the LDS table in the fused kernel and from the table or
     the polynomial in the GEMM epilogue (by kernel), so dh agrees to one bf16 rounding step and dx to the accumulation of those;
     ragged token counts, a dropped sample, the bench size (2 M tokens).  Against fp64: test_mlp_half_* below."""
-    import gpu_wblock as W
+    import support_wblock_cases as W
     from facialmmt_amd._lib import EPI_GELU_BWD
     C = int(os.environ.get("MLP_BWD_TEST_C", "96"))
     for M, rps in ((4096 + 33, 1000), (256 * 40, 3136), (3136 * 640 * 96 // C, 3136 * 96 // C)):

@@ -3,7 +3,7 @@
 on a problem small enough for the host to be the bound (64 x 96 x 96), forward only and forward + backward."""
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from facialmmt_amd import ops
 import facialmmt_amd.torch_ops  # noqa: F401
 dev = torch.device("cuda:0")

@@ -2,7 +2,7 @@
 a captured graph of 20 launches, with a value check against torch (A/B of FMMT_NT_SMALL: one process per setting, same gpurun call)."""
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from facialmmt_amd import ops
 from facialmmt_amd._lib import EPI_GELU, EPI_GELU_BWD
 dev = torch.device("cuda:0")

@@ -1,7 +1,7 @@
 """Development micro-benchmark of the Linear kernels at the bench shapes (bf16)."""
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from facialmmt_amd import ops
 dev = torch.device("cuda:0")
 def timeit(fn, n=10):

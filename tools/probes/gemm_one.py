@@ -2,7 +2,7 @@
 usage: gpu_gemm_one.py M N K mode   (mode: plain | gelu | gelubwd | res | tn | tnscale)"""
 import os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from facialmmt_amd import ops
 from facialmmt_amd._lib import EPI_GELU, EPI_GELU_BWD
 M, N, K = (int(v) for v in sys.argv[1:4])

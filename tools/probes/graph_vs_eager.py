@@ -1,10 +1,10 @@
 """Development check: eager vs graphed training trajectories with a real (2-layer, dropout-free) HF RoBERTa under bf16
 autocast -- per-step worst gradient difference (0 with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0; diverges from the third step
-with ROCm 7.0's default).  Usage: python tests/gpu_graph_vs_eager.py"""
+with ROCm 7.0's default).  Usage: python tools/probes/graph_vs_eager.py"""
 import sys, os, types
 os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 from transformers import RobertaConfig
 from facialmmt_amd import models

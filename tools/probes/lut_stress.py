@@ -1,7 +1,7 @@
 """Development aid: the kernels that read the GELU table from LDS, many launches at the bench size, outputs compared bit for bit."""
 import os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from facialmmt_amd import ops
 dev = torch.device("cuda:0")
 torch.manual_seed(0)

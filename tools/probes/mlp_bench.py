@@ -2,7 +2,7 @@
 activation recomputed on load, at the Swin stage-0 / stage-1 sizes of the bench (640 frames)."""
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from facialmmt_amd import ops
 from facialmmt_amd._lib import EPI_GELU
 dev = torch.device("cuda:0")

@@ -2,7 +2,7 @@
 result compared bit for bit with the first; other work is queued on a second stream to vary the timing."""
 import os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from facialmmt_amd import ops
 dev = torch.device("cuda:0")
 torch.manual_seed(0)

@@ -1,7 +1,7 @@
 """Development aid: the stage-0 fused Mlp forward (training form) alone, a few launches (for tools/pmc_kernel.sh)."""
 import os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from facialmmt_amd import ops
 dev = torch.device("cuda:0")
 M, C = 2007040, 96

@@ -2,7 +2,7 @@
 process per setting, same gpurun call); --vendor adds hipBLASLt (torch.nn.functional.linear) on the same operands."""
 import os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from facialmmt_amd import _lib
 if os.environ.get("PROBE_LIB"):                                # A/B of two builds in one gpurun call
     _lib.LIB_PATH = os.environ["PROBE_LIB"]

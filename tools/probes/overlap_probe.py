@@ -2,7 +2,7 @@
 forward/backward (large launches) when issued on a second HIP stream?  Prints sequential vs concurrent time."""
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from transformers import RobertaConfig, RobertaModel
 from facialmmt_amd import synth
 from facialmmt_amd.modules.SwinTransformer import Swin_Transformer as S

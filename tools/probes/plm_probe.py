@@ -2,7 +2,7 @@
 vendor library, per launch from a captured graph of 20 launches."""
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from facialmmt_amd import ops
 from facialmmt_amd._lib import EPI_GELU
 dev = torch.device("cuda:0")

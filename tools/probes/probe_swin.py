@@ -1,5 +1,5 @@
 """Development probe: the Swin modules on the HIP path against the golden fixtures (fp32) and
-bf16-vs-fp32 drift.  python tests/gpu_probe_swin.py > gpurun_out/probe_swin.log 2>&1"""
+bf16-vs-fp32 drift.  python tools/probes/probe_swin.py > gpurun_out/probe_swin.log 2>&1"""
 import os
 import sys
 import time
@@ -8,7 +8,7 @@ import traceback
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from facialmmt_amd import synth  # noqa: E402
 from facialmmt_amd.modules.SwinTransformer import Swin_Transformer as S  # noqa: E402
 from facialmmt_amd.modules.SwinTransformer.backbone_def import BackboneFactory  # noqa: E402

@@ -1,7 +1,7 @@
 """Development aid: the stage-1 / stage-2 GELU' input-gradient launches repeated, outputs compared bit for bit with the first."""
 import os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from facialmmt_amd import ops
 from facialmmt_amd._lib import EPI_GELU_BWD, EPI_GELU
 dev = torch.device("cuda:0")

@@ -3,7 +3,7 @@ for bit with the first pass; names of the tensors that differ (a race shows up a
 order points at the kernel)."""
 import os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from facialmmt_amd import synth
 from facialmmt_amd.modules.SwinTransformer import Swin_Transformer as S
 from facialmmt_amd.modules.SwinTransformer.backbone_def import BackboneFactory

@@ -1,7 +1,7 @@
 """Development timing: Swin fwd / fwd+bwd at the bench size (bf16, N frames), eager vs HIP-graph replay."""
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from facialmmt_amd import synth
 from facialmmt_amd.modules.SwinTransformer import Swin_Transformer as S
 from facialmmt_amd.modules.SwinTransformer.backbone_def import BackboneFactory

@@ -1,8 +1,8 @@
 """Development aid: the stage-2/3 weight-gradient launches alone, timed with HIP events (A/B of the FMMT_TN_* switches: one
-process per setting, same gpurun call), or bare for PMC passes (rocprofv3 --pmc ... -- python tests/gpu_tn_probe.py --bare)."""
+process per setting, same gpurun call), or bare for PMC passes (rocprofv3 --pmc ... -- python tools/probes/tn_probe.py --bare)."""
 import os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from facialmmt_amd import ops
 dev = torch.device("cuda:0")
 bare = "--bare" in sys.argv

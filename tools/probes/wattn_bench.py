@@ -1,7 +1,7 @@
 """Development micro-benchmark of the window-attention core at the bench geometry (bf16, 640 frames)."""
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from facialmmt_amd import ops
 from oracle import swin as OS
 dev = torch.device("cuda:0")

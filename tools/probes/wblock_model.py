@@ -1,7 +1,7 @@
 """Development probe: forward error of the bf16 Swin (N frames) against its own fp32 run, per stage, fused attention half on / off."""
 import os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from facialmmt_amd import ops, synth
 from facialmmt_amd.modules.SwinTransformer import Swin_Transformer as S
 from facialmmt_amd.modules.SwinTransformer.backbone_def import BackboneFactory

@@ -36,12 +36,12 @@ python tools/summarize_prof.py pmc $O/pmc_MFMA_$TAG > $S/pmc_mfma.md
 python tools/summarize_prof.py pmc $O/pmc_LDS_$TAG > $S/pmc_lds.md
 python tools/timeline.py $O/prof_$TAG > $S/timeline.txt 2>&1
 rm -rf $O/prof_$TAG $O/profiso_$TAG $O/pmc_FETCH_SIZE_$TAG $O/pmc_WRITE_SIZE_$TAG $O/pmc_MFMA_$TAG $O/pmc_LDS_$TAG
-GEMM_BENCH_VENDOR=1 timeout 600 python tests/gpu_gemm_bench.py > $S/gemm_shapes.txt 2>&1
-timeout 300 python tests/gpu_nt_probe.py --vendor > $S/nt_shapes.txt 2>&1
-timeout 300 python tests/gpu_tn_probe.py > $S/tn_shapes.txt 2>&1
-timeout 200 python tests/gpu_few_probe.py > $S/few_shapes.txt 2>&1
+GEMM_BENCH_VENDOR=1 timeout 600 python tools/probes/gemm_bench.py > $S/gemm_shapes.txt 2>&1
+timeout 300 python tools/probes/nt_probe.py --vendor > $S/nt_shapes.txt 2>&1
+timeout 300 python tools/probes/tn_probe.py > $S/tn_shapes.txt 2>&1
+timeout 200 python tools/probes/few_probe.py > $S/few_shapes.txt 2>&1
 # Swin forward + backward alone (640 frames) with its own per-kernel table, and the fused stage-0 launches one by one
-timeout 300 python tests/gpu_time_swin.py 640 > $S/swin_time.txt 2>&1
+timeout 300 python tools/probes/time_swin.py 640 > $S/swin_time.txt 2>&1
 bash tools/prof_swin.sh > /dev/null 2>&1; cp $O/swin_kernel_stats.md $S/swin_kernel_stats.md
-timeout 300 python tests/gpu_wblock.py --speed > $S/wblock_speed.txt 2>&1
+timeout 300 python tests/support_wblock_cases.py --speed > $S/wblock_speed.txt 2>&1
 cut -c1-300 $S/bench.json
