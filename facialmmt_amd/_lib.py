@@ -39,6 +39,7 @@ SIGNATURES = {
     "fmmt_window_attn_bwd_workspace": (_sz, [_i]),
     "fmmt_window_attn_bwd": (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p, _p, _p, _sz, _p]),
     "fmmt_window_block_fwd": (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "fmmt_window_block_fwd_ref": (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p]),
     "fmmt_window_block_attn_bwd": (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _sz, _p]),
     "fmmt_mha_fwd": (_i, [_i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i, _f, _p, _f, _u64, _p, _p, _i, _p, _p]),
     "fmmt_mha_bwd": (_i, [_i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i, _f, _p, _f, _u64, _p, _p, _p, _i, _p, _p, _i, _p, _p, _i, _p]),

@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libfmmt_hip.so")
-SOURCES = ["gemm.hip", "layernorm.hip", "attn.hip", "wattn_mfma.hip", "wblock.hip", "mha_mfma.hip", "misc.hip", "preproc.hip", "mlp_fused.hip", "patch_ln.hip"]
+SOURCES = ["gemm.hip", "layernorm.hip", "attn.hip", "wattn_mfma.hip", "wblock.hip", "wblock_ref.hip", "mha_mfma.hip", "misc.hip", "preproc.hip", "mlp_fused.hip", "patch_ln.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast"]
 
 
@@ -22,14 +22,19 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, tag: str = "") -> str:
+    """`tag` (or FMMT_BUILD_TAG): a second build beside the product library -- objects in build_<tag>/, output libfmmt_hip_<tag>.so --
+    for same-call A/B of a development switch (FMMT_CFLAGS=-DFMMT_EXP_...=1; the probes load it through PROBE_LIB)"""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    headers = [os.path.join(CSRC, "fmmt_common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(CSRC, "wattn_args.h"), os.path.join(CSRC, "wattn_geom.h"), os.path.join(CSRC, "mha_args.h"), os.path.join(HERE, "..", "include", "fmmt.h")]
-    objdir = os.path.join(HERE, "build")
+    tag = tag or os.environ.get("FMMT_BUILD_TAG", "")
+    csrc = os.environ.get("FMMT_CSRC_DIR", CSRC) if tag else CSRC      # a tagged build may come from another source tree (an earlier commit)
+    headers = [os.path.join(csrc, "fmmt_common.h"), os.path.join(csrc, "gemm_common.h"), os.path.join(csrc, "wattn_args.h"), os.path.join(csrc, "wattn_geom.h"), os.path.join(csrc, "mha_args.h"), os.path.join(csrc, "wblock_common.h"), os.path.join(csrc, "..", "..", "include", "fmmt.h")]
+    objdir = os.path.join(HERE, "build_" + tag if tag else "build")
+    out = os.path.join(HERE, f"libfmmt_hip_{tag}.so") if tag else OUT
     os.makedirs(objdir, exist_ok=True)
     jobs = []
     for s in SOURCES:
-        src = os.path.join(CSRC, s)
+        src = os.path.join(csrc, s)
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
         if force or _stale(obj, [src] + headers):
             jobs.append((src, obj))
@@ -44,14 +49,13 @@ def build(force: bool = False, verbose: bool = True) -> str:
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(cc, jobs))
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
-    if force or jobs or _stale(OUT, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+    if force or jobs or _stale(out, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(OUT)
+    print(build(force="--force" in sys.argv))

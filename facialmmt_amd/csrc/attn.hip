@@ -625,8 +625,10 @@ extern "C" int fmmt_window_attn_fwd(int dtype, int n_img, int H, int W, int C, i
     return 0;
 }
 
+static size_t wa_part_bytes(int num_heads) { return ((size_t)num_heads * (WA_BWD_WAVES_PER_HEAD_MAX + 1) * TOK * TOK * sizeof(float) + 255) / 256 * 256; }
+
 extern "C" size_t fmmt_window_attn_bwd_workspace(int num_heads) {
-    return (size_t)num_heads * (WA_BWD_WAVES_PER_HEAD_MAX + 1) * TOK * TOK * sizeof(float);   // per-wave partials + dense
+    return wa_part_bytes(num_heads) + WA_SINK_BYTES;        // per-wave partials + dense, then the store sink (wattn_args.h)
 }
 
 extern "C" int fmmt_window_attn_bwd(int dtype, int n_img, int H, int W, int C, int num_heads, int shift,
@@ -641,6 +643,7 @@ extern "C" int fmmt_window_attn_bwd(int dtype, int n_img, int H, int W, int C, i
     a.n_img = n_img; a.H = H; a.W = W; a.C = C; a.nH = num_heads; a.shift = shift; a.qkv = qkv; a.table = table;
     a.index = index; a.mask = mask; a.nW_mask = nW_mask; a.mask_is_shift = mask_is_shift; a.scale = scale; a.out = const_cast<void*>(out);
     a.lse = const_cast<float*>(lse); a.dout = dout; a.dqkv = dqkv; a.part = reinterpret_cast<float*>(workspace);
+    a.sink = reinterpret_cast<char*>(workspace) + wa_part_bytes(num_heads);
     const int B_ = n_img * (H / WS) * (W / WS);
     a.groups_per_head = wa_groups_per_head(B_, num_heads, true, dtype == FMMT_BF16);
     a.xcd_grouped = wa_xcd_grouped(a.groups_per_head, dtype == FMMT_BF16);
@@ -668,6 +671,7 @@ extern "C" int fmmt_window_block_attn_bwd(int dtype, int n_img, int H, int W, in
     a.n_img = n_img; a.H = H; a.W = W; a.C = C; a.nH = num_heads; a.shift = shift; a.table = table; a.index = index; a.scale = scale;
     a.mask_is_shift = shift > 0; a.out = const_cast<void*>(attn_out); a.lse = const_cast<float*>(lse); a.dout = dy; a.dqkv = dqkv;
     a.part = reinterpret_cast<float*>(workspace);
+    a.sink = reinterpret_cast<char*>(workspace) + wa_part_bytes(num_heads);
     a.xn = xn; a.wqkv = wqkv; a.bqkv = bqkv; a.wproj = wproj; a.rowscale = rowscale;
     const int B_ = n_img * (H / WS) * (W / WS);
     a.groups_per_head = fmmt_wattn_bwd_groups(B_, num_heads, 4);

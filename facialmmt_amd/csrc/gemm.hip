@@ -534,6 +534,7 @@ __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    FMMT_YOUNG_HALF_PRIO(wave);
     const int wm = wave >> 2, wn = wave & 3;
     const int li = lane & 15, lg = lane >> 4;
     const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
@@ -1720,6 +1721,7 @@ __global__ __launch_bounds__(512) void linear_tn_dma_kernel(TnArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    FMMT_YOUNG_HALF_PRIO(wave);
     const int wn = wave / WK, wk = wave % WK;
     const int li = lane & 15, lg = lane >> 4;
     const int tiles = p.tiles_n * p.tiles_k;

@@ -28,7 +28,13 @@ struct WaArgs {
     const float* bqkv;
     const void* wproj;
     const float* rowscale;
+    // 16 KB behind the d(bias) partials of the workspace: where the backward's lanes without a token (pad slots 49..63, idle tail
+    // iterations) put their 16-byte stores.  Unconditional stores keep the kernel's store COUNT static, and with it the compiler's
+    // vmcnt arithmetic: behind conditional stores every wait for a prefetched load degrades to vmcnt(0), i.e. to waiting out the
+    // previous problem's write latency as well.
+    void* sink;
 };
+constexpr size_t WA_SINK_BYTES = 16 * 1024;
 
 int fmmt_wattn_mfma_fwd_launch(const WaArgs& a, int grid, hipStream_t st);
 int fmmt_wattn_mfma_bwd_launch(const WaArgs& a, int grid, hipStream_t st);

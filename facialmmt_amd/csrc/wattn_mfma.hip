@@ -208,6 +208,7 @@ void wattn_mfma_bwd_kernel(WaArgs p) {
     bf16* __restrict__ dqkv = reinterpret_cast<bf16*>(p.dqkv);
     const LaneGeom G = lane_geom(li, lg, p.shift);
     bf16 *kt_ = Kt[pair], *qt_ = Qt[pair], *gt_ = Gt[pair], *vt_ = Vt[pair];
+    bf16* const sinkp = reinterpret_cast<bf16*>(p.sink) + threadIdx.x * 8;
     const Slot own[2] = {slot_of((2 * h) * 16 + li), slot_of((2 * h + 1) * 16 + li)};
 
     fill_bias_mfma(p, head, Bs, NT);
@@ -235,13 +236,67 @@ void wattn_mfma_bwd_kernel(WaArgs p) {
         for (int b = 0; b < 4; ++b) dbias[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int iters = (B_ + stride - 1) / stride;
+    // The (window, head) problem of iteration it + 1 is requested while iteration it is being worked on (RC == 0: its q / k / v /
+    // d(out) / out fragments and log-sum-exp, 42 registers; RC: the LN1(x) / dy / out rows of the wave's tokens, 58 at C = 96, in
+    // flight under the two passes) -- an iteration is otherwise a chain of HBM round trip -> LDS -> barrier -> 56 MFMAs -> stores
+    // on two workgroups per CU with nothing to cover the round trip.
+    constexpr int FKS = RC ? RC / 32 : 1;
+    struct Fetch {
+        bf16x8 q[2], k[2], v[2], g[2];                     // RC == 0
+        bf16x8 x[2][FKS], y[2][FKS];                       // RC != 0: LN1(x) and dy rows of the two own tokens
+        bf16x8 o[2];
+        float ls[2], rs;
+        int tok[2];                                        // token index (n_img * H * W < 2^31)
+    };
+    auto fetch = [&](int it, Fetch& F) {
+        const int b_raw = it * stride + grp * NP + pair;
+        const int b_ = b_raw < B_ ? b_raw : B_ - 1;
+        const WinPos P = win_pos(p, b_);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            F.tok[a] = (int)tok_of(p, P, own[a].di, own[a].dj);
+            if constexpr (RC == 0) {
+                const bf16* row = qkv + (size_t)F.tok[a] * 3 * p.C + head * HD + lg * 8;
+                F.q[a] = ld_frag(row);
+                F.k[a] = ld_frag(row + p.C);
+                F.v[a] = ld_frag(row + 2 * p.C);
+                F.g[a] = ld_frag(dog + (size_t)F.tok[a] * p.C + head * HD + lg * 8);
+            } else {
+                const bf16* xr = reinterpret_cast<const bf16*>(p.xn) + (size_t)F.tok[a] * RC + lg * 8;
+                const bf16* yr = dog + (size_t)F.tok[a] * RC + lg * 8;
+#pragma unroll
+                for (int ks = 0; ks < FKS; ++ks) {
+                    F.x[a][ks] = ld_frag(xr + ks * 32);
+                    F.y[a][ks] = ld_frag(yr + ks * 32);
+                }
+            }
+            F.o[a] = ld_frag(og + (size_t)F.tok[a] * p.C + head * HD + lg * 8);
+            const int slot = (2 * h + a) * 16 + li;
+            F.ls[a] = p.lse[((size_t)b_ * p.nH + head) * TOK + (slot < TOK ? slot : TOK - 1)];
+        }
+        if constexpr (RC != 0) F.rs = p.rowscale ? p.rowscale[P.img] : 1.0f;
+    };
+    Fetch cur;
+    constexpr int NLD = RC ? 2 * (2 * FKS + 1) : 10;       // 16-byte loads of a fetch (plus the scalars)
+    {
+        // Every path into the loop head carries the same instruction counts behind the fetch (12 loads, then 6 stores): the compiler's
+        // vmcnt bookkeeping merges the loop's entry and its back edge, and an entry without the six stores turns the head's
+        // "fragments have landed" into vmcnt(0) -- the previous problem's stores waited out on every iteration.  Hence six sink
+        // stores here, and an unconditional (clamped: problem B_ - 1 again) fetch in the loop.
+        fetch(0, cur);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            *reinterpret_cast<bf16x8*>(sinkp) = zero_frag();
+            asm volatile("" ::: "memory");                 // six store instructions, not one
+        }
+    }
     for (int it = 0; it < iters; ++it) {
         const int b_raw = it * stride + grp * NP + pair;
         const bool wactive = b_raw < B_;
         const int b_ = wactive ? b_raw : B_ - 1;
         const WinPos P = win_pos(p, b_);
         const float* mbase = (MM == 2) ? p.mask + (size_t)(b_ % p.nW_mask) * TOK * TOK : nullptr;
-        size_t tok[2];
+        int tok[2];
         bf16x8 qf[2], kf[2], gf[2];
         float ls[2], dl[2];
         __syncthreads();                                   // previous iteration finished with the LDS tiles
@@ -249,28 +304,25 @@ void wattn_mfma_bwd_kernel(WaArgs p) {
         if constexpr (RC == 0) {
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
-                tok[a] = tok_of(p, P, own[a].di, own[a].dj);
-                const bf16* row = qkv + tok[a] * 3 * p.C + head * HD + lg * 8;
-                qf[a] = ld_frag(row);
-                kf[a] = ld_frag(row + p.C);
-                vv[a] = ld_frag(row + 2 * p.C);
-                gf[a] = ld_frag(dog + tok[a] * p.C + head * HD + lg * 8);
+                tok[a] = cur.tok[a];
+                qf[a] = cur.q[a];
+                kf[a] = cur.k[a];
+                vv[a] = cur.v[a];
+                gf[a] = cur.g[a];
             }
         } else {
             constexpr int KS = RC / 32;
             bf16x8 xf[2][KS], yf[2][KS];
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
-                tok[a] = tok_of(p, P, own[a].di, own[a].dj);
-                const bf16* xr = reinterpret_cast<const bf16*>(p.xn) + tok[a] * RC + lg * 8;
-                const bf16* yr = dog + tok[a] * RC + lg * 8;
+                tok[a] = cur.tok[a];
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    xf[a][ks] = ld_frag(xr + ks * 32);
-                    yf[a][ks] = ld_frag(yr + ks * 32);
+                    xf[a][ks] = cur.x[a][ks];
+                    yf[a][ks] = cur.y[a][ks];
                 }
             }
-            const float rs = p.rowscale ? p.rowscale[P.img] : 1.0f;
+            const float rs = cur.rs;
             // part 0..2: q, k, v = LN1(x) . W^T + b ; part 3: d(attention output) = rowscale * dy . Wproj[:, head]
 #pragma unroll
             for (int part = 0; part < 4; ++part) {
@@ -314,12 +366,12 @@ void wattn_mfma_bwd_kernel(WaArgs p) {
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             const int slot = (2 * h + a) * 16 + li;
-            const bf16x8 of = ld_frag(og + tok[a] * p.C + head * HD + lg * 8);
+            const bf16x8 of = cur.o[a];
             float d = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) d += (float)gf[a][e] * (float)of[e];
             dl[a] = xor_sum(d);
-            ls[a] = p.lse[((size_t)b_ * p.nH + head) * TOK + (slot < TOK ? slot : TOK - 1)];
+            ls[a] = cur.ls[a];
             const int off = slot * TP + lg * 8;
             *reinterpret_cast<bf16x8*>(kt_ + off) = own[a].valid ? kf[a] : zero_frag();
             *reinterpret_cast<bf16x8*>(qt_ + off) = own[a].valid ? qf[a] : zero_frag();
@@ -331,14 +383,10 @@ void wattn_mfma_bwd_kernel(WaArgs p) {
             }
         }
         __syncthreads();
+        fetch(it + 1, cur);                                // in flight under both passes; consumed at the head of the next iteration
 
         // ------------------------------------------------ pass 1: own QUERY tiles -> dQ, d bias
         {
-            bf16x8 kT[2][2];
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) kT[ks][dt] = tr_fragT(kt_, 32 * ks + 4 * lg, dt, li);
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 const int qt = 2 * h + a;
@@ -367,30 +415,29 @@ void wattn_mfma_bwd_kernel(WaArgs p) {
                     }
                 }
                 const bf16x8 d0 = pack8(&ds[0], &ds[4]), d1 = pack8(&ds[8], &ds[12]);
+                __builtin_amdgcn_sched_barrier(0);
+                bf16x8 kT[2][2];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) kT[ks][dt] = tr_fragT(kt_, 32 * ks + 4 * lg, dt, li);
                 f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
                 a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT[0][0], d0, a0, 0, 0, 0);
                 a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT[1][0], d1, a0, 0, 0, 0);
                 a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT[0][1], d0, a1, 0, 0, 0);
                 a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT[1][1], d1, a1, 0, 0, 0);
-                if (wactive && own[a].valid) {
+                {
                     bf16x8 ob;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { ob[r] = (bf16)(a0[r] * p.scale); ob[4 + r] = (bf16)(a1[r] * p.scale); }
-                    *reinterpret_cast<bf16x8*>(dqkv + tok[a] * 3 * p.C + head * HD + lg * 8) = ob;
+                    *reinterpret_cast<bf16x8*>((wactive && own[a].valid) ? dqkv + (size_t)tok[a] * 3 * p.C + head * HD + lg * 8 : sinkp) = ob;    // WaArgs::sink
                 }
+                __builtin_amdgcn_sched_barrier(0);          // one query tile at a time: interleaved, the two want 30+ more registers
             }
         }
 
         // ------------------------------------------------ pass 2: own KEY tiles -> dK, dV
         {
-            bf16x8 gT[2][2], qT[2][2];
-#pragma unroll
-            for (int qs = 0; qs < 2; ++qs)
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    gT[qs][dt] = tr_fragT(gt_, 32 * qs + 4 * lg, dt, li);
-                    qT[qs][dt] = tr_fragT(qt_, 32 * qs + 4 * lg, dt, li);
-                }
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 const int kt = 2 * h + a;
@@ -419,6 +466,16 @@ void wattn_mfma_bwd_kernel(WaArgs p) {
                 }
                 const bf16x8 p0 = pack8(&pp[0], &pp[4]), p1 = pack8(&pp[8], &pp[12]);
                 const bf16x8 d0 = pack8(&ds[0], &ds[4]), d1 = pack8(&ds[8], &ds[12]);
+                // transposed fragments read per key tile, behind the logits (32 registers that need not be live under them)
+                __builtin_amdgcn_sched_barrier(0);
+                bf16x8 gT[2][2], qT[2][2];
+#pragma unroll
+                for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        gT[qs][dt] = tr_fragT(gt_, 32 * qs + 4 * lg, dt, li);
+                        qT[qs][dt] = tr_fragT(qt_, 32 * qs + 4 * lg, dt, li);
+                    }
                 f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f}, k0 = {0.f, 0.f, 0.f, 0.f}, k1 = {0.f, 0.f, 0.f, 0.f};
                 v0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gT[0][0], p0, v0, 0, 0, 0);
                 v0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gT[1][0], p1, v0, 0, 0, 0);
@@ -428,17 +485,19 @@ void wattn_mfma_bwd_kernel(WaArgs p) {
                 k0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT[1][0], d1, k0, 0, 0, 0);
                 k1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT[0][1], d0, k1, 0, 0, 0);
                 k1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT[1][1], d1, k1, 0, 0, 0);
-                if (wactive && own[a].valid) {
+                {
                     bf16x8 kb, vb;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         kb[r] = (bf16)(k0[r] * p.scale); kb[4 + r] = (bf16)(k1[r] * p.scale);
                         vb[r] = (bf16)v0[r]; vb[4 + r] = (bf16)v1[r];
                     }
-                    bf16* dst = dqkv + tok[a] * 3 * p.C + head * HD + lg * 8;
-                    *reinterpret_cast<bf16x8*>(dst + p.C) = kb;
-                    *reinterpret_cast<bf16x8*>(dst + 2 * p.C) = vb;
+                    const bool live = wactive && own[a].valid;
+                    bf16* dst = dqkv + (size_t)tok[a] * 3 * p.C + head * HD + lg * 8;
+                    *reinterpret_cast<bf16x8*>(live ? dst + p.C : sinkp) = kb;
+                    *reinterpret_cast<bf16x8*>(live ? dst + 2 * p.C : sinkp) = vb;
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }

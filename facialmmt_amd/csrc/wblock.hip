@@ -33,67 +33,15 @@
 // tests/test_gpu_wblock.py holds the two within a bf16 rounding of one another and both to an fp64 restatement.
 // For the backward the kernel also emits what the four launches would have left in HBM minus qkv: LN1(x), the attention output,
 // the row statistics and the log-sum-exp.  Measured (640 frames, stage 0): 0.62 ms against 1.31 ms for the four launches.
-#include "fmmt_common.h"
-#include "../../include/fmmt.h"
-#include "wattn_geom.h"
+#include "wblock_common.h"
 
 namespace {
-
-struct WbArgs {
-    int n_img, H, W, shift;
-    const bf16* x;
-    const float* ln_g;
-    const float* ln_b;
-    float eps;
-    const bf16* wqkv;
-    const float* bqkv;
-    const bf16* wproj;
-    const float* bproj;
-    const float* table;
-    const int32_t* index;
-    float scale;
-    const float* rowscale;
-    bf16* y;
-    bf16* xn;
-    bf16* o;
-    float* mean;
-    float* rstd;
-    float* lse;
-    int B_;
-};
-
-constexpr int WB_BP = 68;            // bias row pitch in floats (272 B: 16 query rows fall on 16 different 16-byte slots)
-
-template <int C>
-struct WbLds {
-    static constexpr int NH = C / 32, PITCH = C + 8;
-    static constexpr int W_BYTES = 4 * C * PITCH * 2;                 // 3C rows of Wqkv + C rows of Wproj, fragment order
-    static constexpr int BIAS_BYTES = NH * TOK * WB_BP * 4;
-    static constexpr int VEC_BYTES = (C + C + 3 * C + C) * 4;         // gamma, beta, bqkv, bproj
-    static constexpr int TOTAL = W_BYTES + BIAS_BYTES + VEC_BYTES;
-};
-
-// LDS weight row d -> source row.  Rows are stored in FRAGMENT order: a 16-row MFMA tile reads 16 consecutive LDS rows.
-// d < 3C : ((head * 3 + part) * 2 + nt) * 16 + i  <->  Wqkv row part * C + head * 32 + (i >> 2) * 8 + nt * 4 + (i & 3)
-// d >= 3C: 3C + (c * 2 + nt) * 16 + i             <->  Wproj row c * 32 + (i >> 2) * 8 + nt * 4 + (i & 3)
-template <int C>
-__device__ __forceinline__ int wb_src_row(int d, bool& is_proj) {
-    is_proj = d >= 3 * C;
-    const int dd = is_proj ? d - 3 * C : d;
-    const int blk = dd >> 5, nt = (dd >> 4) & 1, i = dd & 15;
-    const int within = (i >> 2) * 8 + nt * 4 + (i & 3);
-    if (is_proj) return blk * 32 + within;
-    const int head = blk / 3, part = blk - head * 3;
-    return part * C + head * 32 + within;
-}
 
 // Scheduling fences between the phases of a window: without any, the scheduler hoists the LDS fragment reads of later phases over
 // earlier ones and the kernel wants 450-900 registers.  Kept after each q / k product, the v product and each query tile of the
 // attention core; none after the LayerNorm tiles and the proj tiles (with those two the allocator spills 6 registers -- and a
 // scratch reload behind the window's stores waits for them, see the epilogue).
 #define WB_FENCE() __builtin_amdgcn_sched_barrier(0)
-
-constexpr float WB_LOG2E = 1.4426950408889634f, WB_LN2 = 0.6931471805599453f;
 
 __device__ __forceinline__ f32x2 bf2_to_f2(unsigned u) {                 // two packed bf16 -> two floats
     return f32x2{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
@@ -419,23 +367,48 @@ bool wb_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0;
 
 }  // namespace
 
-extern "C" int fmmt_window_block_fwd(int dtype, int n_img, int H, int W, int C, int num_heads, int shift,
-                                     const void* x, const float* ln_gamma, const float* ln_beta, float eps,
-                                     const void* wqkv, const float* bqkv, const void* wproj, const float* bproj,
-                                     const float* table, const int32_t* index, float scale, const float* rowscale,
-                                     void* y, void* xn, void* attn_out, float* mean, float* rstd, float* lse, void* stream) {
-    if (dtype != FMMT_BF16 || n_img <= 0 || H <= 0 || W <= 0 || H % WS || W % WS || shift < 0 || shift >= WS) return FMMT_EINVAL;
+static int wb_fill(WbArgs& a, int dtype, int n_img, int H, int W, int C, int num_heads, int shift,
+                   const void* x, const float* ln_gamma, const float* ln_beta, float eps,
+                   const void* wqkv, const float* bqkv, const void* wproj, const float* bproj,
+                   const float* table, const int32_t* index, float scale, const float* rowscale,
+                   void* y, void* xn, void* attn_out, float* mean, float* rstd, float* lse) {
+    if ((dtype != FMMT_BF16 && dtype != FMMT_F32) || n_img <= 0 || H <= 0 || W <= 0 || H % WS || W % WS || shift < 0 || shift >= WS) return FMMT_EINVAL;
     if (C != 96 || num_heads * HD != C) return FMMT_EINVAL;                       // other widths: the four-launch form
     if (!x || !ln_gamma || !ln_beta || !wqkv || !wproj || !table || !index || !y || !lse) return FMMT_EINVAL;
     if ((mean == nullptr) != (rstd == nullptr)) return FMMT_EINVAL;
     if (!wb_al16(x) || !wb_al16(wqkv) || !wb_al16(wproj) || !wb_al16(y) || (xn && !wb_al16(xn)) || (attn_out && !wb_al16(attn_out))) return FMMT_EALIGN;
-    WbArgs a{};
+    a = WbArgs{};
     a.n_img = n_img; a.H = H; a.W = W; a.shift = shift;
     a.x = (const bf16*)x; a.ln_g = ln_gamma; a.ln_b = ln_beta; a.eps = eps;
     a.wqkv = (const bf16*)wqkv; a.bqkv = bqkv; a.wproj = (const bf16*)wproj; a.bproj = bproj;
     a.table = table; a.index = index; a.scale = scale; a.rowscale = rowscale;
     a.y = (bf16*)y; a.xn = (bf16*)xn; a.o = (bf16*)attn_out; a.mean = mean; a.rstd = rstd; a.lse = lse;
     a.B_ = n_img * (H / WS) * (W / WS);
+    return 0;
+}
+
+extern "C" int fmmt_window_block_fwd(int dtype, int n_img, int H, int W, int C, int num_heads, int shift,
+                                     const void* x, const float* ln_gamma, const float* ln_beta, float eps,
+                                     const void* wqkv, const float* bqkv, const void* wproj, const float* bproj,
+                                     const float* table, const int32_t* index, float scale, const float* rowscale,
+                                     void* y, void* xn, void* attn_out, float* mean, float* rstd, float* lse, void* stream) {
+    WbArgs a;
+    if (int rc = wb_fill(a, dtype, n_img, H, W, C, num_heads, shift, x, ln_gamma, ln_beta, eps, wqkv, bqkv, wproj, bproj, table, index, scale, rowscale,
+                         y, xn, attn_out, mean, rstd, lse)) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == FMMT_F32) return fmmt_wblock_ref_fwd_launch(FMMT_F32, &a, st);     // parity: fp32 operands, wblock_ref.hip
     return wb_launch<96, 8>(a, st);
+}
+
+// The element-type-generic restatement of the same kernel (wblock_ref.hip): dtype FMMT_F32 = what fmmt_window_block_fwd(FMMT_F32) runs,
+// FMMT_BF16 = the bf16 instantiation of the generic template (a test compares it with the production kernel).
+extern "C" int fmmt_window_block_fwd_ref(int dtype, int n_img, int H, int W, int C, int num_heads, int shift,
+                                         const void* x, const float* ln_gamma, const float* ln_beta, float eps,
+                                         const void* wqkv, const float* bqkv, const void* wproj, const float* bproj,
+                                         const float* table, const int32_t* index, float scale, const float* rowscale,
+                                         void* y, void* xn, void* attn_out, float* mean, float* rstd, float* lse, void* stream) {
+    WbArgs a;
+    if (int rc = wb_fill(a, dtype, n_img, H, W, C, num_heads, shift, x, ln_gamma, ln_beta, eps, wqkv, bqkv, wproj, bproj, table, index, scale, rowscale,
+                         y, xn, attn_out, mean, rstd, lse)) return rc;
+    return fmmt_wblock_ref_fwd_launch(dtype, &a, reinterpret_cast<hipStream_t>(stream));
 }

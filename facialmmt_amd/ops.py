@@ -721,6 +721,9 @@ def window_attn_core(qkv, table, index_i32, mask, n_img, H, W, num_heads, shift,
 # ------------------------------------------------------------------------------------------------
 _WBLOCK = _os.environ.get("FMMT_WBLOCK", "1") != "0"          # A/B switch (read once): 0 = always the four-launch form; 192 = also at stage 1
 _WBLOCK_WIDTHS = (96, 192) if _os.environ.get("FMMT_WBLOCK", "1") == "192" else (96,)
+# fp32 (parity) models take the fused forward too -- its element-type-generic instantiation, csrc/wblock_ref.hip -- so that every fp32 golden of
+# the stage-0 blocks and of the whole Swin reaches the fused kernel's algorithm at 1e-3 (0: the four fp32 launches, as in rounds 1-3)
+_WBLOCK_F32 = _os.environ.get("FMMT_WBLOCK_F32", "1") != "0"
 _WBLOCK_BWD = _os.environ.get("FMMT_WBLOCK_BWD", "1") != "0"  # 0: the backward re-computes qkv with a GEMM and runs fmmt_window_attn_bwd
 
 
@@ -730,7 +733,8 @@ def window_block_fusable(x, C, num_heads, window_size, shift, mask, mask_is_shif
     backward, tests/test_gpu_wblock.py -- and reachable with FMMT_WBLOCK=192, but at stage 1 the recompute backward loses: six heads
     re-read LN(x) / dy and redo 96 MFMAs per wave, 835 us per launch against 480 + 130 for the attention backward and the proj input
     gradient it replaces.)"""
-    return (_WBLOCK and x.is_cuda and x.dtype == torch.bfloat16 and C in _WBLOCK_WIDTHS and num_heads * 32 == C and tuple(window_size) == (7, 7)
+    ok_dtype = x.dtype == torch.bfloat16 or (_WBLOCK_F32 and x.dtype == torch.float32 and C == 96)
+    return (_WBLOCK and x.is_cuda and ok_dtype and C in _WBLOCK_WIDTHS and num_heads * 32 == C and tuple(window_size) == (7, 7)
             and ((shift == 0 and mask is None) or (shift > 0 and mask is not None and mask_is_shift)))
 
 
@@ -810,7 +814,7 @@ def window_block_backward(dy, x2, xn, o, mean, rstd, lse, g, wqkv, bqkv, wproj, 
     dtable = torch.empty_like(tab)
     nbytes = lib.fmmt_window_attn_bwd_workspace(num_heads)
     ws = _ws(nbytes, x2.device)
-    if _WBLOCK_BWD and (m is None or shift > 0):
+    if _WBLOCK_BWD and dt == torch.bfloat16 and (m is None or shift > 0):
         # attention core backward with q, k, v and d(attention output) re-formed inside the kernel (no qkv / d(out) tensors)
         rc = lib.fmmt_window_block_attn_bwd(dtype_code(dt), n_img, H, W, C, num_heads, shift, _p(xn), _p(dy2), _p(o), _p(lse), _p(_lp(wqkv, dt)),
                                             _p(bqkv.detach().float().contiguous() if bqkv is not None else None), _p(_lp(wproj, dt)), _p(tab), _p(index_i32),

@@ -200,12 +200,22 @@ int fmmt_window_attn_bwd(int dtype, int n_img, int H, int W, int C, int num_head
  *     mean / rstd [tokens] fp32 (both or neither), lse [n_img*nW*num_heads*49] fp32 (required).
  * Operand roundings and GEMM accumulation orders are those of fmmt_layernorm_fwd -> fmmt_linear_fwd -> fmmt_window_attn_fwd ->
  * fmmt_linear_fwd; the softmax differs in the last bits (base-2 exponentials, normalisation after the second product).
- * Other widths / dtypes return FMMT_EINVAL (use the four-launch form). */
+ * dtype = FMMT_F32 (x, y, xn, attn_out, wqkv, wproj fp32): the PARITY instantiation -- the same kernel written over an element-type
+ * trait (csrc/wblock_ref.hip: fp32 fragments, 8 x v_mfma_f32_16x16x4_f32 per 32-deep block, nothing rounded), slow, held to the
+ * reference's block goldens at 1e-3.  Other widths return FMMT_EINVAL (use the four-launch form). */
 int fmmt_window_block_fwd(int dtype, int n_img, int H, int W, int C, int num_heads, int shift,
                           const void* x, const float* ln_gamma, const float* ln_beta, float eps,
                           const void* wqkv, const float* bqkv, const void* wproj, const float* bproj,
                           const float* table, const int32_t* index, float scale, const float* rowscale,
                           void* y, void* xn, void* attn_out, float* mean, float* rstd, float* lse, void* stream);
+/* The element-type-generic restatement itself (same arguments): FMMT_F32 = what fmmt_window_block_fwd(FMMT_F32) runs; FMMT_BF16 = the
+ * bf16 instantiation of the generic template, which tests compare with the production kernel -- the link between the kernel the
+ * benchmark runs and the instantiation the 1e-3 goldens reach (Swin_Transformer.py:233-266, :113-144). */
+int fmmt_window_block_fwd_ref(int dtype, int n_img, int H, int W, int C, int num_heads, int shift,
+                              const void* x, const float* ln_gamma, const float* ln_beta, float eps,
+                              const void* wqkv, const float* bqkv, const void* wproj, const float* bproj,
+                              const float* table, const int32_t* index, float scale, const float* rowscale,
+                              void* y, void* xn, void* attn_out, float* mean, float* rstd, float* lse, void* stream);
 
 /* Backward of the attention core for the fused block half, WITHOUT a materialised qkv (bf16; C = 96 or 192):
  *   dqkv [tokens, 3C] = d(loss) / d(qkv) of WindowAttention (Swin_Transformer.py:120-141) and dtable [169, num_heads],

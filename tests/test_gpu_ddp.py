@@ -152,6 +152,77 @@ def test_rccl_world_size_one_runs_the_exchange_path(tmp_path):
     assert moved > 0                                         # the bf16 wire really carried the gradients
 
 
+def _aux_batch(dev, rank, step_i):
+    g = torch.Generator(device=dev).manual_seed(500 + 10 * rank + step_i)
+    imgs = torch.randint(0, 256, (6, 112, 112, 3), generator=g, device=dev, dtype=torch.uint8)
+    return imgs, torch.randint(0, 7, (6,), generator=g, device=dev)
+
+
+def _aux_worker(rank, world, port, out_dir, backend):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": dev} if backend == "nccl" else {}))
+    from facialmmt_amd.parallel import GradientAverager, broadcast_parameters
+    from facialmmt_amd.train_step import GraphedAuxStep
+    cfg, swin, _ = _build(dev, 1)
+    cfg.aux_accumulation_steps = 1
+    swin.swin.input_resize, swin.swin.input_dtype = "pil", torch.float32
+    if rank == 1:
+        with torch.no_grad():
+            for p in swin.parameters():
+                p.add_(0.25)
+    broadcast_parameters(swin)
+    params = [p for p in swin.parameters() if p.requires_grad]
+    opt = torch.optim.SGD(params, lr=0.02)
+    avg = GradientAverager(params, hooks=False, bucket_mb=8)
+    assert len(avg.buckets) >= 4                             # Swin's 46.8 M gradients: 187 MB fp32 in 8 MiB buckets
+    step = GraphedAuxStep(swin, opt, None, cfg, *_aux_batch(dev, rank, 0), averager=avg)
+    for i in range(STEPS):
+        step(*_aux_batch(dev, rank, i))
+    torch.cuda.synchronize()
+    torch.save({k: v.detach().cpu() for k, v in swin.named_parameters()}, os.path.join(out_dir, f"aux{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def _two_rank_aux(tmp_path, backend):
+    """The auxiliary step (train.py:15-41: the step whose gradients -- Swin's 46.8 M -- ARE exchanged) on two ranks against
+    single-process SGD on the mean of the two ranks' gradients; BatchNorm1d per replica, so the reference runs the batches apart."""
+    import torch.nn.functional as F
+    world = 2
+    mp.spawn(_aux_worker, args=(world, _free_port(), str(tmp_path), backend), nprocs=world, join=True)
+    ret = [torch.load(os.path.join(str(tmp_path), f"aux{r}.pt"), weights_only=True) for r in range(world)]
+    dev = torch.device("cuda:0")
+    cfg, swin, _ = _build(dev, 1)
+    swin.swin.input_resize, swin.swin.input_dtype = "pil", torch.float32
+    params = [p for p in swin.parameters() if p.requires_grad]
+    opt = torch.optim.SGD(params, lr=0.02)
+    for s in range(STEPS):
+        opt.zero_grad(set_to_none=True)
+        for r in range(world):
+            imgs, labels = _aux_batch(dev, r, s)
+            (swin(imgs, False, labels, F.cross_entropy) / world).backward()
+        torch.nn.utils.clip_grad_norm_(params, cfg.clip)
+        opt.step()
+    moved = 0
+    for k, w in swin.named_parameters():
+        w = w.detach().cpu()
+        for r in range(world):
+            assert (ret[r][k] - w).abs().max().item() <= 2e-4 * max(1.0, w.abs().max().item()), (k, r)
+        moved += 1
+    assert torch.equal(ret[0]["swin.patch_embed.proj.weight"], ret[1]["swin.patch_embed.proj.weight"]) and moved > 100
+
+
+def test_two_rank_auxiliary_step_equals_mean_gradient_step(tmp_path):
+    _two_rank_aux(tmp_path, "gloo")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one device per rank: two GPUs")
+def test_two_rank_auxiliary_step_on_rccl(tmp_path):
+    _two_rank_aux(tmp_path, "nccl")
+
+
 def _early_text_bucket(rank, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

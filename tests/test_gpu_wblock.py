@@ -84,9 +84,125 @@ def test_entry_point_refuses_what_it_does_not_cover(dev):
     args = lambda dtype, C, nh: (dtype, 1, 7, 7, C, nh, 0, x.data_ptr(), z.data_ptr(), z.data_ptr(), 1e-5, w.data_ptr(), None, w.data_ptr(), None,
                                  z.data_ptr(), idx.data_ptr(), 0.17, None, x.data_ptr(), None, None, None, None, z.data_ptr(), None)
     assert lib.fmmt_window_block_fwd(*args(_lib.BF16, 192, 6)) == -1                     # FMMT_EINVAL: other widths take the four-launch form
-    assert lib.fmmt_window_block_fwd(*args(_lib.F32, 96, 3)) == -1                      # parity mode is the four-launch form
-    assert not ops.window_block_fusable(x.float(), 96, 3, (7, 7), 0, None, False)
+    assert lib.fmmt_window_block_fwd(*args(_lib.F32, 192, 6)) == -1
+    assert lib.fmmt_window_block_fwd_ref(*args(_lib.BF16, 192, 6)) == -1
+    assert ops.window_block_fusable(x[:, :96].float(), 96, 3, (7, 7), 0, None, False)    # fp32 (parity): the generic instantiation, C = 96 only
+    assert not ops.window_block_fusable(x.float(), 192, 6, (7, 7), 0, None, False)
     assert not ops.window_block_fusable(x, 96, 3, (7, 7), 3, torch.zeros(1, 49, 49, device=dev), False)     # a non-standard mask tensor
+
+
+def _raw_block(lib, entry, dtype, x2, P, index, n_img, H, nh, shift, rs):
+    """one call of a fused block-half entry point on explicit operands; returns (y, xn, attn_out, mean, rstd, lse)"""
+    from facialmmt_amd import _lib
+    code = _lib.dtype_code(dtype)
+    M, C = x2.shape
+    dev = x2.device
+    y, xn, o = torch.empty_like(x2), torch.empty_like(x2), torch.empty_like(x2)
+    mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    lse = torch.empty(n_img * (H // 7) ** 2 * nh * 49, device=dev)
+    keep = [P["g"].detach().float().contiguous(), P["b"].detach().float().contiguous(), P["wqkv"].detach().to(dtype).contiguous(), P["bqkv"].detach().float().contiguous(),
+            P["wproj"].detach().to(dtype).contiguous(), P["bproj"].detach().float().contiguous(), P["table"].detach().float().contiguous()]
+    rc = getattr(lib, entry)(code, n_img, H, H, C, nh, shift, x2.data_ptr(), keep[0].data_ptr(), keep[1].data_ptr(), 1e-5, keep[2].data_ptr(), keep[3].data_ptr(),
+                             keep[4].data_ptr(), keep[5].data_ptr(), keep[6].data_ptr(), index.data_ptr(), 32 ** -0.5, rs.data_ptr() if rs is not None else None,
+                             y.data_ptr(), xn.data_ptr(), o.data_ptr(), mean.data_ptr(), rstd.data_ptr(), lse.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, (entry, rc)
+    torch.cuda.synchronize()
+    return y, xn, o, mean, rstd, lse
+
+
+GENERIC_CASES = [(1, 7, 0, False), (2, 14, 3, True), (3, 56, 0, True), (2, 56, 3, False), (5, 28, 3, True)]
+
+
+@pytest.mark.parametrize("n_img,H,shift,use_rs", GENERIC_CASES)
+def test_generic_template_in_bf16_reproduces_the_production_kernel(dev, n_img, H, shift, use_rs):
+    """csrc/wblock_ref.hip is wblock.hip's kernel written over an element-type trait.  Its bf16 instantiation must reproduce the kernel the
+    benchmark runs: the attention output, log-sum-exp and y to at most one bf16 rounding step (the LayerNorm affine is packed fp32
+    arithmetic in one and scalar in the other; everything behind it is the same instruction sequence on the same operands)."""
+    import support_wblock_cases as W
+    from facialmmt_amd import _lib
+    from oracle import swin as OS
+    lib = _lib.load()
+    C, nh = 96, 3
+    index = OS.relative_position_index(7).to(dev).int().contiguous()
+    P = W.params(C, nh, seed=20 + n_img)
+    x2 = W.rnd("xg", (n_img * H * H, C), 31, dtype=torch.bfloat16)
+    rs = None
+    if use_rs:
+        rs = W.rnd("rs", (n_img,), 5).abs() + 0.5
+        rs[0] = 0.0
+    prod = _raw_block(lib, "fmmt_window_block_fwd", torch.bfloat16, x2, P, index, n_img, H, nh, shift, rs)
+    gen = _raw_block(lib, "fmmt_window_block_fwd_ref", torch.bfloat16, x2, P, index, n_img, H, nh, shift, rs)
+    for name, a, b in zip(("y", "xn", "attn_out", "mean", "rstd", "lse"), prod, gen):
+        a, b = a.float(), b.float()
+        scale = b.abs().max().item()
+        tol = 2.0 ** -7 * scale if name in ("y", "xn", "attn_out") else 1e-5 * max(1.0, scale)
+        assert (a - b).abs().max().item() <= tol, (name, (a - b).abs().max().item(), scale)
+        if name in ("y", "xn", "attn_out"):                  # and almost everywhere identical
+            assert (a != b).float().mean().item() <= 0.05, name
+
+
+@pytest.mark.parametrize("n_img,H,shift,use_rs", GENERIC_CASES)
+def test_fp32_instantiation_of_the_fused_block_against_fp64(dev, n_img, H, shift, use_rs):
+    """The fp32 instantiation of the same template (fp32 fragments, 8 x v_mfma_f32_16x16x4_f32 per 32-deep block, nothing rounded to bf16):
+    north_star's 1e-3 on the fused kernel's ALGORITHM -- window / shift addressing, fragment-order weights, mask derivation, base-2
+    softmax normalised after the second product -- against an fp64 restatement: forward, the saved LayerNorm output, statistics and
+    log-sum-exp; and every gradient of the op (fused fp32 forward + the fp32 parity backward) against fp64 autograd."""
+    import support_wblock_cases as W
+    from facialmmt_amd import _lib
+    from oracle import swin as OS
+    lib = _lib.load()
+    C, nh = 96, 3
+    index = OS.relative_position_index(7).to(dev).int().contiguous()
+    P = W.params(C, nh, seed=40 + n_img)
+    x = W.rnd("xf", (n_img, H * H, C), 41).requires_grad_(True)
+    mask = OS.shift_mask(H, H, 7, shift).to(dev) if shift else None
+    rs = None
+    if use_rs:
+        rs = W.rnd("rs", (n_img,), 5).abs() + 0.5
+        rs[0] = 0.0
+    y, xn, o, mean, rstd, lse = _raw_block(lib, "fmmt_window_block_fwd", torch.float32, x.detach().reshape(-1, C), P, index, n_img, H, nh, shift, rs)
+    r64 = W.ref64(x.detach(), P, mask, n_img, H, nh, shift, rs)
+    assert (y.double() - r64).abs().max().item() <= 1e-4 * max(1.0, r64.abs().max().item())      # fp32 arithmetic: well inside north_star's 1e-3
+    x64 = x.detach().double().reshape(-1, C)
+    xn64 = torch.nn.functional.layer_norm(x64, (C,), P["g"].detach().double(), P["b"].detach().double(), 1e-5)
+    assert (xn.double() - xn64).abs().max().item() <= 1e-4
+    assert (mean.double() - x64.mean(-1)).abs().max().item() <= 1e-5
+    # through autograd: the op with fp32 operands = this forward + the fp32 parity backward
+    assert ops.window_block_fusable(x, C, nh, (7, 7), shift, mask, shift > 0)
+    yo = ops.window_block(x, P["g"], P["b"], 1e-5, P["wqkv"], P["bqkv"], P["wproj"], P["bproj"], P["table"], index, mask, n_img, H, H, nh, shift, 32 ** -0.5, rs)
+    assert torch.equal(yo.reshape(-1, C), y)
+    dy = W.rnd("dyf", (n_img, H * H, C), 43)
+    names = ["x", "g", "b", "wqkv", "bqkv", "wproj", "bproj", "table"]
+    gf = torch.autograd.grad(yo, [x] + [P[k] for k in names[1:]], dy)
+    xd = x.detach().double().requires_grad_(True)
+    P64 = {k: v.detach().double().requires_grad_(True) for k, v in P.items()}
+    g64 = torch.autograd.grad(W.ref64(xd, P64, mask, n_img, H, nh, shift, rs), [xd] + [P64[k] for k in names[1:]], dy.double().reshape(-1, C))
+    for nm, a, c in zip(names, gf, g64):
+        assert _rel(a, c.reshape(a.shape)) <= 1e-3, nm
+
+
+@pytest.mark.parametrize("shift", [0, 3])
+def test_fp32_swin_block_reaches_the_golden_through_the_fused_kernel(dev, golden, shift, monkeypatch):
+    """`block_s0_shift{0,3}` (outputs of the reference's SwinTransformerBlock) at 1e-3 through the fp32 module, whose attention half must
+    have been ONE call of fmmt_window_block_fwd (the generic instantiation), not the four parity launches."""
+    from facialmmt_amd import _lib
+    from facialmmt_amd.modules.SwinTransformer.Swin_Transformer import SwinTransformerBlock
+    blk = SwinTransformerBlock(96, (56, 56), 3, window_size=7, shift_size=shift, drop_path=0.0).eval()
+    synth.fill_state_dict(blk, seed=10, prefix="blk0.")
+    blk.to(dev)
+    x = synth.tensor("blk_in0", (2, 3136, 96), seed=0).to(dev)
+    lib = _lib.load()
+    calls = []
+    real = lib.fmmt_window_block_fwd
+    monkeypatch.setattr(lib, "fmmt_window_block_fwd", lambda *a: (calls.append(a[0]), real(*a))[1])
+    with torch.no_grad():
+        y32 = blk(x)
+    assert calls == [_lib.F32]
+    golden.check("swin_parts", f"block_s0_shift{shift}", y32, atol=1e-3, rtol=1e-3)
+    monkeypatch.setattr(ops, "_WBLOCK_F32", False)           # and the four fp32 launches agree with it
+    with torch.no_grad():
+        y4 = blk(x)
+    assert len(calls) == 1 and (y4 - y32).abs().max().item() <= 2e-5 * max(1.0, y32.abs().max().item())
 
 
 @pytest.mark.parametrize("shift", [0, 3])

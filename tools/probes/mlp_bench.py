@@ -3,6 +3,9 @@ activation recomputed on load, at the Swin stage-0 / stage-1 sizes of the bench 
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from facialmmt_amd import _lib
+if os.environ.get("PROBE_LIB"):                                # A/B of two builds in one gpurun call
+    _lib.LIB_PATH = os.environ["PROBE_LIB"]
 from facialmmt_amd import ops
 from facialmmt_amd._lib import EPI_GELU
 dev = torch.device("cuda:0")

@@ -3,6 +3,9 @@ process per setting, same gpurun call), or bare for PMC passes (rocprofv3 --pmc 
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from facialmmt_amd import _lib
+if os.environ.get("PROBE_LIB"):                                # A/B of two builds in one gpurun call
+    _lib.LIB_PATH = os.environ["PROBE_LIB"]
 from facialmmt_amd import ops
 dev = torch.device("cuda:0")
 bare = "--bare" in sys.argv

@@ -2,6 +2,9 @@
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from facialmmt_amd import _lib
+if os.environ.get("PROBE_LIB"):                                # A/B of two builds in one gpurun call
+    _lib.LIB_PATH = os.environ["PROBE_LIB"]
 from facialmmt_amd import ops, synth
 from facialmmt_amd.modules.SwinTransformer import Swin_Transformer as S
 from facialmmt_amd.modules.SwinTransformer.backbone_def import BackboneFactory
