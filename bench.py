@@ -442,9 +442,10 @@ def cpu_baseline(args, cfg):
     # call ran at 16 frames/s where 8-frame calls reach 75 on the same 16 threads -- round-3 VERDICT weak 10): sweep the chunk size,
     # time the utterance as ceil(frames / chunk) calls of the BEST chunk, and keep the one-call figure as a side note.
     chunk_fps = {}
+    swin_fwd_of(synth.tensor("frames", (4, 3, 224, 224), seed=1))()        # thread pool / allocator warm-up outside the sweep
     for nF in (4, 8, 16, 32):
         xs = synth.tensor("frames", (nF, 3, 224, 224), seed=1)
-        t, _ = timed(swin_fwd_of(xs), reps=3, warm=1, bound=5.0)
+        t, _ = timed(swin_fwd_of(xs), reps=3, warm=2, bound=5.0)
         chunk_fps[nF] = nF / t
     nF = max(chunk_fps, key=chunk_fps.get)
     x = synth.tensor("frames", (nF, 3, 224, 224), seed=1)

@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfmmt_hip.so")
 
 F32, BF16 = 0, 1
+GENERIC = 0x100          # dtype flag of the fused Mlp entry points: the element-type-generic restatement (include/fmmt.h)
 EPI_NONE, EPI_GELU, EPI_GELU_BWD = 0, 1, 2
 RESIZE_PIL, RESIZE_CV2 = 0, 1
 
@@ -41,6 +42,7 @@ SIGNATURES = {
     "fmmt_window_block_fwd": (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p]),
     "fmmt_window_block_fwd_ref": (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p]),
     "fmmt_window_block_attn_bwd": (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _sz, _p]),
+    "fmmt_window_block_attn_bwd_ref": (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _sz, _p]),
     "fmmt_mha_fwd": (_i, [_i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i, _f, _p, _f, _u64, _p, _p, _i, _p, _p]),
     "fmmt_mha_bwd": (_i, [_i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i, _f, _p, _f, _u64, _p, _p, _p, _i, _p, _p, _i, _p, _p, _i, _p]),
     "fmmt_mha_avg_weights": (_i, [_i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _f, _p, _f, _u64, _p, _p, _p, _p]),

@@ -658,13 +658,14 @@ extern "C" int fmmt_window_attn_bwd(int dtype, int n_img, int H, int W, int C, i
     return fmmt_wattn_dtable_finish(a.part, num_heads, dtype == FMMT_BF16 ? a.groups_per_head : a.groups_per_head * 4, index, dtable, st);
 }
 
-extern "C" int fmmt_window_block_attn_bwd(int dtype, int n_img, int H, int W, int C, int num_heads, int shift,
-                                          const void* xn, const void* dy, const void* attn_out, const float* lse,
-                                          const void* wqkv, const float* bqkv, const void* wproj,
-                                          const float* table, const int32_t* index, float scale, const float* rowscale,
-                                          void* dqkv, float* dtable, void* workspace, size_t workspace_bytes, void* stream) {
+static int wba_run(bool generic, int dtype, int n_img, int H, int W, int C, int num_heads, int shift,
+                   const void* xn, const void* dy, const void* attn_out, const float* lse,
+                   const void* wqkv, const float* bqkv, const void* wproj,
+                   const float* table, const int32_t* index, float scale, const float* rowscale,
+                   void* dqkv, float* dtable, void* workspace, size_t workspace_bytes, void* stream) {
     if (int e = wa_check(dtype, n_img, H, W, C, num_heads, shift)) return e;
-    if (dtype != FMMT_BF16 || (C != 96 && C != 192)) return FMMT_EINVAL;                // other widths: fmmt_window_attn_bwd on a materialised qkv
+    generic = generic || dtype == FMMT_F32;                                              // fp32 = the generic restatement (wattn_bwd_ref.hip), C = 96
+    if ((dtype != FMMT_BF16 && dtype != FMMT_F32) || (C != 96 && C != 192) || (generic && C != 96)) return FMMT_EINVAL;   // other widths: fmmt_window_attn_bwd on a materialised qkv
     if (!xn || !dy || !attn_out || !lse || !wqkv || !wproj || !table || !index || !dqkv || !dtable || !workspace) return FMMT_EINVAL;
     if (workspace_bytes < fmmt_window_attn_bwd_workspace(num_heads)) return FMMT_EWORKSPACE;
     WaArgs a{};
@@ -674,11 +675,36 @@ extern "C" int fmmt_window_block_attn_bwd(int dtype, int n_img, int H, int W, in
     a.sink = reinterpret_cast<char*>(workspace) + wa_part_bytes(num_heads);
     a.xn = xn; a.wqkv = wqkv; a.bqkv = bqkv; a.wproj = wproj; a.rowscale = rowscale;
     const int B_ = n_img * (H / WS) * (W / WS);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (generic) {
+        a.groups_per_head = fmmt_wattn_bwd_groups(B_, num_heads, 1);                    // one pair of waves (one window at a time) per workgroup
+        if (int rc = fmmt_wattn_bwd_ref_launch(dtype, a, num_heads * a.groups_per_head, st)) return rc;
+        return fmmt_wattn_dtable_finish(a.part, num_heads, a.groups_per_head, index, dtable, st);
+    }
     a.groups_per_head = fmmt_wattn_bwd_groups(B_, num_heads, 4);
     a.xcd_grouped = wa_xcd_grouped(a.groups_per_head, true);
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (int rc = fmmt_wattn_mfma_bwd_rc_launch(a, num_heads * a.groups_per_head, st)) return rc;
     return fmmt_wattn_dtable_finish(a.part, num_heads, a.groups_per_head, index, dtable, st);
+}
+
+extern "C" int fmmt_window_block_attn_bwd(int dtype, int n_img, int H, int W, int C, int num_heads, int shift,
+                                          const void* xn, const void* dy, const void* attn_out, const float* lse,
+                                          const void* wqkv, const float* bqkv, const void* wproj,
+                                          const float* table, const int32_t* index, float scale, const float* rowscale,
+                                          void* dqkv, float* dtable, void* workspace, size_t workspace_bytes, void* stream) {
+    return wba_run(false, dtype, n_img, H, W, C, num_heads, shift, xn, dy, attn_out, lse, wqkv, bqkv, wproj, table, index, scale, rowscale,
+                   dqkv, dtable, workspace, workspace_bytes, stream);
+}
+
+// the element-type-generic restatement (wattn_bwd_ref.hip): FMMT_F32 = what fmmt_window_block_attn_bwd(FMMT_F32) runs; FMMT_BF16 = the
+// generic template's bf16 instantiation, compared with the production kernel by tests/test_gpu_wblock.py
+extern "C" int fmmt_window_block_attn_bwd_ref(int dtype, int n_img, int H, int W, int C, int num_heads, int shift,
+                                              const void* xn, const void* dy, const void* attn_out, const float* lse,
+                                              const void* wqkv, const float* bqkv, const void* wproj,
+                                              const float* table, const int32_t* index, float scale, const float* rowscale,
+                                              void* dqkv, float* dtable, void* workspace, size_t workspace_bytes, void* stream) {
+    return wba_run(true, dtype, n_img, H, W, C, num_heads, shift, xn, dy, attn_out, lse, wqkv, bqkv, wproj, table, index, scale, rowscale,
+                   dqkv, dtable, workspace, workspace_bytes, stream);
 }
 
 // per-workgroup dense d(bias) partials [num_heads][parts_per_head][49 * 49] (in a workspace of fmmt_window_attn_bwd_workspace bytes)

@@ -47,17 +47,6 @@ struct FmmtLdsOnce {
     }
 };
 
-// 8-wave workgroups place two waves on each SIMD; the second-dispatched half (waves 4-7) loses every issue arbitration against its
-// older partner and arrives last at every barrier.  One static s_setprio 1 for that half before the main loop
-// (MI355X_MICROARCH.md, "Two waves per SIMD", item 4).  FMMT_EXP_SETPRIO: development build switch until measured.
-#ifndef FMMT_EXP_SETPRIO
-#define FMMT_EXP_SETPRIO 0
-#endif
-#define FMMT_YOUNG_HALF_PRIO(wave)                                   \
-    do {                                                             \
-        if (FMMT_EXP_SETPRIO && (wave) >= 4) __builtin_amdgcn_s_setprio(1); \
-    } while (0)
-
 #define FMMT_CHECK_LAUNCH()                                   \
     do {                                                      \
         hipError_t e__ = hipGetLastError();                   \

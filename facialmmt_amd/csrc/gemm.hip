@@ -534,7 +534,6 @@ __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    FMMT_YOUNG_HALF_PRIO(wave);
     const int wm = wave >> 2, wn = wave & 3;
     const int li = lane & 15, lg = lane >> 4;
     const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
@@ -671,6 +670,10 @@ __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
     const int tstep = G;
     const int ntile = first < total ? (total - first + G - 1) / G : 0;
     const int nsteps = ntile * nk;
+    // (A start stagger -- workgroups delayed by a hashed fraction of a tile period, on the theory that 256 persistent workgroups in
+    //  lockstep all write their tiles in the same 3.6 us window and meet the HBM write ceiling there -- was measured, round 4, same call:
+    //  only the workgroups with one tile fewer delayed: +-1 % on every shape; everyone by up to half / a whole period: -2...-40 %, in
+    //  proportion to the delay.  The epilogue's cost is per CU, not a chip-wide write queue.)
     // issue-side cursor
     int it = first, ik = 0, ipar = 0, islot = 0;
     tile_offsets((first / p.tiles_n) * BM, (first % p.tiles_n) * BN);
@@ -1721,7 +1724,6 @@ __global__ __launch_bounds__(512) void linear_tn_dma_kernel(TnArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    FMMT_YOUNG_HALF_PRIO(wave);
     const int wn = wave / WK, wk = wave % WK;
     const int li = lane & 15, lg = lane >> 4;
     const int tiles = p.tiles_n * p.tiles_k;

@@ -25,34 +25,9 @@
 // Accumulation orders equal those of the two-launch path (K ascending in both products, bf16 rounding of h before product 2),
 // so the result is bit-identical to fmmt_linear_fwd(GELU) followed by fmmt_linear_fwd(residual): tests/support_op_cases.py::t_mlp_fused.
 #include "gemm_common.h"
+#include "mlp_args.h"
 
 namespace {
-
-struct MlpArgs {
-    int M;
-    const bf16* x;
-    const bf16* w1;
-    const float* b1;
-    const bf16* w2;
-    const float* b2;
-    const bf16* res;
-    const float* rowscale;
-    int rows_per_scale;
-    bf16* y;
-    bf16* h_pre;
-    bf16* h_act;
-    int tiles;
-    // LN mode (fmmt_mlp_ln_fwd): x is the block's residual stream, the Mlp runs on LayerNorm(x) formed in registers, res == x
-    const float* ln_g;
-    const float* ln_b;
-    float eps;
-    bf16* xn;
-    float* mean;
-    float* rstd;
-    // LN-backward epilogue of the input-gradient kernel (fmmt_mlp_ln_bwd_input): the LayerNorm's input, and per-workgroup partial sums
-    const bf16* ln_x;
-    float* ln_part;
-};
 
 // (Two workgroups per CU at C = 96 -- 76.8 KB of LDS each, registers forced to 128 -- were measured: the inference form gains
 //  13 %, the training forms, whose time goes into the hidden-tensor stores, lose 0-19 % to the 20 spilled registers.)
@@ -72,7 +47,6 @@ __global__ __launch_bounds__(512) void mlp_fused_fwd_kernel(MlpArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    FMMT_YOUNG_HALF_PRIO(wave);
     const int li = lane & 15, lg = lane >> 4;
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
@@ -373,7 +347,6 @@ __global__ __launch_bounds__(512) void mlp_fused_bwd_kernel(MlpArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    FMMT_YOUNG_HALF_PRIO(wave);
     const int li = lane & 15, lg = lane >> 4;
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
@@ -694,19 +667,24 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 extern "C" int fmmt_mlp_fwd(int dtype, int M, int C, const void* x, const void* w1, const float* b1, const void* w2, const float* b2,
                             const void* res, const float* rowscale, int rows_per_scale, void* y, void* h_pre, void* h_act, void* stream) {
-    if (dtype != FMMT_BF16 || M <= 0 || (C != 96 && C != 192)) return FMMT_EINVAL;      // other widths: fmmt_linear_fwd twice
+    const int el = dtype & 0xff;
+    const bool generic = (dtype & FMMT_GENERIC) || el == FMMT_F32;                       // parity instantiations: csrc/mlp_ref.hip
+    if ((el != FMMT_BF16 && el != FMMT_F32) || M <= 0 || (C != 96 && C != 192)) return FMMT_EINVAL;      // other widths: fmmt_linear_fwd twice
     if (!x || !w1 || !b1 || !w2 || !b2 || !y) return FMMT_EINVAL;
     if (rowscale && rows_per_scale <= 0) return FMMT_EINVAL;
     if (!al16(x) || !al16(w1) || !al16(b1) || !al16(w2) || !al16(b2) || !al16(y) || (res && !al16(res)) || (h_pre && !al16(h_pre)) || (h_act && !al16(h_act))) return FMMT_EALIGN;
     MlpArgs a{M, (const bf16*)x, (const bf16*)w1, b1, (const bf16*)w2, b2, (const bf16*)res, rowscale, rows_per_scale, (bf16*)y, (bf16*)h_pre, (bf16*)h_act, (M + 255) / 256};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (generic) return fmmt_mlp_ref_fwd_launch(el, C, false, a, st);
     return C == 96 ? launch_mlp<96, false>(a, st) : launch_mlp<192, false>(a, st);
 }
 
 extern "C" int fmmt_mlp_ln_fwd(int dtype, int M, int C, const void* x, const float* ln_gamma, const float* ln_beta, float eps,
                                const void* w1, const float* b1, const void* w2, const float* b2, const float* rowscale, int rows_per_scale,
                                void* y, void* xn, float* mean, float* rstd, void* h_pre, void* h_act, void* stream) {
-    if (dtype != FMMT_BF16 || M <= 0 || (C != 96 && C != 192)) return FMMT_EINVAL;
+    const int el = dtype & 0xff;
+    const bool generic = (dtype & FMMT_GENERIC) || el == FMMT_F32;
+    if ((el != FMMT_BF16 && el != FMMT_F32) || M <= 0 || (C != 96 && C != 192)) return FMMT_EINVAL;
     if (!x || !ln_gamma || !ln_beta || !w1 || !b1 || !w2 || !b2 || !y) return FMMT_EINVAL;
     if ((mean == nullptr) != (rstd == nullptr) || (rowscale && rows_per_scale <= 0)) return FMMT_EINVAL;
     if (!al16(x) || !al16(ln_gamma) || !al16(ln_beta) || !al16(w1) || !al16(b1) || !al16(w2) || !al16(b2) || !al16(y) || (xn && !al16(xn)) ||
@@ -714,18 +692,22 @@ extern "C" int fmmt_mlp_ln_fwd(int dtype, int M, int C, const void* x, const flo
     MlpArgs a{M, (const bf16*)x, (const bf16*)w1, b1, (const bf16*)w2, b2, nullptr, rowscale, rows_per_scale, (bf16*)y, (bf16*)h_pre, (bf16*)h_act, (M + 255) / 256,
               ln_gamma, ln_beta, eps, (bf16*)xn, mean, rstd};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (generic) return fmmt_mlp_ref_fwd_launch(el, C, true, a, st);
     return C == 96 ? launch_mlp<96, true>(a, st) : launch_mlp<192, true>(a, st);
 }
 
 extern "C" int fmmt_mlp_bwd_input(int dtype, int M, int C, const void* dy, const void* h_pre, const void* w2t, const void* w1t,
                                   const float* rowscale, int rows_per_scale, void* dh, void* dx, void* stream) {
-    if (dtype != FMMT_BF16 || M <= 0 || (C != 96 && C != 192)) return FMMT_EINVAL;
+    const int el = dtype & 0xff;
+    const bool generic = (dtype & FMMT_GENERIC) || el == FMMT_F32;
+    if ((el != FMMT_BF16 && el != FMMT_F32) || M <= 0 || (C != 96 && C != 192)) return FMMT_EINVAL;
     if (!dy || !h_pre || !w2t || !w1t || !dh || !dx || (rowscale && rows_per_scale <= 0)) return FMMT_EINVAL;
     if (!al16(dy) || !al16(h_pre) || !al16(w2t) || !al16(w1t) || !al16(dh) || !al16(dx)) return FMMT_EALIGN;
     MlpArgs a{};
     a.M = M; a.x = (const bf16*)dy; a.w1 = (const bf16*)w2t; a.w2 = (const bf16*)w1t; a.rowscale = rowscale; a.rows_per_scale = rows_per_scale;
     a.y = (bf16*)dx; a.h_pre = (bf16*)const_cast<void*>(h_pre); a.h_act = (bf16*)dh; a.tiles = (M + 255) / 256;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (generic) return fmmt_mlp_ref_bwd_launch(el, C, false, a, st);
     return C == 96 ? launch_mlp_bwd<96>(a, st) : launch_mlp_bwd<192>(a, st);
 }
 
@@ -735,7 +717,9 @@ extern "C" int fmmt_mlp_ln_bwd_input(int dtype, int M, int C, const void* dy, co
                                      const float* rowscale, int rows_per_scale, const void* x, const float* mean, const float* rstd,
                                      const float* ln_gamma, void* dh, void* dx, float* dgamma, float* dbeta, void* workspace,
                                      size_t workspace_bytes, void* stream) {
-    if (dtype != FMMT_BF16 || M <= 0 || (C != 96 && C != 192)) return FMMT_EINVAL;       // other widths: fmmt_mlp_bwd_input + fmmt_layernorm_bwd
+    const int el = dtype & 0xff;
+    const bool generic = (dtype & FMMT_GENERIC) || el == FMMT_F32;
+    if ((el != FMMT_BF16 && el != FMMT_F32) || M <= 0 || (C != 96 && C != 192)) return FMMT_EINVAL;       // other widths: fmmt_mlp_bwd_input + fmmt_layernorm_bwd
     if (!dy || !h_pre || !w2t || !w1t || !dh || !dx || !x || !mean || !rstd || !ln_gamma || !dgamma || !dbeta || !workspace) return FMMT_EINVAL;
     if (rowscale && rows_per_scale <= 0) return FMMT_EINVAL;
     if (workspace_bytes < fmmt_mlp_ln_bwd_input_workspace(C)) return FMMT_EWORKSPACE;
@@ -745,6 +729,13 @@ extern "C" int fmmt_mlp_ln_bwd_input(int dtype, int M, int C, const void* dy, co
     a.y = (bf16*)dx; a.h_pre = (bf16*)const_cast<void*>(h_pre); a.h_act = (bf16*)dh; a.tiles = (M + 255) / 256;
     a.ln_g = ln_gamma; a.mean = const_cast<float*>(mean); a.rstd = const_cast<float*>(rstd); a.ln_x = (const bf16*)x; a.ln_part = (float*)workspace;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (generic) {
+        if (int rc = fmmt_mlp_ref_bwd_launch(el, C, true, a, st)) return rc;
+        const int g = a.tiles < 256 ? a.tiles : 256;                                    // the generic kernel's tiles are 256 tokens at either width
+        hipLaunchKernelGGL(mlp_ln_part_reduce_kernel, dim3((2 * C + 63) / 64), dim3(1024), 0, st, (const float*)workspace, g, C, dgamma, dbeta);
+        FMMT_CHECK_LAUNCH();
+        return 0;
+    }
     if (int rc = C == 96 ? launch_mlp_bwd<96, true>(a, st) : launch_mlp_bwd<192, true>(a, st)) return rc;
     const int tiles = (M + (C == 96 ? 256 : 128) - 1) / (C == 96 ? 256 : 128), grid = tiles < 256 ? tiles : 256;
     hipLaunchKernelGGL(mlp_ln_part_reduce_kernel, dim3((2 * C + 63) / 64), dim3(1024), 0, st, (const float*)workspace, grid, C, dgamma, dbeta);

@@ -39,6 +39,7 @@ constexpr size_t WA_SINK_BYTES = 16 * 1024;
 int fmmt_wattn_mfma_fwd_launch(const WaArgs& a, int grid, hipStream_t st);
 int fmmt_wattn_mfma_bwd_launch(const WaArgs& a, int grid, hipStream_t st);
 int fmmt_wattn_mfma_bwd_rc_launch(const WaArgs& a, int grid, hipStream_t st);      // recompute variant: 8-wave workgroups, C = 96 / 192
+int fmmt_wattn_bwd_ref_launch(int dtype, const WaArgs& a, int grid, hipStream_t st);   // wattn_bwd_ref.hip: its element-type-generic restatement, C = 96
 
 // attn.hip: fixed-order reduction of the per-workgroup dense d(bias) partials [num_heads][parts_per_head][49 * 49] that sit at the head
 // of a fmmt_window_attn_bwd_workspace(num_heads) workspace into dtable [169][num_heads]; workgroups per head for an 8-wave backward

@@ -372,6 +372,13 @@ def mlp_fused_raw(x2, w1l, b1, w2l, b2, res2, rowscale, rows_per_scale, h_pre, h
 
 
 _MLP_FUSED = _os.environ.get("FMMT_MLP_FUSED", "1") != "0"       # A/B switch (read once): 0 = always the two-launch form
+# fp32 (parity) models take the fused Mlp entry points too -- their element-type-generic instantiations, csrc/mlp_ref.hip -- so that the
+# fp32 goldens reach the fused kernels' algorithm at 1e-3 (0: LayerNorm + two GEMM launches, as in rounds 1-3)
+_MLP_F32 = _os.environ.get("FMMT_MLP_F32", "1") != "0"
+
+
+def _mlp_dtype_ok(dt):
+    return dt == torch.bfloat16 or (_MLP_F32 and dt == torch.float32)
 # The fused forward also stores the activation and fc2's weight gradient reads it (storing only the pre-activation and recomputing
 # gelu() while the weight-gradient kernel stages its operand measured slower: 0.75 vs 0.40 ms per stage-0 launch; round 2)
 _MLP_SAVE_H = True
@@ -379,7 +386,7 @@ _MLP_SAVE_H = True
 
 def _mlp_fusable(x2, w1, w2, b1, b2):
     C = x2.shape[1]
-    return (_MLP_FUSED and x2.dtype == torch.bfloat16 and C in (96, 192) and w1.shape == (4 * C, C) and w2.shape == (C, 4 * C)
+    return (_MLP_FUSED and _mlp_dtype_ok(x2.dtype) and C in (96, 192) and w1.shape == (4 * C, C) and w2.shape == (C, 4 * C)
             and b1 is not None and b2 is not None and x2.shape[0] >= 4096)
 
 
@@ -433,7 +440,7 @@ def mlp_bwd_input_raw(dy2, h_pre, w1, w2, rowscale, rows_per_scale):
     """(dh, dx) of the Mlp: one launch where the fused kernel applies (bf16, C = 96), the two GEMM launches otherwise"""
     M, C = dy2.shape
     dt = dy2.dtype
-    if _MLP_BWD_FUSED and dt == torch.bfloat16 and C in _MLP_BWD_WIDTHS and w1.shape == (4 * C, C) and M >= 4096:
+    if _MLP_BWD_FUSED and _mlp_dtype_ok(dt) and C in _MLP_BWD_WIDTHS and w1.shape == (4 * C, C) and M >= 4096:
         dh = torch.empty((M, 4 * C), dtype=dt, device=dy2.device)
         dx = torch.empty_like(dy2)
         rc = _lib.load().fmmt_mlp_bwd_input(dtype_code(dt), M, C, _p(dy2), _p(h_pre), _p(_lp(w2, dt, transpose=True)), _p(_lp(w1, dt, transpose=True)),
@@ -480,7 +487,7 @@ class MlpLnFn(Function):
         lib = _lib.load()
         dy2 = dy.reshape(-1, C).contiguous()
         M, dt = x2.shape[0], x2.dtype
-        if _MLP_BWD_FUSED and _MLP_BWD_LN and dt == torch.bfloat16 and C in _MLP_BWD_WIDTHS and M >= 4096:
+        if _MLP_BWD_FUSED and _MLP_BWD_LN and _mlp_dtype_ok(dt) and C in _MLP_BWD_WIDTHS and M >= 4096:
             # input gradient of the Mlp AND the LayerNorm backward in one launch (fmmt_mlp_ln_bwd_input)
             dh = torch.empty((M, 4 * C), dtype=dt, device=x2.device)
             dx = torch.empty_like(x2)
@@ -511,7 +518,7 @@ class MlpLnFn(Function):
 
 def mlp_ln_fusable(x, w1, w2, b1, b2):
     C = x.shape[-1]
-    return (_MLP_FUSED and x.is_cuda and x.dtype == torch.bfloat16 and C in (96, 192) and w1.shape == (4 * C, C) and w2.shape == (C, 4 * C)
+    return (_MLP_FUSED and x.is_cuda and _mlp_dtype_ok(x.dtype) and C in (96, 192) and w1.shape == (4 * C, C) and w2.shape == (C, 4 * C)
             and b1 is not None and b2 is not None and x.numel() // C >= 4096)
 
 
@@ -814,7 +821,8 @@ def window_block_backward(dy, x2, xn, o, mean, rstd, lse, g, wqkv, bqkv, wproj, 
     dtable = torch.empty_like(tab)
     nbytes = lib.fmmt_window_attn_bwd_workspace(num_heads)
     ws = _ws(nbytes, x2.device)
-    if _WBLOCK_BWD and dt == torch.bfloat16 and (m is None or shift > 0):
+    if _WBLOCK_BWD and (dt == torch.bfloat16 or (_WBLOCK_F32 and dt == torch.float32 and C == 96)) and (m is None or shift > 0):
+        # (fp32: the same entry point runs the generic restatement of the recompute kernel, csrc/wattn_bwd_ref.hip)
         # attention core backward with q, k, v and d(attention output) re-formed inside the kernel (no qkv / d(out) tensors)
         rc = lib.fmmt_window_block_attn_bwd(dtype_code(dt), n_img, H, W, C, num_heads, shift, _p(xn), _p(dy2), _p(o), _p(lse), _p(_lp(wqkv, dt)),
                                             _p(bqkv.detach().float().contiguous() if bqkv is not None else None), _p(_lp(wproj, dt)), _p(tab), _p(index_i32),

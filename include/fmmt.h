@@ -26,6 +26,12 @@ extern "C" {
 
 #define FMMT_F32 0
 #define FMMT_BF16 1
+/* dtype flag (OR-ed into FMMT_BF16) understood by the fused Mlp entry points (fmmt_mlp_fwd, fmmt_mlp_ln_fwd, fmmt_mlp_bwd_input,
+ * fmmt_mlp_ln_bwd_input): run the kernel's element-type-generic restatement (csrc/mlp_ref.hip) instead of the tuned kernel.  The
+ * same restatement with fp32 fragments is what dtype = FMMT_F32 selects on those entry points (all activation / weight operands fp32,
+ * nothing rounded: the parity instantiation, held to the reference's goldens at 1e-3); FMMT_BF16 | FMMT_GENERIC exists so that tests
+ * can hold the generic template against the kernel the benchmark runs.  (The block-half kernels have _ref entry points instead.) */
+#define FMMT_GENERIC 0x100
 
 #define FMMT_EINVAL (-1)   /* bad shape / unsupported size */
 #define FMMT_EALIGN (-2)   /* pointer or leading dimension not 16-byte aligned */
@@ -219,6 +225,7 @@ int fmmt_window_block_fwd_ref(int dtype, int n_img, int H, int W, int C, int num
 
 /* Backward of the attention core for the fused block half, WITHOUT a materialised qkv (bf16; C = 96 or 192):
  *   dqkv [tokens, 3C] = d(loss) / d(qkv) of WindowAttention (Swin_Transformer.py:120-141) and dtable [169, num_heads],
+ * (fp32 parity form: see fmmt_window_block_attn_bwd_ref below)
  * from xn = LayerNorm(x) [tokens, C], dy = the gradient of the block half's OUTPUT [tokens, C] (not of the attention output), the saved
  * attention output and log-sum-exp, wqkv / bqkv / wproj and the DropPath scale.  Each wave re-forms the q, k, v fragments of its
  * (window, head, token tiles) with the head's rows of wqkv and d(attention output) = rowscale * dy . wproj[:, head] with the head's
@@ -231,6 +238,14 @@ int fmmt_window_block_attn_bwd(int dtype, int n_img, int H, int W, int C, int nu
                                const void* wqkv, const float* bqkv, const void* wproj,
                                const float* table, const int32_t* index, float scale, const float* rowscale,
                                void* dqkv, float* dtable, void* workspace, size_t workspace_bytes, void* stream);
+/* The same backward restated over an element-type trait (csrc/wattn_bwd_ref.hip; C = 96): dtype FMMT_F32 -- also what
+ * fmmt_window_block_attn_bwd(FMMT_F32) runs -- takes fp32 xn / dy / attn_out / wqkv / wproj / dqkv and rounds nothing (parity: the reference's
+ * gradient goldens at 1e-3); FMMT_BF16 is the generic template's bf16 instantiation, which tests compare with the production kernel. */
+int fmmt_window_block_attn_bwd_ref(int dtype, int n_img, int H, int W, int C, int num_heads, int shift,
+                                   const void* xn, const void* dy, const void* attn_out, const float* lse,
+                                   const void* wqkv, const float* bqkv, const void* wproj,
+                                   const float* table, const int32_t* index, float scale, const float* rowscale,
+                                   void* dqkv, float* dtable, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Multi-head attention core of the cross-modal encoder.  Replaces multihead_attention.py:85

@@ -142,11 +142,50 @@ def test_generic_template_in_bf16_reproduces_the_production_kernel(dev, n_img, H
 
 
 @pytest.mark.parametrize("n_img,H,shift,use_rs", GENERIC_CASES)
+def test_generic_backward_template_in_bf16_reproduces_the_production_kernel(dev, n_img, H, shift, use_rs):
+    """csrc/wattn_bwd_ref.hip (the recompute backward over an element-type trait) in bf16 against the kernel behind
+    fmmt_window_block_attn_bwd on the same saved tensors: dqkv to one bf16 rounding step and almost everywhere identical (same products,
+    same rounding points; the fast kernel's transposing LDS reads and prefetch change no value), d(table) to fp32 summation order."""
+    import support_wblock_cases as W
+    from facialmmt_amd import _lib
+    from oracle import swin as OS
+    lib = _lib.load()
+    C, nh = 96, 3
+    index = OS.relative_position_index(7).to(dev).int().contiguous()
+    P = W.params(C, nh, seed=60 + n_img)
+    x2 = W.rnd("xb", (n_img * H * H, C), 61, dtype=torch.bfloat16)
+    rs = None
+    if use_rs:
+        rs = W.rnd("rs", (n_img,), 5).abs() + 0.5
+        rs[0] = 0.0
+    _, xn, o, _, _, lse = _raw_block(lib, "fmmt_window_block_fwd", torch.bfloat16, x2, P, index, n_img, H, nh, shift, rs)
+    dy = W.rnd("dyb", (n_img * H * H, C), 63, dtype=torch.bfloat16)
+    wq, bq, wp, tab = P["wqkv"].detach().bfloat16().contiguous(), P["bqkv"].detach().float().contiguous(), P["wproj"].detach().bfloat16().contiguous(), P["table"].detach().float().contiguous()
+    nbytes = lib.fmmt_window_attn_bwd_workspace(nh)
+    res = []
+    for entry in ("fmmt_window_block_attn_bwd", "fmmt_window_block_attn_bwd_ref"):
+        dqkv = torch.zeros(x2.shape[0], 3 * C, dtype=torch.bfloat16, device=dev)
+        dtab = torch.empty_like(tab)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        rc = getattr(lib, entry)(_lib.BF16, n_img, H, H, C, nh, shift, xn.data_ptr(), dy.data_ptr(), o.data_ptr(), lse.data_ptr(), wq.data_ptr(), bq.data_ptr(), wp.data_ptr(),
+                                 tab.data_ptr(), index.data_ptr(), 32 ** -0.5, rs.data_ptr() if rs is not None else None, dqkv.data_ptr(), dtab.data_ptr(),
+                                 ws.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, (entry, rc)
+        torch.cuda.synchronize()
+        res.append((dqkv.float(), dtab))
+    (d0, t0), (d1, t1) = res
+    scale = d1.abs().max().item()
+    assert (d0 - d1).abs().max().item() <= 2.0 ** -7 * scale and (d0 != d1).float().mean().item() <= 0.02
+    assert (t0 - t1).abs().max().item() <= 1e-4 * max(1e-6, t1.abs().max().item())
+
+
+@pytest.mark.parametrize("n_img,H,shift,use_rs", GENERIC_CASES)
 def test_fp32_instantiation_of_the_fused_block_against_fp64(dev, n_img, H, shift, use_rs):
     """The fp32 instantiation of the same template (fp32 fragments, 8 x v_mfma_f32_16x16x4_f32 per 32-deep block, nothing rounded to bf16):
     north_star's 1e-3 on the fused kernel's ALGORITHM -- window / shift addressing, fragment-order weights, mask derivation, base-2
     softmax normalised after the second product -- against an fp64 restatement: forward, the saved LayerNorm output, statistics and
-    log-sum-exp; and every gradient of the op (fused fp32 forward + the fp32 parity backward) against fp64 autograd."""
+    log-sum-exp; and every gradient of the op against fp64 autograd -- its backward is the fp32 instantiation of the recompute kernel
+    (csrc/wattn_bwd_ref.hip, through fmmt_window_block_attn_bwd) plus the fp32 GEMM / LayerNorm launches."""
     import support_wblock_cases as W
     from facialmmt_amd import _lib
     from oracle import swin as OS
@@ -291,6 +330,90 @@ def test_mlp_half_with_layernorm_prologue(dev, C, M, use_rs):
         g3 = torch.autograd.grad(y3, leaves, dy)
         for a, b in zip(g1, g3):
             assert torch.equal(a, b)
+
+
+def _mlp_operands(C, M, use_rs, dtype, seed):
+    import support_wblock_cases as W
+    x = W.rnd("mx", (M, C), seed, dtype=dtype)
+    P = dict(g=1.0 + 0.2 * W.rnd("g", (C,), seed + 1), b=0.1 * W.rnd("b", (C,), seed + 2), w1=W.rnd("w1", (4 * C, C), seed + 3, C ** -0.5),
+             b1=0.1 * W.rnd("b1", (4 * C,), seed + 4), w2=W.rnd("w2", (C, 4 * C), seed + 5, (4 * C) ** -0.5), b2=0.1 * W.rnd("b2", (C,), seed + 6))
+    rps, rs = 1024, None
+    if use_rs:
+        rs = W.rnd("rs", ((M + rps - 1) // rps,), 5).abs() + 0.5
+        rs[1] = 0.0
+    return x, P, rs, rps
+
+
+@pytest.mark.parametrize("C,M,use_rs", [(96, 8192 + 77, True), (192, 4096 + 130, False)])
+def test_generic_mlp_templates_in_bf16_reproduce_the_production_kernels(dev, C, M, use_rs):
+    """csrc/mlp_ref.hip (the fused Mlp forward / input-gradient kernels over an element-type trait, weights read as fragments instead of
+    through the DMA ring) in bf16 -- dtype FMMT_BF16 | FMMT_GENERIC on the same entry points -- against the kernels the benchmark runs:
+    every output to one bf16 rounding step and almost everywhere identical; the LayerNorm-backward partial sums to fp32 summation order."""
+    from facialmmt_amd import _lib
+    lib = _lib.load()
+    x, P, rs, rps = _mlp_operands(C, M, use_rs, torch.bfloat16, 70)
+    w1, w2 = P["w1"].bfloat16().contiguous(), P["w2"].bfloat16().contiguous()
+    w1t, w2t = w1.t().contiguous(), w2.t().contiguous()
+    st = lambda: torch.cuda.current_stream().cuda_stream
+    outs = []
+    for code in (_lib.BF16, _lib.BF16 | _lib.GENERIC):
+        y, xn, hp, ha = torch.empty_like(x), torch.empty_like(x), torch.empty(M, 4 * C, dtype=x.dtype, device=dev), torch.empty(M, 4 * C, dtype=x.dtype, device=dev)
+        mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
+        rc = lib.fmmt_mlp_ln_fwd(code, M, C, x.data_ptr(), P["g"].data_ptr(), P["b"].data_ptr(), 1e-5, w1.data_ptr(), P["b1"].data_ptr(), w2.data_ptr(), P["b2"].data_ptr(),
+                                 rs.data_ptr() if rs is not None else None, rps, y.data_ptr(), xn.data_ptr(), mean.data_ptr(), rstd.data_ptr(), hp.data_ptr(), ha.data_ptr(), st())
+        assert rc == 0
+        res = [("y", y), ("xn", xn), ("h_pre", hp), ("h_act", ha), ("mean", mean), ("rstd", rstd)]
+        if C == 96:                                          # the input gradient with the norm2 backward as its epilogue (C = 96 in production)
+            dy = torch.randn(M, C, device=dev, generator=torch.Generator(device=dev).manual_seed(3)).bfloat16()
+            dh, dx = torch.empty(M, 4 * C, dtype=x.dtype, device=dev), torch.empty_like(x)
+            dg, db = torch.empty(C, device=dev), torch.empty(C, device=dev)
+            nb = lib.fmmt_mlp_ln_bwd_input_workspace(C)
+            ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+            rc = lib.fmmt_mlp_ln_bwd_input(code, M, C, dy.data_ptr(), outs[0][2][1].data_ptr() if outs else hp.data_ptr(), w2t.data_ptr(), w1t.data_ptr(),
+                                           rs.data_ptr() if rs is not None else None, rps, x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), P["g"].data_ptr(),
+                                           dh.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), nb, st())
+            assert rc == 0
+            res += [("dh", dh), ("dx", dx), ("dgamma", dg), ("dbeta", db)]
+        torch.cuda.synchronize()
+        outs.append(res)
+    for (name, a), (_, b) in zip(*outs):
+        a, b = a.float(), b.float()
+        scale = max(b.abs().max().item(), 1e-6)
+        if a.dtype == torch.float32 and name in ("mean", "rstd", "dgamma", "dbeta"):
+            assert (a - b).abs().max().item() <= 2e-4 * scale, name
+        else:
+            assert (a - b).abs().max().item() <= 2.0 ** -7 * scale and (a != b).float().mean().item() <= 0.02, (name, (a - b).abs().max().item(), scale)
+
+
+@pytest.mark.parametrize("C,M,use_rs", [(96, 8192 + 77, True), (192, 4096 + 130, False), (96, 3136 * 2, False)])
+def test_fp32_instantiation_of_the_fused_mlp_against_fp64(dev, C, M, use_rs):
+    """The fp32 instantiations of the same templates (what fmmt_mlp_ln_fwd / fmmt_mlp_ln_bwd_input / fmmt_mlp_fwd / fmmt_mlp_bwd_input run for
+    dtype FMMT_F32; erf GELU, nothing rounded): the op x + s * Mlp(LayerNorm(x)) forward and every gradient against fp64 at 1e-3 or better,
+    and the op without the LayerNorm (ops.mlp) likewise."""
+    x, P, rs, rps = _mlp_operands(C, M, use_rs, torch.float32, 80)
+    x.requires_grad_(True)
+    leaves = [x] + [P[k].requires_grad_(True) for k in ("g", "b", "w1", "b1", "w2", "b2")]
+    assert ops.mlp_ln_fusable(x, P["w1"], P["w2"], P["b1"], P["b2"])
+    y = ops.mlp_ln(x, P["g"], P["b"], 1e-5, P["w1"], P["b1"], P["w2"], P["b2"], rs, rps)
+    l64 = [t.detach().double().requires_grad_(True) for t in leaves]
+    x64, g64, b64, w164, b164, w264, b264 = l64
+    s64 = rs.double().repeat_interleave(rps)[:M, None] if rs is not None else 1.0
+    r64 = x64 + s64 * (torch.nn.functional.gelu(torch.nn.functional.layer_norm(x64, (C,), g64, b64, 1e-5) @ w164.t() + b164) @ w264.t() + b264)
+    assert (y.double() - r64).abs().max().item() <= 1e-4 * max(1.0, r64.abs().max().item())
+    dy = torch.randn(M, C, device=dev, generator=torch.Generator(device=dev).manual_seed(5))
+    ga = torch.autograd.grad(y, leaves, dy)
+    gr = torch.autograd.grad(r64, l64, dy.double())
+    for i, (a, c) in enumerate(zip(ga, gr)):
+        assert _rel(a, c) <= 1e-3, i
+    # without the LayerNorm: ops.mlp (fmmt_mlp_fwd / fmmt_mlp_bwd_input in fp32)
+    res = torch.randn(M, C, device=dev, generator=torch.Generator(device=dev).manual_seed(6))
+    y2 = ops.mlp(x, P["w1"], P["b1"], P["w2"], P["b2"], res=res, rowscale=rs, rows_per_scale=rps)
+    r2 = res.double() + s64 * (torch.nn.functional.gelu(x64 @ w164.t() + b164) @ w264.t() + b264)
+    assert (y2.double() - r2).abs().max().item() <= 1e-4 * max(1.0, r2.abs().max().item())
+    g2 = torch.autograd.grad(y2, [x, P["w1"], P["b1"], P["w2"], P["b2"]], dy)
+    gr2 = torch.autograd.grad(r2, [x64, w164, b164, w264, b264], dy.double())
+    for i, (a, c) in enumerate(zip(g2, gr2)):
+        assert _rel(a, c) <= 1e-3, i
 
 
 def test_fused_mlp_input_gradient_launch(dev):
