@@ -16,6 +16,7 @@
 // accumulated in registers across windows) and once with lanes owning key columns (dK, dV); two waves share a
 // (window, head) problem, each owning half of the token tiles in both passes.  d(bias table) is reduced
 // through per-workgroup partials in a fixed order.
+#include <type_traits>
 #include "fmmt_common.h"
 #include "../../include/fmmt.h"
 #include "wattn_args.h"
@@ -23,10 +24,13 @@
 
 namespace {
 
-__device__ __forceinline__ void fill_bias_mfma(const WaArgs& p, int head, float* Bs, int nthreads = 256) {
+constexpr float WA_LOG2E = 1.4426950408889634f;
+
+// mul = log2(e) for the kernels whose softmax runs on base-2 exponentials (v_exp_f32 is base 2: one multiply per logit less)
+__device__ __forceinline__ void fill_bias_mfma(const WaArgs& p, int head, float* Bs, int nthreads = 256, float mul = 1.0f) {
     for (int t = threadIdx.x; t < 64 * BPM; t += nthreads) {
         const int q = t / BPM, k = t - q * BPM;
-        Bs[t] = (q < TOK && k < TOK) ? p.table[p.index[q * TOK + k] * p.nH + head] : NEG_BIG;
+        Bs[t] = (q < TOK && k < TOK) ? p.table[p.index[q * TOK + k] * p.nH + head] * mul : NEG_BIG;
     }
 }
 
@@ -211,7 +215,8 @@ void wattn_mfma_bwd_kernel(WaArgs p) {
     bf16* const sinkp = reinterpret_cast<bf16*>(p.sink) + threadIdx.x * 8;
     const Slot own[2] = {slot_of((2 * h) * 16 + li), slot_of((2 * h + 1) * 16 + li)};
 
-    fill_bias_mfma(p, head, Bs, NT);
+    fill_bias_mfma(p, head, Bs, NT, WA_LOG2E);              // logits in base 2: bias, scale, mask constant and log-sum-exp all carry log2(e)
+    const float sc2 = p.scale * WA_LOG2E;
     if constexpr (RC != 0) {
         // rows in FRAGMENT order: (part * 2 + nt) * 16 + i <-> Wqkv row part * C + head * 32 + (i >> 2) * 8 + nt * 4 + (i & 3);
         // 96 + nt * 16 + i <-> COLUMN head * 32 + (i >> 2) * 8 + nt * 4 + (i & 3) of Wproj (row c of Wproj -> LDS column c)
@@ -371,12 +376,17 @@ void wattn_mfma_bwd_kernel(WaArgs p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) d += (float)gf[a][e] * (float)of[e];
             dl[a] = xor_sum(d);
-            ls[a] = cur.ls[a];
+            ls[a] = cur.ls[a] * WA_LOG2E;
             const int off = slot * TP + lg * 8;
-            *reinterpret_cast<bf16x8*>(kt_ + off) = own[a].valid ? kf[a] : zero_frag();
-            *reinterpret_cast<bf16x8*>(qt_ + off) = own[a].valid ? qf[a] : zero_frag();
-            *reinterpret_cast<bf16x8*>(gt_ + off) = own[a].valid ? gf[a] : zero_frag();
-            *reinterpret_cast<bf16x8*>(vt_ + off) = own[a].valid ? vv[a] : zero_frag();
+            // pad slots (49..63) hold zeros, in the LDS tiles AND in the register copies the passes below use for the wave's own tiles
+            kf[a] = own[a].valid ? kf[a] : zero_frag();
+            qf[a] = own[a].valid ? qf[a] : zero_frag();
+            gf[a] = own[a].valid ? gf[a] : zero_frag();
+            vv[a] = own[a].valid ? vv[a] : zero_frag();
+            *reinterpret_cast<bf16x8*>(kt_ + off) = kf[a];
+            *reinterpret_cast<bf16x8*>(qt_ + off) = qf[a];
+            *reinterpret_cast<bf16x8*>(gt_ + off) = gf[a];
+            *reinterpret_cast<bf16x8*>(vt_ + off) = vv[a];
             if (lg == 0) {
                 Ls[pair][slot] = ls[a];
                 Dl[pair][slot] = dl[a];
@@ -385,42 +395,70 @@ void wattn_mfma_bwd_kernel(WaArgs p) {
         __syncthreads();
         fetch(it + 1, cur);                                // in flight under both passes; consumed at the head of the next iteration
 
+        // Both passes need the natural-layout fragments of all four token tiles of K / V (pass 1) and Q / d(out) (pass 2).  The wave's own
+        // two tiles are in its registers; only the PARTNER's two come from the pair's LDS tiles, read once per pass for both own tiles
+        // (round 3 read all four from LDS for each own tile: 34 ds_read_b128 and their waits per problem, now 8).  Register arrays
+        // want compile-time indices, so the tiles are walked in the order own, own, partner, partner (t' = 0..3 <-> tile
+        // t' < 2 ? 2h + t' : 2(1 - h) + t' - 2): the contraction order of a 64-key (64-query) sum is free, and everything that depends
+        // on the actual tile index -- bias / statistics addresses, mask-bit shifts, the transposed fragments' row blocks, where d(bias)
+        // goes at the end -- is an LDS address or a shift amount, which may be run-time values.  (RC != 0, the recompute variant: its
+        // prefetch already holds 58 registers in flight and the 24 more this takes spill; it keeps reading all four tiles from LDS.)
+        // OWNREG: the own-first walk with the own tiles from registers; HOIST: the partner's fragments read once per pass and kept for both own
+        // tiles (16 registers more: the recompute variant at C = 96 has no room for them and re-reads them per own tile -- 34 -> 16 reads)
+        constexpr bool OWNREG = (RC == 0 || RC == 96) && MM != 2;   // (MM == 2, an arbitrary mask tensor: test-only path, already over the register budget)
+        constexpr bool HOIST = OWNREG && RC == 0;
+        const int tile_of[4] = {2 * h, 2 * h + 1, 2 * (1 - h), 2 * (1 - h) + 1};
         // ------------------------------------------------ pass 1: own QUERY tiles -> dQ, d bias
         {
+            bf16x8 pk[2], pv[2];
+            if constexpr (HOIST) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    pk[j] = ld_frag(kt_ + (tile_of[2 + j] * 16 + li) * TP + lg * 8);
+                    pv[j] = ld_frag(vt_ + (tile_of[2 + j] * 16 + li) * TP + lg * 8);
+                }
+            }
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 const int qt = 2 * h + a;
                 const int q = qt * 16 + li;
-                float ds[16];
+                float ds[8];
+                bf16x8 dpk[2];
                 const unsigned mb = (MM == 1) ? std_mask_bits(G, P, qt) : 0u;
 #pragma unroll
-                for (int kt = 0; kt < 4; ++kt) {
-                    const bf16x8 kfk = ld_frag(kt_ + (kt * 16 + li) * TP + lg * 8);
+                for (int ktp = 0; ktp < 4; ++ktp) {
+                    const int kt = OWNREG ? tile_of[ktp] : ktp;              // actual key tile (run time where tiles are walked own-first)
+                    const bf16x8 kfk = OWNREG && ktp < 2 ? kf[ktp & 1] : HOIST ? pk[ktp & 1] : ld_frag(kt_ + (kt * 16 + li) * TP + lg * 8);
                     const f32x4 sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfk, qf[a], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                    const bf16x8 vfk = ld_frag(vt_ + (kt * 16 + li) * TP + lg * 8);
+                    const bf16x8 vfk = OWNREG && ktp < 2 ? vv[ktp & 1] : HOIST ? pv[ktp & 1] : ld_frag(vt_ + (kt * 16 + li) * TP + lg * 8);
                     const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfk, gf[a], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                     const f32x4 b = *reinterpret_cast<const f32x4*>(&Bs[q * BPM + kt * 16 + lg * 4]);
+                    const unsigned mbk = mb >> (kt * 4);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float s = sa[r] * p.scale + b[r];
-                        if constexpr (MM == 1) s += ((mb >> (kt * 4 + r)) & 1u) ? -100.0f : 0.0f;
+                        float s = sa[r] * sc2 + b[r];
                         if constexpr (MM == 2) {
                             const int key = kt * 16 + lg * 4 + r;
-                            s += mbase[(q < TOK ? q : TOK - 1) * TOK + (key < TOK ? key : TOK - 1)];
+                            s += mbase[(q < TOK ? q : TOK - 1) * TOK + (key < TOK ? key : TOK - 1)] * WA_LOG2E;
                         }
-                        const float pij = __expf(s - ls[a]);
+                        float pij = __builtin_amdgcn_exp2f(s - ls[a]);
+                        // SW-MSA mask (Swin_Transformer.py:222 adds -100 to the logit): exp(s - 100 - lse) < 4e-44 x P is zero in every bf16 operand it
+                        // reaches, so the probability is zeroed instead -- a select BEHIND the exponential, which the scheduler cannot hoist
+                        // (the added form let it form all 16 addends of a tile early: 25 more live registers)
+                        if constexpr (MM == 1) pij = ((mbk >> r) & 1u) ? 0.0f : pij;
                         const float d = pij * (dp[r] - dl[a]);
-                        ds[kt * 4 + r] = d;
-                        if (wactive) dbias[a][kt][r] += d;
+                        ds[(ktp & 1) * 4 + r] = d;
+                        if (wactive) dbias[a][ktp][r] += d;                   // OWNREG: indexed by walk position, un-permuted at the end
                     }
+                    if (ktp & 1) dpk[ktp >> 1] = pack8(&ds[0], &ds[4]);      // packed as soon as a k-slot block is complete (registers)
                 }
-                const bf16x8 d0 = pack8(&ds[0], &ds[4]), d1 = pack8(&ds[8], &ds[12]);
+                const bf16x8 d0 = dpk[0], d1 = dpk[1];
                 __builtin_amdgcn_sched_barrier(0);
                 bf16x8 kT[2][2];
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
+                for (int ks = 0; ks < 2; ++ks)                      // k-slot block ks of d0 / d1 = walk positions 2 ks, 2 ks + 1 = row block tile_of[2 ks] / 2
 #pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) kT[ks][dt] = tr_fragT(kt_, 32 * ks + 4 * lg, dt, li);
+                    for (int dt = 0; dt < 2; ++dt) kT[ks][dt] = tr_fragT(kt_, 32 * (OWNREG ? tile_of[2 * ks] >> 1 : ks) + 4 * lg, dt, li);
                 f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
                 a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT[0][0], d0, a0, 0, 0, 0);
                 a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT[1][0], d1, a0, 0, 0, 0);
@@ -438,34 +476,48 @@ void wattn_mfma_bwd_kernel(WaArgs p) {
 
         // ------------------------------------------------ pass 2: own KEY tiles -> dK, dV
         {
+            bf16x8 pq[2], pg[2];
+            if constexpr (HOIST) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    pq[j] = ld_frag(qt_ + (tile_of[2 + j] * 16 + li) * TP + lg * 8);
+                    pg[j] = ld_frag(gt_ + (tile_of[2 + j] * 16 + li) * TP + lg * 8);
+                }
+            }
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 const int kt = 2 * h + a;
                 const int key = kt * 16 + li;
-                const bf16x8 vfk = ld_frag(vt_ + (kt * 16 + li) * TP + lg * 8);
-                float pp[16], ds[16];
+                const bf16x8 vfk = OWNREG ? vv[a] : ld_frag(vt_ + (kt * 16 + li) * TP + lg * 8);
+                float pp[8], ds[8];
+                bf16x8 ppk[2], dpk[2];
                 const unsigned mb = (MM == 1) ? std_mask_bits(G, P, kt) : 0u;
 #pragma unroll
-                for (int qt = 0; qt < 4; ++qt) {
-                    const bf16x8 qfq = ld_frag(qt_ + (qt * 16 + li) * TP + lg * 8);
-                    const bf16x8 gfq = ld_frag(gt_ + (qt * 16 + li) * TP + lg * 8);
+                for (int qtp = 0; qtp < 4; ++qtp) {
+                    const int qt = OWNREG ? tile_of[qtp] : qtp;
+                    const bf16x8 qfq = OWNREG && qtp < 2 ? qf[qtp & 1] : HOIST ? pq[qtp & 1] : ld_frag(qt_ + (qt * 16 + li) * TP + lg * 8);
+                    const bf16x8 gfq = OWNREG && qtp < 2 ? gf[qtp & 1] : HOIST ? pg[qtp & 1] : ld_frag(gt_ + (qt * 16 + li) * TP + lg * 8);
                     const f32x4 sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfq, kf[a], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                     const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gfq, vfk, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                     const f32x4 lq = *reinterpret_cast<const f32x4*>(&Ls[pair][qt * 16 + lg * 4]);
                     const f32x4 dq = *reinterpret_cast<const f32x4*>(&Dl[pair][qt * 16 + lg * 4]);
+                    const unsigned mbq = mb >> (qt * 4);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int q = qt * 16 + lg * 4 + r;
-                        float s = sa[r] * p.scale + Bs[q * BPM + key];
-                        if constexpr (MM == 1) s += ((mb >> (qt * 4 + r)) & 1u) ? -100.0f : 0.0f;
-                        if constexpr (MM == 2) s += mbase[(q < TOK ? q : TOK - 1) * TOK + (key < TOK ? key : TOK - 1)];
-                        const float pij = __expf(s - lq[r]);
-                        pp[qt * 4 + r] = pij;
-                        ds[qt * 4 + r] = pij * (dp[r] - dq[r]);
+                        float s = sa[r] * sc2 + Bs[q * BPM + key];
+                        if constexpr (MM == 2) s += mbase[(q < TOK ? q : TOK - 1) * TOK + (key < TOK ? key : TOK - 1)] * WA_LOG2E;
+                        float pij = __builtin_amdgcn_exp2f(s - lq[r]);
+                        if constexpr (MM == 1) pij = ((mbq >> r) & 1u) ? 0.0f : pij;
+                        pp[(qtp & 1) * 4 + r] = pij;
+                        ds[(qtp & 1) * 4 + r] = pij * (dp[r] - dq[r]);
+                    }
+                    if (qtp & 1) {
+                        ppk[qtp >> 1] = pack8(&pp[0], &pp[4]);
+                        dpk[qtp >> 1] = pack8(&ds[0], &ds[4]);
                     }
                 }
-                const bf16x8 p0 = pack8(&pp[0], &pp[4]), p1 = pack8(&pp[8], &pp[12]);
-                const bf16x8 d0 = pack8(&ds[0], &ds[4]), d1 = pack8(&ds[8], &ds[12]);
+                const bf16x8 p0 = ppk[0], p1 = ppk[1], d0 = dpk[0], d1 = dpk[1];
                 // transposed fragments read per key tile, behind the logits (32 registers that need not be live under them)
                 __builtin_amdgcn_sched_barrier(0);
                 bf16x8 gT[2][2], qT[2][2];
@@ -473,8 +525,9 @@ void wattn_mfma_bwd_kernel(WaArgs p) {
                 for (int qs = 0; qs < 2; ++qs)
 #pragma unroll
                     for (int dt = 0; dt < 2; ++dt) {
-                        gT[qs][dt] = tr_fragT(gt_, 32 * qs + 4 * lg, dt, li);
-                        qT[qs][dt] = tr_fragT(qt_, 32 * qs + 4 * lg, dt, li);
+                        const int rb = OWNREG ? tile_of[2 * qs] >> 1 : qs;     // row block of k-slot block qs (see pass 1)
+                        gT[qs][dt] = tr_fragT(gt_, 32 * rb + 4 * lg, dt, li);
+                        qT[qs][dt] = tr_fragT(qt_, 32 * rb + 4 * lg, dt, li);
                     }
                 f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f}, k0 = {0.f, 0.f, 0.f, 0.f}, k1 = {0.f, 0.f, 0.f, 0.f};
                 v0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gT[0][0], p0, v0, 0, 0, 0);
@@ -512,12 +565,13 @@ void wattn_mfma_bwd_kernel(WaArgs p) {
                 const int q = (2 * h + a) * 16 + li;
                 if (q >= TOK) continue;
 #pragma unroll
-                for (int kt = 0; kt < 4; ++kt)
+                for (int ktp = 0; ktp < 4; ++ktp)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
+                        const int kt = ((RC == 0 || RC == 96) && MM != 2) ? (ktp < 2 ? 2 * h + ktp : 2 * (1 - h) + ktp - 2) : ktp;     // walk position -> key tile (pass 1)
                         const int key = kt * 16 + lg * 4 + r;
                         if (key < TOK) {
-                            const float v = dbias[a][kt][r];
+                            const float v = dbias[a][ktp][r];
                             acc[q * TOK + key] = (w < 2) ? v : acc[q * TOK + key] + v;
                         }
                     }

@@ -18,3 +18,9 @@ def pytest_configure(config):
 def golden():
     from tests.golden_util import Golden
     return Golden()
+
+
+# development hook: run the suite against another build of the library (same-call A/B of a tagged build, facialmmt_amd/build.py)
+if os.environ.get("PROBE_LIB"):
+    from facialmmt_amd import _lib as _fmmt_lib
+    _fmmt_lib.LIB_PATH = os.environ["PROBE_LIB"]
