@@ -11,7 +11,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include "gelu_lut_data.h"
+#include "gelu_poly_data.h"
 
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -101,100 +101,82 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     return cdf + x * pdf;
 }
 
-// Throughput (bf16) mode: the same erf GELU evaluated two elements at a time with packed fp32 math.
-//   erfc(|u|) = t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-u^2),  t = 1 / (1 + 0.3275911 |u|)   (Abramowitz-Stegun
-//   7.1.26, |error| <= 1.5e-7), u = x / sqrt(2);  Phi(x) = 1 - erfc/2 for x >= 0 and erfc/2 for x < 0 (no
-//   cancellation in the negative tail).  exp(-u^2) = exp(-x^2/2) is also the Gaussian of GELU', so the
-//   derivative costs one extra FMA.  |gelu error| <= 5e-7 absolute and <= 2e-3 relative in the far negative tail
-//   -- both below bf16 rounding of the stored result; the fp32 (parity) kernels keep erff.
-// The libm erff used above costs ~32 VALU instructions per element and made the fc1 / fc2-dgrad epilogues
-// VALU-bound (64 outputs per lane per tile against 48..96 MFMAs); this form is ~8 issue slots per element.
+// Throughput (bf16) mode: Phi(x) and gelu'(x) = Phi(x) + x phi(x) as ODD POLYNOMIALS around 1/2, two elements at a time in packed
+// fp32 math and nothing but FMAs:
+//     xc = clamp(x, -R, R);  u = 2 (xc / R)^2 - 1;  f(x) ~ 1/2 + xc * P(u)          (gelu_poly_data.h, tools/gen_gelu_poly.py)
+// Phi: R = 4, 8 terms, |error| <= 4.9e-5; gelu': R = 4.5, 10 terms, <= 6.4e-5 (measured with this fp32 Horner form over [-10, 10]) --
+// 1/40 of the bf16 rounding of what is stored; the fp32 (parity) kernels keep erff.  Per PAIR of elements: 2 v_med3 + 1 v_pk_mul
+// + 9 / 11 v_pk_fma (+ the product with x or dy) = 6.5 / 7.5 issue slots per element, no transcendental, no LDS, no wait.
+// History.  Round 1: libm erff, ~32 VALU instructions per element.  Round 2: Abramowitz-Stegun 7.1.26 with v_rcp + v_exp (quarter rate),
+// ~20 issue slots per element: 57 % of the fused Mlp's cycles.  Round 3: a (value, slope) table in LDS, 6 VALU + 1 ds_read_b64 per element --
+// fewer instructions, but each lookup is a dependent LDS round trip and the compiler waits for them four at a time (eight exposed LDS
+// latencies per 32-element stage; the fused Mlp forward's waves spent 45 % of their cycles parked on s_waitcnt, 31 % issue-stalled:
+// profiles/r03_pmc_mlp_fused_fwd_sq1.md) plus three register moves per pair to un-interleave the pairs for the packed FMA.
 typedef __attribute__((ext_vector_type(2))) float f32x2;
-__device__ __forceinline__ void gelu_parts2(f32x2 x, f32x2& cdf, f32x2& gauss) {
-    const f32x2 u = x * 0.70710678118654752f;
-    const f32x2 au = {__builtin_fabsf(u.x), __builtin_fabsf(u.y)};
-    const f32x2 d = au * 0.3275911f + 1.0f;
-    const f32x2 t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
-    const f32x2 e2 = u * u * -1.4426950408889634f;
-    gauss = f32x2{__builtin_amdgcn_exp2f(e2.x), __builtin_amdgcn_exp2f(e2.y)};
-    f32x2 q = t * 1.061405429f + -1.453152027f;
-    q = q * t + 1.421413741f;
-    q = q * t + -0.284496736f;
-    q = q * t + 0.254829592f;
-    const f32x2 h = q * t * gauss * 0.5f;              // erfc(|u|) / 2
-    cdf = f32x2{u.x >= 0.f ? 1.0f - h.x : h.x, u.y >= 0.f ? 1.0f - h.y : h.y};
+// NP pairs in lockstep: consecutive instructions belong to different pairs, so no packed FMA consumes its predecessor's result (a
+// dependent v_pk_fma_f32 pair costs the compiler an s_nop between them, and a lone Horner chain exposes the VALU latency)
+template <int N, int NP>
+__device__ __forceinline__ void fmmt_odd_poly2(const float (&c)[N], float R, const f32x2 (&x)[NP], f32x2 (&out)[NP]) {
+    f32x2 xc[NP], u[NP], q[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) xc[j] = f32x2{__builtin_amdgcn_fmed3f(x[j].x, -R, R), __builtin_amdgcn_fmed3f(x[j].y, -R, R)};
+#pragma unroll
+    for (int j = 0; j < NP; ++j) u[j] = xc[j] * xc[j] * (2.0f / (R * R)) - 1.0f;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) q[j] = u[j] * c[N - 1] + c[N - 2];
+#pragma unroll
+    for (int k = N - 3; k >= 0; --k)
+#pragma unroll
+        for (int j = 0; j < NP; ++j) q[j] = q[j] * u[j] + c[k];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) out[j] = q[j] * xc[j] + 0.5f;
 }
-__device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
-    f32x2 cdf, g;
-    gelu_parts2(x, cdf, g);
-    return x * cdf;
+// v[e] <- gelu(v[e]) / v[e] <- v[e] * gelu'(pre[e]), n = 2 NP elements
+template <int NP> __device__ __forceinline__ void gelu_poly_inplace(float* v) {
+    f32x2 x[NP], ph[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) x[j] = f32x2{v[2 * j], v[2 * j + 1]};
+    fmmt_odd_poly2(fmmt_gelu_phi_poly, FMMT_GELU_PHI_R, x, ph);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const f32x2 y = x[j] * ph[j];
+        v[2 * j] = y.x;
+        v[2 * j + 1] = y.y;
+    }
 }
-__device__ __forceinline__ f32x2 gelu_grad_fast2(f32x2 x) {
-    f32x2 cdf, g;
-    gelu_parts2(x, cdf, g);
-    return x * g * 0.3989422804014327f + cdf;
+template <int NP> __device__ __forceinline__ void gelu_grad_poly_mul_inplace(float* v, const float* pre) {
+    f32x2 x[NP], g[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) x[j] = f32x2{pre[2 * j], pre[2 * j + 1]};
+    fmmt_odd_poly2(fmmt_gelu_grad_poly, FMMT_GELU_GRAD_R, x, g);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        v[2 * j] *= g[j].x;
+        v[2 * j + 1] *= g[j].y;
+    }
 }
-// Table form for the bf16 kernels whose epilogue is VALU-bound (fused Mlp: 32 activations per lane and 64-channel stage against 36 MFMAs;
-// GELU / GELU' epilogues of the GEMMs): the polynomial above is ~20 issue slots per element with its two quarter-rate transcendentals
-// (57 % of the fused Mlp's cycles).  Phi(x) -- or gelu'(x) = Phi(x) + x phi(x) -- tabulated on [-8, 8) in steps of 1/64 as
-// (value, difference to the next entry) pairs (gelu_lut_data.h, generated in double precision by tools/gen_gelu_lut.py), copied into
-// LDS (8 KB) by the kernel, linear interpolation: fma, med3, cvt, fract, address, ds_read_b64, fma = 6 VALU + 1 LDS read.
-// Interpolation error h^2/8 |f''|: <= 8e-6 absolute for Phi (relative <= 2e-3 out to x = -8: the curvature decays with the function),
-// <= 3e-5 for gelu' -- below the bf16 rounding of what is stored.  The fp32 (parity) kernels keep erff.
-constexpr int GELU_LUT_N = 1024;
-constexpr int GELU_LUT_BYTES = GELU_LUT_N * 8;
-typedef __attribute__((ext_vector_type(2))) float lut2_t;
-// copy a table into LDS: 512 chunks of 16 bytes; the caller makes it visible (barrier) before the first gelu_lut()
-__device__ __forceinline__ void gelu_lut_copy(lut2_t* tab, const float* src, int tid, int nthreads) {
-    for (int i = tid; i < GELU_LUT_BYTES / 16; i += nthreads)
-        reinterpret_cast<f32x4*>(tab)[i] = reinterpret_cast<const f32x4*>(src)[i];
-}
-__device__ __forceinline__ float gelu_lut(const lut2_t* tab, float x) {
-    float t = __builtin_fmaf(x, 64.0f, (float)(GELU_LUT_N / 2));
-    t = __builtin_amdgcn_fmed3f(t, 0.0f, (float)GELU_LUT_N - 0.001f);
-    const lut2_t e = tab[(int)t];
-    return __builtin_fmaf(__builtin_amdgcn_fractf(t), e.y, e.x);
-}
-// v[e] <- gelu(v[e]) / v[e] <- v[e] * gelu'(pre[e]) through a table in LDS (nullptr: the polynomial)
-template <typename T> __device__ __forceinline__ void gelu_inplace_lut(const lut2_t* tab, float* v, int n);
-template <typename T> __device__ __forceinline__ void gelu_grad_mul_inplace_lut(const lut2_t* tab, float* v, const float* pre, int n);
 
-// element-type dispatch used by the GEMM epilogue: exact for float, packed-fast for bf16
-template <typename T> __device__ __forceinline__ void gelu_inplace(float* v, int n) {
+// element-type dispatch used by the GEMM epilogues: exact for float, packed polynomial for bf16 (n = 4 or a multiple of 8)
+// IL = pairs evaluated in lockstep (4; 2 where the registers are short)
+template <typename T, int IL = 4> __device__ __forceinline__ void gelu_inplace(float* v, int n) {
     if constexpr (sizeof(T) == 4) {
 #pragma unroll
         for (int e = 0; e < n; ++e) v[e] = gelu_f(v[e]);
     } else {
+        if (n == 4) return gelu_poly_inplace<2>(v);
 #pragma unroll
-        for (int e = 0; e < n; e += 2) {
-            const f32x2 r = gelu_fast2(f32x2{v[e], v[e + 1]});
-            v[e] = r.x;
-            v[e + 1] = r.y;
-        }
+        for (int e = 0; e < n; e += 2 * IL) gelu_poly_inplace<IL>(v + e);
     }
 }
-template <typename T> __device__ __forceinline__ void gelu_grad_mul_inplace(float* v, const float* pre, int n) {
+template <typename T, int IL = 4> __device__ __forceinline__ void gelu_grad_mul_inplace(float* v, const float* pre, int n) {
     if constexpr (sizeof(T) == 4) {
 #pragma unroll
         for (int e = 0; e < n; ++e) v[e] *= gelu_grad_f(pre[e]);
     } else {
+        if (n == 4) return gelu_grad_poly_mul_inplace<2>(v, pre);
 #pragma unroll
-        for (int e = 0; e < n; e += 2) {
-            const f32x2 r = gelu_grad_fast2(f32x2{pre[e], pre[e + 1]});
-            v[e] *= r.x;
-            v[e + 1] *= r.y;
-        }
+        for (int e = 0; e < n; e += 2 * IL) gelu_grad_poly_mul_inplace<IL>(v + e, pre + e);
     }
-}
-template <typename T> __device__ __forceinline__ void gelu_inplace_lut(const lut2_t* tab, float* v, int n) {
-    if (sizeof(T) == 4 || !tab) return gelu_inplace<T>(v, n);
-#pragma unroll
-    for (int e = 0; e < n; ++e) v[e] *= gelu_lut(tab, v[e]);
-}
-template <typename T> __device__ __forceinline__ void gelu_grad_mul_inplace_lut(const lut2_t* tab, float* v, const float* pre, int n) {
-    if (sizeof(T) == 4 || !tab) return gelu_grad_mul_inplace<T>(v, pre, n);
-#pragma unroll
-    for (int e = 0; e < n; ++e) v[e] *= gelu_lut(tab, pre[e]);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -693,18 +693,6 @@ __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
         issue_bias(ipar);
         issue_advance();
     };
-    // GELU epilogue of the 256-wide tile (fc1 forward of stages 2 / 3): Phi table in LDS behind the wave slabs (fmmt_common.h), copied
-    // before the first DMA goes out (the copy's own loads are ordinary ones: waited for with vmcnt(0)); the first K step's barrier
-    // publishes it
-    const lut2_t* lut = nullptr;
-    if constexpr (BN == 256 && !HASOP) {
-        if (p.epi == FMMT_EPI_GELU) {
-            lut2_t* l = reinterpret_cast<lut2_t*>(smem + (size_t)NBUF * STAGE * sizeof(T) + 2 * 256 * sizeof(float) + 8 * (16 * 144));
-            gelu_lut_copy(l, fmmt_gelu_lut_phi, tid, 512);
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            lut = l;
-        }
-    }
 #pragma unroll
     for (int s = 0; s < NBUF - 1; ++s)
         if (s < nsteps) issue_next();
@@ -870,7 +858,7 @@ __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
                             float t[8];
 #pragma unroll
                             for (int e = 0; e < 8; ++e) t[e] = acc[a][2 * c + (e >> 2)][e & 3];
-                            if (gelu) gelu_inplace_lut<T>(lut, t, 8);
+                            if (gelu) gelu_inplace<T>(t, 8);
                             bf16x8 v;
 #pragma unroll
                             for (int e = 0; e < 8; ++e) v[e] = (bf16)t[e];
@@ -962,7 +950,7 @@ __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
 
 template <int BN, int BK, int NBUF, bool BATCH, bool HASOP, bool PIPE = false>
 int launch_p256_b(const LinArgs& a, hipStream_t st) {
-    constexpr size_t lds = (size_t)NBUF * (BN + 256) * BK * 2 + 2 * 256 * sizeof(float) + (BN == 256 ? 8 * 16 * 144 + GELU_LUT_BYTES : 2 * (BN == 192 ? 32 : 16) * (BN * 2 + 16));   // ring, bias slabs, epilogue scratch (BN = 256: wave-private slabs + the GELU table)
+    constexpr size_t lds = (size_t)NBUF * (BN + 256) * BK * 2 + 2 * 256 * sizeof(float) + (BN == 256 ? 8 * 16 * 144 : 2 * (BN == 192 ? 32 : 16) * (BN * 2 + 16));   // ring, bias slabs, epilogue scratch (BN = 256: wave-private slabs)
     static_assert(lds <= 160 * 1024, "LDS");
     static FmmtLdsOnce lds_once;
     if (int rc_ = lds_once.set(reinterpret_cast<const void*>(&linear_nt_p256_kernel<BN, BK, NBUF, BATCH, HASOP, PIPE>), (int)lds)) return rc_;

@@ -31,7 +31,9 @@ namespace {
 
 // (Two workgroups per CU at C = 96 -- 76.8 KB of LDS each, registers forced to 128 -- were measured: the inference form gains
 //  13 %, the training forms, whose time goes into the hidden-tensor stores, lose 0-19 % to the 20 spilled registers.)
-template <int C, bool LN>
+// FULL: M is a multiple of the 256-token tile -- no token guard anywhere, the stage body is branch-free (the stores of a ragged tail
+// are conditional: branches, which end the compiler's scheduling regions inside the stage)
+template <int C, bool LN, bool FULL>
 __global__ __launch_bounds__(512) void mlp_fused_fwd_kernel(MlpArgs p) {
     using T = bf16;
     constexpr int H = 4 * C, HS = 64, NS = H / HS;          // hidden channels per ring stage, stages per tile
@@ -50,33 +52,47 @@ __global__ __launch_bounds__(512) void mlp_fused_fwd_kernel(MlpArgs p) {
     const int li = lane & 15, lg = lane >> 4;
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
-    lut2_t* lut = reinterpret_cast<lut2_t*>(smem + NBUF * STAGE_B);          // Phi(x) table (fmmt_common.h), behind the ring
-    gelu_lut_copy(lut, fmmt_gelu_lut_phi, tid, 512);
-    __syncthreads();
     auto swz = [](int row) { return ((row >> 3) ^ (row >> 2)) & 3; };       // 16-byte chunk swizzle of 64-byte rows (as linear_nt_deep32)
     const int r16 = lane >> 2, c4 = lane & 3;
 
+    // A DMA piece's global address = (uniform: matrix base + the stage's first hidden channel) + (this lane's 32-bit byte offset inside
+    // the stage, fixed for the kernel): the SGPR-base form of the instruction, one VGPR per piece (as 64-bit pointers formed per stage
+    // the pieces cost ~10 VALU instructions each, or -- hoisted by the compiler -- two registers each, which at C = 192 spilled)
+    unsigned loff[CNT];
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) {
+        const int j = i * 8 + wave;                          // wave-uniform
+        if (j < KS * 4) {                                    // W1: K slice ks, hidden rows r0 .. r0 + 15 of the stage
+            const int ks = j >> 2, r = (j & 3) * 16 + r16;
+            loff[i] = (unsigned)(r * C + ks * 32 + ((c4 ^ swz(r)) << 3)) * 2u;
+        } else {                                             // W2: hidden block b, output-channel rows r0 .. r0 + 15
+            const int q = j - KS * 4, b = q / (C / 16), r = (q % (C / 16)) * 16 + r16;
+            loff[i] = (unsigned)(r * H + b * 32 + ((c4 ^ swz(r)) << 3)) * 2u;
+        }
+    }
     auto issue = [&](int slot, int hs) {
         char* base = smem + slot * STAGE_B;
+        const char* u1 = reinterpret_cast<const char*>(p.w1 + (size_t)hs * HS * C);
+        const char* u2 = reinterpret_cast<const char*>(p.w2 + (size_t)hs * HS);
 #pragma unroll
         for (int i = 0; i < CNT; ++i) {
-            const int j = i * 8 + wave;                      // wave-uniform
-            const T* src;
+            const int j = i * 8 + wave;
             T* dst;
-            if (j < KS * 4) {                                // W1: K slice ks, hidden rows r0 .. r0 + 15 of the stage
-                const int ks = j >> 2, r0 = (j & 3) * 16, r = r0 + r16;
-                src = p.w1 + (size_t)(hs * HS + r) * C + ks * 32 + ((c4 ^ swz(r)) << 3);
+            if (j < KS * 4) {
+                const int ks = j >> 2, r0 = (j & 3) * 16;
                 dst = reinterpret_cast<T*>(base) + ks * (HS * 32) + r0 * 32;
-            } else {                                         // W2: hidden block b, output-channel rows r0 .. r0 + 15
-                const int q = j - KS * 4, b = q / (C / 16), r0 = (q % (C / 16)) * 16, r = r0 + r16;
-                src = p.w2 + (size_t)r * H + hs * HS + b * 32 + ((c4 ^ swz(r)) << 3);
+            } else {
+                const int q = j - KS * 4, b = q / (C / 16), r0 = (q % (C / 16)) * 16;
                 dst = reinterpret_cast<T*>(base) + W1_EL + b * (C * 32) + r0 * 32;
             }
-            __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)dst, 16, 0, 0);
+            unsigned lo = loff[i];
+            asm volatile("" : "+v"(lo));                     // keep the offset a 32-bit register (hoisted as a zero-extended pair otherwise)
+            __builtin_amdgcn_global_load_lds((gptr_t*)((j < KS * 4 ? u1 : u2) + (size_t)lo), (lptr_t*)dst, 16, 0, 0);
         }
         if (wave == 7) {                                     // 64 bias values (lanes 16.. re-read the last 16 bytes into the slot's unused tail)
-            const float* bsrc = p.b1 + hs * HS + min(lane, 15) * 4;
-            __builtin_amdgcn_global_load_lds((gptr_t*)bsrc, (lptr_t*)(base + (W1_EL + W2_EL) * 2), 16, 0, 0);
+            unsigned bo = (unsigned)min(lane, 15) * 16u;
+            asm volatile("" : "+v"(bo));
+            __builtin_amdgcn_global_load_lds((gptr_t*)(reinterpret_cast<const char*>(p.b1 + hs * HS) + (size_t)bo), (lptr_t*)(base + (W1_EL + W2_EL) * 2), 16, 0, 0);
         }
     };
     // Stage s has landed when all but the youngest N of this wave's memory operations are complete, N = what was issued after
@@ -125,6 +141,13 @@ __global__ __launch_bounds__(512) void mlp_fused_fwd_kernel(MlpArgs p) {
         if (s < nsteps) issue_next();
 
     bf16x8 xf[2][KS];
+    // LN, C = 96: the residual of the tile's epilogue is x itself, and an accumulator element of product 2 (token li; channel
+    // (nt / 2) * 32 + lg * 8 + (nt % 2) * 4 + r) is the element (nt % 2) * 4 + r of THIS lane's x fragment nt / 2 -- the raw fragments are
+    // kept (24 registers) and handed to nt_epilogue as its prefetched operand: no second read of x (385 MB per stage-0 launch), no load --
+    // and so no memory round trip -- between the tile's last MFMA and its stores.  The rows' DropPath scales travel with the x loads.
+    constexpr bool KEEPX = LN && C == 96;
+    EpiPre<2, NT2> pre;
+    float rsn[2] = {1.f, 1.f};
     auto load_x = [&](int tile) {
         const int t0 = tile * 256 + wave * 32;
 #pragma unroll
@@ -132,6 +155,7 @@ __global__ __launch_bounds__(512) void mlp_fused_fwd_kernel(MlpArgs p) {
             const int tok = min(t0 + mt * 16 + li, p.M - 1);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) xf[mt][ks] = *reinterpret_cast<const bf16x8*>(p.x + (size_t)tok * C + ks * 32 + lg * 8);
+            if constexpr (KEEPX) rsn[mt] = row_scale(p.rowscale, tok, p.rows_per_scale);
         }
     };
     f32x4 acc2[2][NT2];
@@ -145,7 +169,7 @@ __global__ __launch_bounds__(512) void mlp_fused_fwd_kernel(MlpArgs p) {
     for (int s = 0; s < nsteps; ++s) {
         // hs > 0: the previous step belonged to this tile and stored its four pre-activation vectors (a tile's first step
         // follows the previous tile's epilogue instead: more, not fewer, younger operations -- the plain count stays safe)
-        const bool full = hs > 0 && tile * 256 + wave * 32 + 32 <= p.M;
+        const bool full = hs > 0 && (FULL || tile * 256 + wave * 32 + 32 <= p.M);
         wait_landed(s + 1 < nsteps, full ? 4 * (int)(p.h_pre != nullptr) + 4 * (int)(p.h_act != nullptr) : 0);
         __builtin_amdgcn_s_barrier();                        // stage s is in LDS for every wave; the stage read in step s - 1 is free
         if (s + NBUF - 1 < nsteps) issue_next();
@@ -160,6 +184,11 @@ __global__ __launch_bounds__(512) void mlp_fused_fwd_kernel(MlpArgs p) {
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
                     const int tok = t0 + mt * 16 + li;
+                    if constexpr (KEEPX) {
+                        pre.rs[mt] = rsn[mt];
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks) pre.full[mt][ks] = xf[mt][ks];
+                    }
                     float v[KS * 8];
                     float sum = 0.f;
 #pragma unroll
@@ -188,15 +217,143 @@ __global__ __launch_bounds__(512) void mlp_fused_fwd_kernel(MlpArgs p) {
                             o[4 + e] = (bf16)(v[ks * 8 + 4 + e] * rstd * g1[e] + b1[e]);
                         }
                         xf[mt][ks] = o;
-                        if (p.xn && tok < p.M) *reinterpret_cast<bf16x8*>(p.xn + (size_t)tok * C + ks * 32 + lg * 8) = o;
+                        if (p.xn && (FULL || tok < p.M)) *reinterpret_cast<bf16x8*>(p.xn + (size_t)tok * C + ks * 32 + lg * 8) = o;
                     }
-                    if (p.mean && tok < p.M && lg == 0) {
+                    if (p.mean && (FULL || tok < p.M) && lg == 0) {
                         p.mean[tok] = mean;
                         p.rstd[tok] = rstd;
                     }
                 }
             }
         }
+        if constexpr (C == 96) {
+        // ---- C = 96: the stage as ONE software pipeline over its two 32-channel hidden blocks:
+        //     RB R1(0) R2(0) | P1(0) | R1(1) | P1(1) + E(0) | P2(0) + E(1) | R2(1) | stores | P2(1)
+        // (R = fragment reads, issued by hand a whole block at a time and one phase ahead of their use; P1 / P2 = the products' 12 MFMAs
+        // each; E = bias + GELU + conversions): three lgkmcnt waits per stage -- behind the barrier, behind P1(0)'s MFMAs, behind the
+        // stores -- instead of the ~13 the compiler places in front of groups of 2-4 MFMAs in the straightforward order (the C = 192 body
+        // below).  The W1 / W2 fragment registers are reused by the second block's reads (issued after the MFMAs that consume the first
+        // block's have been issued; the data comes back >= 64 cycles later).  Offsets inside a stage are immediates of the reads.
+        // What it bought, and why not more (round 4; all same-call): inference form 0.831 -> 0.810 ms, training form 1.043 -> 1.025.  The
+        // ablations -- GELU removed 0.60 ms, GELU and product 2 removed 0.49, DMA + barrier removed 0.73, residual / next-x loads of the
+        // tile end removed 0.64 -- and the issue-rate probe (tools/probes/valu_rate.hip, profiles/r04_issue_rates.txt) say the stage is
+        // ISSUE-bound, not latency-bound: on gfx950 a SIMD's two waves do not overlap VALU with MFMA issue -- 8 v_pk_fma_f32 + 1 MFMA
+        // take 67 cycles where the VALU alone takes 40 and the MFMA alone 16.6 --, VOP3 / packed fp32 instructions cost ~5 cycles per
+        // wave instruction (VOP2 2.6), so the ~370 VALU + 48 MFMA instructions of a wave-stage cost their sum whatever their order.
+        static_assert(HS * 32 * 2 == 4096 && 32 * 32 * 2 == 2048 && C * 32 * 2 == 6144 && (W1_EL + W2_EL) * 2 == 24576, "literal offsets of the reads below");
+        const unsigned sbase = (unsigned)(uintptr_t)(lptr_t*)smem + (unsigned)cslot * STAGE_B;
+        const unsigned a10 = sbase + (unsigned)w1off[0] * 2u, a11 = sbase + (unsigned)w1off[1] * 2u;
+        const unsigned a20 = sbase + (unsigned)w2off[0] * 2u, a21 = sbase + (unsigned)w2off[1] * 2u;     // w2off[nt] = w2off[nt & 1] + (nt >> 1) * 1024
+        const unsigned ab = sbase + 24576u + (unsigned)lg * 32u;
+        bf16x8 w1f[KS][2], w2f[NT2];
+        f32x4 bbf[2][2];
+#define FMMT_RD(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr) : "memory")
+#define FMMT_PIN(x) asm volatile("" : "+v"(x))
+        FMMT_RD(bbf[0][0], ab, 0); FMMT_RD(bbf[0][1], ab, 16); FMMT_RD(bbf[1][0], ab, 128); FMMT_RD(bbf[1][1], ab, 144);
+        FMMT_RD(w1f[0][0], a10, 0); FMMT_RD(w1f[0][1], a11, 0); FMMT_RD(w1f[1][0], a10, 4096); FMMT_RD(w1f[1][1], a11, 4096);
+        FMMT_RD(w1f[2][0], a10, 8192); FMMT_RD(w1f[2][1], a11, 8192);
+        FMMT_RD(w2f[0], a20, 0); FMMT_RD(w2f[1], a21, 0); FMMT_RD(w2f[2], a20, 2048); FMMT_RD(w2f[3], a21, 2048);
+        FMMT_RD(w2f[4], a20, 4096); FMMT_RD(w2f[5], a21, 4096);
+        auto pin_w1 = [&]() {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) { FMMT_PIN(w1f[ks][0]); FMMT_PIN(w1f[ks][1]); }
+        };
+        auto pin_w2 = [&]() {
+#pragma unroll
+            for (int nt = 0; nt < NT2; ++nt) FMMT_PIN(w2f[nt]);
+        };
+        auto prod1 = [&](f32x4 (&acc1)[2][2]) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) acc1[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) acc1[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[ks][nt], xf[mt][ks], acc1[mt][nt], 0, 0, 0);
+        };
+        auto prod2 = [&](const bf16x8 (&hf)[2]) {
+#pragma unroll
+            for (int nt = 0; nt < NT2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) acc2[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[nt], hf[mt], acc2[mt][nt], 0, 0, 0);
+        };
+        // epilogue 1 of a block: this lane holds, per token tile, hidden channels lg * 8 .. + 7 of the block for token li
+        auto epi1 = [&](const f32x4 (&acc1)[2][2], const f32x4 (&bb)[2], bf16x8 (&pre)[2], bf16x8 (&hf)[2]) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                float v[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = acc1[mt][0][r] + bb[0][r];
+                    v[4 + r] = acc1[mt][1][r] + bb[1][r];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pre[mt][e] = (bf16)v[e];
+                gelu_inplace<T>(v, 8);                       // packed polynomial (fmmt_common.h): FMAs only, no table, no wait
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hf[mt][e] = (bf16)v[e];
+            }
+        };
+        f32x4 acc1a[2][2], acc1b[2][2];
+        bf16x8 pre0[2], pre1[2], hf0[2], hf1[2];
+        asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");   // bias + W1(0) are in
+        FMMT_PIN(bbf[0][0]); FMMT_PIN(bbf[0][1]); FMMT_PIN(bbf[1][0]); FMMT_PIN(bbf[1][1]);
+        pin_w1();
+        prod1(acc1a);
+        FMMT_RD(w1f[0][0], a10, 2048); FMMT_RD(w1f[0][1], a11, 2048); FMMT_RD(w1f[1][0], a10, 6144); FMMT_RD(w1f[1][1], a11, 6144);
+        FMMT_RD(w1f[2][0], a10, 10240); FMMT_RD(w1f[2][1], a11, 10240);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // W2(0), W1(1)
+        pin_w1();
+        pin_w2();
+        // P1(1) under E(0): one MFMA (16 cycles of the matrix pipe) per group of VALU instructions, in program order -- left to itself the
+        // compiler issues the 12 MFMAs back to back (the wave's in-order issue then stands for ~190 cycles) and the ~150 VALU behind them
+        constexpr int VPM = 12;                              // VALU instructions per MFMA slot (E = ~150 VALU, 12 MFMAs)
+        __builtin_amdgcn_sched_barrier(0);
+        prod1(acc1b);
+        epi1(acc1a, bbf[0], pre0, hf0);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        prod2(hf0);                                          // P2(0) under E(1), the same way
+        epi1(acc1b, bbf[1], pre1, hf1);
+        FMMT_PIN(hf1[0]); FMMT_PIN(hf1[1]); FMMT_PIN(pre1[0]); FMMT_PIN(pre1[1]);   // (keeps E(1) here: the IR-level sinking pass moves it to its first use otherwise)
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+            __builtin_amdgcn_sched_group_barrier(0x002, VPM, 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        FMMT_RD(w2f[0], a20, 6144); FMMT_RD(w2f[1], a21, 6144); FMMT_RD(w2f[2], a20, 8192); FMMT_RD(w2f[3], a21, 8192);
+        FMMT_RD(w2f[4], a20, 10240); FMMT_RD(w2f[5], a21, 10240);
+        // a token's 64 hidden values of this stage are one 128-byte line of h_pre / h_act: the two 64-byte halves go out back to back
+        // (the stores' address arithmetic covers the latency of the W2(1) reads)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int tok = t0 + mt * 16 + li;
+            if (FULL || tok < p.M) {
+                const size_t off = (size_t)tok * H + hs * HS + lg * 8;
+                if (p.h_pre) {
+                    *reinterpret_cast<bf16x8*>(p.h_pre + off) = pre0[mt];
+                    *reinterpret_cast<bf16x8*>(p.h_pre + off + 32) = pre1[mt];
+                }
+                if (p.h_act) {
+                    *reinterpret_cast<bf16x8*>(p.h_act + off) = hf0[mt];
+                    *reinterpret_cast<bf16x8*>(p.h_act + off + 32) = hf1[mt];
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // W2(1)
+        pin_w2();
+        prod2(hf1);
+#undef FMMT_RD
+#undef FMMT_PIN
+        } else {
         // a token's 64 hidden values of this stage are one 128-byte line of h_pre / h_act: block 0's half is held back and
         // written together with block 1's, so that the two 64-byte halves reach L2 back to back
         bf16x8 keep_pre[2], keep_act[2];
@@ -233,14 +390,13 @@ __global__ __launch_bounds__(512) void mlp_fused_fwd_kernel(MlpArgs p) {
                 bf16x8 pre8;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) pre8[e] = (bf16)v[e];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= gelu_lut(lut, v[e]);
+                gelu_inplace<T, C == 96 ? 4 : 2>(v, 8);      // packed polynomial (fmmt_common.h): FMAs only, no table, no wait
 #pragma unroll
                 for (int e = 0; e < 8; ++e) hf[mt][e] = (bf16)v[e];
                 if (blk == 0) {
                     keep_pre[mt] = pre8;
                     keep_act[mt] = hf[mt];
-                } else if (tok < p.M) {
+                } else if (FULL || tok < p.M) {
                     const size_t off = (size_t)tok * H + hs * HS + lg * 8;
                     if (p.h_pre) {
                         *reinterpret_cast<bf16x8*>(p.h_pre + off) = keep_pre[mt];
@@ -260,6 +416,7 @@ __global__ __launch_bounds__(512) void mlp_fused_fwd_kernel(MlpArgs p) {
                 for (int mt = 0; mt < 2; ++mt) acc2[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf2, hf[mt], acc2[mt][nt], 0, 0, 0);
             }
         }
+        }
         cslot = cslot + 1 == NBUF ? 0 : cslot + 1;
         if (++hs == NS) {
             // tile done: the x fragments are dead -- fetch the next tile's while this one's result is finished and stored
@@ -275,7 +432,8 @@ __global__ __launch_bounds__(512) void mlp_fused_fwd_kernel(MlpArgs p) {
             e.ldres = C;
             e.rowscale = p.rowscale;
             e.rows_per_scale = p.rows_per_scale;
-            nt_epilogue<T, 2, NT2>(e, acc2, t0, 0, li, lg);
+            if constexpr (KEEPX) nt_epilogue<T, 2, NT2, false, true>(e, acc2, t0, 0, li, lg, &pre);
+            else nt_epilogue<T, 2, NT2>(e, acc2, t0, 0, li, lg);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -350,9 +508,7 @@ __global__ __launch_bounds__(512) void mlp_fused_bwd_kernel(MlpArgs p) {
     const int li = lane & 15, lg = lane >> 4;
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
-    lut2_t* lut = reinterpret_cast<lut2_t*>(smem + NBUF * STAGE_B);          // gelu'(x) table (fmmt_common.h), behind the ring
-    gelu_lut_copy(lut, fmmt_gelu_lut_grad, tid, 512);
-    float* gam_s = reinterpret_cast<float*>(smem + NBUF * STAGE_B + GELU_LUT_BYTES);                 // LNB: gamma [C]
+    float* gam_s = reinterpret_cast<float*>(smem + NBUF * STAGE_B);                                  // LNB: gamma [C]
     float* slot_s = reinterpret_cast<float*>(smem);                                                  // LNB, after the last step: [8 waves][4 lg][2 NV] over the ring
     if constexpr (LNB) {
         if (tid < C) gam_s[tid] = p.ln_g[tid];
@@ -362,23 +518,36 @@ __global__ __launch_bounds__(512) void mlp_fused_bwd_kernel(MlpArgs p) {
     const int r16 = lane >> 2, c4 = lane & 3;
 
     // p.w1 = W2^T [4C][C] (rows: hidden), p.w2 = W1^T [C][4C] (rows: input channels): the stage layout of the forward kernel
+    unsigned loff[CNT];                                      // per-piece lane offsets: see the forward kernel
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) {
+        const int j = i * 8 + wave;
+        if (j < KS * 4) {
+            const int ks = j >> 2, r = (j & 3) * 16 + r16;
+            loff[i] = (unsigned)(r * C + ks * 32 + ((c4 ^ swz(r)) << 3)) * 2u;
+        } else {
+            const int q = j - KS * 4, b = q / (C / 16), r = (q % (C / 16)) * 16 + r16;
+            loff[i] = (unsigned)(r * H + b * 32 + ((c4 ^ swz(r)) << 3)) * 2u;
+        }
+    }
     auto issue = [&](int slot, int hs) {
         char* base = smem + slot * STAGE_B;
+        const char* u1 = reinterpret_cast<const char*>(p.w1 + (size_t)hs * HS * C);
+        const char* u2 = reinterpret_cast<const char*>(p.w2 + (size_t)hs * HS);
 #pragma unroll
         for (int i = 0; i < CNT; ++i) {
             const int j = i * 8 + wave;
-            const T* src;
             T* dst;
             if (j < KS * 4) {
-                const int ks = j >> 2, r0 = (j & 3) * 16, r = r0 + r16;
-                src = p.w1 + (size_t)(hs * HS + r) * C + ks * 32 + ((c4 ^ swz(r)) << 3);
+                const int ks = j >> 2, r0 = (j & 3) * 16;
                 dst = reinterpret_cast<T*>(base) + ks * (HS * 32) + r0 * 32;
             } else {
-                const int q = j - KS * 4, b = q / (C / 16), r0 = (q % (C / 16)) * 16, r = r0 + r16;
-                src = p.w2 + (size_t)r * H + hs * HS + b * 32 + ((c4 ^ swz(r)) << 3);
+                const int q = j - KS * 4, b = q / (C / 16), r0 = (q % (C / 16)) * 16;
                 dst = reinterpret_cast<T*>(base) + W1_EL + b * (C * 32) + r0 * 32;
             }
-            __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)dst, 16, 0, 0);
+            unsigned lo = loff[i];
+            asm volatile("" : "+v"(lo));                     // keep the offset a 32-bit register (hoisted as a zero-extended pair otherwise)
+            __builtin_amdgcn_global_load_lds((gptr_t*)((j < KS * 4 ? u1 : u2) + (size_t)lo), (lptr_t*)dst, 16, 0, 0);
         }
     };
 
@@ -505,8 +674,9 @@ __global__ __launch_bounds__(512) void mlp_fused_bwd_kernel(MlpArgs p) {
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) ax[e] = (float)cur[mt * 2 + blk][e];
+                gelu_grad_mul_inplace<T, C == 96 ? 4 : 2>(v, ax, 8);   // v *= gelu'(pre): packed polynomial (fmmt_common.h)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) hf[mt][e] = (bf16)(v[e] * gelu_lut(lut, ax[e]) * rsv[mt]);
+                for (int e = 0; e < 8; ++e) hf[mt][e] = (bf16)(v[e] * rsv[mt]);
                 const int tok = t0 + mt * 16 + li;
                 if (blk == 0) keep[mt] = hf[mt];
                 else if (tok < p.M) {
@@ -637,7 +807,7 @@ __global__ __launch_bounds__(1024) void mlp_ln_part_reduce_kernel(const float* _
 
 template <int C, bool LNB = false>
 int launch_mlp_bwd(const MlpArgs& a0, hipStream_t st) {
-    constexpr size_t lds = (size_t)3 * (((C / 32) * 64 * 32 + 2 * C * 32) * 2) + GELU_LUT_BYTES + (LNB ? C * sizeof(float) : 0);
+    constexpr size_t lds = (size_t)3 * (((C / 32) * 64 * 32 + 2 * C * 32) * 2) + (LNB ? C * sizeof(float) : 0);
     static_assert(lds <= 160 * 1024, "LDS");
     static FmmtLdsOnce lds_once;
     if (int rc_ = lds_once.set(reinterpret_cast<const void*>(&mlp_fused_bwd_kernel<C, LNB>), (int)lds)) return rc_;
@@ -650,15 +820,19 @@ int launch_mlp_bwd(const MlpArgs& a0, hipStream_t st) {
     return 0;
 }
 
-template <int C, bool LN>
-int launch_mlp(const MlpArgs& a, hipStream_t st) {
-    constexpr size_t lds = (size_t)3 * (((C / 32) * 64 * 32 + 2 * C * 32) * 2 + 1024) + GELU_LUT_BYTES;
+template <int C, bool LN, bool FULL>
+int launch_mlp_f(const MlpArgs& a, hipStream_t st) {
+    constexpr size_t lds = (size_t)3 * (((C / 32) * 64 * 32 + 2 * C * 32) * 2 + 1024);
     static FmmtLdsOnce lds_once;
-    if (int rc_ = lds_once.set(reinterpret_cast<const void*>(&mlp_fused_fwd_kernel<C, LN>), (int)lds)) return rc_;
+    if (int rc_ = lds_once.set(reinterpret_cast<const void*>(&mlp_fused_fwd_kernel<C, LN, FULL>), (int)lds)) return rc_;
     const int grid = a.tiles < 256 ? a.tiles : 256;
-    hipLaunchKernelGGL((mlp_fused_fwd_kernel<C, LN>), dim3(grid), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((mlp_fused_fwd_kernel<C, LN, FULL>), dim3(grid), dim3(512), lds, st, a);
     FMMT_CHECK_LAUNCH();
     return 0;
+}
+template <int C, bool LN>
+int launch_mlp(const MlpArgs& a, hipStream_t st) {
+    return a.M % 256 == 0 ? launch_mlp_f<C, LN, true>(a, st) : launch_mlp_f<C, LN, false>(a, st);
 }
 
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

@@ -52,14 +52,7 @@ __global__ __launch_bounds__(512) void mlp_ref_fwd_kernel(MlpArgs p) {
     using E = MrEl<T>;
     using F = typename E::frag;
     constexpr int H = 4 * C, HS = 64, NS = H / HS, KS = C / 32, NT2 = C / 16, CW2 = 4 * NT2;
-    __shared__ __attribute__((aligned(16))) lut2_t lut_s[sizeof(T) == 2 ? GELU_LUT_N : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
-    const lut2_t* lut = nullptr;
-    if constexpr (sizeof(T) == 2) {
-        gelu_lut_copy(lut_s, fmmt_gelu_lut_phi, tid, 512);
-        __syncthreads();
-        lut = lut_s;
-    }
     const T* xg = reinterpret_cast<const T*>(p.x);
     const T* w1 = reinterpret_cast<const T*>(p.w1);
     const T* w2 = reinterpret_cast<const T*>(p.w2);
@@ -146,8 +139,7 @@ __global__ __launch_bounds__(512) void mlp_ref_fwd_kernel(MlpArgs p) {
                     F pre8;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) pre8[e] = E::cv(v[e]);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = sizeof(T) == 2 ? v[e] * gelu_lut(lut, v[e]) : gelu_f(v[e]);
+                    gelu_inplace<T>(v, 8);                   // fp32: erff; bf16: the production kernels' packed polynomial (fmmt_common.h)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) hf[mt][e] = E::cv(v[e]);
                     if (tok < p.M) {
@@ -186,15 +178,8 @@ __global__ __launch_bounds__(512) void mlp_ref_bwd_kernel(MlpArgs p) {
     using F = typename E::frag;
     constexpr int H = 4 * C, HS = 64, NS = H / HS, KS = C / 32, NT2 = C / 16, CW2 = 4 * NT2;
     constexpr int NV = KS * 8;
-    __shared__ __attribute__((aligned(16))) lut2_t lut_s[sizeof(T) == 2 ? GELU_LUT_N : 1];
     __shared__ float colsum_s[8][2 * C];                     // LNB: per-wave d(gamma) | d(beta) column sums
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
-    const lut2_t* lut = nullptr;
-    if constexpr (sizeof(T) == 2) {
-        gelu_lut_copy(lut_s, fmmt_gelu_lut_grad, tid, 512);
-        __syncthreads();
-        lut = lut_s;
-    }
     const T* dyg = reinterpret_cast<const T*>(p.x);
     const T* w2t = reinterpret_cast<const T*>(p.w1);
     const T* w1t = reinterpret_cast<const T*>(p.w2);
@@ -244,12 +229,15 @@ __global__ __launch_bounds__(512) void mlp_ref_bwd_kernel(MlpArgs p) {
                 for (int mt = 0; mt < 2; ++mt) {
                     const int tokc = min(t0 + mt * 16 + li, p.M - 1), tok = t0 + mt * 16 + li;
                     const F ax = E::ld(hpre + (size_t)tokc * H + h0 + lg * 8);
+                    float a[8], pre[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const float a = e < 4 ? acc1[mt][0][e] : acc1[mt][1][e - 4];
-                        const float gd = sizeof(T) == 2 ? gelu_lut(lut, (float)ax[e]) : gelu_grad_f((float)ax[e]);
-                        hf[mt][e] = E::cv(a * gd * rsv[mt]);
+                        a[e] = e < 4 ? acc1[mt][0][e] : acc1[mt][1][e - 4];
+                        pre[e] = (float)ax[e];
                     }
+                    gelu_grad_mul_inplace<T>(a, pre, 8);     // fp32: erff / expf; bf16: the production kernels' packed polynomial
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) hf[mt][e] = E::cv(a[e] * rsv[mt]);
                     if (tok < p.M) E::st(dhg + (size_t)tok * H + h0 + lg * 8, hf[mt]);
                 }
 #pragma unroll

@@ -36,4 +36,18 @@ for (M, C) in [(2007040, 96), (501760, 192)]:
     tw = timeit(lambda: ops.wgrad_raw(dy, h, True, rs, 49))
     twg = timeit(lambda: ops.wgrad_raw(dy, hp, True, rs, 49, x_gelu=True))
     print(f"   weight gradient of fc2: stored activation {tw*1e3:.3f} ms | recomputed gelu(pre) {twg*1e3:.3f} ms", flush=True)
+    # input gradient: fused launch (C = 96; C = 192 goes to the two GELU' / plain GEMM launches unless FMMT_MLP_BWD_FUSED=192)
+    tb = timeit(lambda: ops.mlp_bwd_input_raw(dy, hp, w1, w2, rs, 49))
+    print(f"   input gradient (dh stored): {tb*1e3:.3f} ms", flush=True)
     del x, res, hp, h, dy
+# GELU / GELU' epilogues of the stage-2 / stage-3 GEMMs against the plain launch of the same shape
+from facialmmt_amd._lib import EPI_GELU_BWD
+for (M, N, K) in [(125440, 1536, 384), (31360, 3072, 768)]:
+    dt = torch.bfloat16
+    x = torch.randn(M, K, device=dev, dtype=dt); w = torch.randn(N, K, device=dev, dtype=dt) * K ** -0.5; b = torch.randn(N, device=dev)
+    pre = torch.empty(M, N, device=dev, dtype=dt); aux = torch.randn(M, N, device=dev, dtype=dt)
+    t0 = timeit(lambda: ops.linear_raw(x, w, b))
+    t1 = timeit(lambda: ops.linear_raw(x, w, b, epi=EPI_GELU, y_pre=pre))
+    t2 = timeit(lambda: ops.linear_raw(x, w, None, epi=EPI_GELU_BWD, aux=aux))
+    print(f"{M}x{N}x{K}: plain {t0*1e3:.3f} ms | gelu + pre-activation {t1*1e3:.3f} ms | gelu' {t2*1e3:.3f} ms", flush=True)
+    del x, w, pre, aux

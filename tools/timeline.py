@@ -81,3 +81,30 @@ for n, c in cnt.most_common(45):
     print(f"  {c:5d} {tim[n] / 1e6:7.3f} {tim[n] / c / 1e3:7.1f}  {n[:120]}")
 small = sum(c for n, c in cnt.items() if tim[n] / c < 8e3); smallt = sum(tim[n] for n, c in cnt.items() if tim[n] / c < 8e3)
 print(f"kernels averaging < 8 us: {small} launches, {smallt / 1e6:.2f} ms")
+# coarse phase map: per millisecond of the step and per hardware queue, the busy time and the kernel that holds most of it
+print("phase map (ms offset | per queue: busy us, dominant kernel):")
+qs = [q for (q, st), v in sorted(byq.items(), key=lambda kv: -kv[1])][:3]
+nb = int((t1 - t0) / 1e6) + 1
+bins = [{q: collections.Counter() for q in qs} for _ in range(nb)]
+for s_, e_, n, q, st in step:
+    if q not in qs:
+        continue
+    b0, b1 = int((s_ - t0) / 1e6), int((min(e_, t1) - 1 - t0) / 1e6)
+    for b in range(b0, b1 + 1):
+        lo, hi = max(s_, t0 + b * 1000000), min(e_, t0 + (b + 1) * 1000000)
+        if hi > lo and 0 <= b < nb:
+            bins[b][q][n] += hi - lo
+def short(n):
+    n = n.replace("(anonymous namespace)::", "").replace("void ", "")
+    for k in ("_ZN12_GLOBAL__N_1",):
+        if n.startswith(k):
+            n = n[len(k):].lstrip("0123456789")
+    return n[:34]
+for b in range(nb):
+    cells = []
+    for q in qs:
+        c = bins[b][q]
+        busy = sum(c.values()) / 1e3
+        top = short(c.most_common(1)[0][0]) if c else "-"
+        cells.append(f"q{q}: {busy:5.0f} {top:34s}")
+    print(f"  {b:3d} | " + " | ".join(cells))
