@@ -5,7 +5,6 @@ the hot path.  Every op raises if the library is missing or a launch fails (no f
 from __future__ import annotations
 
 import math
-import os as _os
 import weakref
 
 import torch
@@ -371,10 +370,10 @@ def mlp_fused_raw(x2, w1l, b1, w2l, b2, res2, rowscale, rows_per_scale, h_pre, h
     return y
 
 
-_MLP_FUSED = _os.environ.get("FMMT_MLP_FUSED", "1") != "0"       # A/B switch (read once): 0 = always the two-launch form
+_MLP_FUSED = True            # module constants, not environment switches: the tests and probes patch them (False = always the two-launch form)
 # fp32 (parity) models take the fused Mlp entry points too -- their element-type-generic instantiations, csrc/mlp_ref.hip -- so that the
 # fp32 goldens reach the fused kernels' algorithm at 1e-3 (0: LayerNorm + two GEMM launches, as in rounds 1-3)
-_MLP_F32 = _os.environ.get("FMMT_MLP_F32", "1") != "0"
+_MLP_F32 = True
 
 
 def _mlp_dtype_ok(dt):
@@ -429,11 +428,11 @@ class MlpFn(Function):
         return dx, dw1, db1, dw2, db2, (dy if ctx.has_res else None), None, None, None
 
 
-_MLP_BWD_FUSED = _os.environ.get("FMMT_MLP_BWD_FUSED", "1") != "0"   # A/B switch (read once): 0 = GELU' GEMM + input-gradient GEMM as two launches
+_MLP_BWD_FUSED = True        # False = GELU' GEMM + input-gradient GEMM as two launches
 # "192" adds stage 1 (one token tile per wave there: no spill, all tests pass, and 0.1 ms SLOWER per Swin forward + backward than the two
 # GEMM launches + LayerNorm backward it replaces: 43.69 against 43.57 ms, same call) -- off
-_MLP_BWD_WIDTHS = (96, 192) if _os.environ.get("FMMT_MLP_BWD_FUSED", "1") == "192" else (96,)
-_MLP_BWD_LN = _os.environ.get("FMMT_MLP_BWD_LN", "1") != "0"     # A/B switch (read once): 0 = fmmt_mlp_bwd_input + fmmt_layernorm_bwd
+_MLP_BWD_WIDTHS = (96,)      # (96, 192) adds stage 1 (one token tile per wave: no spill, all tests pass, measured 0.1 ms slower than the launches it replaces)
+_MLP_BWD_LN = True           # False = fmmt_mlp_bwd_input + fmmt_layernorm_bwd
 
 
 def mlp_bwd_input_raw(dy2, h_pre, w1, w2, rowscale, rows_per_scale):
@@ -581,7 +580,7 @@ def layer_norm(x, gamma, beta, eps=1e-5, merge_hw=0):
     return LayerNormFn.apply(x, gamma, beta, eps, merge_hw)
 
 
-_PATCH_LN = _os.environ.get("FMMT_PATCH_LN", "1") != "0"    # A/B switch (read once): 0 = projection and LayerNorm as two launches
+_PATCH_LN = True             # False = projection and LayerNorm as two launches
 
 
 class PatchProjLnFn(Function):
@@ -726,18 +725,18 @@ def window_attn_core(qkv, table, index_i32, mask, n_img, H, W, num_heads, shift,
 # ------------------------------------------------------------------------------------------------
 # the attention half of a Swin block as ONE launch (csrc/wblock.hip): y = x + s * proj(W-MSA(LN(x) Wqkv^T + b))
 # ------------------------------------------------------------------------------------------------
-_WBLOCK = _os.environ.get("FMMT_WBLOCK", "1") != "0"          # A/B switch (read once): 0 = always the four-launch form; 192 = also at stage 1
-_WBLOCK_WIDTHS = (96, 192) if _os.environ.get("FMMT_WBLOCK", "1") == "192" else (96,)
+_WBLOCK = True               # False = always the four-launch form
+_WBLOCK_WIDTHS = (96,)       # (96, 192): the four-launch block op at stage 1 as well
 # fp32 (parity) models take the fused forward too -- its element-type-generic instantiation, csrc/wblock_ref.hip -- so that every fp32 golden of
 # the stage-0 blocks and of the whole Swin reaches the fused kernel's algorithm at 1e-3 (0: the four fp32 launches, as in rounds 1-3)
-_WBLOCK_F32 = _os.environ.get("FMMT_WBLOCK_F32", "1") != "0"
-_WBLOCK_BWD = _os.environ.get("FMMT_WBLOCK_BWD", "1") != "0"  # 0: the backward re-computes qkv with a GEMM and runs fmmt_window_attn_bwd
+_WBLOCK_F32 = True
+_WBLOCK_BWD = True           # False: the backward re-computes qkv with a GEMM and runs fmmt_window_attn_bwd
 
 
 def window_block_fusable(x, C, num_heads, window_size, shift, mask, mask_is_shift):
     """the block-half op runs where it pays: the bf16 stage-0 geometry (C = 96, head_dim 32, 7x7 windows) with no mask or the standard
     SW-MSA mask -- fused forward kernel + recompute backward.  (C = 192 is implemented -- four forward launches, the same recompute
-    backward, tests/test_gpu_wblock.py -- and reachable with FMMT_WBLOCK=192, but at stage 1 the recompute backward loses: six heads
+    backward, tests/test_gpu_wblock.py -- and reachable with _WBLOCK_WIDTHS = (96, 192), but at stage 1 the recompute backward loses: six heads
     re-read LN(x) / dy and redo 96 MFMAs per wave, 835 us per launch against 480 + 130 for the attention backward and the proj input
     gradient it replaces.)"""
     ok_dtype = x.dtype == torch.bfloat16 or (_WBLOCK_F32 and x.dtype == torch.float32 and C == 96)

@@ -343,15 +343,18 @@ class VendorLayerNorm(torch.nn.LayerNorm):
         return ops.PlmLayerNormFn.apply(x, self.weight, self.bias, self.eps)
 
 
+# Module constants (the probes patch them), not environment switches: each is the off-switch of one fused launch family
+PLM_COLSUM, PLM_LN, FUSED_ADAMW, PIN_SHADOWS = True, True, True, True
+
+
 def use_colsum_bias_gradients(module):
     """Re-class every nn.Linear of `module` (a Hugging Face text encoder) as VendorLinear: the bias gradients of its ~146 Linear
     layers then cost one 4 us launch each instead of a memset + a multi-block reduction (measured: 3.2 + 0.8 ms per step).
-    FMMT_PLM_COLSUM=0 leaves the module alone.  Returns the number of layers changed."""
-    import os
-    if os.environ.get("FMMT_PLM_COLSUM", "1") == "0":
+    PLM_COLSUM = False (module constant) leaves the module alone.  Returns the number of layers changed."""
+    if not PLM_COLSUM:
         return 0
     n = 0
-    ln = os.environ.get("FMMT_PLM_LN", "1") != "0"
+    ln = PLM_LN
     for m in module.modules():
         if type(m) is torch.nn.Linear and m.bias is not None:
             m.__class__ = VendorLinear
@@ -548,8 +551,7 @@ class FusedClipAdamW:
 
     @staticmethod
     def eligible(opt, params):
-        import os
-        if os.environ.get("FMMT_FUSED_ADAMW", "1") == "0" or type(opt) not in (torch.optim.AdamW, HFAdamW) or len(opt.param_groups) != 1:
+        if not FUSED_ADAMW or type(opt) not in (torch.optim.AdamW, HFAdamW) or len(opt.param_groups) != 1:
             return False
         g = opt.param_groups[0]
         return (torch.is_tensor(g["lr"]) and g["lr"].is_cuda and not g.get("amsgrad", False) and not g.get("maximize", False)
@@ -598,9 +600,8 @@ def _ops_pinned_scope(shadows):
 
 
 def _pin_shadows(modules):
-    """ops.PinnedShadows over the parameters of `modules` (FMMT_PIN_SHADOWS=0: per-weight casts inside the graph, as before)"""
-    import os
-    if os.environ.get("FMMT_PIN_SHADOWS", "1") == "0":
+    """ops.PinnedShadows over the parameters of `modules` (PIN_SHADOWS = False: per-weight casts inside the graph, as before)"""
+    if not PIN_SHADOWS:
         return None
     from . import ops
     seen, params = set(), []

@@ -3,7 +3,7 @@ attention, proj, DropPath scale, residual (Swin_Transformer.py:233-266).  Parity
   * against an fp64 restatement of the reference maths (the same helpers the per-op probe uses; window gather by index tables),
   * against the four-launch composition on the same kernels (LayerNorm -> Linear -> attention core -> Linear), forward and every
     gradient, including a dropped DropPath sample, ragged last workgroups and a single window,
-  * through the module: SwinTransformerBlock / BasicLayer with the fused path on and off (FMMT_WBLOCK switch of ops.py), and the
+  * through the module: SwinTransformerBlock / BasicLayer with the fused path on and off (ops._WBLOCK), and the
     reference-generated block goldens in bf16."""
 import os
 import sys

@@ -36,7 +36,7 @@ for (M, C) in [(2007040, 96), (501760, 192)]:
     tw = timeit(lambda: ops.wgrad_raw(dy, h, True, rs, 49))
     twg = timeit(lambda: ops.wgrad_raw(dy, hp, True, rs, 49, x_gelu=True))
     print(f"   weight gradient of fc2: stored activation {tw*1e3:.3f} ms | recomputed gelu(pre) {twg*1e3:.3f} ms", flush=True)
-    # input gradient: fused launch (C = 96; C = 192 goes to the two GELU' / plain GEMM launches unless FMMT_MLP_BWD_FUSED=192)
+    # input gradient: fused launch (C = 96; C = 192 goes to the two GELU' / plain GEMM launches unless ops._MLP_BWD_WIDTHS = (96, 192))
     tb = timeit(lambda: ops.mlp_bwd_input_raw(dy, hp, w1, w2, rs, 49))
     print(f"   input gradient (dh stored): {tb*1e3:.3f} ms", flush=True)
     del x, res, hp, h, dy
