@@ -30,6 +30,8 @@ SIGNATURES = {
     "fmmt_mlp_fwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p]),
     "fmmt_mlp_ln_fwd": (_i, [_i, _i, _i, _p, _p, _p, _f, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p]),
     "fmmt_mlp_bwd_input": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p]),
+    "fmmt_linear_ln_bwd_workspace": (_sz, [_i]),
+    "fmmt_linear_ln_bwd": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "fmmt_mlp_ln_bwd_input_workspace": (_sz, [_i]),
     "fmmt_mlp_ln_bwd_input": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "fmmt_linear_wgrad_finish": (_i, [_i, _i, _i, _i, _p, _p, _p, _sz, _p]),

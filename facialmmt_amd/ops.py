@@ -731,6 +731,7 @@ _WBLOCK_WIDTHS = (96,)       # (96, 192): the four-launch block op at stage 1 as
 # the stage-0 blocks and of the whole Swin reaches the fused kernel's algorithm at 1e-3 (0: the four fp32 launches, as in rounds 1-3)
 _WBLOCK_F32 = True
 _WBLOCK_BWD = True           # False: the backward re-computes qkv with a GEMM and runs fmmt_window_attn_bwd
+_WBLOCK_LNBWD = True         # False: d(LN out) GEMM and LayerNorm backward as two launches
 
 
 def window_block_fusable(x, C, num_heads, window_size, shift, mask, mask_is_shift):
@@ -835,13 +836,22 @@ def window_block_backward(dy, x2, xn, o, mean, rstd, lse, g, wqkv, bqkv, wproj, 
                                       _p(m), nWm, 1 if m is not None else 0, scale, _p(dqkv), _p(dtable), _p(ws), nbytes, _st())
         check(rc, "fmmt_window_attn_bwd")
         del qkv, do
+    dx = torch.empty_like(x2)
+    dg = torch.empty(C, dtype=torch.float32, device=x2.device)
+    db = torch.empty(C, dtype=torch.float32, device=x2.device)
+    if _WBLOCK_LNBWD and dt == torch.bfloat16 and C == 96:
+        # d(LN out) = dqkv . Wqkv, LayerNorm' and the residual gradient in one launch (fmmt_linear_ln_bwd): d(LN out) is never written
+        nb2 = lib.fmmt_linear_ln_bwd_workspace(C)
+        ws2 = _ws(nb2, x2.device)
+        rc = lib.fmmt_linear_ln_bwd(dtype_code(dt), x2.shape[0], C, 3 * C, _p(dqkv), _p(_lp(wqkv, dt, transpose=True)), _p(x2), _p(mean), _p(rstd), _p(g),
+                                    _p(dy2), _p(dx), _p(dg), _p(db), _p(ws2), nb2, _st())
+        check(rc, "fmmt_linear_ln_bwd(window_block)")
+        dwq, dbq = wgrad_raw(dqkv, xn, bqkv is not None)
+        return dx.reshape(xshape), dg, db, dwq, dbq, dwp, dbp, dtable
     dxn = linear_raw(dqkv, _lp(wqkv, dt, transpose=True), None)
     dwq, dbq = wgrad_raw(dqkv, xn, bqkv is not None)
     del dqkv
     # LayerNorm backward + the residual branch's gradient
-    dx = torch.empty_like(x2)
-    dg = torch.empty(C, dtype=torch.float32, device=x2.device)
-    db = torch.empty(C, dtype=torch.float32, device=x2.device)
     nb2 = lib.fmmt_layernorm_bwd_workspace(C)
     ws2 = _ws(nb2, x2.device)
     rc = lib.fmmt_layernorm_bwd(dtype_code(dt), x2.shape[0], C, _p(dxn), _p(x2), _p(mean), _p(rstd), _p(g), _p(dy2), _p(dx), _p(dg), _p(db), 0,

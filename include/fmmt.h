@@ -238,6 +238,17 @@ int fmmt_window_block_attn_bwd(int dtype, int n_img, int H, int W, int C, int nu
                                const void* wqkv, const float* bqkv, const void* wproj,
                                const float* table, const int32_t* index, float scale, const float* rowscale,
                                void* dqkv, float* dtable, void* workspace, size_t workspace_bytes, void* stream);
+/* Input gradient of "LayerNorm -> Linear" in one launch: the tail of the fused block half's backward (Swin_Transformer.py:239-243,
+ * attn(norm1(x)); replaces autograd through nn.LayerNorm + the qkv nn.Linear, i.e. fmmt_linear_fwd on W^T followed by fmmt_layernorm_bwd):
+ *   dx[M,C] = LayerNorm'( dz[M,K] . w ; x, mean, rstd, ln_gamma ) + dres[M,C]         (dres: the residual stream's gradient, or NULL)
+ * plus d(gamma) / d(beta) of the LayerNorm (per-workgroup partial sums in `workspace`, summed in fixed order by a second small launch).
+ * wt = w^T [C, K] (the transposed bf16 copy the two-launch form also reads); mean / rstd: the statistics the forward saved.
+ * bf16, C = 96, K = 288 (FMMT_EINVAL otherwise: the two launches).  d(LN out) is never written. */
+size_t fmmt_linear_ln_bwd_workspace(int C);
+int fmmt_linear_ln_bwd(int dtype, int M, int C, int K, const void* dz, const void* wt, const void* x, const float* mean, const float* rstd,
+                       const float* ln_gamma, const void* dres, void* dx, float* dgamma, float* dbeta, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
 /* The same backward restated over an element-type trait (csrc/wattn_bwd_ref.hip; C = 96): dtype FMMT_F32 -- also what
  * fmmt_window_block_attn_bwd(FMMT_F32) runs -- takes fp32 xn / dy / attn_out / wqkv / wproj / dqkv and rounds nothing (parity: the reference's
  * gradient goldens at 1e-3); FMMT_BF16 is the generic template's bf16 instantiation, which tests compare with the production kernel. */

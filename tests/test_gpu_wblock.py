@@ -476,3 +476,59 @@ def test_patch_embed_projection_and_layernorm_in_one_launch(dev, monkeypatch, go
     assert _rel(y, r64) <= 2e-2 and _rel(y, y2) <= 1e-2
     for a, b, c in zip(g1, g2, g64):
         assert _rel(a, c) <= 4e-2 and _rel(b, c) <= 4e-2
+
+
+@pytest.mark.parametrize("M,with_res", [(8192 + 77, True), (3136 * 2, False), (300, True)])
+def test_linear_and_layernorm_backward_in_one_launch(dev, M, with_res):
+    """fmmt_linear_ln_bwd (d(LN out) = dz . W, LayerNorm', residual gradient, d(gamma) / d(beta): the tail of the stage-0 attention
+    half's backward, Swin_Transformer.py:239-243) against an fp64 restatement through autograd, and against the two launches it replaces
+    (fmmt_linear_fwd on W^T + fmmt_layernorm_bwd, which round d(LN out) to bf16 in between); ragged tail and a tile-less M included."""
+    C, K = 96, 288
+    g = torch.Generator(device=dev).manual_seed(90 + M % 7)
+    rnd = lambda *s: torch.randn(*s, device=dev, generator=g)
+    x = (rnd(M, C) * 1.5 + 0.3).bfloat16()
+    dz = rnd(M, K).bfloat16()
+    w = (rnd(K, C) * C ** -0.5).bfloat16()
+    gamma = 1.0 + 0.2 * rnd(C)
+    from facialmmt_amd import _lib
+    dres = rnd(M, C).bfloat16() if with_res else None
+    xf = x.float()
+    mean = xf.mean(1)
+    rstd = (xf.var(1, unbiased=False) + 1e-5).rsqrt()
+    lib = _lib.load()
+    dx = torch.empty_like(x)
+    dg = torch.empty(C, device=dev)
+    db = torch.empty(C, device=dev)
+    nb = lib.fmmt_linear_ln_bwd_workspace(C)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    wt = w.t().contiguous()
+    st = torch.cuda.current_stream().cuda_stream
+    rc = lib.fmmt_linear_ln_bwd(1, M, C, K, dz.data_ptr(), wt.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                                dres.data_ptr() if with_res else None, dx.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), nb, st)
+    assert rc == 0
+    # fp64: y = LN(x) * gamma (+ beta), contracted with the incoming gradient dz . w
+    x64 = x.double().requires_grad_(True)
+    g64 = gamma.double().requires_grad_(True)
+    b64 = torch.zeros(C, dtype=torch.float64, device=dev, requires_grad=True)
+    y64 = torch.nn.functional.layer_norm(x64, (C,), g64, b64, 1e-5)
+    dxn64 = dz.double() @ w.double()
+    gx, gg, gb = torch.autograd.grad(y64, [x64, g64, b64], dxn64)
+    if with_res:
+        gx = gx + dres.double()
+    assert _rel(dx, gx) <= 2e-2 and _rel(dg, gg) <= 2e-2 and _rel(db, gb) <= 2e-2
+    # the two launches
+    dxn = ops.linear_raw(dz, wt, None)
+    dx2 = torch.empty_like(x)
+    dg2 = torch.empty(C, device=dev)
+    db2 = torch.empty(C, device=dev)
+    nb2 = lib.fmmt_layernorm_bwd_workspace(C)
+    ws2 = torch.empty(nb2, dtype=torch.uint8, device=dev)
+    rc = lib.fmmt_layernorm_bwd(1, M, C, dxn.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                                dres.data_ptr() if with_res else None, dx2.data_ptr(), dg2.data_ptr(), db2.data_ptr(), 0, ws2.data_ptr(), nb2, st)
+    assert rc == 0
+    assert _rel(dx, dx2) <= 1.5e-2 and _rel(dg, dg2) <= 1e-2 and _rel(db, db2) <= 1e-2
+    # shapes the kernel does not cover are refused, not mis-computed
+    assert lib.fmmt_linear_ln_bwd(1, M, 192, 576, dz.data_ptr(), wt.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                                  None, dx.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), nb, st) == -1
+    assert lib.fmmt_linear_ln_bwd(0, M, C, K, dz.data_ptr(), wt.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                                  None, dx.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), nb, st) == -1
