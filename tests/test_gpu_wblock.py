@@ -291,7 +291,7 @@ def test_fused_block_against_the_reference_generated_golden(dev, golden, shift):
     golden.check("swin_parts", f"block_s0_shift{shift}", y32, atol=1e-3, rtol=1e-3)
 
 
-@pytest.mark.parametrize("C,M,use_rs", [(96, 8192 + 77, True), (192, 4096, False), (96, 3136 * 2, False)])
+@pytest.mark.parametrize("C,M,use_rs", [(96, 8192 + 77, True), (192, 4096, False), (96, 3136 * 2, False), (96, 8192, True)])   # last: M % 256 == 0, the guard-free instantiation
 def test_mlp_half_with_layernorm_prologue(dev, C, M, use_rs):
     """fmmt_mlp_ln_fwd (norm2 -> Mlp -> DropPath -> residual in one launch) against fmmt_layernorm_fwd followed by fmmt_mlp_fwd, and
     both against fp64: forward, the saved LayerNorm output and statistics, every gradient; ragged last tile, dropped sample."""
