@@ -90,7 +90,7 @@ def parse():
     ap.add_argument("--plm-dtype", default="bf16", choices=["bf16", "fp32"], help="parameter dtype of the text encoder in --graphs 2: bf16 with fp32 master weights in the optimizer, or fp32 under autocast")
     ap.add_argument("--grad-comm", default="bf16", choices=["fp32", "bf16"], help="element type of the gradient all-reduce (N > 1): bf16 halves the bytes on the xGMI links (0.87 GB instead of 1.74 GB per step)")
     ap.add_argument("--other-configs", type=int, default=1, help="N = 1 only: after the timed region also run 4 steps of configs[3] and configs[4] (per-GPU legs, own processes) and report them under `other_configs`")
-    ap.add_argument("--parallel-fusion", type=int, default=1, help="capture independent halves of the fusion stack as parallel graph branches")
+    ap.add_argument("--parallel-fusion", type=int, default=0, help="1: capture independent halves of the fusion stack as parallel graph branches (round 4, same call: 64.9-65.0 ms per step against 63.5-63.7 without -- a fork / join pair of the replayed graph costs more than the 50-250-workgroup launches it lets overlap)")
     ap.add_argument("--discarded-swin-gradients", choices=["compute", "skip"], default="compute",
                     help="'compute' (default): the target step back-propagates through Swin as the reference does, although nothing reads those gradients "
                          "(train.py:20,33,140-143); 'skip': train_step's option that does not compute them (same training to fp32 rounding, reported as a "

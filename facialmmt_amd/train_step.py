@@ -152,7 +152,7 @@ class _Branch(torch.nn.Module):
         return self._fn(*args)
 
 
-def graph_multimodal(mm, sample_args, autocast_dtype=None, overlap_text=True, parallel_fusion=True):
+def graph_multimodal(mm, sample_args, autocast_dtype=None, overlap_text=True, parallel_fusion=False):
     """Capture forward and backward of the multimodal model as HIP graphs (torch.cuda.make_graphed_callables):
     its ~4000 small launches per step (24 PLM layers, 7 self-attention layers, 8 cross-modal layer calls) are
     host-bound when issued one by one (measured: 112 ms of host time per step against 105 ms of GPU work).
@@ -649,7 +649,7 @@ class GraphedTargetStep:
     Parity: tests/test_gpu_train_step.py walks this against the eager TargetStep (same losses, same parameters)."""
 
     def __init__(self, swin_model, multimodal_model, optimizer, scheduler, args, batch, autocast_dtype=None,
-                 overlap_text=True, parallel_fusion=True, averager=None, warmup_iters=2, masters=None, discarded_swin_gradients="compute",
+                 overlap_text=True, parallel_fusion=False, averager=None, warmup_iters=2, masters=None, discarded_swin_gradients="compute",
                  swin_cut: int = 0):
         """`averager`: GradientAverager(hooks=False) over the parameters the optimizer steps (default: the multimodal
         model's); `swin_cut`: with an exchange to hide (N > 1), the Swin stage behind which the backward graph is cut (0: the second

@@ -37,7 +37,7 @@ params = step_parameters(mm, masters)
 flat = GradientAverager(params, hooks=False)
 opt = HFAdamW(params, lr=torch.tensor(cfg.trg_lr, device=dev), weight_decay=cfg.weight_decay)
 step = GraphedTargetStep(swin, mm, opt, None, cfg, batch, autocast_dtype=torch.bfloat16, averager=flat, masters=masters,
-                         overlap_text=os.environ.get("OVERLAP_TEXT", "1") == "1", parallel_fusion=os.environ.get("PARALLEL_FUSION", "1") == "1")
+                         overlap_text=os.environ.get("OVERLAP_TEXT", "1") == "1", parallel_fusion=os.environ.get("PARALLEL_FUSION", "0") == "1")
 reps = int(os.environ.get("REPS", "40"))
 first, nbad = None, 0
 for it in range(reps):
