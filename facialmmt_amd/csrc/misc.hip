@@ -299,6 +299,75 @@ __global__ __launch_bounds__(256) void cast_batch_kernel(const CastDesc* __restr
 // lr, t and total_norm are device scalars (graph replays), the gradients are read once and NOT written back: against
 // clip_grad_norm_ + fused AdamW + the multi-tensor re-rounding of the bf16 text encoder this saves the scaling pass over the
 // gradients (read + write) and one pass over the fp32 parameters.
+// Gradient hand-over + the clip norm in one pass: every fresh gradient of the step (fp32 or bf16, wherever autograd allocated it) is
+// written -- or, with accumulation, added -- into its slot of the flat fp32 buffers the optimizer and the all-reduce work on, and the sum
+// of squares of what the slot then holds is formed on the way (per-block partial sums, finished in fixed order by ONE block).  Replaces
+// a multi-tensor copy (23 launches) and a multi-tensor L2 norm (22 launches + 8 small ones) over the same 435 M values: 1.3 ms of kernel
+// time in the step's serial tail, where nothing else runs.
+struct HoDesc {
+    const void* src; float* dst;
+    long long n;
+    int blk_begin, flags;                                       // flags bit 0: src is bf16 (else fp32); bit 1: dst += src (else dst = src)
+};
+__global__ __launch_bounds__(256) void grad_handover_kernel(const HoDesc* __restrict__ desc, int n_desc, float* __restrict__ partial) {
+    __shared__ float red[4];
+    int lo = 0, hi = n_desc - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (desc[mid].blk_begin <= (int)blockIdx.x) lo = mid;
+        else hi = mid - 1;
+    }
+    const HoDesc d = desc[lo];
+    const long long base = (long long)((int)blockIdx.x - d.blk_begin) * 4096;
+    const bool bf = d.flags & 1, acc = d.flags & 2;
+    const float* sf = reinterpret_cast<const float*>(d.src);
+    const bf16* sb = reinterpret_cast<const bf16*>(d.src);
+    float ss = 0.f;
+    const bool vec = base + 4096 <= d.n && ((reinterpret_cast<uintptr_t>(d.src) | reinterpret_cast<uintptr_t>(d.dst)) & 15) == 0;   // block-uniform
+    if (vec) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long long o = base + (long long)(i * 256 + threadIdx.x) * 4;
+            f32x4 v;
+            if (bf) {
+                const bf16x4 t = *reinterpret_cast<const bf16x4*>(sb + o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (float)t[e];
+            } else {
+                v = *reinterpret_cast<const f32x4*>(sf + o);
+            }
+            if (acc) v += *reinterpret_cast<const f32x4*>(d.dst + o);
+            *reinterpret_cast<f32x4*>(d.dst + o) = v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ss += v[e] * v[e];
+        }
+    } else {
+        for (long long o = base + threadIdx.x; o < base + 4096 && o < d.n; o += 256) {
+            float v = bf ? (float)sb[o] : sf[o];
+            if (acc) v += d.dst[o];
+            d.dst[o] = v;
+            ss += v * v;
+        }
+    }
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+// norm = sqrt(sum of the per-block partial sums): one block, fixed order (strided per-thread sums, then a tree over the 1024 threads)
+__global__ __launch_bounds__(1024) void sumsq_finish_kernel(const float* __restrict__ partial, int n, float* __restrict__ out) {
+    __shared__ float red[1024];
+    float a = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) a += partial[i];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sqrtf(red[0]);
+}
+
 struct AdamDesc {
     float* p; const void* g; float* m; float* v; bf16* low;     // low may be null
     long long n;
@@ -595,6 +664,16 @@ extern "C" int fmmt_cast_batch(int n_desc, int n_tiles, const void* desc, void* 
     if (n_desc <= 0 || n_tiles <= 0 || !desc) return FMMT_EINVAL;
     hipLaunchKernelGGL(cast_batch_kernel, dim3((unsigned)n_tiles), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        reinterpret_cast<const CastDesc*>(desc), n_desc);
+    FMMT_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int fmmt_grad_handover(int n_desc, int n_blocks, const void* desc, float* partial, float* norm_out, void* stream) {
+    if (n_desc <= 0 || n_blocks <= 0 || !desc || !partial || !norm_out) return FMMT_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(grad_handover_kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, reinterpret_cast<const HoDesc*>(desc), n_desc, partial);
+    FMMT_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(1024), 0, st, (const float*)partial, n_blocks, norm_out);
     FMMT_CHECK_LAUNCH();
     return 0;
 }

@@ -344,7 +344,7 @@ class VendorLayerNorm(torch.nn.LayerNorm):
 
 
 # Module constants (the probes patch them), not environment switches: each is the off-switch of one fused launch family
-PLM_COLSUM, PLM_LN, FUSED_ADAMW, PIN_SHADOWS = True, True, True, True
+PLM_COLSUM, PLM_LN, FUSED_ADAMW, PIN_SHADOWS, FUSED_HANDOVER = True, True, True, True, True
 
 
 def use_colsum_bias_gradients(module):
@@ -542,6 +542,59 @@ class HFAdamW(torch.optim.Optimizer):
         return sd
 
 
+class FusedHandOver:
+    """_hand_over_gradients + the clip norm as ONE pass (fmmt_grad_handover): every fresh gradient is written (accumulation: added) into its
+    slot of the flat fp32 buffers and the L2 norm of what the slots then hold lands in `norm_out` -- instead of a multi-tensor copy and a
+    multi-tensor norm over the same 435 M values (23 + 30 launches, 1.3 ms of kernel time in the step's serial tail).  Returns False --
+    nothing touched -- when a parameter has no gradient (its slot would keep a stale value the norm must still see) or a gradient is not a
+    contiguous fp32 / bf16 tensor: the caller then takes the two-pass path.  The tables are built from the gradients' addresses on every call
+    (warm-up passes, then once under capture: a captured step replays the copy of the one pinned table made then)."""
+
+    def __init__(self, n_records: int):
+        # pinned host tables, allocated HERE (a host allocation is illegal while a stream captures): two, used alternately -- an eager
+        # (warm-up) call waits for the stream before it rewrites one, the call under capture leaves its table untouched for the replays
+        self.hosts = [torch.empty(32 * max(1, n_records), dtype=torch.uint8).pin_memory() for _ in range(2)]
+        self.calls = 0
+        self.keep = []                                       # (device table, partial sums): alive as long as the graphs
+
+    @torch.no_grad()
+    def __call__(self, pairs, flat_view_of, accumulate: bool, norm_out) -> bool:
+        import numpy as np
+        from . import _lib
+        grads = []
+        for p, master in pairs:
+            g = p.grad
+            if g is None or not g.is_cuda or not g.is_contiguous() or g.dtype not in (torch.float32, torch.bfloat16) or g.numel() != flat_view_of[master].numel():
+                return False
+            grads.append(g)
+        if not grads:
+            return False
+        dev = grads[0].device
+        arr = np.zeros(len(grads), dtype=np.dtype([("src", "<u8"), ("dst", "<u8"), ("n", "<i8"), ("bb", "<i4"), ("flags", "<i4")]))
+        blocks = 0
+        for i, (g, (p, master)) in enumerate(zip(grads, pairs)):
+            arr[i] = (g.data_ptr(), flat_view_of[master].data_ptr(), g.numel(), blocks, (1 if g.dtype == torch.bfloat16 else 0) | (2 if accumulate else 0))
+            blocks += (g.numel() + 4095) // 4096
+        raw = torch.from_numpy(arr.view(np.uint8))
+        if raw.numel() > self.hosts[0].numel():
+            return False
+        if not torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream(dev).synchronize()     # an earlier eager call's copy has read its table
+        host = self.hosts[self.calls % 2][:raw.numel()]
+        self.calls += 1
+        host.copy_(raw)
+        table = torch.empty(raw.numel(), dtype=torch.uint8, device=dev)
+        table.copy_(host, non_blocking=True)
+        partial = torch.empty(blocks, dtype=torch.float32, device=dev)
+        rc = _lib.load().fmmt_grad_handover(len(grads), blocks, table.data_ptr(), partial.data_ptr(), norm_out.data_ptr(),
+                                            torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(rc, "fmmt_grad_handover")
+        self.keep = self.keep[-3:] + [(table, partial)]
+        for p, _ in pairs:
+            p.grad = None
+        return True
+
+
 class FusedClipAdamW:
     """clip_grad_norm_ + AdamW.step() (torch.optim.AdamW, or HFAdamW = the reference's transformers.AdamW) (+ the bf16 re-rounding of parameters stepped through fp32 masters) as one
     multi-tensor norm and ONE kernel launch (fmmt_adamw_batch): the gradients are read once and not scaled in place, the fp32
@@ -569,6 +622,7 @@ class FusedClipAdamW:
         self.m = [torch.zeros_like(p) for p in params]
         self.v = [torch.zeros_like(p) for p in params]
         self.norm = torch.zeros((), dtype=torch.float32, device=dev)
+        self.norm_ready = False                              # set by the caller when FusedHandOver already left the norm in self.norm
         recs, blocks = [], 0
         self.keep = (params, [low_of.get(id(p)) for p in params])
         for p, gr, m, v, low in zip(params, self.grads, self.m, self.v, self.keep[1]):
@@ -590,7 +644,9 @@ class FusedClipAdamW:
     def update(self):
         from . import ops
         self.step.add_(1.0)
-        self.norm.copy_(torch.nn.utils.get_total_norm(self.grads, 2.0, foreach=True))
+        if not self.norm_ready:
+            self.norm.copy_(torch.nn.utils.get_total_norm(self.grads, 2.0, foreach=True))
+        self.norm_ready = False
         ops.adamw_batch(self.n, self.blocks, self.desc, self.lr, self.step, self.norm, self.b1, self.b2, self.eps, self.wd, self.max_norm, self.hf)
 
 
@@ -685,6 +741,8 @@ class GraphedTargetStep:
         self.fused = None
         if FusedClipAdamW.eligible(optimizer, self.flat.params):
             self.fused = FusedClipAdamW(optimizer, self.flat.params, self.flat_view_of, low_of, args.clip)
+        # hand-over and clip norm in one pass -- only where nothing changes the flat buffers between the hand-over and the update (no exchange)
+        self.handover = FusedHandOver(len(self.pairs)) if (self.fused is not None and FUSED_HANDOVER and not bool(getattr(self.flat, "active", False))) else None
         self.accumulate = args.trg_accumulation_steps > 1
         self.mm.text_stream = None
         # inside ONE graph the fork / join below become parallel branches; which hardware queue the branches replay on is the
@@ -790,7 +848,10 @@ class GraphedTargetStep:
         loss = F.cross_entropy(logits.float(), labels) / args.trg_accumulation_steps
         if whole:                                            # one piece: autograd runs the text branch's backward beside Swin's
             loss.backward()
-            _hand_over_gradients(self.pairs, self.flat_view_of, self.accumulate)
+            if self.handover is not None and self.handover(self.pairs, self.flat_view_of, self.accumulate, self.fused.norm):
+                self.fused.norm_ready = True
+            else:
+                _hand_over_gradients(self.pairs, self.flat_view_of, self.accumulate)
             return loss.detach(), new_mask, None
         # backward, first piece: every leaf the optimizer steps plus Swin's output (the autograd graph below `preds` -- Swin -- is
         # left untouched, with its saved activations, for the second piece)
@@ -926,6 +987,7 @@ class GraphedAuxStep:
         self.flat_view_of = {p: p.grad for p in self.flat.params}
         self.pairs = [(p, p) for p in self.flat.params]
         self.fused = FusedClipAdamW(optimizer, self.flat.params, self.flat_view_of, {}, args.clip) if FusedClipAdamW.eligible(optimizer, self.flat.params) else None
+        self.handover = FusedHandOver(len(self.flat.params)) if (self.fused is not None and FUSED_HANDOVER and not bool(getattr(self.flat, "active", False))) else None
         for p in self.flat.params:
             p.grad = None
         self.accumulate = args.aux_accumulation_steps > 1
@@ -961,7 +1023,10 @@ class GraphedAuxStep:
             self.shadows.refresh()
         loss = self.swin(self.images, False, self.labels, F.cross_entropy) / self.args.aux_accumulation_steps
         loss.backward()
-        _hand_over_gradients(self.pairs, self.flat_view_of, self.accumulate)
+        if self.handover is not None and self.handover(self.pairs, self.flat_view_of, self.accumulate, self.fused.norm):
+            self.fused.norm_ready = True
+        else:
+            _hand_over_gradients(self.pairs, self.flat_view_of, self.accumulate)
         return loss.detach()
 
     def _update(self):

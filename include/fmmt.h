@@ -346,6 +346,14 @@ int fmmt_layernorm_bwd_bf16(int M, int C, float eps, const void* dy, const void*
  * tile_begin = tiles of all earlier records; n_tiles = their total.  The caller builds the table once. */
 int fmmt_cast_batch(int n_desc, int n_tiles, const void* desc, void* stream);
 
+/* Gradient hand-over + the norm of `clip_grad_norm_` in one pass (train.py:135-140: the backward's gradients -> the buffers the optimizer
+ * reads; the reference's clip_grad_norm_ computes this norm over the same values): every record's gradient is written (flags bit 1: added)
+ * into its fp32 slot and norm_out[0] = sqrt(sum of squares of everything the slots then hold).  desc: DEVICE array of n_desc records
+ *   { const void* src; float* dst; int64 n; int32 blk_begin, flags; }     (32 bytes; flags bit 0: src is bf16, else fp32)
+ * one block per 4096 elements, blk_begin = blocks of all earlier records, n_blocks = their total; partial: n_blocks floats of scratch.
+ * Fixed summation order (per-block sums, finished by one block): replays are bit-identical. */
+int fmmt_grad_handover(int n_desc, int n_blocks, const void* desc, float* partial, float* norm_out, void* stream);
+
 /* Gradient clipping + AdamW + bf16 re-rounding of the parameters in one launch over every tensor of the step's optimizer.
  * Replaces `clip_grad_norm_(model.parameters(), clip)` (its scaling pass; the norm itself is the caller's, a device scalar) and
  * `optimizer.step()` (train.py:135-143), and the re-rounding of bf16 parameters that are stepped through fp32 masters.

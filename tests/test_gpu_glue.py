@@ -302,3 +302,55 @@ def test_bf16_layernorm_backward_for_the_text_encoder(dev):
         e_ref = (outs[0][1].float() - x32.grad).abs().max().item()
         e_new = (outs[1][1].float() - x32.grad).abs().max().item()
         assert e_new <= 1.5 * e_ref + 1e-3 * x32.grad.abs().max().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_gradient_hand_over_and_clip_norm_in_one_pass(dev, accumulate):
+    """train_step.FusedHandOver (fmmt_grad_handover) against _hand_over_gradients + get_total_norm (train.py:135-140): fp32 and bf16 gradients,
+    sizes off the 4096-element block and the 4-element vector (1, 5, 4096, 4097, 70001), overwrite and accumulate; the slots bit for bit, the
+    norm to fp32 summation order; a missing gradient makes it decline without touching anything; two calls give bit-identical results."""
+    from facialmmt_amd import train_step as TS
+    g = torch.Generator(device="cpu").manual_seed(17)
+    shapes = [((1,), torch.float32), ((5,), torch.bfloat16), ((64, 64), torch.float32), ((4097,), torch.bfloat16), ((70001,), torch.float32), ((130, 70), torch.bfloat16)]
+    params = [torch.nn.Parameter(torch.zeros(sh, device=dev, dtype=dt)) for sh, dt in shapes]
+    grads = [torch.randn(sh, generator=g).to(dev, dt) for sh, dt in shapes]
+    def slots(fill):
+        off, views = 0, {}
+        n = sum((p.numel() + 3) // 4 * 4 for p in params)
+        flat = torch.full((n,), 0.0, device=dev)
+        for p in params:
+            views[p] = flat[off:off + p.numel()].view_as(p)
+            views[p].copy_(fill[id(p)])
+            off += (p.numel() + 3) // 4 * 4
+        return flat, views
+    old = {id(p): torch.randn(p.shape, generator=g).to(dev) if accumulate else torch.zeros(p.shape, device=dev) for p in params}
+    pairs = [(p, p) for p in params]
+    # two-pass reference
+    flat_r, views_r = slots(old)
+    for p, gr in zip(params, grads):
+        p.grad = gr.clone()
+    TS._hand_over_gradients(pairs, views_r, accumulate)
+    norm_r = torch.nn.utils.get_total_norm([views_r[p] for p in params], 2.0)
+    outs = []
+    for rep in range(2):
+        flat_f, views_f = slots(old)
+        for p, gr in zip(params, grads):
+            p.grad = gr.clone()
+        ho = TS.FusedHandOver(len(pairs))
+        norm = torch.zeros((), device=dev)
+        assert ho(pairs, views_f, accumulate, norm)
+        torch.cuda.synchronize()
+        assert all(p.grad is None for p in params)
+        assert torch.equal(flat_f, flat_r)
+        assert abs(norm.item() - norm_r.item()) <= 1e-5 * norm_r.item()
+        outs.append(norm.clone())
+    assert torch.equal(outs[0], outs[1])
+    # a parameter without a gradient: declined, nothing touched
+    flat_f, views_f = slots(old)
+    for p, gr in zip(params, grads):
+        p.grad = gr.clone()
+    params[2].grad = None
+    before = flat_f.clone()
+    assert not TS.FusedHandOver(len(pairs))(pairs, views_f, accumulate, torch.zeros((), device=dev))
+    assert torch.equal(flat_f, before) and params[0].grad is not None

@@ -108,3 +108,14 @@ for b in range(nb):
         top = short(c.most_common(1)[0][0]) if c else "-"
         cells.append(f"q{q}: {busy:5.0f} {top:34s}")
     print(f"  {b:3d} | " + " | ".join(cells))
+# the launches in front of the optimizer's one kernel (hand-over, norm): name, start offset, duration, gap to the previous launch's end
+ad = [i for i, r in enumerate(step) if "adamw_batch" in r[2]]
+if ad:
+    i1 = ad[-1]
+    i0 = max(0, i1 - 70)
+    print("launches in front of adamw_batch_kernel (offset ms | us | gap us | queue | kernel):")
+    prev_end = None
+    for s_, e_, n, q, st in step[i0:i1 + 2]:
+        gap = (s_ - prev_end) / 1e3 if prev_end is not None else 0.0
+        print(f"  {(s_ - t0) / 1e6:8.3f} {(e_ - s_) / 1e3:8.1f} {gap:8.1f}  q{q}  {short(n)}")
+        prev_end = max(prev_end or e_, e_)
