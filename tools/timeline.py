@@ -119,3 +119,23 @@ if ad:
         gap = (s_ - prev_end) / 1e3 if prev_end is not None else 0.0
         print(f"  {(s_ - t0) / 1e6:8.3f} {(e_ - s_) / 1e3:8.1f} {gap:8.1f}  q{q}  {short(n)}")
         prev_end = max(prev_end or e_, e_)
+# TL_WINDOW="a,b" (ms offsets into the step): every launch that starts inside, in start order, with the idle time in front of it on ANY queue
+import os as _os
+if _os.environ.get("TL_WINDOW"):
+    a_, b_ = [float(v) for v in _os.environ["TL_WINDOW"].split(",")]
+    print(f"launches in [{a_}, {b_}) ms (offset ms | us | gap us | queue | kernel):")
+    prev_end = None
+    agg = collections.Counter(); cnt2 = collections.Counter()
+    for s_, e_, n, q, st in step:
+        off = (s_ - t0) / 1e6
+        if off < a_ or off >= b_:
+            if off < a_:
+                prev_end = max(prev_end or e_, e_)
+            continue
+        gap = (s_ - prev_end) / 1e3 if prev_end is not None else 0.0
+        print(f"  {off:8.3f} {(e_ - s_) / 1e3:8.1f} {max(gap, 0.0):8.1f}  q{q}  {short(n)}")
+        prev_end = max(prev_end or e_, e_)
+        agg[short(n)] += e_ - s_; cnt2[short(n)] += 1
+    print("  by kernel (count, total us):")
+    for n, v in agg.most_common(30):
+        print(f"    {cnt2[n]:4d} {v / 1e3:9.1f}  {n}")
