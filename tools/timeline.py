@@ -99,6 +99,11 @@ def short(n):
     for k in ("_ZN12_GLOBAL__N_1",):
         if n.startswith(k):
             n = n[len(k):].lstrip("0123456789")
+    if n.startswith("at::native::") or "elementwise" in n:      # keep the functor: "vectorized_elementwise_kernel<4, CUDAFunctor_add<float>"
+        import re as _re
+        m = _re.search(r"(\w+Functor\w*<[^,>]*|\w+_kernel_cuda\w*|\w+KernelImpl\w*|masked_scale_kernel<[^,>]*,[^,>]*|FillFunctor<[^>]*>|\w+_copy_kernel\w*)", n)
+        if m:
+            return (n.split("<")[0].replace("at::native::", "")[:22] + ":" + m.group(1))[:60]
     return n[:34]
 for b in range(nb):
     cells = []
@@ -106,7 +111,7 @@ for b in range(nb):
         c = bins[b][q]
         busy = sum(c.values()) / 1e3
         top = short(c.most_common(1)[0][0]) if c else "-"
-        cells.append(f"q{q}: {busy:5.0f} {top:34s}")
+        cells.append(f"q{q}: {busy:5.0f} {top[:34]:34s}")
     print(f"  {b:3d} | " + " | ".join(cells))
 # the launches in front of the optimizer's one kernel (hand-over, norm): name, start offset, duration, gap to the previous launch's end
 ad = [i for i, r in enumerate(step) if "adamw_batch" in r[2]]
