@@ -341,6 +341,9 @@ class KernelTimer:
             "fmmt_colsum": lambda a: ("", 0.0, a[2] * a[3] * float(es(a))),
             "fmmt_cast_batch": lambda a: ("", 0.0, a[1] * 4096 * 6.0),                           # 64 x 64 tiles: fp32 in, bf16 out
             "fmmt_adamw_batch": lambda a: ("", 0.0, a[1] * 4096 * 30.0),                         # p, m, v read + written, g read, bf16 twin written
+            "fmmt_grad_handover": lambda a: ("", 0.0, a[1] * 4096 * 7.0),                        # gradient in (bf16 or fp32: ~3 B on this model's mix), fp32 slot out
+            # d(LN out) = dz . W (2 M K C), LayerNorm', residual: dz, x, dres in, dx out
+            "fmmt_linear_ln_bwd": lambda a: (f"<C={a[2]},K={a[3]}>", 2.0 * a[1] * a[2] * a[3], a[1] * (a[3] + a[2] * (2 + nz(a[10]))) * 2.0),
         }
 
     def install_abi(self):
@@ -355,7 +358,7 @@ class KernelTimer:
                     if not timer.enabled:
                         return fn(*a)
                     suffix, fl, by = cost(a)
-                    fp32 = name not in ("fmmt_layernorm_bwd_bf16", "fmmt_cast_batch", "fmmt_adamw_batch") and a[0] == 0
+                    fp32 = name not in ("fmmt_layernorm_bwd_bf16", "fmmt_cast_batch", "fmmt_adamw_batch", "fmmt_grad_handover") and a[0] == 0
                     tag = name + ("<fp32>" if fp32 else "") + suffix
                     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     s.record()
@@ -1005,7 +1008,7 @@ def kernel_symbol(bn):
                  "fmmt_mlp_ln_fwd": "mlp_fused_fwd_kernel<LN>", "fmmt_mlp_bwd_input": "mlp_fused_bwd_kernel", "fmmt_mlp_ln_bwd_input": "mlp_fused_bwd_kernel<LN'>",
                  "fmmt_window_block_attn_bwd": "wattn_mfma_bwd_kernel<recompute>", "fmmt_patch_embed_ln_fwd": "patch_embed_ln_kernel",
                  "fmmt_patch_embed_u8": "patch_embed_u8_kernel", "fmmt_mha_fwd": "mha_mfma_fwd_kernel", "fmmt_mha_bwd": "mha_mfma_bwd_kernel",
-                 "fmmt_adamw_batch": "adamw_batch_kernel", "fmmt_cast_batch": "cast_batch_kernel", "fmmt_batchnorm1d_fwd": "bn1d_fwd_kernel",
+                 "fmmt_adamw_batch": "adamw_batch_kernel", "fmmt_cast_batch": "cast_batch_kernel", "fmmt_grad_handover": "grad_handover_kernel", "fmmt_linear_ln_bwd": "lin_lnbwd_kernel", "fmmt_batchnorm1d_fwd": "bn1d_fwd_kernel",
                  "fmmt_batchnorm1d_bwd": "bn1d_bwd_kernel", "fmmt_linear_wgrad_finish": "reduce_partials_kernel", "fmmt_colsum": "colsum_kernel",
                  "fmmt_layernorm_bwd_bf16": "lnp_bwd_kernel", "fmmt_linear_fwd_splitk": "linear_splitk_kernel", "fmmt_linear_wgrad": "linear_tn_few_kernel"}
         return names.get(base, base) + ("<" + rest if rest else "")
