@@ -1013,7 +1013,8 @@ int p256_plan(const LinArgs& a) {
     // epilogue is ~11 k VALU cycles per wave tile against 4.6 k MFMA cycles of a K = 384 tile, and one workgroup per CU has no
     // second workgroup whose K loop could run under it; 0 = none.
     // (round 4: mode 2 re-measured with gelu' from an LDS table in this kernel's unused epilogue scratch instead of the polynomial: 125440 x 1536 x 384
-    //  328 -> 364 us, 501760 x 768 x 192 522 -> 561, 31360 x 3072 x 768 267 -> 253 -- still a loss where it matters; stays 1)
+    //  328 -> 364 us, 501760 x 768 x 192 522 -> 561, 31360 x 3072 x 768 267 -> 253 -- still a loss where it matters; stays 1.
+    //  And once more with the polynomial GELU' that replaced the tables: 314 -> 340, 491 -> 529, 258 -> 241 us.)
     static const int ops_mode = fmmt_const("FMMT_NT_P256_OPS", 1);
     const bool has_op = a.res || a.aux || a.rowscale;
     if (has_op && (!ops_mode || (a.aux && (ops_mode < 2 || a.res)) || a.ldres % 8 || a.ldaux % 8)) return 0;

@@ -10,7 +10,7 @@
 // owns tokens [32 w, 32 w + 32) for both products; product 1 is D1[hidden][token] with the hidden-row permutation chan_of<8> that makes
 // a lane's two accumulator tiles the 8 consecutive hidden channels of its token -- the B fragment of product 2; product 2 accumulates
 // D2[channel][token] with chan_of<4 NT2>; LayerNorm rows sit in the four lanes li + 16 g.  What the trait replaces: fragments of 8
-// fp32, the 32-deep product as 8 x v_mfma_f32_16x16x4_f32, erf / its derivative instead of the LDS tables; and the weights are read
+// fp32, the 32-deep product as 8 x v_mfma_f32_16x16x4_f32, erf / its derivative instead of the packed polynomials; and the weights are read
 // as fragments straight from memory instead of streaming through the DMA ring (how operands reach the CU is not part of the
 // algorithm being checked).  Selected by the FMMT_GENERIC dtype flag (bf16) or by dtype FMMT_F32 on the fused entry points.
 #include "gemm_common.h"
