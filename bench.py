@@ -212,7 +212,7 @@ def tn_dma_tile(M, N, K, scaled, rows_per_scale, x_gelu):
     else:
         return None
     tiles = (N // tn) * (K // tk)
-    if tiles < 4 or tiles > 128:
+    if tiles < 2 or tiles > 128:
         return None
     splits = 256 // tiles
     chunk = (-(-M // splits) + 63) // 64 * 64

@@ -27,7 +27,7 @@ for (M, N, K, scaled) in SHAPES:
         e1.record(); torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / 10)
     tot += best
-    gb = M * (N + K) * 2 / 1e9
+    gb = M * (N + K) * 2 / 1e6       # MB; / ms = GB/s
     print(f"  tn01 {M:8d}x{N:4d}x{K:4d}{' scaled' if scaled else '       '}: {best*1e3:7.1f} us  {gb/best:6.0f} GB/s  {2.0*M*N*K/best/1e9:6.1f} TF/s", flush=True)
     del dy, x
 print(f"  total {tot*1e3:.1f} us")
