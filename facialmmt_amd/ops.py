@@ -372,7 +372,7 @@ def mlp_fused_raw(x2, w1l, b1, w2l, b2, res2, rowscale, rows_per_scale, h_pre, h
 
 _MLP_FUSED = True            # module constants, not environment switches: the tests and probes patch them (False = always the two-launch form)
 # fp32 (parity) models take the fused Mlp entry points too -- their element-type-generic instantiations, csrc/mlp_ref.hip -- so that the
-# fp32 goldens reach the fused kernels' algorithm at 1e-3 (0: LayerNorm + two GEMM launches, as in rounds 1-3)
+# fp32 goldens reach the fused kernels' algorithm at 1e-3 (False: LayerNorm + two GEMM launches, as in rounds 1-3; see set_fp32_route)
 _MLP_F32 = True
 
 
@@ -728,10 +728,21 @@ def window_attn_core(qkv, table, index_i32, mask, n_img, H, W, num_heads, shift,
 _WBLOCK = True               # False = always the four-launch form
 _WBLOCK_WIDTHS = (96,)       # (96, 192): the four-launch block op at stage 1 as well
 # fp32 (parity) models take the fused forward too -- its element-type-generic instantiation, csrc/wblock_ref.hip -- so that every fp32 golden of
-# the stage-0 blocks and of the whole Swin reaches the fused kernel's algorithm at 1e-3 (0: the four fp32 launches, as in rounds 1-3)
+# the stage-0 blocks and of the whole Swin reaches the fused kernel's algorithm at 1e-3 (False: the four fp32 launches, as in rounds 1-3)
 _WBLOCK_F32 = True
 _WBLOCK_BWD = True           # False: the backward re-computes qkv with a GEMM and runs fmmt_window_attn_bwd
 _WBLOCK_LNBWD = True         # False: d(LN out) GEMM and LayerNorm backward as two launches
+
+
+def set_fp32_route(fused: bool) -> None:
+    """Which kernels an fp32 (parity-mode) model runs at Swin stages 0/1.  True (default): the element-type-generic restatements of the fused
+    bf16 kernels (csrc/wblock_ref.hip, mlp_ref.hip, wattn_bwd_ref.hip) -- the parity instantiations the goldens are held to; they read weights
+    as fragments from memory, spill, and run several times slower than the bf16 kernels (they exist to be checked, not to be fast).
+    False: the rounds 1-3 fp32 path (LayerNorm + GEMM launches + the VALU window-attention kernels), ~2x faster in fp32 and a different
+    algorithm from what the benchmark runs.  bf16 models are not affected."""
+    global _MLP_F32, _WBLOCK_F32
+    _MLP_F32 = bool(fused)
+    _WBLOCK_F32 = bool(fused)
 
 
 def window_block_fusable(x, C, num_heads, window_size, shift, mask, mask_is_shift):

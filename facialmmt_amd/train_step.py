@@ -477,6 +477,9 @@ def _reset_optimizer_state(opt):
         for v in st.values():
             if torch.is_tensor(v):
                 v.zero_()
+    for g in opt.param_groups:                              # HFAdamW keeps its (device) step counter in the group, not in opt.state
+        if torch.is_tensor(g.get("step")):
+            g["step"].zero_()
 
 
 class HFAdamW(torch.optim.Optimizer):
@@ -530,6 +533,23 @@ class HFAdamW(torch.optim.Optimizer):
                 torch._foreach_add_(ps, dec)
         return loss
 
+    def load_hf_state_dict(self, sd):
+        """load a `transformers.AdamW` state dict (the reference's checkpoints, train.py:316-331: an int `step` per parameter, none in the
+        groups): the per-parameter counters must agree within a group and become the group's device counter, so that the next step()
+        continues the bias correction at t + 1 instead of restarting it with non-zero moments"""
+        sd = {"state": {k: dict(v) for k, v in sd["state"].items()}, "param_groups": [dict(g) for g in sd["param_groups"]]}
+        steps = []
+        for g in sd["param_groups"]:
+            ns = {int(sd["state"][i].pop("step")) for i in g["params"] if i in sd["state"] and "step" in sd["state"][i]}
+            if len(ns) > 1:
+                raise ValueError(f"per-parameter step counters of one group disagree: {sorted(ns)}")
+            steps.append(ns.pop() if ns else None)
+        self.load_state_dict(sd)
+        for g, n in zip(self.param_groups, steps):
+            if n is not None:
+                dev = g["params"][0].device
+                g["step"] = torch.full((), float(n), dtype=torch.float32, device=dev)
+
     def hf_state_dict(self):
         """`state_dict()` in transformers.AdamW's layout: an int `step` per parameter beside exp_avg / exp_avg_sq, none in the groups"""
         sd = self.state_dict()
@@ -554,6 +574,10 @@ class FusedHandOver:
         # pinned host tables, allocated HERE (a host allocation is illegal while a stream captures): two, used alternately -- an eager
         # (warm-up) call waits for the stream before it rewrites one, the call under capture leaves its table untouched for the replays
         self.hosts = [torch.empty(32 * max(1, n_records), dtype=torch.uint8).pin_memory() for _ in range(2)]
+        # a call UNDER CAPTURE gets a table of its own that no later call rewrites (the captured copy node re-reads it on every replay: an
+        # eager call after the capture -- a re-capture, a debugging pass -- must not land in it); four captures per object, then it raises
+        self.capture_hosts = [torch.empty(32 * max(1, n_records), dtype=torch.uint8).pin_memory() for _ in range(4)]
+        self.captures = 0
         self.calls = 0
         self.keep = []                                       # (device table, partial sums): alive as long as the graphs
 
@@ -578,10 +602,15 @@ class FusedHandOver:
         raw = torch.from_numpy(arr.view(np.uint8))
         if raw.numel() > self.hosts[0].numel():
             return False
-        if not torch.cuda.is_current_stream_capturing():
+        if torch.cuda.is_current_stream_capturing():
+            if self.captures >= len(self.capture_hosts):
+                raise RuntimeError("FusedHandOver: more captures than pinned capture tables")
+            host = self.capture_hosts[self.captures][:raw.numel()]
+            self.captures += 1
+        else:
             torch.cuda.current_stream(dev).synchronize()     # an earlier eager call's copy has read its table
-        host = self.hosts[self.calls % 2][:raw.numel()]
-        self.calls += 1
+            host = self.hosts[self.calls % 2][:raw.numel()]
+            self.calls += 1
         host.copy_(raw)
         table = torch.empty(raw.numel(), dtype=torch.uint8, device=dev)
         table.copy_(host, non_blocking=True)
