@@ -58,6 +58,9 @@ SIGNATURES = {
     "fmmt_cast_batch": (_i, [_i, _i, _p, _p]),
     "fmmt_layernorm_bwd_bf16_workspace": (_sz, [_i, _i]),
     "fmmt_layernorm_bwd_bf16": (_i, [_i, _i, _f, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "fmmt_plm_dropadd_ln_fwd": (_i, [_i, _i, _f, _p, _p, _p, _p, _f, _u64, _p, _u64, _p, _p, _p]),
+    "fmmt_plm_dropadd_ln_bwd_workspace": (_sz, [_i, _i]),
+    "fmmt_plm_dropadd_ln_bwd": (_i, [_i, _i, _f, _p, _p, _p, _f, _u64, _p, _u64, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "fmmt_grad_handover": (_i, [_i, _i, _p, _p, _p, _p]),
     "fmmt_adamw_batch": (_i, [_i, _i, _p, _p, _p, _p, _f, _f, _f, _f, _f, _i, _p]),
     "fmmt_resize_table": (_i, [_i, _i, _i, _p, _p]),

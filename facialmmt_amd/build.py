@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libfmmt_hip.so")
-SOURCES = ["gemm.hip", "layernorm.hip", "attn.hip", "wattn_mfma.hip", "wattn_bwd_ref.hip", "wblock.hip", "wblock_ref.hip", "mha_mfma.hip", "misc.hip", "preproc.hip", "mlp_fused.hip", "mlp_ref.hip", "patch_ln.hip", "lin_lnbwd.hip"]
+SOURCES = ["gemm.hip", "layernorm.hip", "attn.hip", "wattn_mfma.hip", "wattn_bwd_ref.hip", "wblock.hip", "wblock_ref.hip", "mha_mfma.hip", "misc.hip", "preproc.hip", "mlp_fused.hip", "mlp_ref.hip", "patch_ln.hip", "lin_lnbwd.hip", "plm_fused.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast"]
 
 
@@ -41,7 +41,7 @@ def build(force: bool = False, verbose: bool = True, tag: str = "") -> str:
 
     def cc(job):
         src, obj = job
-        cmd = [hipcc] + FLAGS + os.environ.get("FMMT_CFLAGS", "").split() + ["-c", src, "-o", obj]      # FMMT_CFLAGS: development builds (e.g. -DFMMT_P256_TRACE)
+        cmd = [hipcc] + FLAGS + os.environ.get("FMMT_CFLAGS", "").split() + ["-c", src, "-o", obj]      # FMMT_CFLAGS: development builds
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

@@ -1,0 +1,227 @@
+// The tail of a BERT / RoBERTa sublayer as one launch per direction (bf16 module, bf16 affine parameters):
+//     y = LayerNorm( dropout(h) + res )            transformers' RobertaSelfOutput / RobertaOutput (BertSelfOutput / BertOutput), src/models.py:75-91
+// h = the sublayer's dense output (its GEMM stays with the vendor library, R4.3: hipBLASLt owns the 2048-token shapes).
+// Stock PyTorch runs this as fused_dropout + add + layer_norm forward (3 launches) and, backward, LayerNorm' (2-3), masked_scale (1) and the dense
+// bias' column sum (1): 48 sublayers x ~8 dependent launches of 4-25 us in a chain that runs largely alone on the GPU (the text encoder's forward in
+// front of Swin's, the tail of its backward behind it).  Here: one forward launch, one backward launch + one reduction.
+//   * the dropout mask is not stored: keep(e) = hash_uniform(seed, salt + e) >= p, replayed bit for bit in the backward (the counter-based generator of
+//     the attention dropout, fmmt_common.h); `seed` is a device int64 word (graph-replay safe), `salt` separates the call sites;
+//   * rounding follows the bf16 module op by op: t = bf16(h * keep / (1 - p)), x = bf16(t + res), LayerNorm on x in fp32, y = bf16(...);
+//   * backward: dx = LayerNorm'(dy) rounded to bf16 IS the residual branch's gradient; dh = bf16(dx * keep / (1 - p)); partial sums of d gamma, d beta
+//     and of the dense bias' gradient colsum(dh) per block, finished in a fixed order by the reduction.
+// One wave per token row, rows grid-strided; C % 8 == 0, C <= 2048.
+#include "fmmt_common.h"
+#include "../../include/fmmt.h"
+
+namespace {
+
+constexpr int PF_MAXV = 4;                                  // 8-element vectors per lane: C <= 2048
+
+
+
+__global__ __launch_bounds__(256) void plm_dropadd_ln_fwd_kernel(int M, int C, float eps, const bf16* __restrict__ h, const bf16* __restrict__ res,
+                                                                 const bf16* __restrict__ gamma, const bf16* __restrict__ beta, float p,
+                                                                 unsigned long long seed_i, const unsigned long long* __restrict__ seed_ptr, unsigned long long salt,
+                                                                 bf16* __restrict__ xsum, bf16* __restrict__ y) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = C / 8;
+    const float invC = 1.0f / (float)C, scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    const unsigned long long seed = seed_ptr ? seed_ptr[0] : seed_i;
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        bf16x8 xv[PF_MAXV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < PF_MAXV; ++i) {
+            const int v = lane + 64 * i;
+            if (v < nv) {
+                const size_t o = (size_t)row * C + v * 8;
+                const bf16x8 hv = *reinterpret_cast<const bf16x8*>(h + o), rv = *reinterpret_cast<const bf16x8*>(res + o);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float t = (float)hv[e];
+                    if (p > 0.f) t = hash_uniform(seed, salt + o + e) >= p ? (float)(bf16)(t * scale) : 0.f;
+                    xv[i][e] = (bf16)(t + (float)rv[e]);
+                    s += (float)xv[i][e];
+                }
+                *reinterpret_cast<bf16x8*>(xsum + o) = xv[i];
+            }
+        }
+        const float mean = wave_sum(s) * invC;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < PF_MAXV; ++i)
+            if (lane + 64 * i < nv) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = (float)xv[i][e] - mean; q += d * d; }
+            }
+        const float rstd = rsqrtf(wave_sum(q) * invC + eps);
+#pragma unroll
+        for (int i = 0; i < PF_MAXV; ++i) {
+            const int v = lane + 64 * i;
+            if (v < nv) {
+                const bf16x8 gm = *reinterpret_cast<const bf16x8*>(gamma + v * 8), bt = *reinterpret_cast<const bf16x8*>(beta + v * 8);
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (bf16)(((float)xv[i][e] - mean) * rstd * (float)gm[e] + (float)bt[e]);
+                *reinterpret_cast<bf16x8*>(y + (size_t)row * C + v * 8) = o;
+            }
+        }
+    }
+}
+
+// part: [block][3][C] fp32 (d gamma, d beta, d dense-bias)
+__global__ __launch_bounds__(256) void plm_dropadd_ln_bwd_kernel(int M, int C, float eps, const bf16* __restrict__ dy, const bf16* __restrict__ x,
+                                                                 const bf16* __restrict__ gamma, float p, unsigned long long seed_i,
+                                                                 const unsigned long long* __restrict__ seed_ptr, unsigned long long salt, bf16* __restrict__ dx, bf16* __restrict__ dh,
+                                                                 float* __restrict__ part) {
+    __shared__ float red[4][3][64 * 8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = C / 8;
+    float dg[PF_MAXV][8], db[PF_MAXV][8], dc[PF_MAXV][8];
+#pragma unroll
+    for (int i = 0; i < PF_MAXV; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dg[i][e] = db[i][e] = dc[i][e] = 0.f;
+    const float invC = 1.0f / (float)C, scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    const unsigned long long seed = seed_ptr ? seed_ptr[0] : seed_i;
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        bf16x8 xv[PF_MAXV], gv[PF_MAXV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < PF_MAXV; ++i) {
+            const int v = lane + 64 * i;
+            if (v < nv) {
+                xv[i] = *reinterpret_cast<const bf16x8*>(x + (size_t)row * C + v * 8);
+                gv[i] = *reinterpret_cast<const bf16x8*>(dy + (size_t)row * C + v * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += (float)xv[i][e];
+            }
+        }
+        const float mean = wave_sum(s) * invC;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < PF_MAXV; ++i)
+            if (lane + 64 * i < nv) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = (float)xv[i][e] - mean; q += d * d; }
+            }
+        const float rstd = rsqrtf(wave_sum(q) * invC + eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < PF_MAXV; ++i) {
+            const int v = lane + 64 * i;
+            if (v < nv) {
+                const bf16x8 gm = *reinterpret_cast<const bf16x8*>(gamma + v * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xh = ((float)xv[i][e] - mean) * rstd, dyv = (float)gv[i][e], g = dyv * (float)gm[e];
+                    s1 += g;
+                    s2 += g * xh;
+                    dg[i][e] += dyv * xh;
+                    db[i][e] += dyv;
+                }
+            }
+        }
+        s1 = wave_sum(s1) * invC;
+        s2 = wave_sum(s2) * invC;
+#pragma unroll
+        for (int i = 0; i < PF_MAXV; ++i) {
+            const int v = lane + 64 * i;
+            if (v < nv) {
+                const size_t o = (size_t)row * C + v * 8;
+                const bf16x8 gm = *reinterpret_cast<const bf16x8*>(gamma + v * 8);
+                bf16x8 ox, oh;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xh = ((float)xv[i][e] - mean) * rstd, g = (float)gv[i][e] * (float)gm[e];
+                    ox[e] = (bf16)(rstd * (g - s1 - xh * s2));
+                    float t = (float)ox[e];
+                    if (p > 0.f) t = hash_uniform(seed, salt + o + e) >= p ? t * scale : 0.f;
+                    oh[e] = (bf16)t;
+                    dc[i][e] += (float)oh[e];
+                }
+                *reinterpret_cast<bf16x8*>(dx + o) = ox;
+                *reinterpret_cast<bf16x8*>(dh + o) = oh;
+            }
+        }
+    }
+    float* pb = part + (size_t)blockIdx.x * 3 * C;
+#pragma unroll
+    for (int i = 0; i < PF_MAXV; ++i) {
+        if (64 * i >= nv) break;
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red[wave][0][lane * 8 + e] = dg[i][e];
+            red[wave][1][lane * 8 + e] = db[i][e];
+            red[wave][2][lane * 8 + e] = dc[i][e];
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < 3 * 512; t += 256) {
+            const int which = t >> 9, col = t & 511, ch = i * 512 + col;
+            if (ch < C) pb[which * C + ch] = (red[0][which][col] + red[1][which][col]) + (red[2][which][col] + red[3][which][col]);
+        }
+    }
+}
+
+// 1024 threads = 32 columns x 32 partial groups, fixed-order tree over the blocks' [3][C] partials
+__global__ __launch_bounds__(1024) void plm_dropadd_ln_reduce_kernel(const float* __restrict__ part, int nblocks, int C, bf16* __restrict__ dgamma,
+                                                                    bf16* __restrict__ dbeta, bf16* __restrict__ dbias) {
+    __shared__ float red[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + tx;                     // column of the [3][C] triple
+    float a = 0.f;
+    if (i < 3 * C)
+        for (int b = ty; b < nblocks; b += 32) a += part[(size_t)b * 3 * C + i];
+    red[ty][tx] = a;
+    __syncthreads();
+    if (ty == 0 && i < 3 * C) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 32; ++g) t += red[g][tx];
+        if (i < C) dgamma[i] = (bf16)t;
+        else if (i < 2 * C) dbeta[i - C] = (bf16)t;
+        else if (dbias) dbias[i - 2 * C] = (bf16)t;
+    }
+}
+
+int pf_blocks(int M) { return M / 4 < 1 ? 1 : (M / 4 > 256 ? 256 : M / 4); }
+bool pf_misaligned(const void* a, const void* b, const void* c, const void* d) {
+    return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) | reinterpret_cast<uintptr_t>(d)) & 15) != 0;
+}
+
+}  // namespace
+
+extern "C" int fmmt_plm_dropadd_ln_fwd(int M, int C, float eps, const void* h, const void* res, const void* gamma, const void* beta, float p,
+                                       uint64_t seed, const uint64_t* seed_dev, uint64_t salt, void* xsum, void* y, void* stream) {
+    if (M <= 0 || C <= 0 || C % 8 || C > 2048 || !(p >= 0.f && p < 1.f)) return FMMT_EINVAL;
+    if (!h || !res || !gamma || !beta || !xsum || !y) return FMMT_EINVAL;
+    if (pf_misaligned(h, res, xsum, y) || pf_misaligned(gamma, beta, gamma, beta)) return FMMT_EALIGN;
+    hipLaunchKernelGGL(plm_dropadd_ln_fwd_kernel, dim3(pf_blocks(M)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), M, C, eps, (const bf16*)h,
+                       (const bf16*)res, (const bf16*)gamma, (const bf16*)beta, p, (unsigned long long)seed, (const unsigned long long*)seed_dev, (unsigned long long)salt, (bf16*)xsum, (bf16*)y);
+    FMMT_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" size_t fmmt_plm_dropadd_ln_bwd_workspace(int M, int C) {
+    if (M <= 0 || C <= 0) return 0;
+    return (size_t)pf_blocks(M) * 3 * (size_t)C * sizeof(float);
+}
+
+extern "C" int fmmt_plm_dropadd_ln_bwd(int M, int C, float eps, const void* dy, const void* xsum, const void* gamma, float p, uint64_t seed,
+                                       const uint64_t* seed_dev, uint64_t salt, void* dx, void* dh, void* dgamma, void* dbeta, void* dbias, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+    if (M <= 0 || C <= 0 || C % 8 || C > 2048 || !(p >= 0.f && p < 1.f)) return FMMT_EINVAL;
+    if (!dy || !xsum || !gamma || !dx || !dh || !dgamma || !dbeta || !workspace) return FMMT_EINVAL;
+    if (workspace_bytes < fmmt_plm_dropadd_ln_bwd_workspace(M, C)) return FMMT_EWORKSPACE;
+    if (pf_misaligned(dy, xsum, dx, dh) || pf_misaligned(gamma, gamma, gamma, gamma)) return FMMT_EALIGN;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int blocks = pf_blocks(M);
+    hipLaunchKernelGGL(plm_dropadd_ln_bwd_kernel, dim3(blocks), dim3(256), 0, st, M, C, eps, (const bf16*)dy, (const bf16*)xsum, (const bf16*)gamma, p, (unsigned long long)seed,
+                       (const unsigned long long*)seed_dev, (unsigned long long)salt, (bf16*)dx, (bf16*)dh, reinterpret_cast<float*>(workspace));
+    FMMT_CHECK_LAUNCH();
+    hipLaunchKernelGGL(plm_dropadd_ln_reduce_kernel, dim3((3 * C + 31) / 32), dim3(1024), 0, st, reinterpret_cast<const float*>(workspace), blocks, C,
+                       (bf16*)dgamma, (bf16*)dbeta, (bf16*)dbias);
+    FMMT_CHECK_LAUNCH();
+    return 0;
+}

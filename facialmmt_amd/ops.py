@@ -360,6 +360,71 @@ class VendorLinearFn(torch.autograd.Function):
         return dx, dw, db
 
 
+class PlmSublayerTailFn(torch.autograd.Function):
+    """y = LayerNorm(dropout(x W^T + b) + res): a BERT / RoBERTa sublayer behind its attention / GELU (transformers' *SelfOutput / *Output,
+    src/models.py:75-91) as the vendor library's GEMM + ONE launch (fmmt_plm_dropadd_ln_fwd); backward: one launch + its reduction
+    (dx of the LayerNorm = the residual's gradient, the dropout'ed gradient of the dense output, d gamma, d beta and the dense bias' gradient),
+    then the two GEMMs autograd would issue.  No mask is stored: it is replayed from (`seed`: python int or 1-element int64 CUDA tensor, `salt`).
+    bf16 activations and parameters.  8 launches per sublayer and step become 6 of which 2 are small."""
+
+    @staticmethod
+    def forward(ctx, x, res, weight, bias, gamma, beta, eps, p, seed, salt):
+        h = torch.nn.functional.linear(x, weight, bias)
+        C = h.shape[-1]
+        h2, r2 = h.reshape(-1, C), res.reshape(-1, C).contiguous()
+        M = h2.shape[0]
+        xsum, y = torch.empty_like(h2), torch.empty_like(h2)
+        seed_t = seed if isinstance(seed, torch.Tensor) else None
+        seed_i = 0 if seed_t is not None else int(seed)
+        check(_lib.load().fmmt_plm_dropadd_ln_fwd(M, C, float(eps), _p(h2), _p(r2), _p(gamma.detach()), _p(beta.detach()), float(p), seed_i, _p(seed_t),
+                                                  int(salt), _p(xsum), _p(y), _st()), f"fmmt_plm_dropadd_ln_fwd(M={M},C={C})")
+        ctx.save_for_backward(x, weight, xsum, gamma, seed_t)
+        ctx.cfg = (float(eps), float(p), seed_i, int(salt))
+        return y.reshape(h.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, xsum, gamma, seed_t = ctx.saved_tensors
+        eps, p, seed_i, salt = ctx.cfg
+        M, C = xsum.shape
+        dy2 = dy.reshape(M, C).contiguous()
+        lib = _lib.load()
+        dx, dh = torch.empty_like(xsum), torch.empty_like(xsum)
+        dgamma, dbeta, dbias = torch.empty_like(gamma), torch.empty_like(gamma), torch.empty_like(gamma)
+        nbytes = lib.fmmt_plm_dropadd_ln_bwd_workspace(M, C)
+        ws = _ws(nbytes, xsum.device)
+        check(lib.fmmt_plm_dropadd_ln_bwd(M, C, eps, _p(dy2), _p(xsum), _p(gamma.detach()), p, seed_i, _p(seed_t), salt, _p(dx), _p(dh), _p(dgamma), _p(dbeta),
+                                          _p(dbias), _p(ws), nbytes, _st()), f"fmmt_plm_dropadd_ln_bwd(M={M},C={C})")
+        dxin = dh.reshape(dy.shape).matmul(weight) if ctx.needs_input_grad[0] else None
+        dw = dh.t().mm(x.reshape(-1, x.shape[-1])) if ctx.needs_input_grad[2] else None
+        return dxin, dx.reshape(dy.shape), dw, dbias, dgamma, dbeta, None, None, None, None
+
+
+class PlmQkvFn(torch.autograd.Function):
+    """(q, k, v) = x [Wq; Wk; Wv]^T + [bq; bk; bv] as ONE vendor GEMM over the packed weight `w_all` (3E, E) of which the three nn.Linear weights are
+    row slices (train_step.fuse_text_encoder re-points them): transformers' *SelfAttention.query / key / value (src/models.py:75-91).  Backward: the
+    three gradients are gathered into one (M, 3E) matrix (one copy launch), then ONE input-gradient GEMM, ONE weight-gradient GEMM whose row slices are
+    the three weight gradients, one column sum.  3 + 11 launches per layer and step become 1 + 4."""
+
+    @staticmethod
+    def forward(ctx, x, wq, wk, wv, bq, bk, bv, w_all, b_all):
+        ctx.save_for_backward(x, w_all)
+        E = wq.shape[0]
+        y = torch.nn.functional.linear(x, w_all, b_all)
+        return y[..., :E], y[..., E:2 * E], y[..., 2 * E:]
+
+    @staticmethod
+    def backward(ctx, dq, dk, dv):
+        x, w_all = ctx.saved_tensors
+        E = w_all.shape[0] // 3
+        d = torch.cat([dq, dk, dv], dim=-1)
+        d2 = d.reshape(-1, 3 * E)
+        dx = d.matmul(w_all) if ctx.needs_input_grad[0] else None
+        dw = d2.t().mm(x.reshape(-1, x.shape[-1]))
+        db = colsum_raw(d2)
+        return dx, dw[:E], dw[E:2 * E], dw[2 * E:], db[:E], db[E:2 * E], db[2 * E:], None, None
+
+
 def mlp_fused_raw(x2, w1l, b1, w2l, b2, res2, rowscale, rows_per_scale, h_pre, h_act=None):
     """one launch: y = res + rowscale * (gelu(x W1^T + b1) W2^T + b2); h_pre / h_act (or None) receive the pre-activation / activation"""
     M, C = x2.shape

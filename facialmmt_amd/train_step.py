@@ -6,6 +6,8 @@ cumsum / searchsorted / index_put on the device (parity pin
 loop restatement in oracle/train_glue.py, reference quirk included)."""
 from __future__ import annotations
 
+import types
+
 import torch
 import torch.nn.functional as F
 
@@ -345,6 +347,7 @@ class VendorLayerNorm(torch.nn.LayerNorm):
 
 # Module constants (the probes patch them), not environment switches: each is the off-switch of one fused launch family
 PLM_COLSUM, PLM_LN, FUSED_ADAMW, PIN_SHADOWS, FUSED_HANDOVER = True, True, True, True, True
+PLM_FUSE_TAILS, PLM_FUSE_QKV = True, True                  # fuse_text_encoder: sublayer tails as one launch per direction / packed query-key-value GEMM
 
 
 def use_colsum_bias_gradients(module):
@@ -362,6 +365,101 @@ def use_colsum_bias_gradients(module):
         elif ln and type(m) is torch.nn.LayerNorm and m.elementwise_affine and m.bias is not None:
             m.__class__ = VendorLayerNorm                    # two backward launches instead of three (fmmt_layernorm_bwd_bf16)
     return n
+
+
+class _SeedBox:
+    """one device int64 word per forward of the text encoder, drawn inside the step (graph-replay safe: torch's captured generator) by a forward
+    pre-hook; every fused sublayer reads it and adds its own salt"""
+
+    def __init__(self):
+        self.t = None
+
+    def draw(self, device):
+        self.t = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64, device=device)
+
+
+def _sublayer_tail_forward(self, hidden_states, input_tensor):
+    """forward of a re-classed transformers *SelfOutput / *Output: dense + dropout + residual + LayerNorm = the vendor GEMM + one launch"""
+    d, ln = self.dense, self.LayerNorm
+    p = float(self.dropout.p) if self.training else 0.0
+    box = self._fmmt_seed
+    if (not hidden_states.is_cuda or hidden_states.dtype != torch.bfloat16 or d.weight.dtype != torch.bfloat16 or ln.weight.dtype != torch.bfloat16
+            or d.bias is None or ln.bias is None or d.weight.shape[0] % 8 or d.weight.shape[0] > 2048 or not torch.is_grad_enabled()
+            or (p > 0.0 and box.t is None)):
+        return self._fmmt_stock_forward(hidden_states, input_tensor)
+    from . import ops
+    return ops.PlmSublayerTailFn.apply(hidden_states, input_tensor, d.weight, d.bias, ln.weight, ln.bias, ln.eps, p,
+                                       box.t if p > 0.0 else 0, self._fmmt_salt)
+
+
+def _packed_qkv_forward(self, hidden_states, *args, **kwargs):
+    """forward of a re-classed transformers *SelfAttention: query / key / value as one GEMM over the packed weight they are slices of; everything
+    behind the projections (head split, the attention interface, dropout) is the stock method's, fed through three pass-through Linear stand-ins"""
+    w, b = self._fmmt_qkv
+    q, k, v = self.query, self.key, self.value
+    ok = (hidden_states.is_cuda and hidden_states.dtype == w.dtype and torch.is_grad_enabled() and q.weight.data_ptr() == w.data_ptr()
+          and k.weight.data_ptr() == w.data_ptr() + w[0].numel() * w.shape[0] // 3 * w.element_size()
+          and v.weight.data_ptr() == w.data_ptr() + 2 * w[0].numel() * w.shape[0] // 3 * w.element_size() and q.bias.data_ptr() == b.data_ptr())
+    if not ok:
+        return self._fmmt_stock_forward(hidden_states, *args, **kwargs)
+    from . import ops
+    yq, yk, yv = ops.PlmQkvFn.apply(hidden_states, q.weight, k.weight, v.weight, q.bias, k.bias, v.bias, w, b)
+    saved = (self.query, self.key, self.value)
+    try:                                                     # the stock forward calls self.query(x) ...: hand it the projections already made
+        self.__dict__["_modules"] = dict(self._modules, query=_Fixed(yq), key=_Fixed(yk), value=_Fixed(yv))
+        return self._fmmt_stock_forward(hidden_states, *args, **kwargs)
+    finally:
+        self.__dict__["_modules"] = dict(self._modules, query=saved[0], key=saved[1], value=saved[2])
+
+
+class _Fixed(torch.nn.Module):
+    def __init__(self, y):
+        super().__init__()
+        self.y = y
+
+    def forward(self, x):
+        return self.y
+
+
+def fuse_text_encoder(plm, tails: bool = True, qkv: bool = True):
+    """Launch diet for a bf16 Hugging Face BERT / RoBERTa encoder (src/models.py:75-91), call it AFTER the module has its final dtype / device
+    (MasterWeights): (a) every *SelfOutput / *Output runs dense + dropout + residual + LayerNorm as the vendor GEMM + one fused launch, backward one
+    launch + a reduction + the two GEMMs (ops.PlmSublayerTailFn); (b) every *SelfAttention computes query / key / value with ONE GEMM over a packed
+    (3E, E) weight of which the three nn.Linear parameters become row slices (same Parameter objects, same names, same state_dict; the optimizer's
+    views keep working).  Returns (tails changed, attentions packed).  Numerics: (a) rounds like the bf16 module op by op, with its own dropout
+    stream (counter-based, replayed in the backward instead of a stored mask); (b) is the same arithmetic as three GEMMs."""
+    box = _SeedBox()
+    n_tail = n_qkv = 0
+    salt = 0
+    for name, m in plm.named_modules():
+        cls = type(m).__name__
+        if tails and cls.endswith(("SelfOutput", "Output")) and hasattr(m, "dense") and hasattr(m, "LayerNorm") and hasattr(m, "dropout") \
+                and not hasattr(m, "_fmmt_stock_forward"):
+            m._fmmt_stock_forward = m.forward
+            m._fmmt_seed = box
+            salt += 1
+            m._fmmt_salt = salt << 40                       # 2^40 elements per call site
+            m.forward = types.MethodType(_sublayer_tail_forward, m)
+            n_tail += 1
+        elif qkv and cls.endswith("SelfAttention") and all(hasattr(m, a) for a in ("query", "key", "value")) and not hasattr(m, "_fmmt_stock_forward"):
+            q, k, v = m.query, m.key, m.value
+            if not (q.weight.shape == k.weight.shape == v.weight.shape and q.bias is not None and k.bias is not None and v.bias is not None
+                    and q.weight.dtype == k.weight.dtype == v.weight.dtype):
+                continue
+            with torch.no_grad():
+                w = torch.cat([q.weight.data, k.weight.data, v.weight.data], dim=0).contiguous()
+                b = torch.cat([q.bias.data, k.bias.data, v.bias.data], dim=0).contiguous()
+                E = q.weight.shape[0]
+                for i, lin in enumerate((q, k, v)):
+                    lin.weight.data = w[i * E:(i + 1) * E]
+                    lin.bias.data = b[i * E:(i + 1) * E]
+            m._fmmt_qkv = (w, b)
+            m._fmmt_stock_forward = m.forward
+            m.forward = types.MethodType(_packed_qkv_forward, m)
+            n_qkv += 1
+    if n_tail:
+        plm.register_forward_pre_hook(lambda mod, args, kwargs=None: box.draw(next(mod.parameters()).device) if mod.training else None)
+    return n_tail, n_qkv
 
 
 class MasterWeights:
@@ -395,6 +493,7 @@ class MasterWeights:
                             if id(t) not in trainable and t.is_floating_point() and t.dtype == torch.float32}
         module.to(dtype)                                    # in place: the Parameter objects survive, their data becomes bf16
         self.colsum_layers = use_colsum_bias_gradients(module)
+        self.fused_layers = fuse_text_encoder(module, tails=PLM_FUSE_TAILS, qkv=PLM_FUSE_QKV)
         self.low = low
         self.flat = flat
         self.module = module
@@ -735,17 +834,25 @@ class GraphedTargetStep:
 
     def __init__(self, swin_model, multimodal_model, optimizer, scheduler, args, batch, autocast_dtype=None,
                  overlap_text=True, parallel_fusion=False, averager=None, warmup_iters=2, masters=None, discarded_swin_gradients="compute",
-                 swin_cut: int = 0):
+                 swin_cut: int = 0, pipeline_swin: bool = False):
         """`averager`: GradientAverager(hooks=False) over the parameters the optimizer steps (default: the multimodal
         model's); `swin_cut`: with an exchange to hide (N > 1), the Swin stage behind which the backward graph is cut (0: the second
         piece is stage 0's backward, ~10 ms; 1: stages 1 + 0, ~17 ms) -- the caller picks it from a MEASURED exchange time
         (`pick_swin_cut`, bench.py), never from a nominal link rate; `masters`: optional MasterWeights of the text encoder -- then `averager` and the optimizer must have been
-        built over `step_parameters(multimodal_model, masters)`; `discarded_swin_gradients`: "compute" (default) / "skip", SKIP_NOTE."""
+        built over `step_parameters(multimodal_model, masters)`; `discarded_swin_gradients`: "compute" (default) / "skip", SKIP_NOTE;
+        `pipeline_swin` (one rank, no exchange): Swin's FORWARD becomes a graph of its own (S) over two alternating sets of saved activations, and
+        `step(batch, next_batch=...)` replays S for the NEXT batch on a second stream beside this batch's graph A' (frame filter, text encoder,
+        fusion stack, loss, every backward).  Valid because nothing steps Swin in a target step (train.py:20,141: its target-step gradients are
+        discarded) -- the prefetched forward sees the weights the in-order forward would; a Swin parameter whose version moved since the prefetch
+        (an auxiliary step ran in between) makes the step redo the forward in order.  Why: per step ~22 ms of the GPU's time are streams of small
+        launches at low occupancy (text encoder forward and the tail of its backward, the fusion stack, the update) that a 14 ms block of
+        chip-filling Swin kernels can run beside; every step still executes exactly one Swin forward."""
         import os
         from .parallel import GradientAverager
         if discarded_swin_gradients not in ("compute", "skip"):
             raise ValueError("discarded_swin_gradients: 'compute' or 'skip'")
         self.skip_swin_bwd = discarded_swin_gradients == "skip"
+        self.pipeline = bool(pipeline_swin)
         if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "") != "0":
             raise RuntimeError("GraphedTargetStep: DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 must be in the environment before the HIP "
                                "runtime initialises (see facialmmt_amd/__init__.py)")
@@ -803,6 +910,8 @@ class GraphedTargetStep:
         torch.cuda.set_rng_state(rng, dev)
         # -- capture
         self.shadows = _pin_shadows([self.swin, self.mm])
+        self.swin_shadows = self.mm_shadows = None
+        self._swin_params = [q for q in self.swin.parameters()]
         # With an exchange to hide (N > 1) the forward/backward is TWO graphs, cut where the multimodal gradients are complete; alone on
         # the GPU it stays ONE graph: inside it the text encoder's backward runs as a branch beside Swin's backward, which a cut in
         # front of Swin's backward would serialise (measured at N = 1: 72.1 ms per step cut, 69 ms uncut).
@@ -810,8 +919,32 @@ class GraphedTargetStep:
         if swin_cut not in (0, 1, 2):
             raise ValueError("swin_cut: 0, 1 or 2")
         self.SWIN_CUT = int(swin_cut)                      # the window behind the cut has to hold the exchange: see pick_swin_cut
+        if self.pipeline and (self.split or self.skip_swin_bwd):
+            raise ValueError("pipeline_swin: one rank without a gradient exchange, Swin's backward computed")
         self.graph_a, self.graph_a2, self.graph_b = torch.cuda.CUDAGraph(), (torch.cuda.CUDAGraph() if self.split else None), torch.cuda.CUDAGraph()
-        with capture_window(), _ops_pinned_scope(self.shadows):
+        self.sets, self.side_stream, self.cur, self.prefetched = [], None, 0, None
+        if self.pipeline:
+            # two sets (graph S: Swin forward; graph A': everything else), each in a memory pool of ITS OWN: S of one set replays beside A' of the
+            # other, and inside a shared pool the capture of the second set would reuse blocks the first set's backward freed
+            self.side_stream = distinct_stream(dev, tuple(x for x in (cap, self.text_stream, self.mm.pair_stream) if x is not None))
+            self.swin_shadows, self.mm_shadows = _pin_shadows([self.swin]), _pin_shadows([self.mm])
+            with capture_window(), _ops_pinned_scope(self.shadows):
+                for k in range(2):
+                    frames_k = self.static[8] if k == 0 else self.static[8].clone()
+                    g_s, g_a = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g_s, stream=cap):
+                        preds = self._swin_forward(frames_k)
+                    with torch.cuda.graph(g_a, pool=g_s.pool(), stream=cap):
+                        loss, new_mask, _ = self._fwd_bwd_multimodal(whole=True, preds=preds)
+                    del preds
+                    self.sets.append(types.SimpleNamespace(S=g_s, A=g_a, frames=frames_k, loss=loss, mask=new_mask,
+                                                           ev_s=torch.cuda.Event(), ev_a=torch.cuda.Event()))
+                    _KEEP_GRAPHS.append((g_s, g_a))
+                with torch.cuda.graph(self.graph_b, stream=cap):
+                    self._update()
+            self.loss, self.new_mask = self.sets[0].loss, self.sets[0].mask
+        else:
+          with capture_window(), _ops_pinned_scope(self.shadows):
             if self.split:
                 with torch.cuda.graph(self.graph_a, stream=cap):
                     self.loss, self.new_mask, swin_out = self._fwd_bwd_multimodal()
@@ -833,9 +966,16 @@ class GraphedTargetStep:
         loss, new_mask, _ = self._fwd_bwd_multimodal(whole=True)
         return loss, new_mask
 
-    def _fwd_bwd_multimodal(self, whole=False):
+    def _swin_forward(self, frames):
+        """pipeline_swin, graph S: Swin's forward alone (its bf16 shadows refreshed at the head: an auxiliary step may have moved the weights)"""
+        if self.swin_shadows is not None:
+            self.swin_shadows.refresh()
+        return self.swin(frames, is_trg_task=True)
+
+    def _fwd_bwd_multimodal(self, whole=False, preds=None):
         """forward of everything + backward of the loss down to (a) the multimodal parameters and (b) Swin's output; returns
-        (loss, kept-frame mask, (Swin output, its gradient)) -- the second piece continues from the latter"""
+        (loss, kept-frame mask, (Swin output, its gradient)) -- the second piece continues from the latter.  `preds` (pipeline_swin): Swin's
+        output comes from graph S; this piece starts behind it and its backward runs through S's autograd graph."""
         (ids, attn_mask, sep_mask, audio, audio_mask, vision_inputs, vision_mask, labels, frames, num_imgs, utt_idx) = self.static
         mm, args = self.mm, self.args
         ctx = (lambda: torch.autocast("cuda", dtype=self.autocast_dtype)) if self.autocast_dtype is not None else None
@@ -843,14 +983,19 @@ class GraphedTargetStep:
         ac = ctx if ctx is not None else contextlib.nullcontext
         main = torch.cuda.current_stream()
         pending = None
-        if self.shadows is not None:
+        if preds is not None:
+            if self.mm_shadows is not None:
+                self.mm_shadows.refresh()                   # Swin's shadows belong to graph S
+        elif self.shadows is not None:
             self.shadows.refresh()                          # every bf16 weight shadow of the step, one launch (ops.PinnedShadows)
         if self.text_stream is not None:
             self.text_stream.wait_stream(main)             # fork: the text branch does not depend on the visual path
             with torch.cuda.stream(self.text_stream), ac():
                 pending = mm.text_branch(ids, attn_mask, sep_mask, torch.as_tensor(utt_idx, device=ids.device))
         cut, hook = {}, None
-        if self.skip_swin_bwd:
+        if preds is not None:
+            pass
+        elif self.skip_swin_bwd:
             with torch.no_grad():
                 preds = self.swin(frames, is_trg_task=True)
         else:
@@ -939,9 +1084,63 @@ class GraphedTargetStep:
         for l, _ in self.pairs:                              # the next backward must produce fresh gradient tensors
             l.grad = None
 
-    def __call__(self, batch):
+    def _swin_version(self):
+        ps = self._swin_params
+        return (ps[0]._version, ps[-1]._version)
+
+    def _launch_swin(self, k, frames):
+        """graph S of set k for `frames` on the side stream: behind whatever produced `frames` (the current stream so far) and behind the last
+        graph A' that read the set's activations"""
+        st, side = self.sets[k], self.side_stream
+        side.wait_stream(torch.cuda.current_stream())
+        side.wait_event(st.ev_a)
+        with torch.cuda.stream(side), torch.no_grad():
+            if frames is not st.frames:
+                if tuple(frames.shape) != tuple(st.frames.shape):
+                    raise ValueError(f"GraphedTargetStep: frames of shape {tuple(frames.shape)}, the captured graphs are for {tuple(st.frames.shape)}")
+                st.frames.copy_(frames, non_blocking=True)
+                frames.record_stream(side)
+            st.S.replay()
+            st.ev_s.record(side)
+
+    def _call_pipelined(self, batch, next_batch):
+        k, st = self.cur, self.sets[self.cur]
+        with torch.no_grad():
+            for i, (dst, src) in enumerate(zip(self.static, batch)):
+                if i == 8 or dst is src:
+                    continue
+                src = src if torch.is_tensor(src) else torch.as_tensor(src)
+                if tuple(src.shape) != tuple(dst.shape):
+                    raise ValueError(f"GraphedTargetStep: batch entry {i} has shape {tuple(src.shape)}, the captured graphs are for {tuple(dst.shape)}")
+                dst.copy_(src, non_blocking=True)
+        pf = self.prefetched
+        if not (pf is not None and pf[0] == k and pf[1] is batch[8] and pf[2] == batch[8]._version and pf[3] == self._swin_version()):
+            self._launch_swin(k, batch[8])                  # nothing (valid) prefetched: Swin's forward for this batch, in order
+        self.prefetched = None
+        if next_batch is not None:                          # enqueued BEFORE graph A': the two then run side by side
+            self._launch_swin(k ^ 1, next_batch[8])
+            self.prefetched = (k ^ 1, next_batch[8], next_batch[8]._version, self._swin_version())
+        main = torch.cuda.current_stream()
+        main.wait_event(st.ev_s)
+        st.A.replay()
+        st.ev_a.record(main)
+        self.cur = k ^ 1
+        self.i_batch += 1
+        if self.i_batch % self.args.trg_accumulation_steps == 0:
+            self.graph_b.replay()
+            _bump_versions(self.flat.params)
+            if self.sched is not None:
+                self.sched.step()
+        self.loss, self.new_mask = st.loss, st.mask
+        return st.loss, st.mask
+
+    def __call__(self, batch, next_batch=None):
+        """`next_batch` (pipeline_swin only): the batch the NEXT call will be given -- its Swin forward is replayed now, beside this step.  Pass
+        None in front of an auxiliary step (it moves Swin's weights: the prefetch would be thrown away) and for the last step of an epoch."""
         if len(batch) != len(self.static):
             raise ValueError(f"GraphedTargetStep: batch of {len(batch)} entries, captured with {len(self.static)}")
+        if self.pipeline:
+            return self._call_pipelined(batch, next_batch)
         with torch.no_grad():
             for i, (dst, src) in enumerate(zip(self.static, batch)):
                 if dst is src:
@@ -984,6 +1183,7 @@ class GraphedTargetStep:
     def start_epoch(self):
         """a partial accumulation window does not carry into the next epoch (train.py:52,54 restart the counter per epoch)"""
         self.i_batch = 0
+        self.prefetched = None
         self.flat.zero_grad()
 
 

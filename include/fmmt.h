@@ -337,6 +337,21 @@ size_t fmmt_layernorm_bwd_bf16_workspace(int M, int C);
 int fmmt_layernorm_bwd_bf16(int M, int C, float eps, const void* dy, const void* x, const void* gamma, void* dx,
                             void* dgamma, void* dbeta, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The tail of a BERT / RoBERTa sublayer, y = LayerNorm(dropout(h) + res), as ONE launch per direction (+ the fixed-order reduction of the
+ * backward's parameter gradients): transformers' RobertaSelfOutput / RobertaOutput and BertSelfOutput / BertOutput (the text encoder the
+ * reference builds at src/models.py:75-91) after their dense layer, whose GEMM stays with the vendor library.  Replaces fused_dropout + add +
+ * layer_norm (forward) and LayerNorm' + masked_scale + the dense bias' column sum (backward).  bf16 activations and bf16 affine parameters.
+ *   forward : t = bf16(h * keep / (1 - p)); xsum = bf16(t + res) (saved for the backward); y = LayerNorm(xsum) * gamma + beta
+ *   backward: dx = LayerNorm'(dy) (= the residual branch's gradient); dh = bf16(dx * keep / (1 - p)); dgamma, dbeta; dbias = colsum(dh) (may be NULL)
+ * keep(e) = hash(seed, salt + e) >= p with the counter-based generator of fmmt_mha_fwd: no mask is stored, the backward replays it from the same
+ * (seed | *seed_dev, salt).  h, res, xsum, y, dy, dx, dh: bf16 [M][C]; gamma, beta, dgamma, dbeta, dbias: bf16 [C]; C % 8 == 0, C <= 2048, 0 <= p < 1. */
+int fmmt_plm_dropadd_ln_fwd(int M, int C, float eps, const void* h, const void* res, const void* gamma, const void* beta, float p,
+                            uint64_t seed, const uint64_t* seed_dev, uint64_t salt, void* xsum, void* y, void* stream);
+size_t fmmt_plm_dropadd_ln_bwd_workspace(int M, int C);
+int fmmt_plm_dropadd_ln_bwd(int M, int C, float eps, const void* dy, const void* xsum, const void* gamma, float p, uint64_t seed,
+                            const uint64_t* seed_dev, uint64_t salt, void* dx, void* dh, void* dgamma, void* dbeta, void* dbias, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
 /* Batched refresh of bf16 weight shadows: one launch casts (fp32 -> bf16, or copies bf16) and optionally transposes n_desc
  * parameter matrices.  The reference keeps fp32 nn.Parameters (train.py:336-349 builds the optimizer over them); the bf16 GEMMs
  * read bf16 shadows W and W^T of them, which a training step has to rebuild after every optimizer step -- per weight that

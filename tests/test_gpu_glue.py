@@ -354,3 +354,93 @@ def test_gradient_hand_over_and_clip_norm_in_one_pass(dev, accumulate):
     before = flat_f.clone()
     assert not TS.FusedHandOver(len(pairs))(pairs, views_f, accumulate, torch.zeros((), device=dev))
     assert torch.equal(flat_f, before) and params[0].grad is not None
+
+
+def _small_roberta(dev, p_drop):
+    from transformers import RobertaConfig, RobertaModel
+    torch.manual_seed(0)
+    cfg = RobertaConfig(vocab_size=1000, hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=512, max_position_embeddings=80,
+                        hidden_dropout_prob=p_drop, attention_probs_dropout_prob=0.0)
+    m = RobertaModel(cfg, add_pooling_layer=False)
+    return m.to(dev).to(torch.bfloat16).train()
+
+
+def test_fused_text_encoder_sublayers_match_the_stock_module():
+    """train_step.fuse_text_encoder: (a) *SelfOutput / *Output as the vendor GEMM + fmmt_plm_dropadd_ln_fwd / _bwd, (b) query / key / value as one GEMM
+    over a packed weight whose row slices ARE the three nn.Linear parameters -- same outputs and the same gradients for every parameter as the stock
+    bf16 module (dropout off: its stream is the only thing that differs), same state_dict keys, and an optimizer step through the sliced parameters
+    moves the packed weight."""
+    import copy
+    from facialmmt_amd.train_step import fuse_text_encoder
+    dev = torch.device("cuda:0")
+    stock = _small_roberta(dev, 0.0)
+    fused = copy.deepcopy(stock)
+    assert fuse_text_encoder(fused) == (4, 2)
+    assert list(fused.state_dict()) == list(stock.state_dict())
+    ids = torch.randint(3, 1000, (3, 64), device=dev)
+    mask = torch.ones(3, 64, device=dev, dtype=torch.long)
+    mask[1, 40:] = 0
+    g = torch.randn(3, 64, 256, device=dev, dtype=torch.bfloat16)
+    outs = []
+    for m in (stock, fused):
+        y = m(input_ids=ids, attention_mask=mask).last_hidden_state
+        y.backward(g)
+        outs.append((y.detach().float(), {k: p.grad.detach().float() for k, p in m.named_parameters() if p.grad is not None}))
+    (y0, g0), (y1, g1) = outs
+    assert (y0 - y1).abs().max().item() <= 3e-2 * max(1.0, y0.abs().max().item())
+    assert set(g0) == set(g1)
+    for k in g0:
+        if k.endswith("key.bias"):                               # mathematically zero (a key bias shifts every score of a row alike): rounding noise on both sides
+            continue
+        scale = g0[k].abs().max().item() + 1e-6
+        assert (g0[k] - g1[k]).abs().max().item() <= 4e-2 * scale, (k, (g0[k] - g1[k]).abs().max().item(), scale)
+    att = fused.encoder.layer[0].attention.self
+    w, _ = att._fmmt_qkv
+    before = w.clone()
+    torch.optim.SGD(fused.parameters(), lr=0.1).step()
+    assert not torch.equal(before, w) and att.key.weight.data_ptr() == w[256:].data_ptr()
+
+
+def test_fused_sublayer_tail_dropout_replays_its_mask_in_the_backward():
+    """fmmt_plm_dropadd_ln_fwd / _bwd at p = 0.3: the kept fraction is 1 - p, a second forward with the same (seed, salt) is identical and a different
+    salt is not; the backward's dense-output gradient is zero exactly where the forward dropped and dx * 1 / (1 - p) elsewhere; the bias gradient is its
+    column sum; against torch (LayerNorm of the same dropped sum) at bf16 tolerance."""
+    from facialmmt_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    M, K, C, p = 192, 128, 1024, 0.3
+    x = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
+    res = (0.05 * torch.randn(M, C, device=dev)).to(torch.bfloat16)       # small beside h: a kept element never rounds away in h + res
+    w = (torch.randn(C, K, device=dev) * K ** -0.5).to(torch.bfloat16).requires_grad_(True)
+    b = torch.randn(C, device=dev).to(torch.bfloat16).requires_grad_(True)
+    gm = (1 + 0.1 * torch.randn(C, device=dev)).to(torch.bfloat16).requires_grad_(True)
+    bt = (0.1 * torch.randn(C, device=dev)).to(torch.bfloat16).requires_grad_(True)
+    seed = torch.tensor([12345], device=dev, dtype=torch.int64)
+    xin, rin = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    y = ops.PlmSublayerTailFn.apply(xin, rin, w, b, gm, bt, 1e-5, p, seed, 7 << 40)
+    y2 = ops.PlmSublayerTailFn.apply(x, res, w, b, gm, bt, 1e-5, p, seed, 7 << 40)
+    y3 = ops.PlmSublayerTailFn.apply(x, res, w, b, gm, bt, 1e-5, p, seed, 8 << 40)
+    assert torch.equal(y, y2) and not torch.equal(y, y3)
+    # the mask, exactly: the same launch on h = 1, res = 0 leaves keep / (1 - p) in the saved sum
+    from facialmmt_amd import _lib
+    ones, zeros = torch.ones(M, C, device=dev, dtype=torch.bfloat16), torch.zeros(M, C, device=dev, dtype=torch.bfloat16)
+    probe, junk = torch.empty_like(ones), torch.empty_like(ones)
+    _lib.check(_lib.load().fmmt_plm_dropadd_ln_fwd(M, C, 1e-5, ones.data_ptr(), zeros.data_ptr(), gm.data_ptr(), bt.data_ptr(), p, 0, seed.data_ptr(), 7 << 40,
+                                                   probe.data_ptr(), junk.data_ptr(), torch.cuda.current_stream().cuda_stream), "probe")
+    keep = probe != 0
+    frac = keep.float().mean().item()
+    assert abs(frac - (1 - p)) < 0.01, frac
+    dy = torch.randn(M, C, device=dev, dtype=torch.bfloat16)
+    y.backward(dy)
+    # torch on the same mask
+    w2, b2, gm2, bt2 = (t.detach().clone().requires_grad_(True) for t in (w, b, gm, bt))
+    x2, r2 = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    h2 = torch.nn.functional.linear(x2, w2, b2)
+    t2 = (h2 * keep.to(h2.dtype) * (1.0 / (1.0 - p))).to(torch.bfloat16)
+    yr = torch.nn.functional.layer_norm(t2 + r2, (C,), gm2, bt2, 1e-5)
+    yr.backward(dy)
+    assert (y.float() - yr.float()).abs().max().item() <= 3e-2 * max(1.0, yr.float().abs().max().item())
+    for a, r_, name in ((xin.grad, x2.grad, "dx"), (rin.grad, r2.grad, "dres"), (w.grad, w2.grad, "dW"), (b.grad, b2.grad, "db"),
+                        (gm.grad, gm2.grad, "dgamma"), (bt.grad, bt2.grad, "dbeta")):
+        s = r_.float().abs().max().item() + 1e-6
+        assert (a.float() - r_.float()).abs().max().item() <= 4e-2 * s, (name, (a.float() - r_.float()).abs().max().item(), s)

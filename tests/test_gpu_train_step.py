@@ -76,7 +76,7 @@ def test_scheduled_step_equals_eager_step(mode):
         assert (p0[k] - p1[k]).abs().max().item() <= 1e-4 * max(1.0, p0[k].abs().max().item()), k
 
 
-def _run_six(dev, graphed, accumulation, bf16_plm=False, adamw=False, swin_gradients="compute"):
+def _run_six(dev, graphed, accumulation, bf16_plm=False, adamw=False, swin_gradients="compute", pipeline=False):
     from facialmmt_amd import models
     from facialmmt_amd.config import default_args
     from facialmmt_amd.train_step import GraphedTargetStep, TargetStep
@@ -112,14 +112,17 @@ def _run_six(dev, graphed, accumulation, bf16_plm=False, adamw=False, swin_gradi
     else:
         opt = torch.optim.SGD(mm.parameters(), lr=0.05)
     if graphed:
-        step = GraphedTargetStep(swin, mm, opt, None, cfg, batch, autocast_dtype=None, masters=masters, discarded_swin_gradients=swin_gradients)
+        step = GraphedTargetStep(swin, mm, opt, None, cfg, batch, autocast_dtype=None, masters=masters, discarded_swin_gradients=swin_gradients, pipeline_swin=pipeline)
         assert step.text_stream is not None
         assert (step.fused is not None) == adamw
     else:
         step = TargetStep(swin, mm, opt, None, cfg, autocast_dtype=None, discarded_swin_gradients=swin_gradients)
     losses = []
-    for _ in range(6):
-        loss, kept = step(batch)
+    for i in range(6):
+        if pipeline:                                             # the next step's Swin forward rides beside this step; none behind the last
+            loss, kept = step(batch, next_batch=batch if i < 5 else None)
+        else:
+            loss, kept = step(batch)
         losses.append(float(loss))
     torch.cuda.synchronize()
     if masters is not None:
@@ -145,6 +148,65 @@ def test_whole_step_graphs_equal_eager_step(accumulation):
     assert (rm0 - rm1).abs().max().item() <= 1e-4 * max(1.0, rm0.abs().max().item())
     for k in p0:
         assert (p0[k] - p1[k]).abs().max().item() <= 1e-4 * max(1.0, p0[k].abs().max().item()), k
+
+
+@pytest.mark.parametrize("accumulation", [1, 2])
+def test_pipelined_swin_forward_walks_the_in_order_trajectory(accumulation):
+    """GraphedTargetStep(pipeline_swin=True): Swin's forward of step i + 1 replays as its own graph on a second stream beside step i (two
+    alternating sets of saved activations).  Nothing steps Swin in a target step, so losses, updated parameters, BatchNorm running statistics and
+    the kept-frame mask must be those of the in-order eager step -- six micro-steps, noise-free configuration."""
+    dev = torch.device("cuda:0")
+    l0, p0, rm0, nb0, k0 = _run_six(dev, False, accumulation)
+    l1, p1, rm1, nb1, k1 = _run_six(dev, True, accumulation, pipeline=True)
+    assert l0[0] != l0[-1]
+    for a, b in zip(l0, l1):
+        assert abs(a - b) <= 2e-4 * max(1.0, abs(a)), (l0, l1)
+    for k in p0:
+        assert (p0[k] - p1[k]).abs().max().item() <= 1e-4 * max(1.0, p0[k].abs().max().item()), k
+    assert nb0 == nb1 and torch.allclose(rm0, rm1, rtol=1e-5, atol=1e-6)
+    assert torch.equal(k0, k1)
+
+
+def test_pipelined_step_redoes_a_prefetch_that_an_auxiliary_step_invalidated():
+    """a Swin parameter whose version moved between the prefetch and the step (what GraphedAuxStep's replay does) makes the step run Swin's
+    forward again, in order; an untouched prefetch is used as it is.  (Counted at the launch of graph S: in the noise-free configuration the loss
+    does not see Swin's weights -- Gumbel-softmax at tau = 1e5 --, so the loss cannot tell.)"""
+    import types as _t
+    from facialmmt_amd import models
+    from facialmmt_amd.config import default_args
+    from facialmmt_amd.train_step import GraphedTargetStep, _bump_versions
+    import bench
+    dev = torch.device("cuda:0")
+    cfg = default_args(get_vision_utt_max_lens=6, get_audio_utt_max_lens=24, trg_accumulation_steps=1, plm_module=synth.make_standin_plm(),
+                       hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, crossmodal_attn_dropout_TA=0.0, crossmodal_attn_dropout_TA_V=0.0,
+                       tau=1e5, FacialEmoImpor_threshold=0.1)
+    cfg.compute_dtype = torch.float32
+    swin = models.SwinForAffwildClassification(cfg)
+    mm = models.MultiModalTransformerForClassification(cfg)
+    synth.fill_state_dict(swin, seed=100)
+    synth.fill_state_dict(mm, seed=200)
+    swin.to(dev).train()
+    mm.to(dev).train()
+    args = _t.SimpleNamespace(utts=2, frames=6, dtype="fp32", plm="roberta-large", input="float", resize="pil")
+    batch = list(bench.synth_batch(args, dev, 0, cfg))
+    batch[0] = batch[0] % 1000
+    batch = tuple(batch)
+    step = GraphedTargetStep(swin, mm, torch.optim.SGD(mm.parameters(), lr=0.01), None, cfg, batch, autocast_dtype=None, pipeline_swin=True)
+    launches = []
+    inner = step._launch_swin
+    step._launch_swin = lambda k, frames: (launches.append(k), inner(k, frames))[1]
+    step(batch, next_batch=batch)
+    assert launches == [0, 1]                                    # this batch's forward (nothing prefetched yet) + the prefetch
+    step(batch, next_batch=batch)
+    assert launches == [0, 1, 0]                                 # the prefetched set 1 was used; set 0 prefetched for the next step
+    _bump_versions(list(swin.parameters()))                      # "an auxiliary step ran"
+    step(batch)
+    assert launches == [0, 1, 0, 0]                              # the prefetch is stale: forward redone in order, nothing prefetched
+    other = tuple(t.clone() if torch.is_tensor(t) else t for t in batch)
+    step(batch, next_batch=other)
+    step(batch)                                                  # not the batch that was announced: redone as well
+    torch.cuda.synchronize()
+    assert launches == [0, 1, 0, 0, 1, 0, 0]
 
 
 @pytest.mark.parametrize("graphed", [False, True])
