@@ -45,6 +45,9 @@ SIGNATURES = {
     "fmmt_window_block_fwd_ref": (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p]),
     "fmmt_window_block_attn_bwd": (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _sz, _p]),
     "fmmt_window_block_attn_bwd_ref": (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _sz, _p]),
+    "fmmt_linear_fwd_seg3": (_i, [_i, _i, _i, _i, _p, _i, _p, _p, _p, _i, _i, _p, _p, _p, _p, _i, _p]),
+    "fmmt_select_frames_fwd": (_i, [_i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _f, _p, _p, _p, _p]),
+    "fmmt_select_frames_bwd": (_i, [_i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
     "fmmt_mha_fwd": (_i, [_i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i, _f, _p, _f, _u64, _p, _p, _i, _p, _p]),
     "fmmt_mha_bwd": (_i, [_i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i, _f, _p, _f, _u64, _p, _p, _p, _i, _p, _p, _i, _p, _p, _i, _p]),
     "fmmt_mha_avg_weights": (_i, [_i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _f, _p, _f, _u64, _p, _p, _p, _p]),
@@ -58,6 +61,9 @@ SIGNATURES = {
     "fmmt_cast_batch": (_i, [_i, _i, _p, _p]),
     "fmmt_layernorm_bwd_bf16_workspace": (_sz, [_i, _i]),
     "fmmt_layernorm_bwd_bf16": (_i, [_i, _i, _f, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "fmmt_dropadd_ln_fwd": (_i, [_i, _i, _i, _f, _p, _p, _p, _p, _f, _u64, _p, _u64, _p, _p, _p]),
+    "fmmt_dropadd_ln_bwd_workspace": (_sz, [_i, _i]),
+    "fmmt_dropadd_ln_bwd": (_i, [_i, _i, _i, _f, _p, _p, _p, _f, _u64, _p, _u64, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "fmmt_plm_dropadd_ln_fwd": (_i, [_i, _i, _f, _p, _p, _p, _p, _f, _u64, _p, _u64, _p, _p, _p]),
     "fmmt_plm_dropadd_ln_bwd_workspace": (_sz, [_i, _i]),
     "fmmt_plm_dropadd_ln_bwd": (_i, [_i, _i, _f, _p, _p, _p, _f, _u64, _p, _u64, _p, _p, _p, _p, _p, _p, _sz, _p]),
@@ -69,6 +75,7 @@ SIGNATURES = {
     "fmmt_patch_embed_ln_fwd": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p]),
 }
 
+FMMT_EINVAL, FMMT_EALIGN, FMMT_EWORKSPACE = -1, -2, -3
 _ERR = {-1: "FMMT_EINVAL (bad shape / unsupported size)", -2: "FMMT_EALIGN (pointer or leading dimension not 16-byte aligned)",
         -3: "FMMT_EWORKSPACE (workspace too small)"}
 

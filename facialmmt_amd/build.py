@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libfmmt_hip.so")
-SOURCES = ["gemm.hip", "layernorm.hip", "attn.hip", "wattn_mfma.hip", "wattn_bwd_ref.hip", "wblock.hip", "wblock_ref.hip", "mha_mfma.hip", "misc.hip", "preproc.hip", "mlp_fused.hip", "mlp_ref.hip", "patch_ln.hip", "lin_lnbwd.hip", "plm_fused.hip"]
+SOURCES = ["gemm.hip", "layernorm.hip", "attn.hip", "wattn_mfma.hip", "wattn_bwd_ref.hip", "wblock.hip", "wblock_ref.hip", "mha_mfma.hip", "misc.hip", "preproc.hip", "mlp_fused.hip", "mlp_ref.hip", "patch_ln.hip", "lin_lnbwd.hip", "plm_fused.hip", "frame_filter.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast"]
 
 

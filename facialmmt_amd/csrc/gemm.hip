@@ -55,8 +55,21 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 template <int BM, int NBUF> struct NtWaves { static constexpr int value = (BM == 128) ? (NBUF == 1 ? 3 : 2) : 4; };
 template <typename T, int BM, int BN, int BK, int NBUF, bool GLDS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NtWaves<BM, NBUF>::value)))
-void linear_nt_kernel(LinArgs p) {
+void linear_nt_kernel(LinArgs p_in) {
     constexpr int VEC = Vec<T>::N;
+    LinArgs p = p_in;
+    if constexpr (GLDS) {
+        if (p.wseg_mode == 1) {
+            // output channels in segments of p.wseg, one weight / bias each: re-base this workgroup's pointers so that the global
+            // channel index n addresses row n - s * wseg of its segment (a tile never straddles two: wseg % BN == 0)
+            const int logical_ = xcd_remap(blockIdx.x, gridDim.x);
+            const int s_ = ((logical_ % p.tiles_n) * BN) / p.wseg;
+            const T* ws_ = reinterpret_cast<const T*>(s_ == 0 ? p.w : (s_ == 1 ? p.w1 : p.w2));
+            p.w = ws_ - (ptrdiff_t)s_ * p.wseg * p.ldw;
+            const float* bs_ = s_ == 0 ? p.bias : (s_ == 1 ? p.bias1 : p.bias2);
+            p.bias = bs_ ? bs_ - (ptrdiff_t)s_ * p.wseg : nullptr;
+        }
+    }
     // GLDS: tiles are filled by direct global->LDS DMA (global_load_lds_dwordx4): the LDS image of a wave
     // instruction is lane-linear, so rows are unpadded (128 B) and bank conflicts are removed by an XOR
     // swizzle applied to the *source* chunk index and again on the fragment read (key = (row >> 1) & 7).
@@ -171,10 +184,18 @@ void linear_nt_kernel(LinArgs p) {
         typedef __attribute__((address_space(3))) void lptr_t;
         auto issue = [&](int buf, int k0) {
             const int r8 = lane >> 3, c = lane & 7;
+            // K-segmented weight (wseg_mode 2): this K step's columns live in weight k0 / wseg, at column k0 % wseg
+            const T* wk = wg;
+            int kw = k0;
+            if (p.wseg_mode == 2) {
+                const int s_ = k0 / p.wseg;
+                wk = reinterpret_cast<const T*>(s_ == 0 ? p.w : (s_ == 1 ? p.w1 : p.w2));
+                kw = k0 - s_ * p.wseg;
+            }
 #pragma unroll
             for (int i = 0; i < BN / 32; ++i) {
                 const int grp = i * 4 + wave, row = grp * 8 + r8;
-                const T* src = wg + (size_t)min(n0 + row, p.N - 1) * p.ldw + k0 + ((c ^ ((row >> 1) & 7)) << 3);
+                const T* src = wk + (size_t)min(n0 + row, p.N - 1) * p.ldw + kw + ((c ^ ((row >> 1) & 7)) << 3);
                 __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(Ws + (buf * BN + grp * 8) * PITCH), 16, 0, 0);
             }
 #pragma unroll
@@ -2071,6 +2092,33 @@ extern "C" int fmmt_linear_fwd(int dtype, int M, int N, int K,
     LinArgs a{M, N, K, x, ldx, w, ldw, bias, y, ldy, y_pre, epi, aux, ldaux, res, ldres, rowscale, rows_per_scale, 0, 0, 1, 0, nullptr};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     return dtype == FMMT_BF16 ? dispatch_nt<bf16>(a, st) : dispatch_nt<float>(a, st);
+}
+
+// Few-token Linear over THREE weights in one launch (MELDTransEncoder's query / key / value, modules/Transformer.py:64-103: three nn.Linear over
+// the same hidden states, and their input gradient dx = dq Wq + dk Wk + dv Wv).
+//   seg_mode 1 (along N): y[:, s * N/3 : (s + 1) * N/3] = x @ w_s^T + bias_s        w_s [N/3][K]
+//   seg_mode 2 (along K): y = sum_s x[:, s * K/3 : (s + 1) * K/3] @ w_s^T            w_s [N][K/3]   (no bias)
+// bf16, the direct-to-LDS quarter-tile kernels only (the shapes dispatch_nt sends there: tokens <= 4096, few tiles); anything else: FMMT_EINVAL and
+// the caller issues three fmmt_linear_fwd calls.
+extern "C" int fmmt_linear_fwd_seg3(int dtype, int M, int N, int K, const void* x, int ldx, const void* w0, const void* w1, const void* w2, int ldw,
+                                    int seg_mode, const float* bias0, const float* bias1, const float* bias2, void* y, int ldy, void* stream) {
+    if (dtype != FMMT_BF16 || M <= 0 || N <= 0 || K <= 0 || (seg_mode != 1 && seg_mode != 2)) return FMMT_EINVAL;
+    if (!x || !w0 || !w1 || !w2 || !y) return FMMT_EINVAL;
+    const int seg = seg_mode == 1 ? N / 3 : K / 3;
+    if ((seg_mode == 1 ? N : K) % 3 || seg % 64 || N % 64 || K % 64 || K < 128 || ldx % 8 || ldw % 8 || ldy % 4 || M > 4096) return FMMT_EINVAL;
+    if (seg_mode == 2 && (bias0 || bias1 || bias2)) return FMMT_EINVAL;
+    if (!aligned16(x) || !aligned16(w0) || !aligned16(w1) || !aligned16(w2) || !aligned16(y)) return FMMT_EALIGN;
+    if (((M + 63) / 64) * ((N + 127) / 128) >= 256) return FMMT_EINVAL;                 // dispatch_nt's few-tile rule: larger problems do not come here
+    LinArgs a{M, N, K, x, ldx, w0, ldw, bias0, y, ldy, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 1, 0, 0, 1, 0, nullptr};
+    a.w1 = w1;
+    a.w2 = w2;
+    a.bias1 = bias1;
+    a.bias2 = bias2;
+    a.wseg = seg;
+    a.wseg_mode = seg_mode;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (K >= 2048) return launch_nt<bf16, 32, 64, 64, 4, true>(a, st);
+    return launch_nt<bf16, 32, 64, 64, 2, true>(a, st);
 }
 
 extern "C" size_t fmmt_linear_splitk_workspace(int M, int N, int K) {

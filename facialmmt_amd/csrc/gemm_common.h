@@ -21,6 +21,12 @@ struct LinArgs {
     int reserved;      // launcher-to-kernel A/B bits: 4 direct p256 epilogue, 8 no GELU slab, 16 no block slab, 32 no wave slab
     int ksplit;        // K range per blockIdx.y (split-K); 0 = no split
     float* part;       // split-K: fp32 partials [split][M][N] instead of the epilogue
+    // Segmented weight operand (fmmt_linear_fwd_seg3; few-token direct-to-LDS kernels only): wseg_mode 1 = along N (output channels
+    // [s * wseg, (s + 1) * wseg) come from weight s = w / w1 / w2, bias / bias1 / bias2), 2 = along K (w_s is [N][wseg], the product sums over
+    // the three K ranges of x); 0 = one weight.  A tile (64 channels) / a K step (64) never straddles a segment: wseg % 64 == 0.
+    const void* w1; const void* w2;
+    const float* bias1; const float* bias2;
+    int wseg, wseg_mode;
 };
 
 // Output-channel permutation of a wave tile.  MFMA row i = 4*g + r of n-tile nt becomes output channel

@@ -17,10 +17,24 @@ namespace {
 
 constexpr int PF_MAXV = 4;                                  // 8-element vectors per lane: C <= 2048
 
+// Affine parameters (and their gradients) in bf16 (the text encoder's bf16 module) or fp32 (MELDTransEncoder's fp32 master LayerNorms,
+// modules/Transformer.py:109-137: same op sequence dense -> dropout -> + input -> LayerNorm)
+template <typename P> __device__ __forceinline__ void pf_load8(const P* __restrict__ p, float (&o)[8]);
+template <> __device__ __forceinline__ void pf_load8<bf16>(const bf16* __restrict__ p, float (&o)[8]) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (float)v[e];
+}
+template <> __device__ __forceinline__ void pf_load8<float>(const float* __restrict__ p, float (&o)[8]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[e] = a[e]; o[4 + e] = b[e]; }
+}
 
 
+template <typename P>
 __global__ __launch_bounds__(256) void plm_dropadd_ln_fwd_kernel(int M, int C, float eps, const bf16* __restrict__ h, const bf16* __restrict__ res,
-                                                                 const bf16* __restrict__ gamma, const bf16* __restrict__ beta, float p,
+                                                                 const P* __restrict__ gamma, const P* __restrict__ beta, float p,
                                                                  unsigned long long seed_i, const unsigned long long* __restrict__ seed_ptr, unsigned long long salt,
                                                                  bf16* __restrict__ xsum, bf16* __restrict__ y) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -59,10 +73,12 @@ __global__ __launch_bounds__(256) void plm_dropadd_ln_fwd_kernel(int M, int C, f
         for (int i = 0; i < PF_MAXV; ++i) {
             const int v = lane + 64 * i;
             if (v < nv) {
-                const bf16x8 gm = *reinterpret_cast<const bf16x8*>(gamma + v * 8), bt = *reinterpret_cast<const bf16x8*>(beta + v * 8);
+                float gm[8], bt[8];
+                pf_load8<P>(gamma + v * 8, gm);
+                pf_load8<P>(beta + v * 8, bt);
                 bf16x8 o;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (bf16)(((float)xv[i][e] - mean) * rstd * (float)gm[e] + (float)bt[e]);
+                for (int e = 0; e < 8; ++e) o[e] = (bf16)(((float)xv[i][e] - mean) * rstd * gm[e] + bt[e]);
                 *reinterpret_cast<bf16x8*>(y + (size_t)row * C + v * 8) = o;
             }
         }
@@ -70,8 +86,9 @@ __global__ __launch_bounds__(256) void plm_dropadd_ln_fwd_kernel(int M, int C, f
 }
 
 // part: [block][3][C] fp32 (d gamma, d beta, d dense-bias)
+template <typename P>
 __global__ __launch_bounds__(256) void plm_dropadd_ln_bwd_kernel(int M, int C, float eps, const bf16* __restrict__ dy, const bf16* __restrict__ x,
-                                                                 const bf16* __restrict__ gamma, float p, unsigned long long seed_i,
+                                                                 const P* __restrict__ gamma, float p, unsigned long long seed_i,
                                                                  const unsigned long long* __restrict__ seed_ptr, unsigned long long salt, bf16* __restrict__ dx, bf16* __restrict__ dh,
                                                                  float* __restrict__ part) {
     __shared__ float red[4][3][64 * 8];
@@ -111,10 +128,11 @@ __global__ __launch_bounds__(256) void plm_dropadd_ln_bwd_kernel(int M, int C, f
         for (int i = 0; i < PF_MAXV; ++i) {
             const int v = lane + 64 * i;
             if (v < nv) {
-                const bf16x8 gm = *reinterpret_cast<const bf16x8*>(gamma + v * 8);
+                float gm[8];
+                pf_load8<P>(gamma + v * 8, gm);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float xh = ((float)xv[i][e] - mean) * rstd, dyv = (float)gv[i][e], g = dyv * (float)gm[e];
+                    const float xh = ((float)xv[i][e] - mean) * rstd, dyv = (float)gv[i][e], g = dyv * gm[e];
                     s1 += g;
                     s2 += g * xh;
                     dg[i][e] += dyv * xh;
@@ -129,11 +147,12 @@ __global__ __launch_bounds__(256) void plm_dropadd_ln_bwd_kernel(int M, int C, f
             const int v = lane + 64 * i;
             if (v < nv) {
                 const size_t o = (size_t)row * C + v * 8;
-                const bf16x8 gm = *reinterpret_cast<const bf16x8*>(gamma + v * 8);
+                float gm[8];
+                pf_load8<P>(gamma + v * 8, gm);
                 bf16x8 ox, oh;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float xh = ((float)xv[i][e] - mean) * rstd, g = (float)gv[i][e] * (float)gm[e];
+                    const float xh = ((float)xv[i][e] - mean) * rstd, g = (float)gv[i][e] * gm[e];
                     ox[e] = (bf16)(rstd * (g - s1 - xh * s2));
                     float t = (float)ox[e];
                     if (p > 0.f) t = hash_uniform(seed, salt + o + e) >= p ? t * scale : 0.f;
@@ -165,8 +184,9 @@ __global__ __launch_bounds__(256) void plm_dropadd_ln_bwd_kernel(int M, int C, f
 }
 
 // 1024 threads = 32 columns x 32 partial groups, fixed-order tree over the blocks' [3][C] partials
-__global__ __launch_bounds__(1024) void plm_dropadd_ln_reduce_kernel(const float* __restrict__ part, int nblocks, int C, bf16* __restrict__ dgamma,
-                                                                    bf16* __restrict__ dbeta, bf16* __restrict__ dbias) {
+template <typename P>
+__global__ __launch_bounds__(1024) void plm_dropadd_ln_reduce_kernel(const float* __restrict__ part, int nblocks, int C, P* __restrict__ dgamma,
+                                                                    P* __restrict__ dbeta, P* __restrict__ dbias) {
     __shared__ float red[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int i = blockIdx.x * 32 + tx;                     // column of the [3][C] triple
@@ -179,9 +199,9 @@ __global__ __launch_bounds__(1024) void plm_dropadd_ln_reduce_kernel(const float
         float t = 0.f;
 #pragma unroll
         for (int g = 0; g < 32; ++g) t += red[g][tx];
-        if (i < C) dgamma[i] = (bf16)t;
-        else if (i < 2 * C) dbeta[i - C] = (bf16)t;
-        else if (dbias) dbias[i - 2 * C] = (bf16)t;
+        if (i < C) dgamma[i] = (P)t;
+        else if (i < 2 * C) dbeta[i - C] = (P)t;
+        else if (dbias) dbias[i - 2 * C] = (P)t;
     }
 }
 
@@ -192,36 +212,64 @@ bool pf_misaligned(const void* a, const void* b, const void* c, const void* d) {
 
 }  // namespace
 
-extern "C" int fmmt_plm_dropadd_ln_fwd(int M, int C, float eps, const void* h, const void* res, const void* gamma, const void* beta, float p,
-                                       uint64_t seed, const uint64_t* seed_dev, uint64_t salt, void* xsum, void* y, void* stream) {
+extern "C" int fmmt_dropadd_ln_fwd(int param_dtype, int M, int C, float eps, const void* h, const void* res, const void* gamma, const void* beta, float p,
+                                   uint64_t seed, const uint64_t* seed_dev, uint64_t salt, void* xsum, void* y, void* stream) {
     if (M <= 0 || C <= 0 || C % 8 || C > 2048 || !(p >= 0.f && p < 1.f)) return FMMT_EINVAL;
+    if (param_dtype != FMMT_BF16 && param_dtype != FMMT_F32) return FMMT_EINVAL;
     if (!h || !res || !gamma || !beta || !xsum || !y) return FMMT_EINVAL;
     if (pf_misaligned(h, res, xsum, y) || pf_misaligned(gamma, beta, gamma, beta)) return FMMT_EALIGN;
-    hipLaunchKernelGGL(plm_dropadd_ln_fwd_kernel, dim3(pf_blocks(M)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), M, C, eps, (const bf16*)h,
-                       (const bf16*)res, (const bf16*)gamma, (const bf16*)beta, p, (unsigned long long)seed, (const unsigned long long*)seed_dev, (unsigned long long)salt, (bf16*)xsum, (bf16*)y);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (param_dtype == FMMT_BF16)
+        hipLaunchKernelGGL(plm_dropadd_ln_fwd_kernel<bf16>, dim3(pf_blocks(M)), dim3(256), 0, st, M, C, eps, (const bf16*)h, (const bf16*)res, (const bf16*)gamma,
+                           (const bf16*)beta, p, (unsigned long long)seed, (const unsigned long long*)seed_dev, (unsigned long long)salt, (bf16*)xsum, (bf16*)y);
+    else
+        hipLaunchKernelGGL(plm_dropadd_ln_fwd_kernel<float>, dim3(pf_blocks(M)), dim3(256), 0, st, M, C, eps, (const bf16*)h, (const bf16*)res, (const float*)gamma,
+                           (const float*)beta, p, (unsigned long long)seed, (const unsigned long long*)seed_dev, (unsigned long long)salt, (bf16*)xsum, (bf16*)y);
     FMMT_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" size_t fmmt_plm_dropadd_ln_bwd_workspace(int M, int C) {
+extern "C" size_t fmmt_dropadd_ln_bwd_workspace(int M, int C) {
     if (M <= 0 || C <= 0) return 0;
     return (size_t)pf_blocks(M) * 3 * (size_t)C * sizeof(float);
 }
 
-extern "C" int fmmt_plm_dropadd_ln_bwd(int M, int C, float eps, const void* dy, const void* xsum, const void* gamma, float p, uint64_t seed,
-                                       const uint64_t* seed_dev, uint64_t salt, void* dx, void* dh, void* dgamma, void* dbeta, void* dbias, void* workspace,
-                                       size_t workspace_bytes, void* stream) {
+extern "C" int fmmt_dropadd_ln_bwd(int param_dtype, int M, int C, float eps, const void* dy, const void* xsum, const void* gamma, float p, uint64_t seed,
+                                   const uint64_t* seed_dev, uint64_t salt, void* dx, void* dh, void* dgamma, void* dbeta, void* dbias, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
     if (M <= 0 || C <= 0 || C % 8 || C > 2048 || !(p >= 0.f && p < 1.f)) return FMMT_EINVAL;
+    if (param_dtype != FMMT_BF16 && param_dtype != FMMT_F32) return FMMT_EINVAL;
     if (!dy || !xsum || !gamma || !dx || !dh || !dgamma || !dbeta || !workspace) return FMMT_EINVAL;
-    if (workspace_bytes < fmmt_plm_dropadd_ln_bwd_workspace(M, C)) return FMMT_EWORKSPACE;
+    if (workspace_bytes < fmmt_dropadd_ln_bwd_workspace(M, C)) return FMMT_EWORKSPACE;
     if (pf_misaligned(dy, xsum, dx, dh) || pf_misaligned(gamma, gamma, gamma, gamma)) return FMMT_EALIGN;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int blocks = pf_blocks(M);
-    hipLaunchKernelGGL(plm_dropadd_ln_bwd_kernel, dim3(blocks), dim3(256), 0, st, M, C, eps, (const bf16*)dy, (const bf16*)xsum, (const bf16*)gamma, p, (unsigned long long)seed,
-                       (const unsigned long long*)seed_dev, (unsigned long long)salt, (bf16*)dx, (bf16*)dh, reinterpret_cast<float*>(workspace));
-    FMMT_CHECK_LAUNCH();
-    hipLaunchKernelGGL(plm_dropadd_ln_reduce_kernel, dim3((3 * C + 31) / 32), dim3(1024), 0, st, reinterpret_cast<const float*>(workspace), blocks, C,
-                       (bf16*)dgamma, (bf16*)dbeta, (bf16*)dbias);
+    float* part = reinterpret_cast<float*>(workspace);
+    if (param_dtype == FMMT_BF16) {
+        hipLaunchKernelGGL(plm_dropadd_ln_bwd_kernel<bf16>, dim3(blocks), dim3(256), 0, st, M, C, eps, (const bf16*)dy, (const bf16*)xsum, (const bf16*)gamma, p,
+                           (unsigned long long)seed, (const unsigned long long*)seed_dev, (unsigned long long)salt, (bf16*)dx, (bf16*)dh, part);
+        FMMT_CHECK_LAUNCH();
+        hipLaunchKernelGGL(plm_dropadd_ln_reduce_kernel<bf16>, dim3((3 * C + 31) / 32), dim3(1024), 0, st, (const float*)part, blocks, C, (bf16*)dgamma, (bf16*)dbeta,
+                           (bf16*)dbias);
+    } else {
+        hipLaunchKernelGGL(plm_dropadd_ln_bwd_kernel<float>, dim3(blocks), dim3(256), 0, st, M, C, eps, (const bf16*)dy, (const bf16*)xsum, (const float*)gamma, p,
+                           (unsigned long long)seed, (const unsigned long long*)seed_dev, (unsigned long long)salt, (bf16*)dx, (bf16*)dh, part);
+        FMMT_CHECK_LAUNCH();
+        hipLaunchKernelGGL(plm_dropadd_ln_reduce_kernel<float>, dim3((3 * C + 31) / 32), dim3(1024), 0, st, (const float*)part, blocks, C, (float*)dgamma,
+                           (float*)dbeta, (float*)dbias);
+    }
     FMMT_CHECK_LAUNCH();
     return 0;
+}
+
+// the text encoder's form: bf16 affine parameters
+extern "C" int fmmt_plm_dropadd_ln_fwd(int M, int C, float eps, const void* h, const void* res, const void* gamma, const void* beta, float p,
+                                       uint64_t seed, const uint64_t* seed_dev, uint64_t salt, void* xsum, void* y, void* stream) {
+    return fmmt_dropadd_ln_fwd(FMMT_BF16, M, C, eps, h, res, gamma, beta, p, seed, seed_dev, salt, xsum, y, stream);
+}
+extern "C" size_t fmmt_plm_dropadd_ln_bwd_workspace(int M, int C) { return fmmt_dropadd_ln_bwd_workspace(M, C); }
+extern "C" int fmmt_plm_dropadd_ln_bwd(int M, int C, float eps, const void* dy, const void* xsum, const void* gamma, float p, uint64_t seed,
+                                       const uint64_t* seed_dev, uint64_t salt, void* dx, void* dh, void* dgamma, void* dbeta, void* dbias, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+    return fmmt_dropadd_ln_bwd(FMMT_BF16, M, C, eps, dy, xsum, gamma, p, seed, seed_dev, salt, dx, dh, dgamma, dbeta, dbias, workspace, workspace_bytes, stream);
 }

@@ -123,6 +123,9 @@ class MultiModalTransformerForClassification(nn.Module):
         self.vision_utt_Transformernum = config.vision_utt_Transformernum
         self.get_vision_utt_max_lens = config.get_vision_utt_max_lens
         self.compute_dtype = getattr(config, "compute_dtype", torch.float32)
+        # True: the two directions of each cross-modal encoder run as one sweep over their stacked tokens (same result up to the summation
+        # order of the shared weights' gradients); False: two encoder calls per pair, as the reference spells it
+        self.stack_directions = bool(getattr(config, "stack_directions", True))
 
         plm = self._build_plm(config)
         if self.text_pretrained_model == 'roberta':
@@ -211,7 +214,12 @@ class MultiModalTransformerForClassification(nn.Module):
         """self-attention encoders, four cross-modal calls, pooling, classifier (ref :152-188)"""
         cd = self.compute_dtype
         out_dtype = text_feat.dtype
+        from . import ops
+        # one device draw for every dropout seed of the stack (attention and hidden dropout: ~40 call sites) instead of one launch each
+        with ops.seed_scope(text_feat.device, 96, enabled=self.training and text_feat.is_cuda):
+            return self._fusion_body(text_feat, text_mask, audio_inputs, audio_mask, vision_inputs, new_vision_mask, cd, out_dtype)
 
+    def _fusion_body(self, text_feat, text_mask, audio_inputs, audio_mask, vision_inputs, new_vision_mask, cd, out_dtype):
         def audio_side():
             audio_ext = (1.0 - audio_mask.unsqueeze(1).unsqueeze(2)) * -10000.0
             audio_utt = self.audio_utt_transformer(self.audio_linear(audio_inputs), audio_ext)
@@ -224,12 +232,19 @@ class MultiModalTransformerForClassification(nn.Module):
 
         # cross-modal fusion on the HIP path, time-major, in the module's compute dtype
         a_tm, (v_tm, t_tm) = self._pair(audio_side, vision_side, reads=(audio_inputs, audio_mask))
-        text_x_audio, audio_x_text = self._pair(lambda: self.CrossModalTrans_TA(t_tm, a_tm, a_tm),
-                                                lambda: self.CrossModalTrans_TA(a_tm, t_tm, t_tm), reads=(t_tm, a_tm))
-        ta = torch.cat((text_x_audio, audio_x_text), dim=0)
-        vision_x_ta, ta_x_vision = self._pair(lambda: self.CrossModalTrans_TA_V(v_tm, ta, ta),
-                                              lambda: self.CrossModalTrans_TA_V(ta, v_tm, v_tm), reads=(v_tm, ta))
-        final = torch.cat((ta_x_vision, vision_x_ta), dim=0).transpose(0, 1).to(out_dtype)
+        if self.stack_directions and self.CrossModalTrans_TA.pair_fusable() and self.CrossModalTrans_TA_V.pair_fusable():
+            # both directions of an encoder as one sweep over the stacked tokens (CrossModalTransformerEncoder.forward_pair): the stacked
+            # results ARE the concatenations the reference builds next (ref :173,178)
+            ta = self.CrossModalTrans_TA.forward_pair(t_tm, a_tm)                    # [text x audio ; audio x text]
+            final = self.CrossModalTrans_TA_V.forward_pair(ta, v_tm)                 # [ta x vision ; vision x ta]
+        else:
+            text_x_audio, audio_x_text = self._pair(lambda: self.CrossModalTrans_TA(t_tm, a_tm, a_tm),
+                                                    lambda: self.CrossModalTrans_TA(a_tm, t_tm, t_tm), reads=(t_tm, a_tm))
+            ta = torch.cat((text_x_audio, audio_x_text), dim=0)
+            vision_x_ta, ta_x_vision = self._pair(lambda: self.CrossModalTrans_TA_V(v_tm, ta, ta),
+                                                  lambda: self.CrossModalTrans_TA_V(ta, v_tm, v_tm), reads=(v_tm, ta))
+            final = torch.cat((ta_x_vision, vision_x_ta), dim=0)
+        final = final.transpose(0, 1).to(out_dtype)
         final_mask = torch.cat((text_mask.to(audio_mask.dtype), audio_mask, new_vision_mask), dim=1)
 
         pooled, _ = self.attention(final, final_mask)

@@ -53,7 +53,8 @@ class TransformerEncoderLayer(nn.Module):
         ln = self.layer_norms[i]
         return ops.layer_norm(x, ln.weight, ln.bias, ln.eps)
 
-    def forward(self, x, x_k=None, x_v=None):
+    def forward(self, x, x_k=None, x_v=None, segments=None):
+        """segments (see MultiheadAttention.attend): x and x_k hold several sequences stacked along time; needs the fused path."""
         if self.attn_mask:
             raise NotImplementedError("facialmmt_amd HIP path: future mask (attn_mask=True is never used by the model)")
         fused = not self.training or (self.res_dropout == 0.0 and self.gelu_dropout == 0.0)
@@ -67,8 +68,9 @@ class TransformerEncoderLayer(nn.Module):
         else:
             kn = self._ln(0, x_k)
             vn = kn if x_v is x_k else self._ln(0, x_v)
+        assert segments is None or (fused and vn is kn), "stacked sequences: zero residual / gelu dropout and one key = value tensor"
         if fused:
-            x = self.self_attn.attend(xn, kn, vn, res=x)
+            x = self.self_attn.attend(xn, kn, vn, res=x, segments=segments)
             x, xn = ops.residual_layer_norm(x, ln1.weight, ln1.bias, ln1.eps)
             return ops.mlp(xn, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, res=x)
         # non-zero residual / gelu dropouts (not used by the model's configuration): un-fused epilogues
@@ -116,6 +118,30 @@ class CrossModalTransformerEncoder(nn.Module):
             x_v = x_k if share else self._embed(x_in_v)
         for layer in self.layers:
             x = layer(x, x_k, x_v) if x_k is not None else layer(x)
+        if self.normalize:
+            x = ops.layer_norm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
+        return x
+
+    def pair_fusable(self):
+        """forward_pair needs the fused layer body (no residual / gelu dropout) and the key-side embedding shared with the value side"""
+        l0 = self.layers[0] if len(self.layers) else None
+        return not (self.training and (self.dropout > 0 or (l0 is not None and (l0.res_dropout > 0 or l0.gelu_dropout > 0)))) \
+            and not self.attn_mask
+
+    def forward_pair(self, xa_in, xb_in):
+        """(forward(xa_in, xb_in, xb_in), forward(xb_in, xa_in, xa_in)) -- the two calls src/models.py:171-177 makes per encoder with the
+        modalities' roles swapped -- as ONE sweep over the (La + Lb, B, E) stack of both query sequences: the same weights serve both
+        directions, so LayerNorms, projections, the feed-forward pair and every weight gradient run once over all tokens (half the
+        launches, twice the rows per launch, and no gradient-accumulation adds for parameters used twice); only the attention core is
+        told where a sequence ends.  Returns the stacked result (La + Lb, B, E): rows [:La] = direction a, rows [La:] = direction b --
+        exactly the torch.cat the caller would build next."""
+        ea, eb = self._embed(xa_in), self._embed(xb_in)
+        La, Lb = ea.shape[0], eb.shape[0]
+        x = torch.cat((ea, eb), dim=0)
+        k = torch.cat((eb, ea), dim=0)                         # keys of direction a = sequence b, and vice versa
+        segs = ((0, La, 0, Lb), (La, Lb, Lb, La))
+        for layer in self.layers:
+            x = layer(x, k, k, segments=segs)
         if self.normalize:
             x = ops.layer_norm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
         return x

@@ -98,12 +98,17 @@ class SelfAttention(nn.Module):
     def forward_tm(self, x, key_bias):
         """x (L, B, H) time-major; key_bias (B, L) or None.  softmax(q k^T / sqrt(d) + mask) v with dropout on the
         probabilities (ref :86-103); the (B, nH, L, L) tensors are never materialised."""
+        p = self.dropout.p if self.training else 0.0
+        seed = ops.draw_seed(x.device) if p > 0 else 0
+        scale = 1.0 / math.sqrt(self.attention_head_size)
+        if PACKED_QKV and self.query.bias is not None and self.key.bias is not None and self.value.bias is not None:
+            # the three projections as one launch into a packed (L*B, 3H) buffer the attention core works on in place (ops.SelfAttnQkvFn)
+            return ops.self_attention_qkv(x, self.query.weight, self.query.bias, self.key.weight, self.key.bias, self.value.weight, self.value.bias,
+                                          self.num_attention_heads, scale, p, seed, key_bias)
         q = ops.linear(x, self.query.weight, self.query.bias)
         k = ops.linear(x, self.key.weight, self.key.bias)
         v = ops.linear(x, self.value.weight, self.value.bias)
-        p = self.dropout.p if self.training else 0.0
-        seed = torch.randint(0, 2 ** 62, (1,), device=x.device, dtype=torch.int64) if p > 0 else 0
-        return ops.mha_core(q, k, v, self.num_attention_heads, 1.0 / math.sqrt(self.attention_head_size), p, seed, key_bias)
+        return ops.mha_core(q, k, v, self.num_attention_heads, scale, p, seed, key_bias)
 
     def forward(self, hidden_states, attention_mask):
         B, L, _ = hidden_states.shape
@@ -126,6 +131,21 @@ class TransformerIntermediate(nn.Module):
         return self.intermediate_act_fn(ops.linear(hidden_states, self.dense.weight, self.dense.bias))
 
 
+FUSED_TAILS = True           # module constant (tests patch it): False = dropout, add and LayerNorm as separate launches
+PACKED_QKV = True            # False = query / key / value as three Linear launches (and 3 x 3 in the backward)
+
+
+def _tail(m, h, input_tensor):
+    """LayerNorm(dropout(h) + input) of a training-mode sublayer (ref :121-123,134-136; `m` owns .dropout and .LayerNorm).  bf16 on the GPU: ONE
+    launch (ops.dropadd_layer_norm: counter-based dropout replayed in the backward, bf16 rounding op by op as the three torch / HIP launches it
+    replaces); otherwise those three."""
+    ln = m.LayerNorm
+    if FUSED_TAILS and h.is_cuda and h.dtype == torch.bfloat16 and input_tensor.dtype == torch.bfloat16 and h.shape[-1] % 8 == 0 and h.shape[-1] <= 2048:
+        seed = ops.draw_seed(h.device)                               # drawn on the device: graph-replay safe
+        return ops.dropadd_layer_norm(h, input_tensor, ln.weight, ln.bias, ln.variance_epsilon, m.dropout.p, seed)
+    return ln(m.dropout(h) + input_tensor)
+
+
 class Residual_Norm(nn.Module):
     def __init__(self, config):
         super().__init__()
@@ -135,7 +155,7 @@ class Residual_Norm(nn.Module):
 
     def forward(self, hidden_states, input_tensor):
         if self.training and self.dropout.p > 0:
-            return self.LayerNorm(self.dropout(ops.linear(hidden_states, self.dense.weight, self.dense.bias)) + input_tensor)
+            return _tail(self, ops.linear(hidden_states, self.dense.weight, self.dense.bias), input_tensor)
         # no dropout between dense and residual: the residual add is the GEMM epilogue
         return self.LayerNorm(ops.linear(hidden_states, self.dense.weight, self.dense.bias, res=input_tensor))
 
@@ -149,7 +169,7 @@ class Output_Residual_Norm(nn.Module):
 
     def forward(self, hidden_states, input_tensor):
         if self.training and self.dropout.p > 0:
-            return self.LayerNorm(self.dropout(ops.linear(hidden_states, self.dense.weight, self.dense.bias)) + input_tensor)
+            return _tail(self, ops.linear(hidden_states, self.dense.weight, self.dense.bias), input_tensor)
         return self.LayerNorm(ops.linear(hidden_states, self.dense.weight, self.dense.bias, res=input_tensor))
 
 
@@ -178,8 +198,7 @@ class TransformerEnoderLayer(nn.Module):      # (sic) the reference's spelling i
         epilogue, GELU' in the epilogue of fc2's input-gradient GEMM)."""
         out, inter = self.output, self.intermediate
         if self.training and out.dropout.p > 0:
-            h = ops.mlp(a, inter.dense.weight, inter.dense.bias, out.dense.weight, out.dense.bias)
-            return out.LayerNorm(out.dropout(h) + a)
+            return _tail(out, ops.mlp(a, inter.dense.weight, inter.dense.bias, out.dense.weight, out.dense.bias), a)
         return out.LayerNorm(ops.mlp(a, inter.dense.weight, inter.dense.bias, out.dense.weight, out.dense.bias, res=a))
 
     def forward_tm(self, x, key_bias):

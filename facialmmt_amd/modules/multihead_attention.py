@@ -58,16 +58,24 @@ class MultiheadAttention(nn.Module):
     def in_proj_kv(self, key):
         return self._proj(key, self.embed_dim, 3 * self.embed_dim)
 
-    def attend(self, query, key, value, res=None, need_weights=False):
+    def attend(self, query, key, value, res=None, need_weights=False, segments=None):
         """out_proj(softmax(q k^T) v) [+ res]; `res` fuses the caller's residual add into the GEMM epilogue.
-        need_weights: return (out, head-averaged attention weights (B, Lq, Lk)) instead of out."""
+        need_weights: return (out, head-averaged attention weights (B, Lq, Lk)) instead of out.
+        segments: ((q0, Lq, k0, Lk), ...) -- query / key hold several independent sequences stacked along time, rows q0..q0+Lq of
+        the queries attend to rows k0..k0+Lk of the keys (ops.MhaSegFn): every projection runs once over all of them."""
         tgt_len, bsz, embed_dim = query.size()
         assert embed_dim == self.embed_dim
         assert key.size() == value.size()
         E = self.embed_dim
         p = self.attn_dropout if self.training else 0.0
+        if segments is not None:
+            assert key is value and not need_weights, "stacked sequences: packed [k | v] projection, no attention weights"
+            seeds = ops.draw_seed(query.device, len(segments)) if p > 0 else 0
+            q, kproj = ops.in_proj_q_kv(query, key, self.in_proj_weight, self.in_proj_bias)
+            ctx = ops.mha_core_segments(q, kproj, segments, self.num_heads, self.scaling, p, seeds)
+            return ops.linear(ctx, self.out_proj.weight, self.out_proj.bias, res)
         # fresh seed per call, drawn on the device: no host sync, and a captured hipGraph re-draws it on replay
-        seed = torch.randint(0, 2 ** 62, (1,), device=query.device, dtype=torch.int64) if p > 0 else 0
+        seed = ops.draw_seed(query.device) if p > 0 else 0
         if key is value or (key.data_ptr() == value.data_ptr() and key.shape == value.shape):
             # two GEMMs (q: N = E; [k | v]: N = 2E) whose weight gradients land in one packed (3E, E) gradient: ops.InProjFn
             q, kproj = ops.in_proj_q_kv(query, key, self.in_proj_weight, self.in_proj_bias)

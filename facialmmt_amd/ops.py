@@ -400,6 +400,49 @@ class PlmSublayerTailFn(torch.autograd.Function):
         return dxin, dx.reshape(dy.shape), dw, dbias, dgamma, dbeta, None, None, None, None
 
 
+class DropAddLnFn(Function):
+    """y = LayerNorm(dropout(h) + res) as ONE launch per direction (fmmt_dropadd_ln_fwd / _bwd): the tail of MELDTransEncoder's two sublayers
+    (modules/Transformer.py:109-137: dense -> dropout -> + input -> TF LayerNorm) behind their GEMM.  bf16 activations, fp32 (master) or bf16
+    affine parameters.  Replaces fused_dropout + add + fmmt_layernorm_fwd (forward) and fmmt_layernorm_bwd + its reduction + masked_scale (backward);
+    no mask is stored: it is replayed from (`seed`: python int or 1-element int64 CUDA tensor, `salt`)."""
+
+    @staticmethod
+    def forward(ctx, h, res, gamma, beta, eps, p, seed, salt):
+        _need_cuda(h, "dropadd_layer_norm")
+        C = h.shape[-1]
+        h2, r2 = h.reshape(-1, C).contiguous(), res.reshape(-1, C).contiguous()
+        M = h2.shape[0]
+        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        assert h2.dtype == torch.bfloat16 and r2.dtype == torch.bfloat16 and g.dtype == b.dtype and g.dtype in (torch.float32, torch.bfloat16)
+        xsum, y = torch.empty_like(h2), torch.empty_like(h2)
+        seed_t = seed if isinstance(seed, torch.Tensor) else None
+        seed_i = 0 if seed_t is not None else int(seed)
+        check(_lib.load().fmmt_dropadd_ln_fwd(dtype_code(g.dtype), M, C, float(eps), _p(h2), _p(r2), _p(g), _p(b), float(p), seed_i, _p(seed_t), int(salt),
+                                              _p(xsum), _p(y), _st()), f"fmmt_dropadd_ln_fwd(M={M},C={C})")
+        ctx.save_for_backward(xsum, g, seed_t)
+        ctx.cfg = (float(eps), float(p), seed_i, int(salt))
+        return y.reshape(h.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xsum, g, seed_t = ctx.saved_tensors
+        eps, p, seed_i, salt = ctx.cfg
+        M, C = xsum.shape
+        dy2 = dy.reshape(M, C).contiguous()
+        lib = _lib.load()
+        dx, dh = torch.empty_like(xsum), torch.empty_like(xsum)
+        dgamma, dbeta = torch.empty_like(g), torch.empty_like(g)
+        nbytes = lib.fmmt_dropadd_ln_bwd_workspace(M, C)
+        ws = _ws(nbytes, xsum.device)
+        check(lib.fmmt_dropadd_ln_bwd(dtype_code(g.dtype), M, C, eps, _p(dy2), _p(xsum), _p(g), p, seed_i, _p(seed_t), salt, _p(dx), _p(dh), _p(dgamma),
+                                      _p(dbeta), None, _p(ws), nbytes, _st()), f"fmmt_dropadd_ln_bwd(M={M},C={C})")
+        return dh.reshape(dy.shape), dx.reshape(dy.shape), dgamma, dbeta, None, None, None, None
+
+
+def dropadd_layer_norm(h, res, gamma, beta, eps, p, seed, salt=0):
+    return DropAddLnFn.apply(h, res, gamma, beta, eps, p, seed, salt)
+
+
 class PlmQkvFn(torch.autograd.Function):
     """(q, k, v) = x [Wq; Wk; Wv]^T + [bq; bk; bv] as ONE vendor GEMM over the packed weight `w_all` (3E, E) of which the three nn.Linear weights are
     row slices (train_step.fuse_text_encoder re-points them): transformers' *SelfAttention.query / key / value (src/models.py:75-91).  Backward: the
@@ -1006,6 +1049,227 @@ class MhaCoreFn(Function):
         num_heads, scale, dropout_p, seed = ctx.cfg
         dq, dk, dv = mha_bwd_raw(q, k, v, out, dout.contiguous(), lse, num_heads, scale, dropout_p, seed, seed_t, key_bias)
         return dq, dk, dv, None, None, None, None, None
+
+
+class MhaSegFn(Function):
+    """Several independent attention problems over ROW RANGES of one time-major query tensor q (Lq_tot,B,E) and one packed key / value
+    projection kv (Lk_tot,B,2E): segment i = (q0, Lq, k0, Lk) lets queries q[q0:q0+Lq] attend to kv[k0:k0+Lk].  The two directions of a
+    cross-modal encoder (CrossmodalTransformer.py:60-96 called twice by src/models.py:171-177 with the roles of the modalities swapped)
+    share every per-token launch when their tokens are concatenated; only the attention core has to know where a sequence ends.  One
+    fmmt_mha_fwd / fmmt_mha_bwd call per segment, reading and writing the row ranges in place (no slice copies, no cat).
+    seed: python int, or an int64 CUDA tensor with one word per segment (graph-replay safe)."""
+
+    @staticmethod
+    def forward(ctx, q, kv, segs, num_heads, scale, dropout_p, seed):
+        _need_cuda(q, "multihead_attention")
+        q, kv = q.contiguous(), kv.contiguous()
+        Lq_tot, B, E = q.shape
+        assert kv.shape[1:] == (B, 2 * E), f"packed [k | v] projection expected, got {tuple(kv.shape)}"
+        cover_q = sorted((s[0], s[0] + s[1]) for s in segs)
+        cover_k = sorted((s[2], s[2] + s[3]) for s in segs)
+        for cover, tot in ((cover_q, Lq_tot), (cover_k, kv.shape[0])):       # every row written exactly once (out, dq, dkv are torch.empty)
+            assert cover[0][0] == 0 and cover[-1][1] == tot and all(a[1] == b[0] for a, b in zip(cover, cover[1:])), \
+                f"segments must tile the rows: {segs}"
+        seed_t = seed if isinstance(seed, torch.Tensor) else None
+        assert seed_t is None or seed_t.numel() >= len(segs)
+        es = q.element_size()
+        out = torch.empty_like(q)
+        lses = []
+        lib = _lib.load()
+        for i, (q0, Lq, k0, Lk) in enumerate(segs):
+            lse = torch.empty((B * num_heads * Lq,), dtype=torch.float32, device=q.device)
+            kp = kv.data_ptr() + k0 * B * 2 * E * es
+            rc = lib.fmmt_mha_fwd(dtype_code(q.dtype), Lq, Lk, B, E, num_heads, q.data_ptr() + q0 * B * E * es, E, kp, kp + E * es, 2 * E, scale, None,
+                                  dropout_p, 0 if seed_t is not None else int(seed) + i, (seed_t.data_ptr() + 8 * i) if seed_t is not None else None,
+                                  out.data_ptr() + q0 * B * E * es, E, _p(lse), _st())
+            check(rc, f"fmmt_mha_fwd(segment {i}: Lq={Lq},Lk={Lk},B={B},E={E},heads={num_heads})")
+            lses.append(lse)
+        ctx.save_for_backward(q, kv, out, seed_t, *lses)
+        ctx.cfg = (tuple(segs), num_heads, scale, dropout_p, 0 if seed_t is not None else int(seed))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, kv, out, seed_t, *lses = ctx.saved_tensors
+        segs, num_heads, scale, dropout_p, seed = ctx.cfg
+        _, B, E = q.shape
+        es = q.element_size()
+        dout = dout.contiguous()
+        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        lib = _lib.load()
+        for i, (q0, Lq, k0, Lk) in enumerate(segs):
+            qo, ko = q0 * B * E * es, k0 * B * 2 * E * es
+            rc = lib.fmmt_mha_bwd(dtype_code(q.dtype), Lq, Lk, B, E, num_heads, q.data_ptr() + qo, E, kv.data_ptr() + ko, kv.data_ptr() + ko + E * es, 2 * E,
+                                  scale, None, dropout_p, seed + i if seed_t is None else 0, (seed_t.data_ptr() + 8 * i) if seed_t is not None else None,
+                                  out.data_ptr() + qo, dout.data_ptr() + qo, E, _p(lses[i]), dq.data_ptr() + qo, E, dkv.data_ptr() + ko,
+                                  dkv.data_ptr() + ko + E * es, 2 * E, _st())
+            check(rc, f"fmmt_mha_bwd(segment {i})")
+        return dq, dkv, None, None, None, None, None
+
+
+def mha_core_segments(q, kv, segs, num_heads, scale, dropout_p=0.0, seed=0):
+    return MhaSegFn.apply(q, kv, tuple(tuple(int(v) for v in s) for s in segs), num_heads, scale, float(dropout_p),
+                          seed if isinstance(seed, torch.Tensor) else int(seed))
+
+
+class SelfAttnQkvFn(Function):
+    """ctx = attention(x Wq^T + bq, x Wk^T + bk, x Wv^T + bv) for SELF-attention over x (L,B,H), time-major: MELDTransEncoder's SelfAttention
+    (modules/Transformer.py:64-103, three nn.Linear over the same hidden states).  The three projections are ONE launch writing a packed
+    (L*B, 3H) buffer (fmmt_linear_fwd_seg3, the three weight shadows as they are: no packed copy of the parameters exists), the attention
+    core reads and -- backward -- writes that layout in place (row stride 3H), the input gradient dq Wq + dk Wk + dv Wv is one launch
+    (K-segmented) and the three weight / bias gradients one (3H, H) / (3H) contraction returned as row slices.
+    Per layer: 4 + 13 launches become 2 + 4.  Shapes the segmented kernel does not take (fp32 parity mode, many tokens) run the same
+    arithmetic as three launches per step."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, num_heads, scale, dropout_p, seed, key_bias):
+        _need_cuda(x, "self_attention")
+        x = x.contiguous()
+        L, B, H = x.shape
+        M = L * B
+        x2 = x.reshape(M, H)
+        lib = _lib.load()
+        ws = [_lp(w, x.dtype) for w in (wq, wk, wv)]
+        bs = [b.detach().float().contiguous() if b is not None else None for b in (bq, bk, bv)]
+        qkv = torch.empty((M, 3 * H), dtype=x.dtype, device=x.device)
+        rc = lib.fmmt_linear_fwd_seg3(dtype_code(x.dtype), M, 3 * H, H, _p(x2), H, _p(ws[0]), _p(ws[1]), _p(ws[2]), H, 1, _p(bs[0]), _p(bs[1]), _p(bs[2]),
+                                      _p(qkv), 3 * H, _st())
+        if rc == _lib.FMMT_EINVAL:
+            for i in range(3):
+                qkv[:, i * H:(i + 1) * H] = linear_raw(x2, ws[i], bs[i])
+        else:
+            check(rc, f"fmmt_linear_fwd_seg3(M={M},N={3 * H},K={H})")
+        seed_t = seed if isinstance(seed, torch.Tensor) else None
+        seed_i = 0 if seed_t is not None else int(seed)
+        if key_bias is not None:
+            key_bias = key_bias.detach().to(torch.float32).contiguous()
+            assert key_bias.shape == (B, L)
+        es = x.element_size()
+        out = torch.empty_like(x)
+        lse = torch.empty((B * num_heads * L,), dtype=torch.float32, device=x.device)
+        qp = qkv.data_ptr()
+        rc = lib.fmmt_mha_fwd(dtype_code(x.dtype), L, L, B, H, num_heads, qp, 3 * H, qp + H * es, qp + 2 * H * es, 3 * H, scale, _p(key_bias),
+                              dropout_p, seed_i, _p(seed_t), _p(out), H, _p(lse), _st())
+        check(rc, f"fmmt_mha_fwd(self, L={L},B={B},H={H},heads={num_heads})")
+        ctx.save_for_backward(x2, qkv, out, lse, seed_t, key_bias, wq, wk, wv)
+        ctx.cfg = (num_heads, scale, dropout_p, seed_i, (L, B, H), tuple(b is not None for b in bs))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, qkv, out, lse, seed_t, key_bias, wq, wk, wv = ctx.saved_tensors
+        num_heads, scale, dropout_p, seed_i, (L, B, H), has_b = ctx.cfg
+        M = L * B
+        lib = _lib.load()
+        es = x2.element_size()
+        dout = dout.contiguous()
+        dqkv = torch.empty_like(qkv)
+        qp, dp = qkv.data_ptr(), dqkv.data_ptr()
+        rc = lib.fmmt_mha_bwd(dtype_code(x2.dtype), L, L, B, H, num_heads, qp, 3 * H, qp + H * es, qp + 2 * H * es, 3 * H, scale, _p(key_bias),
+                              dropout_p, seed_i, _p(seed_t), _p(out), _p(dout), H, _p(lse), dp, 3 * H, dp + H * es, dp + 2 * H * es, 3 * H, _st())
+        check(rc, "fmmt_mha_bwd(self)")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wt = [_lp(w, x2.dtype, transpose=True) for w in (wq, wk, wv)]
+            dx = torch.empty_like(x2)
+            rc = lib.fmmt_linear_fwd_seg3(dtype_code(x2.dtype), M, H, 3 * H, dp, 3 * H, _p(wt[0]), _p(wt[1]), _p(wt[2]), H, 2, None, None, None, _p(dx), H, _st())
+            if rc == _lib.FMMT_EINVAL:
+                dx = sum(linear_raw(dqkv[:, i * H:(i + 1) * H].contiguous(), wt[i], None) for i in range(3))
+            else:
+                check(rc, f"fmmt_linear_fwd_seg3(M={M},N={H},K={3 * H})")
+            dx = dx.reshape(L, B, H)
+        dw, db = wgrad_raw(dqkv, x2, True)
+        g = []
+        for i in range(3):
+            g += [dw[i * H:(i + 1) * H], db[i * H:(i + 1) * H] if has_b[i] else None]
+        return (dx, *g, None, None, None, None, None)
+
+
+def self_attention_qkv(x, wq, bq, wk, bk, wv, bv, num_heads, scale, dropout_p=0.0, seed=0, key_bias=None):
+    return SelfAttnQkvFn.apply(x, wq, bq, wk, bk, wv, bv, num_heads, scale, float(dropout_p), seed if isinstance(seed, torch.Tensor) else int(seed), key_bias)
+
+
+class SelectFramesFn(Function):
+    """train_step.select_frames as one launch per direction (fmmt_select_frames_fwd / _bwd; train.py:75-114)."""
+
+    @staticmethod
+    def forward(ctx, preds, vision_inputs, vision_mask, num_imgs, threshold):
+        _need_cuda(preds, "select_frames")
+        nF, NL = preds.shape
+        B, Lv, D = vision_inputs.shape
+        p32 = preds.detach().float().contiguous()
+        vin = vision_inputs.detach().contiguous()
+        vm = vision_mask.detach().float().contiguous()
+        n = num_imgs.to(device=preds.device, dtype=torch.int64).contiguous()
+        out = torch.empty((B, Lv, D + NL), dtype=vin.dtype, device=vin.device)
+        new_mask = torch.empty((B, Lv), dtype=torch.float32, device=vin.device)
+        src = torch.empty((B, Lv), dtype=torch.int32, device=vin.device)
+        check(_lib.load().fmmt_select_frames_fwd(dtype_code(vin.dtype), nF, NL, B, Lv, D, _p(p32), _p(vin), _p(vm), _p(n), float(threshold), _p(out),
+                                                 _p(new_mask), _p(src), _st()), f"fmmt_select_frames_fwd(nF={nF},B={B},Lv={Lv},D={D})")
+        ctx.save_for_backward(src)
+        ctx.cfg = (nF, NL, B, Lv, D, preds.dtype)
+        new_mask = new_mask.to(vision_mask.dtype)
+        ctx.mark_non_differentiable(new_mask)
+        return out, new_mask
+
+    @staticmethod
+    def backward(ctx, dout, _dmask):
+        (src,) = ctx.saved_tensors
+        nF, NL, B, Lv, D, pdt = ctx.cfg
+        dout = dout.contiguous()
+        dp = torch.empty((nF, NL), dtype=torch.float32, device=dout.device)
+        check(_lib.load().fmmt_select_frames_bwd(dtype_code(dout.dtype), nF, NL, B, Lv, D, _p(dout), _p(src), _p(dp), _st()), "fmmt_select_frames_bwd")
+        return dp.to(pdt), None, None, None, None
+
+
+def select_frames_fusable(preds, vision_inputs, vision_mask):
+    B, Lv, _ = vision_inputs.shape
+    return (preds.is_cuda and vision_inputs.is_cuda and not vision_inputs.requires_grad and vision_inputs.dtype in (torch.float32, torch.bfloat16)
+            and preds.shape[0] <= 8192 and B <= 256 and B * Lv <= 8192 and preds.shape[1] <= 256)
+
+
+def select_frames(preds, vision_inputs, vision_mask, num_imgs, threshold):
+    return SelectFramesFn.apply(preds, vision_inputs, vision_mask, num_imgs, float(threshold))
+
+
+# ------------------------------------------------------------------------------------------------
+# dropout seeds: one device draw per scope instead of one per call site
+# ------------------------------------------------------------------------------------------------
+_SEED_SCOPES: list = []
+
+
+class seed_scope:
+    """`with seed_scope(device, n):` -- ONE torch.randint launch draws n int64 seed words; every draw_seed() inside the scope hands out the next
+    word as a 1-element view (a plain pointer offset for the kernels) instead of launching its own draw (~5 us each inside the fusion stack's
+    chain of dependent launches, three per encoder layer).  Graph-replay safe like the single draws: the one randint is part of the graph.
+    Nested scopes and draws beyond n fall back to individual draws."""
+
+    def __init__(self, device, n: int = 64, enabled: bool = True):
+        self.device, self.n, self.enabled = device, int(n), enabled
+        self.words, self.next = None, 0
+
+    def __enter__(self):
+        if self.enabled:
+            self.words = torch.randint(0, 2 ** 62, (self.n,), device=self.device, dtype=torch.int64)
+            self.next = 0
+            _SEED_SCOPES.append(self)
+        return self
+
+    def __exit__(self, *exc):
+        if self.enabled:
+            _SEED_SCOPES.remove(self)
+        return False
+
+
+def draw_seed(device, n: int = 1):
+    """n (default 1) device-resident int64 dropout seed words (see seed_scope)"""
+    if _SEED_SCOPES:
+        sc = _SEED_SCOPES[-1]
+        if sc.words.device == torch.device(device) and sc.next + n <= sc.n:
+            w = sc.words[sc.next:sc.next + n]
+            sc.next += n
+            return w
+    return torch.randint(0, 2 ** 62, (n,), device=device, dtype=torch.int64)
 
 
 def mha_avg_weights(q, k, lse, num_heads, scale, dropout_p=0.0, seed=0, key_bias=None):

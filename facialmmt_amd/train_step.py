@@ -12,6 +12,9 @@ import torch
 import torch.nn.functional as F
 
 
+SELECT_FRAMES_KERNEL = True      # module constant (tests patch it): False = the torch restatement below (~55 launches)
+
+
 def select_frames(preds, vision_inputs, vision_mask, num_imgs, threshold):
     """Device-side, sync-free version of train.py:75-114.
 
@@ -23,7 +26,11 @@ def select_frames(preds, vision_inputs, vision_mask, num_imgs, threshold):
     B, Lv, D = vision_inputs.shape
     dev = preds.device
     nF = preds.shape[0]
-    n = num_imgs.to(dev).long()
+    if SELECT_FRAMES_KERNEL and torch.is_tensor(num_imgs):
+        from . import ops
+        if ops.select_frames_fusable(preds, vision_inputs, vision_mask):
+            return ops.select_frames(preds, vision_inputs, vision_mask, num_imgs, threshold)      # one launch (csrc/frame_filter.hip): same index arithmetic
+    n = torch.as_tensor(num_imgs).to(dev).long()
     importance = (preds * preds).sum(dim=1)                       # == diag(P P^T)
     sel = importance > threshold                                   # (nF,)
     g = torch.arange(nF, device=dev)

@@ -65,6 +65,15 @@ int fmmt_linear_fwd(int dtype, int M, int N, int K,
                     const void* res, int ldres, const float* rowscale, int rows_per_scale,
                     void* stream);
 
+/* Few-token Linear over three weights in one launch: the query / key / value projections of MELDTransEncoder's SelfAttention
+ * (modules/Transformer.py:64-103: three nn.Linear applied to the same hidden states) and their input gradient.
+ *   seg_mode 1: y[:, s*N/3:(s+1)*N/3] = x @ w_s^T + bias_s, w_s [N/3][K] (bias_s may be NULL);
+ *   seg_mode 2: y = sum_s x[:, s*K/3:(s+1)*K/3] @ w_s^T, w_s [N][K/3], no bias.
+ * bf16; M <= 4096, N, K, N/3 resp. K/3 multiples of 64, few tiles (the fusion stack's shapes).  FMMT_EINVAL for anything else: issue three
+ * fmmt_linear_fwd calls instead. */
+int fmmt_linear_fwd_seg3(int dtype, int M, int N, int K, const void* x, int ldx, const void* w0, const void* w1, const void* w2, int ldw,
+                         int seg_mode, const float* bias0, const float* bias1, const float* bias2, void* y, int ldy, void* stream);
+
 /* Split-K variant for skinny problems (few output tiles, very long K: the 49*768 -> 512 embedding head,
  * Swin_Transformer.py:493).  y = x . w^T + bias only (no activation / residual).  The K range is cut
  * across workgroups into fp32 partials in `workspace` and summed in a fixed order.
@@ -351,6 +360,30 @@ size_t fmmt_plm_dropadd_ln_bwd_workspace(int M, int C);
 int fmmt_plm_dropadd_ln_bwd(int M, int C, float eps, const void* dy, const void* xsum, const void* gamma, float p, uint64_t seed,
                             const uint64_t* seed_dev, uint64_t salt, void* dx, void* dh, void* dgamma, void* dbeta, void* dbias, void* workspace,
                             size_t workspace_bytes, void* stream);
+
+/* The same pair with the affine parameters' type as an argument (param_dtype FMMT_BF16 | FMMT_F32: gamma, beta, dgamma, dbeta, dbias in that type;
+ * activations bf16): also serves MELDTransEncoder's sublayer tails, LayerNorm(dropout(dense(h)) + input) with fp32 master parameters
+ * (modules/Transformer.py:109-137).  fmmt_plm_dropadd_ln_* = these with FMMT_BF16. */
+int fmmt_dropadd_ln_fwd(int param_dtype, int M, int C, float eps, const void* h, const void* res, const void* gamma, const void* beta, float p,
+                        uint64_t seed, const uint64_t* seed_dev, uint64_t salt, void* xsum, void* y, void* stream);
+size_t fmmt_dropadd_ln_bwd_workspace(int M, int C);
+int fmmt_dropadd_ln_bwd(int param_dtype, int M, int C, float eps, const void* dy, const void* xsum, const void* gamma, float p, uint64_t seed,
+                        const uint64_t* seed_dev, uint64_t salt, void* dx, void* dh, void* dgamma, void* dbeta, void* dbias, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
+/* Facial-emotion frame filter of a target-task step (train.py:75-114), one launch per direction.  preds [nF][NL] fp32: per-face emotion
+ * distribution (Gumbel-softmax of the Swin logits); vision_inputs [B][Lv][D] and out [B][Lv][D + NL] in `dtype`; vision_mask, new_mask [B][Lv] fp32;
+ * num_imgs [B] int64 on the DEVICE (real frames per utterance, <= Lv).  Faces with sum(p^2) > threshold are kept; utterance u owns the faces
+ * [b_{u-1}, b_u), b_u = sum_{i<=u} n_i - u (the reference's margin arithmetic), packs its kept faces to the front of its Lv slots with the matching
+ * vision rows, the NL probabilities appended, new_mask = 1 on the filled slots; if no face of the batch passes: out = [vision_inputs | preds of the
+ * real frames in order], new_mask = vision_mask.  src_face [B][Lv] int32 receives the face that fed each slot's probability columns (-1: none).
+ * _bwd: dpreds [nF][NL] fp32 = gather of dout[..., D:] through src_face (vision_inputs are data: no gradient).
+ * nF <= 8192, B <= 256, B * Lv <= 8192, else FMMT_EINVAL. */
+int fmmt_select_frames_fwd(int dtype, int nF, int NL, int B, int Lv, int D, const float* preds, const void* vision_inputs,
+                           const float* vision_mask, const int64_t* num_imgs, float threshold, void* out, float* new_mask,
+                           int32_t* src_face, void* stream);
+int fmmt_select_frames_bwd(int dtype, int nF, int NL, int B, int Lv, int D, const void* dout, const int32_t* src_face, float* dpreds,
+                           void* stream);
 
 /* Batched refresh of bf16 weight shadows: one launch casts (fp32 -> bf16, or copies bf16) and optionally transposes n_desc
  * parameter matrices.  The reference keeps fp32 nn.Parameters (train.py:336-349 builds the optimizer over them); the bf16 GEMMs

@@ -359,3 +359,50 @@ def test_meld_utt_and_multimodal_lv320(golden, dev):
     inp = [t.to(dev) for t in synth_multimodal_inputs(synth, B=3, T=64, La=24, Lv=320)]
     with torch.no_grad():
         golden.check("lv320", "mm/roberta_lv320", mm(*inp), **TOL)
+
+
+@pytest.mark.parametrize("La,Lb,B", [(38, 128, 4), (166, 160, 1)])
+def test_encoder_forward_pair_against_goldens_and_two_calls(golden, dev, enc, La, Lb, B):
+    """CrossModalTransformerEncoder.forward_pair: both directions of an encoder as one sweep over the stacked tokens (ops.MhaSegFn keeps the
+    sequences apart in the attention core).  fp32: each half reaches the reference's golden of the corresponding single call at 1e-3;
+    gradients (inputs and every parameter, one backward over both directions) against the sum of the two single-call backwards."""
+    xa, xb = _seq(dev, f"x{La}", La, B, 5 if La == 38 else 0), _seq(dev, f"x{Lb}", Lb, B, 5 if Lb == 38 else 0)
+    with torch.no_grad():
+        y = enc.forward_pair(xa, xb)
+    assert y.shape == (La + Lb, B, 768)
+    golden.check("crossmodal", f"enc/{La}_{Lb}_b{B}", y[:La], **TOL)
+    golden.check("crossmodal", f"enc/{Lb}_{La}_b{B}", y[La:], **TOL)
+    params = list(enc.parameters())
+    wa, wb = synth.tensor("wa", (La, B, 768), seed=81).to(dev), synth.tensor("wb", (Lb, B, 768), seed=82).to(dev)
+    xa_g, xb_g = xa.clone().requires_grad_(True), xb.clone().requires_grad_(True)
+    yp = enc.forward_pair(xa_g, xb_g)
+    gp = torch.autograd.grad((yp[:La] * wa).sum() + (yp[La:] * wb).sum(), [xa_g, xb_g] + params, allow_unused=True)
+    ya, yb = enc(xa_g, xb_g, xb_g), enc(xb_g, xa_g, xa_g)
+    gs = torch.autograd.grad((ya * wa).sum() + (yb * wb).sum(), [xa_g, xb_g] + params, allow_unused=True)
+    for a, b in zip(gp, gs):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert (a - b).abs().max().item() <= 1e-4 * max(b.abs().max().item(), 1e-6) + 1e-6
+    # bf16 (what the bench runs): stacked against the two calls
+    with torch.no_grad():
+        y16 = enc.forward_pair(xa.bfloat16(), xb.bfloat16()).float()
+        r16 = torch.cat((enc(xa.bfloat16(), xb.bfloat16(), xb.bfloat16()), enc(xb.bfloat16(), xa.bfloat16(), xa.bfloat16())), 0).float()
+    assert (y16 - r16).abs().max().item() <= 1e-2 * r16.abs().max().item()
+
+
+def test_encoder_forward_pair_dropout_segments_use_their_own_streams(dev, enc):
+    """training mode: attention dropout is drawn per segment (one seed word each); same torch seed -> same result, and the stacked result's halves
+    differ from the eval-mode halves (dropout active in both)"""
+    xa, xb = _seq(dev, "x38", 38, 2, 0).bfloat16(), _seq(dev, "x128", 128, 2, 0).bfloat16()
+    enc.train()
+    try:
+        torch.manual_seed(5)
+        y1 = enc.forward_pair(xa, xb)
+        torch.manual_seed(5)
+        y2 = enc.forward_pair(xa, xb)
+    finally:
+        enc.eval()
+    with torch.no_grad():
+        y0 = enc.forward_pair(xa, xb)
+    assert torch.equal(y1, y2) and torch.isfinite(y1.float()).all()
+    assert not torch.equal(y1[:38], y0[:38]) and not torch.equal(y1[38:], y0[38:])

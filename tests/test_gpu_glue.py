@@ -444,3 +444,185 @@ def test_fused_sublayer_tail_dropout_replays_its_mask_in_the_backward():
                         (gm.grad, gm2.grad, "dgamma"), (bt.grad, bt2.grad, "dbeta")):
         s = r_.float().abs().max().item() + 1e-6
         assert (a.float() - r_.float()).abs().max().item() <= 4e-2 * s, (name, (a.float() - r_.float()).abs().max().item(), s)
+
+
+def test_dropadd_layer_norm_with_fp32_parameters_against_torch_on_the_same_mask():
+    """ops.dropadd_layer_norm (fmmt_dropadd_ln_fwd / _bwd, param_dtype FMMT_F32): the training-mode tail of MELDTransEncoder's sublayers
+    (modules/Transformer.py:121-123,134-136) with fp32 master LayerNorm parameters and the TF epsilon 1e-12.  p = 0: equal to LayerNorm(h + res) of the same
+    bf16 sum; p = 0.1: against torch on the mask the kernel drew (read back by a probe launch), forward and all four gradients, fp32 parameter gradients."""
+    from facialmmt_amd import _lib, ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(2)
+    M, C = 640, 768
+    h = torch.randn(M, C, device=dev).to(torch.bfloat16)
+    res = (0.05 * torch.randn(M, C, device=dev)).to(torch.bfloat16)
+    gm = (1 + 0.1 * torch.randn(C, device=dev)).requires_grad_(True)
+    bt = (0.1 * torch.randn(C, device=dev)).requires_grad_(True)
+    seed = torch.tensor([777], device=dev, dtype=torch.int64)
+    y0 = ops.dropadd_layer_norm(h, res, gm, bt, 1e-12, 0.0, seed, 3)
+    r0 = torch.nn.functional.layer_norm((h + res).float(), (C,), gm, bt, 1e-12)
+    assert (y0.float() - r0).abs().max().item() <= 1e-2 * r0.abs().max().item()
+    for p in (0.1,):
+        ones, zeros = torch.ones(M, C, device=dev, dtype=torch.bfloat16), torch.zeros(M, C, device=dev, dtype=torch.bfloat16)
+        probe, junk = torch.empty_like(ones), torch.empty_like(ones)
+        _lib.check(_lib.load().fmmt_dropadd_ln_fwd(_lib.dtype_code(torch.float32), M, C, 1e-12, ones.data_ptr(), zeros.data_ptr(), gm.data_ptr(), bt.data_ptr(), p, 0,
+                                                   seed.data_ptr(), 3, probe.data_ptr(), junk.data_ptr(), torch.cuda.current_stream().cuda_stream), "probe")
+        keep = probe != 0
+        assert abs(keep.float().mean().item() - (1 - p)) < 0.01
+        hin, rin = h.clone().requires_grad_(True), res.clone().requires_grad_(True)
+        y = ops.dropadd_layer_norm(hin, rin, gm, bt, 1e-12, p, seed, 3)
+        dy = torch.randn(M, C, device=dev, dtype=torch.bfloat16)
+        gh, gr, gg, gb = torch.autograd.grad(y, [hin, rin, gm, bt], dy)
+        assert gg.dtype == torch.float32 and gb.dtype == torch.float32
+        h2, r2 = h.clone().requires_grad_(True), res.clone().requires_grad_(True)
+        gm2, bt2 = gm.detach().clone().requires_grad_(True), bt.detach().clone().requires_grad_(True)
+        t2 = (h2 * keep.to(h2.dtype) * (1.0 / (1.0 - p))).to(torch.bfloat16)
+        yr = torch.nn.functional.layer_norm((t2 + r2).float(), (C,), gm2, bt2, 1e-12)
+        rh, rr, rg, rb = torch.autograd.grad(yr, [h2, r2, gm2, bt2], dy.float())
+        assert (y.float() - yr).abs().max().item() <= 2e-2 * yr.abs().max().item()
+        for a, r_, name in ((gh, rh, "dh"), (gr, rr, "dres"), (gg, rg, "dgamma"), (gb, rb, "dbeta")):
+            s = r_.float().abs().max().item() + 1e-6
+            assert (a.float() - r_.float()).abs().max().item() <= 3e-2 * s, (name, (a.float() - r_.float()).abs().max().item(), s)
+        assert torch.equal((gh != 0) | ~keep, torch.ones_like(keep)) or (gh[~keep] == 0).all()      # the dense gradient is zero where the forward dropped
+        assert (gh[~keep] == 0).all()
+
+
+def test_meld_encoder_training_mode_fused_tails_match_the_separate_launches():
+    """MELDTransEncoder in training mode, bf16: with hidden dropout forced to 0 inside _tail the fused launch and the three separate launches agree (same
+    bf16 rounding op by op); with p = 0.1 both run, finite, and two passes under the same torch seed are identical (device-drawn seeds)."""
+    import types
+    from facialmmt_amd.config import default_args
+    from facialmmt_amd.modules import Transformer as TM
+    dev = torch.device("cuda:0")
+    cfg = default_args()
+    torch.manual_seed(0)
+    m = TM.MELDTransEncoder(cfg, 2, 160, 768).to(dev).train()
+    m.compute_dtype = torch.bfloat16
+    x = (0.5 * torch.randn(4, 160, 768, device=dev)).requires_grad_(True)
+    mask = torch.ones(4, 160, device=dev)
+    mask[1, 100:] = 0
+    ext = (1.0 - mask.unsqueeze(1).unsqueeze(2)) * -10000.0
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.1
+    torch.manual_seed(11)
+    y1 = m(x, ext)
+    g1 = torch.autograd.grad(y1.square().mean(), [x] + list(m.parameters()))
+    torch.manual_seed(11)
+    y2 = m(x, ext)
+    assert torch.equal(y1, y2) and torch.isfinite(y1).all() and all(torch.isfinite(g).all() for g in g1)
+    # attention dropout off, hidden dropout "on" with p -> 0: the fused tail against the separate launches
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 1e-9 if not isinstance(getattr(mod, "_is_attn", None), bool) else 0.0
+    for layer in m.layer:
+        layer.transformer_self_attention.selfatt.dropout.p = 0.0
+    outs = []
+    for fused in (True, False):
+        TM.FUSED_TAILS = fused
+        try:
+            y = m(x, ext)
+            outs.append((y, torch.autograd.grad(y.square().mean(), [x] + list(m.parameters()))))
+        finally:
+            TM.FUSED_TAILS = True
+    (ya, ga), (yb, gb) = outs
+    assert (ya - yb).abs().max().item() <= 2e-2 * yb.abs().max().item()
+    for a, b in zip(ga, gb):
+        assert (a.float() - b.float()).abs().max().item() <= 5e-2 * (b.float().abs().max().item() + 1e-8)
+
+
+@pytest.mark.parametrize("M,H", [(640, 768), (512, 768), (152, 768), (64, 128)])
+def test_linear_fwd_seg3_against_three_products(M, H):
+    """fmmt_linear_fwd_seg3: three weights in one launch, segmented along the output channels (query / key / value of one input) and along the
+    contraction (their input gradient), against fp64 products of the same bf16 operands."""
+    from facialmmt_amd import _lib
+    dev = torch.device("cuda:0")
+    torch.manual_seed(M + H)
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.randn(M, H, device=dev).to(torch.bfloat16)
+    ws = [(torch.randn(H, H, device=dev) * H ** -0.5).to(torch.bfloat16) for _ in range(3)]
+    bs = [torch.randn(H, device=dev) for _ in range(3)]
+    y = torch.empty(M, 3 * H, device=dev, dtype=torch.bfloat16)
+    _lib.check(lib.fmmt_linear_fwd_seg3(_lib.dtype_code(torch.bfloat16), M, 3 * H, H, x.data_ptr(), H, ws[0].data_ptr(), ws[1].data_ptr(), ws[2].data_ptr(), H, 1,
+                                        bs[0].data_ptr(), bs[1].data_ptr(), None, y.data_ptr(), 3 * H, st), "seg3 N")
+    for i in range(3):
+        ref = x.double() @ ws[i].double().t() + (bs[i].double() if i < 2 else 0.0)
+        assert (y[:, i * H:(i + 1) * H].double() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item(), i
+    d = torch.randn(M, 3 * H, device=dev).to(torch.bfloat16)
+    dx = torch.empty(M, H, device=dev, dtype=torch.bfloat16)
+    wt = [w.t().contiguous() for w in ws]                        # [N = H_in][K = H_out]
+    _lib.check(lib.fmmt_linear_fwd_seg3(_lib.dtype_code(torch.bfloat16), M, H, 3 * H, d.data_ptr(), 3 * H, wt[0].data_ptr(), wt[1].data_ptr(), wt[2].data_ptr(), H, 2,
+                                        None, None, None, dx.data_ptr(), H, st), "seg3 K")
+    ref = sum(d[:, i * H:(i + 1) * H].double() @ ws[i].double() for i in range(3))
+    assert (dx.double() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
+    # refusals: fp32, a bias with the K form, a segment that is not a multiple of 64
+    assert lib.fmmt_linear_fwd_seg3(_lib.dtype_code(torch.float32), M, 3 * H, H, x.data_ptr(), H, ws[0].data_ptr(), ws[1].data_ptr(), ws[2].data_ptr(), H, 1,
+                                    None, None, None, y.data_ptr(), 3 * H, st) == _lib.FMMT_EINVAL
+    assert lib.fmmt_linear_fwd_seg3(_lib.dtype_code(torch.bfloat16), M, H, 3 * H, d.data_ptr(), 3 * H, wt[0].data_ptr(), wt[1].data_ptr(), wt[2].data_ptr(), H, 2,
+                                    bs[0].data_ptr(), None, None, dx.data_ptr(), H, st) == _lib.FMMT_EINVAL
+    assert lib.fmmt_linear_fwd_seg3(_lib.dtype_code(torch.bfloat16), M, 3 * 96, H, x.data_ptr(), H, ws[0].data_ptr(), ws[1].data_ptr(), ws[2].data_ptr(), H, 1,
+                                    None, None, None, y.data_ptr(), 3 * 96, st) == _lib.FMMT_EINVAL
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_self_attention_packed_qkv_matches_three_linears(dtype):
+    """modules.Transformer.SelfAttention with PACKED_QKV (ops.SelfAttnQkvFn: one projection launch, attention core on the packed buffer, one input-
+    gradient launch, one weight-gradient contraction) against the three-Linear formulation: outputs and every gradient (fp32: the packed path falls
+    back to three launches inside the op, same arithmetic)."""
+    from facialmmt_amd.config import default_args
+    from facialmmt_amd.modules import Transformer as TM
+    dev = torch.device("cuda:0")
+    torch.manual_seed(4)
+    att = TM.SelfAttention(default_args()).to(dev).eval()
+    for lin in (att.query, att.key, att.value):
+        torch.nn.init.normal_(lin.bias, std=0.1)
+    L, B = 160, 4
+    x = torch.randn(L, B, 768, device=dev).to(dtype).requires_grad_(True)
+    kb = torch.zeros(B, L, device=dev)
+    kb[2, 120:] = -10000.0
+    w = torch.randn(L, B, 768, device=dev).to(dtype)
+    res = []
+    for packed in (True, False):
+        TM.PACKED_QKV = packed
+        try:
+            y = att.forward_tm(x, kb)
+            g = torch.autograd.grad((y.float() * w.float()).sum(), [x] + list(att.parameters()))
+        finally:
+            TM.PACKED_QKV = True
+        res.append((y, g))
+    (ya, ga), (yb, gb) = res
+    tol = 2e-2 if dtype == torch.bfloat16 else 1e-5
+    assert (ya.float() - yb.float()).abs().max().item() <= tol * yb.float().abs().max().item()
+    names = ["dx"] + [n for n, _ in att.named_parameters()]
+    for n, a, b in zip(names, ga, gb):
+        if n == "key.bias":                                       # mathematically zero: rounding noise on both sides
+            continue
+        assert (a.float() - b.float()).abs().max().item() <= 2 * tol * (b.float().abs().max().item() + 1e-8), n
+
+
+@pytest.mark.parametrize("vis_dtype", [torch.float32, torch.bfloat16])
+def test_select_frames_kernel_matches_torch_restatement_with_gradients(dev, vis_dtype):
+    """fmmt_select_frames_fwd / _bwd (one launch each) against train_step.select_frames' torch formulation (SELECT_FRAMES_KERNEL = False), which the
+    literal-loop test above pins: outputs bit for bit, d(preds) through the appended probability columns equal, both branches, bench geometry too."""
+    from facialmmt_amd import train_step as TS
+    g = torch.Generator().manual_seed(7)
+    cases = [(_filter_case(g, B, 12, 12, peaky=(t % 2 == 0)), thr) for t, (B, thr) in enumerate([(1, 0.2), (3, 0.5), (5, 0.2), (4, 1.5), (2, 0.0), (5, 0.99)])]
+    cases.append((_filter_case(g, 4, 160, 160, peaky=True, D=512), 0.2))
+    cases.append((_filter_case(g, 4, 160, 160, peaky=False, D=512), 1.5))
+    for (preds, vis, mask, num), thr in cases:
+        res = []
+        for kernel in (True, False):
+            TS.SELECT_FRAMES_KERNEL = kernel
+            try:
+                p = preds.to(dev).requires_grad_(True)
+                out, m = TS.select_frames(p, vis.to(dev).to(vis_dtype), mask.to(dev), num.to(dev), thr)
+                w = torch.randn(out.shape, generator=torch.Generator().manual_seed(1)).to(dev)
+                (gp,) = torch.autograd.grad((out.float() * w).sum(), [p])
+            finally:
+                TS.SELECT_FRAMES_KERNEL = True
+            res.append((out, m, gp))
+        (oa, ma, ga), (ob, mb, gb) = res
+        assert oa.dtype == ob.dtype and ma.dtype == mb.dtype
+        assert torch.equal(oa, ob) and torch.equal(ma, mb)
+        assert torch.allclose(ga, gb, rtol=0, atol=0 if vis_dtype == torch.float32 else 1e-6), (ga - gb).abs().max()
