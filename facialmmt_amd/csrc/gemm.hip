@@ -53,23 +53,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // overlap inside a workgroup), so they need the three workgroups per CU that their 43-53 KB of LDS allows, i.e.
 // <= 168 VGPRs+AGPRs; the double-buffered 128-row kernels are LDS-limited to two per CU (<= 256 registers).
 template <int BM, int NBUF> struct NtWaves { static constexpr int value = (BM == 128) ? (NBUF == 1 ? 3 : 2) : 4; };
-template <typename T, int BM, int BN, int BK, int NBUF, bool GLDS>
+template <typename T, int BM, int BN, int BK, int NBUF, bool GLDS, bool SEG = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NtWaves<BM, NBUF>::value)))
-void linear_nt_kernel(LinArgs p_in) {
+void linear_nt_kernel(LinArgs p) {
     constexpr int VEC = Vec<T>::N;
-    LinArgs p = p_in;
-    if constexpr (GLDS) {
-        if (p.wseg_mode == 1) {
-            // output channels in segments of p.wseg, one weight / bias each: re-base this workgroup's pointers so that the global
-            // channel index n addresses row n - s * wseg of its segment (a tile never straddles two: wseg % BN == 0)
-            const int logical_ = xcd_remap(blockIdx.x, gridDim.x);
-            const int s_ = ((logical_ % p.tiles_n) * BN) / p.wseg;
-            const T* ws_ = reinterpret_cast<const T*>(s_ == 0 ? p.w : (s_ == 1 ? p.w1 : p.w2));
-            p.w = ws_ - (ptrdiff_t)s_ * p.wseg * p.ldw;
-            const float* bs_ = s_ == 0 ? p.bias : (s_ == 1 ? p.bias1 : p.bias2);
-            p.bias = bs_ ? bs_ - (ptrdiff_t)s_ * p.wseg : nullptr;
-        }
-    }
+    static_assert(!SEG || GLDS, "segmented weights: direct-to-LDS kernels only");
     // GLDS: tiles are filled by direct global->LDS DMA (global_load_lds_dwordx4): the LDS image of a wave
     // instruction is lane-linear, so rows are unpadded (128 B) and bank conflicts are removed by an XOR
     // swizzle applied to the *source* chunk index and again on the fragment read (key = (row >> 1) & 7).
@@ -91,6 +79,19 @@ void linear_nt_kernel(LinArgs p_in) {
 
     const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
     const T* __restrict__ wg = reinterpret_cast<const T*>(p.w);
+    const float* bias_seg = nullptr;
+    if constexpr (SEG) {
+        // (SEG is its own instantiation: the kernel argument stays untouched -- a modified copy of LinArgs ends up in scratch memory and made
+        //  every launch of this kernel 2-3x slower, measured)
+        if (p.wseg_mode == 1) {
+            // output channels in segments of p.wseg, one weight / bias each: re-base this workgroup's pointers so that the global channel
+            // index n addresses row n - s * wseg of its segment (a tile never straddles two: wseg % BN == 0)
+            const int s_ = ((xcd_remap(blockIdx.x, gridDim.x) % p.tiles_n) * BN) / p.wseg;
+            wg = reinterpret_cast<const T*>(s_ == 0 ? p.w : (s_ == 1 ? p.w1 : p.w2)) - (ptrdiff_t)s_ * p.wseg * p.ldw;
+            const float* bs_ = s_ == 0 ? p.bias : (s_ == 1 ? p.bias1 : p.bias2);
+            bias_seg = bs_ ? bs_ - (ptrdiff_t)s_ * p.wseg : nullptr;
+        }
+    }
 
     const int kbeg = p.ksplit ? blockIdx.y * p.ksplit : 0;
     const int kend = p.ksplit ? min(p.K, kbeg + p.ksplit) : p.K;
@@ -170,7 +171,21 @@ void linear_nt_kernel(LinArgs p_in) {
         }
     };
 
-    auto epilogue = [&](int m0, int n0) { nt_epilogue<T, MT, NT>(p, acc, m0 + wm * WM, n0 + wn * WN, li, lg); };
+    auto epilogue = [&](int m0, int n0) {
+        if constexpr (SEG) {
+            if (bias_seg) {
+#pragma unroll
+                for (int b = 0; b < NT; ++b) {
+                    const f32x4 bb = *reinterpret_cast<const f32x4*>(bias_seg + n0 + wn * WN + chan_of<CW>(b, lg, 0));
+#pragma unroll
+                    for (int a = 0; a < MT; ++a) acc[a][b] += bb;
+                }
+            }
+            nt_epilogue<T, MT, NT, true>(p, acc, m0 + wm * WM, n0 + wn * WN, li, lg);
+        } else {
+            nt_epilogue<T, MT, NT>(p, acc, m0 + wm * WM, n0 + wn * WN, li, lg);
+        }
+    };
 
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (logical / p.tiles_n) * BM, n0 = (logical % p.tiles_n) * BN;
@@ -187,10 +202,12 @@ void linear_nt_kernel(LinArgs p_in) {
             // K-segmented weight (wseg_mode 2): this K step's columns live in weight k0 / wseg, at column k0 % wseg
             const T* wk = wg;
             int kw = k0;
-            if (p.wseg_mode == 2) {
-                const int s_ = k0 / p.wseg;
-                wk = reinterpret_cast<const T*>(s_ == 0 ? p.w : (s_ == 1 ? p.w1 : p.w2));
-                kw = k0 - s_ * p.wseg;
+            if constexpr (SEG) {
+                if (p.wseg_mode == 2) {
+                    const int s_ = k0 / p.wseg;
+                    wk = reinterpret_cast<const T*>(s_ == 0 ? p.w : (s_ == 1 ? p.w1 : p.w2));
+                    kw = k0 - s_ * p.wseg;
+                }
             }
 #pragma unroll
             for (int i = 0; i < BN / 32; ++i) {
@@ -1060,20 +1077,20 @@ int p256_plan(const LinArgs& a) {
     return best;
 }
 
-template <typename T, int BM, int BN, int BK, int NBUF, bool GLDS = false>
+template <typename T, int BM, int BN, int BK, int NBUF, bool GLDS = false, bool SEG = false>
 int launch_nt(const LinArgs& a, hipStream_t st) {
     constexpr int VEC = Vec<T>::N;
     constexpr size_t lds = (size_t)NBUF * (BM + BN) * (GLDS ? BK : BK + VEC) * sizeof(T);
     static FmmtLdsOnce lds_once;
     if (lds > 65536) {
-        if (int rc_ = lds_once.set(reinterpret_cast<const void*>(&linear_nt_kernel<T, BM, BN, BK, NBUF, GLDS>), (int)lds)) return rc_;
+        if (int rc_ = lds_once.set(reinterpret_cast<const void*>(&linear_nt_kernel<T, BM, BN, BK, NBUF, GLDS, SEG>), (int)lds)) return rc_;
     }
     LinArgs p = a;
     p.tiles_n = (a.N + BN - 1) / BN;
     p.tiles_m = (a.M + BM - 1) / BM;
     const int grid = p.tiles_m * p.tiles_n;
     const int splits = a.ksplit ? (a.K + a.ksplit - 1) / a.ksplit : 1;
-    hipLaunchKernelGGL((linear_nt_kernel<T, BM, BN, BK, NBUF, GLDS>), dim3(grid, splits), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((linear_nt_kernel<T, BM, BN, BK, NBUF, GLDS, SEG>), dim3(grid, splits), dim3(256), lds, st, p);
     FMMT_CHECK_LAUNCH();
     return 0;
 }
@@ -2117,8 +2134,8 @@ extern "C" int fmmt_linear_fwd_seg3(int dtype, int M, int N, int K, const void* 
     a.wseg = seg;
     a.wseg_mode = seg_mode;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (K >= 2048) return launch_nt<bf16, 32, 64, 64, 4, true>(a, st);
-    return launch_nt<bf16, 32, 64, 64, 2, true>(a, st);
+    if (K >= 2048) return launch_nt<bf16, 32, 64, 64, 4, true, true>(a, st);
+    return launch_nt<bf16, 32, 64, 64, 2, true, true>(a, st);
 }
 
 extern "C" size_t fmmt_linear_splitk_workspace(int M, int N, int K) {
