@@ -19,9 +19,11 @@
 //     distance allows (a slot is re-staged two phases after its last fragment read):  P4(s-1): W0(s+1) | P1(s): X0(s+1) | P2(s): X1(s+1) | P3(s): W1(s+1);
 //     ONE counted vmcnt per K step (in P4: everything but P4's own two instructions has landed);
 //   * the pipeline is flat over (tile, K step): the staging cursor runs into the workgroup's next tile while the current one is still being multiplied.
-// EPI 0: no output (main loop alone); 1: bias + bf16, whole 128-byte lines through wave-private LDS slabs.
+// EPI 0: no output (main loop alone); 1: bias + bf16, whole 128-byte lines through wave-private LDS slabs, all at the tile boundary;
+// 2: the same rows spread over the phases around the tile boundary (drip; no bias yet).
 // Requirements: N % 256 == 0, K % 64 == 0, K >= 128, M % 8 == 0, 32-bit byte offsets into x and w.
 #pragma once
+#include <type_traits>
 #include "gemm_common.h"
 
 namespace {
@@ -86,12 +88,13 @@ __global__ __launch_bounds__(512) void linear_nt_ph_kernel(LinArgs p) {
         }
     };
     int st_step = 0;                                           // index of the step at the cursor
-    auto advance = [&]() {                                     // cursor to the next K step (stops on the job's last step: harmless re-staging is avoided by the caller)
-        ++st_step;
+    auto advance = [&]() {                                     // cursor to the next K step; it stays ON the job's last step: the steps behind it re-stage
+        if (st_step + 1 >= nsteps) return;                     // that step's half-tiles into slots nobody reads any more -- every step then issues the
+        ++st_step;                                             // same number of DMA instructions and the counted waits are constants
         if (++st_k == nk) {
             st_k = 0;
             st_tile += G;
-            if (st_step < nsteps) tile_offsets(st_tile);
+            tile_offsets(st_tile);
         }
     };
 
@@ -103,11 +106,7 @@ __global__ __launch_bounds__(512) void linear_nt_ph_kernel(LinArgs p) {
     const unsigned xa0 = lds0 + (2 + wm) * HALF + xrow * 128u + sw0, xa1 = lds0 + (2 + wm) * HALF + xrow * 128u + sw1;
     const unsigned wa0 = lds0 + (wn >> 1) * HALF + wrow * 128u + sw0, wa1 = lds0 + (wn >> 1) * HALF + wrow * 128u + sw1;
 
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int a = 0; a < 8; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[8][4];                                          // (never zeroed: a tile's first K step starts every quadrant from a zero C operand)
     bf16x8 tf[4][2], cf[4][2];                                 // token fragments of the current half (4 tiles x 2 K blocks), channel fragments 0-3
 
     auto read_tokens = [&](unsigned base, int half) {          // 8 reads: tiles 4 half .. 4 half + 3
@@ -132,15 +131,23 @@ __global__ __launch_bounds__(512) void linear_nt_ph_kernel(LinArgs p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(tf[i][0]), "+v"(tf[i][1]), "+v"(cf[i][0]), "+v"(cf[i][1]));
     };
-    auto quadrant = [&](int th, int ch) {                      // 16 MFMAs: token tiles 4 th .. + 3 (held in tf), channel tiles 2 ch, 2 ch + 1
+    // 16 MFMAs: token tiles 4 th .. + 3 (held in tf), channel tiles 2 ch, 2 ch + 1.  ZERO (first K step of a tile): the first K block starts from a
+    // zero C operand instead of the accumulator, so that nothing has to re-zero 128 registers per tile and a converted accumulator row is DEAD until
+    // the next tile writes it (the epilogue's registers come out of that)
+    auto quadrant = [&](int th, int ch, auto ZERO_) {
+        constexpr bool ZERO = decltype(ZERO_)::value;
         if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
-                    acc[4 * th + a][2 * ch + b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cf[2 * ch + b][kk], tf[a][kk], acc[4 * th + a][2 * ch + b], 0, 0, 0);
+                for (int b = 0; b < 2; ++b) {
+                    if (ZERO && kk == 0)
+                        acc[4 * th + a][2 * ch + b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cf[2 * ch + b][kk], tf[a][kk], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    else
+                        acc[4 * th + a][2 * ch + b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cf[2 * ch + b][kk], tf[a][kk], acc[4 * th + a][2 * ch + b], 0, 0, 0);
+                }
         if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
     };
     auto bar = [&]() {
@@ -149,101 +156,175 @@ __global__ __launch_bounds__(512) void linear_nt_ph_kernel(LinArgs p) {
         __builtin_amdgcn_sched_barrier(0);
     };
 
+    // ---- drip epilogue (EPI 2) ----
+    // Quadrant j of the wave tile is final after phase j of a tile's LAST K step and is not accumulated into again before phase j of the next
+    // tile's FIRST step: a window of four phases in which its registers can be converted and re-zeroed without a second register set.  The
+    // tile leaves in four pairs of 16-token accumulator rows -- A (rows 0-31), B (32-63) after P2 / P3 of the last step, C (64-95) after its P4,
+    // D (96-127) after P1 of the next step -- each through this wave's 2.3 KB slab (bf16 chunks in, whole 128-byte rows out: the LDS executes a
+    // wave's instructions in order, so write / read / write / read on the one slab need no wait) into 16 registers, stored one phase later.
+    // The stores are spread over four phases, and every counted vmcnt lets the youngest of them stay in flight: a burst of all 16 store
+    // instructions at the tile boundary stalled the next step's DMA wait until the whole chip's tiles had drained to HBM (vmcnt retires in order).
+    bf16x8 rb[4];
+    int em0 = 0, en0 = 0;
+    char* const wslab = smem + 2 * BUF + wave * (16 * 144);
+    const int rr = lane >> 3, rc = lane & 7;
+    auto convert_pair = [&](auto A0) {                         // accumulator rows 16 A0 .. 16 A0 + 31 -> rb
+        constexpr int a0 = decltype(A0)::value;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                bf16x8 v;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (bf16)acc[a0 + t][2 * c + (e >> 2)][e & 3];
+                *reinterpret_cast<bf16x8*>(wslab + li * 144 + (c * 32 + lg * 8) * 2) = v;
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) rb[2 * t + h] = *reinterpret_cast<const bf16x8*>(wslab + (h * 8 + rr) * 144 + rc * 16);
+        }
+    };
+    // buffer stores: rows past M of a ragged last panel carry an offset beyond the descriptor's size and are dropped by the hardware -- the
+    // instruction is issued (and counted by vmcnt) whatever the row, which the counted waits rely on
+    const auto yrs = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (unsigned)p.M * (unsigned)p.ldy * 2u, 0x00020000);
+    const unsigned lane_off = ((unsigned)rr * (unsigned)p.ldy + (unsigned)(rc * 8)) * 2u;     // this lane's 16 bytes inside an 8-row block
+    auto store_pair = [&](int a0) {
+        // address = descriptor base + SCALAR offset of the 8-row block + lane_off: one address register for the whole kernel (per-row-block
+        // vector offsets were hoisted into 15 registers by the compiler and spilled the kernel).  The range check looks at the vector offset alone.
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int m_blk = em0 + (a0 + t) * 16 + h * 8;                                   // wave-uniform
+                const unsigned soff = ((unsigned)m_blk * (unsigned)p.ldy + (unsigned)en0) * 2u;
+                unsigned voff = rr < p.M - m_blk ? lane_off : 0xC0000000u;
+                if constexpr (EPI == 4) voff = (unsigned)blockIdx.x * 131072u + (unsigned)(wave * 16384 + ((a0 + t) * 16 + h * 8 + rr) * 128 + rc * 16);   // probe: a fixed 128 KB per workgroup
+                if constexpr (EPI == 3) asm volatile("" ::"v"(rb[2 * t + h]), "v"(voff));                                                          // probe: everything but the store
+                else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rb[2 * t + h]), yrs, voff, EPI == 4 ? 0u : soff, 0);
+            }
+    };
+
     // ---- prologue: step 0 complete, W0 of step 1 on the way ----
     tile_offsets(first);
     stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
-    if (nsteps > 1) {
-        advance();
-        stage(0, 1);
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    advance();
+    stage(0, 1);
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     bar();
     if (STAGGER && wm == 1) bar();                             // waves 4-7 run one barrier behind
 
-    int ct = first, ck = 0;
-    for (int s = 0; s < nsteps; ++s) {
+    // One K step.  FIRST: the previous tile's pairs C, D leave during this step (first step of a tile that has a predecessor); LAST: this step
+    // completes tile ct.  Compile-time, so that the steps in between carry no epilogue code and no branch: at 16 MFMAs per phase every scalar
+    // branch behind the MFMAs is on the workgroup's critical path (measured: the same epilogue behind run-time conditions cost the main loop 10 %).
+    int ct = first;
+    auto step = [&](auto ZERO_, auto FIRST_, auto LAST_, int s) {
+        constexpr bool FIRST = decltype(FIRST_)::value && EPI >= 2, LAST = decltype(LAST_)::value && EPI >= 2;
         const unsigned base = (unsigned)(s & 1) * (unsigned)BUF;
         const int nb = (s + 1) & 1;                            // buffer of the step being staged (cursor = s + 1 during P1-P3)
-        const bool more = s + 1 < nsteps;                      // step s + 1 exists
         // ---- P1 ----
         read_chans(base, 0);
         __builtin_amdgcn_sched_barrier(0);
         read_tokens(base, 0);
-        if (more) stage(2, nb);
+        stage(2, nb);
         bar();
         landed();
-        quadrant(0, 0);
+        quadrant(0, 0, ZERO_);
+        if constexpr (FIRST) {
+            store_pair(4);                                     // C (converted after the previous step's P4)
+            convert_pair(std::integral_constant<int, 6>{});
+        }
         bar();
         // ---- P2 ----
         read_chans(base, 1);
-        if (more) stage(3, nb);
+        stage(3, nb);
         bar();
         landed();
-        quadrant(0, 1);
+        quadrant(0, 1, ZERO_);
+        if constexpr (LAST) {
+            em0 = (ct / p.tiles_n) * 256 + wm * 128;
+            en0 = (ct % p.tiles_n) * 256 + wn * 64;
+            convert_pair(std::integral_constant<int, 0>{});
+        }
         bar();
         // ---- P3 ----
         read_tokens(base, 1);
-        if (more) stage(1, nb);
+        stage(1, nb);
         bar();
         landed();
-        quadrant(1, 1);
-        bar();
-        // ---- P4 ----
-        const bool more2 = s + 2 < nsteps;
-        if (more) advance();                                   // cursor -> step s + 2
-        if (more2) {
-            stage(0, s & 1);                                   // W0 of step s + 2 into the buffer whose channel half-tiles were last read in P2
-            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // everything of step s + 1 has landed (this wave's part)
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        quadrant(1, 1, ZERO_);
+        if constexpr (LAST) {
+            store_pair(0);
+            convert_pair(std::integral_constant<int, 2>{});
+        } else if constexpr (FIRST) {
+            store_pair(6);                                     // D: the previous tile is out
         }
         bar();
-        quadrant(1, 0);
-        if (++ck == nk) {
-            // ---- epilogue of tile ct ----
-            if constexpr (EPI == 1) {
-                // a wave's 64 channels are one 128-byte line per token row: 16 token rows at a time through this wave's own 2.3 KB slab (no barrier),
-                // written as the 16-byte chunks the accumulator layout gives, read back row-major: every store instruction writes 8 whole lines
-                const int m0 = (ct / p.tiles_n) * 256 + wm * 128, n0 = (ct % p.tiles_n) * 256 + wn * 64;
-                bf16* __restrict__ yg = reinterpret_cast<bf16*>(p.y);
-                char* ws = smem + 2 * BUF + wave * (16 * 144);
-                f32x4 bb[4];
+        // ---- P4 ----
+        advance();                                             // cursor -> step s + 2
+        stage(0, s & 1);                                       // W0 of step s + 2 into the buffer whose channel half-tiles were last read in P2
+        // everything of step s + 1 has landed (this wave's part); younger and allowed in flight: P4's own two DMA instructions and, in the
+        // steps around a tile boundary, the four stores of this step's P3
+        if constexpr ((FIRST || LAST) && EPI != 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        bar();
+        quadrant(1, 0, ZERO_);
+        if constexpr (LAST) {
+            store_pair(2);
+            convert_pair(std::integral_constant<int, 4>{});
+        }
+        bar();
+    };
+    auto tile_done_burst = [&]() {                             // EPI 0 / 1: everything at the tile boundary
+        if constexpr (EPI == 1) {
+            const int m0 = (ct / p.tiles_n) * 256 + wm * 128, n0 = (ct % p.tiles_n) * 256 + wn * 64;
+            bf16* __restrict__ yg = reinterpret_cast<bf16*>(p.y);
+            char* ws = smem + 2 * BUF + wave * (16 * 144);
+            f32x4 bb[4];
 #pragma unroll
-                for (int b = 0; b < 4; ++b) bb[b] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n0 + chan_of<16>(b, lg, 0)) : f32x4{0.f, 0.f, 0.f, 0.f};
-                const int rr = lane >> 3, rc = lane & 7;
+            for (int b = 0; b < 4; ++b) bb[b] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n0 + chan_of<16>(b, lg, 0)) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int a = 0; a < 8; ++a) {
+            for (int a = 0; a < 8; ++a) {
 #pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        bf16x8 v;
+                for (int c = 0; c < 2; ++c) {
+                    bf16x8 v;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = (bf16)(acc[a][2 * c + (e >> 2)][e & 3] + bb[2 * c + (e >> 2)][e & 3]);
-                        *reinterpret_cast<bf16x8*>(ws + li * 144 + (c * 32 + lg * 8) * 2) = v;
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int m = m0 + a * 16 + h * 8 + rr;
-                        const bf16x8 v = *reinterpret_cast<const bf16x8*>(ws + (h * 8 + rr) * 144 + rc * 16);
-                        if (m < p.M) *reinterpret_cast<bf16x8*>(yg + (size_t)m * p.ldy + n0 + rc * 8) = v;
-                    }
+                    for (int e = 0; e < 8; ++e) v[e] = (bf16)(acc[a][2 * c + (e >> 2)][e & 3] + bb[2 * c + (e >> 2)][e & 3]);
+                    *reinterpret_cast<bf16x8*>(ws + li * 144 + (c * 32 + lg * 8) * 2) = v;
                 }
-            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-                for (int a = 0; a < 8; ++a)
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) asm volatile("" ::"v"(acc[a][b]));
+                for (int h = 0; h < 2; ++h) {
+                    const int m = m0 + a * 16 + h * 8 + rr;
+                    const bf16x8 v = *reinterpret_cast<const bf16x8*>(ws + (h * 8 + rr) * 144 + rc * 16);
+                    if (m < p.M) *reinterpret_cast<bf16x8*>(yg + (size_t)m * p.ldy + n0 + rc * 8) = v;
+                }
             }
+        }
+        if constexpr (EPI == 0) {
 #pragma unroll
             for (int a = 0; a < 8; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-            ck = 0;
-            ct += G;
+                for (int b = 0; b < 4; ++b) asm volatile("" ::"v"(acc[a][b]));
         }
-        bar();
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    int s = 0;
+    for (int t = 0; t < ntile; ++t) {
+        if (t == 0) step(T_{}, F_{}, F_{}, s);
+        else step(T_{}, T_{}, F_{}, s);
+        ++s;
+        for (int k = 1; k < nk - 1; ++k, ++s) step(F_{}, F_{}, F_{}, s);
+        step(F_{}, F_{}, T_{}, s);
+        ++s;
+        tile_done_burst();
+        ct += G;
+    }
+    if constexpr (EPI >= 2) {                                  // the job's last tile: pairs C, D
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        store_pair(4);
+        convert_pair(std::integral_constant<int, 6>{});
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        store_pair(6);
     }
     if (STAGGER && wm == 0) bar();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -115,7 +115,14 @@ int main(int argc, char** argv) {
             const float ms = time_ms([&] { pf(); });
             printf("  production plain                                   %8.1f us %7.1f TF/s\n", ms * 1e3, 2.0 * M * N * K / ms / 1e9);
         }
-        run([&](const LinArgs& q) { return launch_ph<1>(q, 0); }, "ph", true);
+        run([&](const LinArgs& q) { return launch_ph<1>(q, 0); }, "ph burst", true);
+        a.bias = nullptr;
+        ref_kernel<<<dim3((N + 255) / 256, NR), 256>>>(x, w, nullptr, rows, NR, N, K, ref);
+        CK(hipMemcpy(href.data(), ref, href.size() * 4, hipMemcpyDeviceToHost));
+        run([&](const LinArgs& q) { return launch_ph<2>(q, 0); }, "ph drip", true);
+        run([&](const LinArgs& q) { return launch_ph<3>(q, 0); }, "ph drip, no store instr", false);
+        run([&](const LinArgs& q) { return launch_ph<4>(q, 0); }, "ph drip, stores to 128KB/WG", false);
+        a.bias = bias;
         run([&](const LinArgs& q) { return launch_ph<0>(q, 0); }, "ph nostore", false);
         run([&](const LinArgs& q) { return launch_ph<0, false>(q, 0); }, "ph nostore lockstep", false);
         run([&](const LinArgs& q) { return launch_ph<0, true, false>(q, 0); }, "ph nostore no setprio", false);
