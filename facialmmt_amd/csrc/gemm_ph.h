@@ -32,7 +32,7 @@ template <int OFF> __device__ __forceinline__ void ph_rd(bf16x8& dst, unsigned a
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
 }
 
-template <int EPI = 1, bool STAGGER = true, bool PRIO = true>
+template <int EPI = 1, bool STAGGER = true, bool PRIO = true, int DBG = 0>
 __global__ __launch_bounds__(512) void linear_nt_ph_kernel(LinArgs p) {
     constexpr int HALF = 128 * 128;                            // bytes per half-tile: 128 rows x 128 B
     constexpr int BUF = 4 * HALF;                              // W0 | W1 | X0 | X1
@@ -167,18 +167,43 @@ __global__ __launch_bounds__(512) void linear_nt_ph_kernel(LinArgs p) {
     bf16x8 rb[4];
     int em0 = 0, en0 = 0;
     char* const wslab = smem + 2 * BUF + wave * (16 * 144);
+    // bias: this wave's 64 channels travel into a 256-byte LDS slot by DMA (4 bytes per lane) at the head of the tile's first K step -- a plain global load
+    // in the epilogue would have to wait, in vmcnt's issue order, for every DMA and store in front of it; two slots by tile parity (the previous tile's
+    // pair D is converted after the next tile's slot has been requested)
+    float* const bslab = reinterpret_cast<float*>(smem + 2 * BUF + 8 * (16 * 144)) + wave * 128;
+    int bpar = 0;                                              // slot of the tile being multiplied
+    auto stage_bias = [&](int t, int par) {
+        if (p.bias) {
+            const int n0w = (t % p.tiles_n) * 256 + wn * 64;
+            __builtin_amdgcn_global_load_lds((gptr_t*)(p.bias + n0w + lane), (lptr_t*)(bslab + par * 64), 4, 0, 0);
+        }
+    };
     const int rr = lane >> 3, rc = lane & 7;
-    auto convert_pair = [&](auto A0) {                         // accumulator rows 16 A0 .. 16 A0 + 31 -> rb
+    auto convert_pair = [&](auto A0, int par) {                // accumulator rows 16 A0 .. 16 A0 + 31 (+ bias) -> rb
         constexpr int a0 = decltype(A0)::value;
+        f32x4 bb[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) bb[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bb[b] = *reinterpret_cast<const f32x4*>(bslab + par * 64 + chan_of<16>(b, lg, 0));
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 bf16x8 v;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (bf16)acc[a0 + t][2 * c + (e >> 2)][e & 3];
+                for (int e = 0; e < 8; ++e) v[e] = (bf16)(acc[a0 + t][2 * c + (e >> 2)][e & 3] + bb[2 * c + (e >> 2)][e & 3]);
                 *reinterpret_cast<bf16x8*>(wslab + li * 144 + (c * 32 + lg * 8) * 2) = v;
             }
+            // The registers of rb still hold the rows store_pair() has just sent: keep them reserved up to here.  The compiler re-uses a store's data
+            // registers two wait states behind the instruction (the documented hazard), but with the vector-memory queue full of DMA the data was
+            // read LATER than that: whole registers of stored rows came out as the next store's address offset (race screen of the probe: ~1000 of
+            // 1e8 elements per launch, none with the burst epilogue).
+            // (DBG 1: reserve them explicitly up to here -- clean as well, but the 16 extra live registers spill; the product form relies on the pause
+            //  behind the stores in store_pair)
+            if constexpr (DBG & 1) asm volatile("" ::"v"(rb[2 * t]), "v"(rb[2 * t + 1]));
 #pragma unroll
             for (int h = 0; h < 2; ++h) rb[2 * t + h] = *reinterpret_cast<const bf16x8*>(wslab + (h * 8 + rr) * 144 + rc * 16);
         }
@@ -186,21 +211,27 @@ __global__ __launch_bounds__(512) void linear_nt_ph_kernel(LinArgs p) {
     // buffer stores: rows past M of a ragged last panel carry an offset beyond the descriptor's size and are dropped by the hardware -- the
     // instruction is issued (and counted by vmcnt) whatever the row, which the counted waits rely on
     const auto yrs = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (unsigned)p.M * (unsigned)p.ldy * 2u, 0x00020000);
+    const auto nullrs = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, 0u, 0x00020000);
     const unsigned lane_off = ((unsigned)rr * (unsigned)p.ldy + (unsigned)(rc * 8)) * 2u;     // this lane's 16 bytes inside an 8-row block
     auto store_pair = [&](int a0) {
         // address = descriptor base + SCALAR offset of the 8-row block + lane_off: one address register for the whole kernel (per-row-block
         // vector offsets were hoisted into 15 registers by the compiler and spilled the kernel).  The range check looks at the vector offset alone.
+        // Rows past M of a ragged last panel: M % 8 == 0, so an 8-row block is valid or invalid as a whole -- a SCALAR choice between the output's
+        // descriptor and an empty one (every access out of range, dropped by the hardware).  The instruction is issued either way, which the counted
+        // waits rely on, and the only address register is lane_off: per-store vector offsets cost registers the kernel does not have (spills), and a
+        // store's registers must not be re-used right behind it (see convert_pair).
+        // non-temporal: the output streams to memory once; as ordinary write-allocating stores each tile round fills the XCD's L2 with dirty lines and
+        // evicts the operand panels the next K steps re-read (125440 x 1536 x 384: 190 -> 135 us, 8192^3: 842 -> 769; `nt sc1` the same, `sc0 sc1` no gain)
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int m_blk = em0 + (a0 + t) * 16 + h * 8;                                   // wave-uniform
-                const unsigned soff = ((unsigned)m_blk * (unsigned)p.ldy + (unsigned)en0) * 2u;
-                unsigned voff = rr < p.M - m_blk ? lane_off : 0xC0000000u;
-                if constexpr (EPI == 4) voff = (unsigned)blockIdx.x * 131072u + (unsigned)(wave * 16384 + ((a0 + t) * 16 + h * 8 + rr) * 128 + rc * 16);   // probe: a fixed 128 KB per workgroup
-                if constexpr (EPI == 3) asm volatile("" ::"v"(rb[2 * t + h]), "v"(voff));                                                          // probe: everything but the store
-                else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rb[2 * t + h]), yrs, voff, EPI == 4 ? 0u : soff, 0);
-            }
+        for (int i = 0; i < 4; ++i) {
+            const int m_blk = em0 + (a0 + (i >> 1)) * 16 + (i & 1) * 8;                          // wave-uniform
+            const unsigned soff = ((unsigned)m_blk * (unsigned)p.ldy + (unsigned)en0) * 2u;
+            if (m_blk < p.M) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rb[i]), yrs, lane_off, soff, 2);
+            else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rb[i]), nullrs, lane_off, 0u, 2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_sleep(2);                           // ~128 cycles before anything may overwrite the stores' data registers (see convert_pair)
+        __builtin_amdgcn_sched_barrier(0);
     };
 
     // ---- prologue: step 0 complete, W0 of step 1 on the way ----
@@ -217,20 +248,21 @@ __global__ __launch_bounds__(512) void linear_nt_ph_kernel(LinArgs p) {
     // branch behind the MFMAs is on the workgroup's critical path (measured: the same epilogue behind run-time conditions cost the main loop 10 %).
     int ct = first;
     auto step = [&](auto ZERO_, auto FIRST_, auto LAST_, int s) {
-        constexpr bool FIRST = decltype(FIRST_)::value && EPI >= 2, LAST = decltype(LAST_)::value && EPI >= 2;
+        constexpr bool FIRST = decltype(FIRST_)::value && EPI == 2, LAST = decltype(LAST_)::value && EPI == 2;
         const unsigned base = (unsigned)(s & 1) * (unsigned)BUF;
         const int nb = (s + 1) & 1;                            // buffer of the step being staged (cursor = s + 1 during P1-P3)
         // ---- P1 ----
         read_chans(base, 0);
         __builtin_amdgcn_sched_barrier(0);
         read_tokens(base, 0);
+        if constexpr (decltype(ZERO_)::value && EPI == 2) stage_bias(ct, bpar);
         stage(2, nb);
         bar();
         landed();
         quadrant(0, 0, ZERO_);
         if constexpr (FIRST) {
             store_pair(4);                                     // C (converted after the previous step's P4)
-            convert_pair(std::integral_constant<int, 6>{});
+            convert_pair(std::integral_constant<int, 6>{}, bpar ^ 1);
         }
         bar();
         // ---- P2 ----
@@ -242,7 +274,7 @@ __global__ __launch_bounds__(512) void linear_nt_ph_kernel(LinArgs p) {
         if constexpr (LAST) {
             em0 = (ct / p.tiles_n) * 256 + wm * 128;
             en0 = (ct % p.tiles_n) * 256 + wn * 64;
-            convert_pair(std::integral_constant<int, 0>{});
+            convert_pair(std::integral_constant<int, 0>{}, bpar);
         }
         bar();
         // ---- P3 ----
@@ -253,7 +285,7 @@ __global__ __launch_bounds__(512) void linear_nt_ph_kernel(LinArgs p) {
         quadrant(1, 1, ZERO_);
         if constexpr (LAST) {
             store_pair(0);
-            convert_pair(std::integral_constant<int, 2>{});
+            convert_pair(std::integral_constant<int, 2>{}, bpar);
         } else if constexpr (FIRST) {
             store_pair(6);                                     // D: the previous tile is out
         }
@@ -263,13 +295,13 @@ __global__ __launch_bounds__(512) void linear_nt_ph_kernel(LinArgs p) {
         stage(0, s & 1);                                       // W0 of step s + 2 into the buffer whose channel half-tiles were last read in P2
         // everything of step s + 1 has landed (this wave's part); younger and allowed in flight: P4's own two DMA instructions and, in the
         // steps around a tile boundary, the four stores of this step's P3
-        if constexpr ((FIRST || LAST) && EPI != 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if constexpr (FIRST || LAST) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         bar();
         quadrant(1, 0, ZERO_);
         if constexpr (LAST) {
             store_pair(2);
-            convert_pair(std::integral_constant<int, 4>{});
+            convert_pair(std::integral_constant<int, 4>{}, bpar);
         }
         bar();
     };
@@ -318,11 +350,12 @@ __global__ __launch_bounds__(512) void linear_nt_ph_kernel(LinArgs p) {
         ++s;
         tile_done_burst();
         ct += G;
+        bpar ^= 1;
     }
-    if constexpr (EPI >= 2) {                                  // the job's last tile: pairs C, D
+    if constexpr (EPI == 2) {                                  // the job's last tile: pairs C, D
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         store_pair(4);
-        convert_pair(std::integral_constant<int, 6>{});
+        convert_pair(std::integral_constant<int, 6>{}, bpar ^ 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         store_pair(6);
     }
@@ -330,16 +363,16 @@ __global__ __launch_bounds__(512) void linear_nt_ph_kernel(LinArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int EPI = 1, bool STAGGER = true, bool PRIO = true>
+template <int EPI = 1, bool STAGGER = true, bool PRIO = true, int DBG = 0>
 int launch_ph(const LinArgs& a, hipStream_t st, int grid = 256) {
-    constexpr int lds = 2 * 4 * 128 * 128 + 8 * 16 * 144;       // ring + wave-private epilogue slabs
+    constexpr int lds = 2 * 4 * 128 * 128 + 8 * 16 * 144 + 8 * 512;   // ring + wave-private epilogue slabs + bias slots
     static FmmtLdsOnce lds_once;
-    if (int rc_ = lds_once.set(reinterpret_cast<const void*>(&linear_nt_ph_kernel<EPI, STAGGER, PRIO>), lds)) return rc_;
+    if (int rc_ = lds_once.set(reinterpret_cast<const void*>(&linear_nt_ph_kernel<EPI, STAGGER, PRIO, DBG>), lds)) return rc_;
     if (a.N % 256 || a.K % 64 || a.K < 128) return FMMT_EINVAL;
     LinArgs p = a;
     p.tiles_m = (a.M + 255) / 256;
     p.tiles_n = a.N / 256;
-    hipLaunchKernelGGL((linear_nt_ph_kernel<EPI, STAGGER, PRIO>), dim3(grid), dim3(512), lds, st, p);
+    hipLaunchKernelGGL((linear_nt_ph_kernel<EPI, STAGGER, PRIO, DBG>), dim3(grid), dim3(512), lds, st, p);
     FMMT_CHECK_LAUNCH();
     return 0;
 }

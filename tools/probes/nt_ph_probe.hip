@@ -36,6 +36,15 @@ __global__ void ref_kernel(const bf16* x, const bf16* w, const float* bias, cons
     out[(size_t)r * N + n] = s + (bias ? bias[n] : 0.f);
 }
 
+__global__ void cmp_kernel(const bf16* a, const bf16* b, size_t n, unsigned long long* bad) {
+    unsigned long long c = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float x = (float)a[i], y = (float)b[i];
+        if (!(fabsf(x - y) <= 0.02f * fabsf(y) + 8e-3f)) ++c;
+    }
+    if (c) atomicAdd(bad, c);
+}
+
 typedef int (*linear_fwd_t)(int, int, int, int, const void*, int, const void*, int, const float*, void*, int, void*, int, const void*, int, const void*, int,
                             const float*, int, void*);
 
@@ -116,16 +125,34 @@ int main(int argc, char** argv) {
             printf("  production plain                                   %8.1f us %7.1f TF/s\n", ms * 1e3, 2.0 * M * N * K / ms / 1e9);
         }
         run([&](const LinArgs& q) { return launch_ph<1>(q, 0); }, "ph burst", true);
+        run([&](const LinArgs& q) { return launch_ph<2>(q, 0); }, "ph drip nt bias", true);
+        if (prod) {                                             // whole-output comparison with the production kernel's result, several launches (race screen)
+            unsigned long long* dbad; CK(hipMalloc(&dbad, 8));
+            auto screen = [&](auto fn, const char* tag) {
+                unsigned long long tot = 0;
+                for (int rep = 0; rep < 8; ++rep) {
+                    CK(hipMemset(y, 0xff, (size_t)M * N * 2)); CK(hipMemset(dbad, 0, 8));
+                    fn(a);
+                    cmp_kernel<<<1024, 256>>>(y, y2, (size_t)M * N, dbad);
+                    unsigned long long hb; CK(hipMemcpy(&hb, dbad, 8, hipMemcpyDeviceToHost));
+                    tot += hb;
+                }
+                printf("    screen %-34s: %llu elements differ over 8 launches\n", tag, tot);
+            };
+            screen([&](const LinArgs& q) { return launch_ph<2>(q, 0); }, "drip bias");
+            a.bias = nullptr;
+            { auto pf = [&]() { return prod(1, M, N, K, x, K, w, K, nullptr, y2, N, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 1, nullptr); }; pf(); CK(hipDeviceSynchronize()); }
+            screen([&](const LinArgs& q) { return launch_ph<2>(q, 0); }, "drip, no bias");
+            a.bias = bias;
+            { auto pf = [&]() { return prod(1, M, N, K, x, K, w, K, bias, y2, N, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 1, nullptr); }; pf(); CK(hipDeviceSynchronize()); }
+            screen([&](const LinArgs& q) { return launch_ph<1>(q, 0); }, "burst bias");
+            screen([&](const LinArgs& q) { return launch_ph<2, false>(q, 0); }, "drip bias lockstep");
+            CK(hipFree(dbad));
+        }
         a.bias = nullptr;
-        ref_kernel<<<dim3((N + 255) / 256, NR), 256>>>(x, w, nullptr, rows, NR, N, K, ref);
-        CK(hipMemcpy(href.data(), ref, href.size() * 4, hipMemcpyDeviceToHost));
-        run([&](const LinArgs& q) { return launch_ph<2>(q, 0); }, "ph drip", true);
-        run([&](const LinArgs& q) { return launch_ph<3>(q, 0); }, "ph drip, no store instr", false);
-        run([&](const LinArgs& q) { return launch_ph<4>(q, 0); }, "ph drip, stores to 128KB/WG", false);
+        run([&](const LinArgs& q) { return launch_ph<2>(q, 0); }, "ph drip nt nobias (time)", false);
         a.bias = bias;
         run([&](const LinArgs& q) { return launch_ph<0>(q, 0); }, "ph nostore", false);
-        run([&](const LinArgs& q) { return launch_ph<0, false>(q, 0); }, "ph nostore lockstep", false);
-        run([&](const LinArgs& q) { return launch_ph<0, true, false>(q, 0); }, "ph nostore no setprio", false);
         fflush(stdout);
     }
     return 0;
