@@ -202,6 +202,17 @@ def p256_tile(M, N, K, kw):
     return best
 
 
+def ph_takes(M, N, K, kw):
+    """mirror of csrc/gemm.hip::ph_plan (four-phase 256 x 256 kernel, csrc/gemm_ph.h): plain / bias launches whose tiles fill whole rounds of 256 workgroups"""
+    if kw.get("epi", 0) or any(kw.get(k) is not None for k in ("y_pre", "res", "aux", "rowscale")):
+        return False
+    if M < 16384 or M % 8 or N % 256 or K % 64 or K < 128:
+        return False
+    tiles = ((M + 255) // 256) * (N // 256)
+    rounds = (tiles + 255) // 256
+    return tiles >= 256 and tiles * 100 >= rounds * 256 * 85
+
+
 def tn_dma_tile(M, N, K, scaled, rows_per_scale, x_gelu):
     """mirror of csrc/gemm.hip::tn_plan_dma + launch_tn_plan (DMA-staged weight-gradient kernel): "256,256" / "192,384" or None"""
     if x_gelu or M <= 8192 or M % 64:
@@ -265,6 +276,8 @@ class KernelTimer:
                 hasop = kw.get("res") is not None or kw.get("rowscale") is not None or kw.get("aux") is not None
                 isop = p256 != 256 and (hasop or (plainop and (K > 1536 or plainop > 1)))
                 bn = f"p256x{p256}" + ("op" if isop else "pipe" if K >= 384 else "")      # launch_p256: pipelined K loop from K = 384
+            if ph_takes(M, N, K, kw):
+                bn = "ph256x256"
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             y = raw(x2, w, bias, **kw)
@@ -1019,6 +1032,8 @@ def kernel_symbol(bn):
                  "fmmt_batchnorm1d_bwd": "bn1d_bwd_kernel", "fmmt_linear_wgrad_finish": "reduce_partials_kernel", "fmmt_colsum": "colsum_kernel",
                  "fmmt_layernorm_bwd_bf16": "lnp_bwd_kernel", "fmmt_linear_fwd_splitk": "linear_splitk_kernel", "fmmt_linear_wgrad": "linear_tn_few_kernel"}
         return names.get(base, base) + ("<" + rest if rest else "")
+    if bn == "ph256x256":
+        return "linear_nt_ph_kernel<drip epilogue>"
     if bn.startswith("p256x"):
         op, pipe = bn.endswith("op"), bn.endswith("pipe")
         w = bn[5:-2] if op else bn[5:-4] if pipe else bn[5:]

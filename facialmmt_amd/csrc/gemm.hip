@@ -7,6 +7,7 @@
 // accumulator fragment of a lane is a run of consecutive output channels of ONE token: the
 // epilogue (bias, GELU, residual, DropPath scale) works on contiguous vectors and stores rows.
 #include "gemm_common.h"
+#include "gemm_ph.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -906,7 +907,10 @@ __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
                         for (int h = 0; h < 2; ++h) {
                             const int m = mw + a * 16 + h * 8 + rr;
                             const bf16x8 v = *reinterpret_cast<const bf16x8*>(ws + (h * 8 + rr) * 144 + rc * 16);
-                            if (m < p.M) *reinterpret_cast<bf16x8*>(dst + (size_t)m * p.ldy + nw + rc * 8) = v;
+                            // non-temporal: whole lines of an output that streams to memory once -- as write-allocating stores a tile round's output fills the
+                            // XCD's L2 with dirty lines and evicts the operand panels (round 5, same call: 125440 x 1152 x 384 165 -> 131 us, x 1536 x 384
+                            // 182 -> 158; not for the partial-line stores of nt_epilogue: 263 -> 316 us there)
+                            if (m < p.M) __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(dst + (size_t)m * p.ldy + nw + rc * 8));
                         }
                     };
                     const bool two = p.epi == FMMT_EPI_GELU && ypre != nullptr;
@@ -958,7 +962,7 @@ __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
                         const int row = pass * PR + r;
                         if (row < rows_left) {
                             const bf16x8 v = *reinterpret_cast<const bf16x8*>(scratch + r * SP + cc * 16);
-                            *reinterpret_cast<bf16x8*>(dst + (size_t)(m0 + wm * 128 + row) * p.ldy + n0 + cc * 8) = v;
+                            __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(dst + (size_t)(m0 + wm * 128 + row) * p.ldy + n0 + cc * 8));
                         }
                     }
                 };
@@ -1125,6 +1129,19 @@ int dispatch_nt_bk(const LinArgs& a, hipStream_t st) {
     }
 }
 
+// The four-phase kernel (gemm_ph.h) takes the plain / bias launches whose 256 x 256 tiles fill whole rounds of 256 workgroups: measured against the
+// persistent kernel above (tools/probes/nt_ph_probe.hip, same call): 31360 x 3072 x 768 143 -> 131 us, x 2304 x 768 113 -> 102, 125440 x 1536 x 384
+// 190 -> 135 (without bias), 31360 x 768 x K (369 tiles = 1.44 rounds) 137 -> 138: no gain where the last round is half empty.
+bool ph_plan(const LinArgs& a) {
+    static const int on = fmmt_const("FMMT_NT_PH", 1);
+    if (!on || a.ksplit || a.part || a.epi || a.y_pre || a.res || a.aux || a.rowscale) return false;
+    if (a.M < 16384 || a.M % 8 || a.N % 256 || a.K % 64 || a.K < 128 || a.ldx % 8 || a.ldw % 8 || a.ldy % 8) return false;
+    if ((unsigned long long)a.M * a.ldx >= (1ull << 31) || (unsigned long long)a.N * a.ldw >= (1ull << 31) || (unsigned long long)a.M * a.ldy >= (1ull << 31)) return false;
+    const long long tiles = (long long)((a.M + 255) / 256) * (a.N / 256);
+    const long long rounds = (tiles + 255) / 256;
+    return tiles >= 256 && tiles * 100 >= rounds * 256 * 85;    // the last round at least ~85 % full on average
+}
+
 template <typename T>
 int dispatch_nt(const LinArgs& a, hipStream_t st) {
     // BN = 96 when it tiles N exactly and 128 would not (C = 96, 288, 192, 576 ...)
@@ -1160,6 +1177,7 @@ int dispatch_nt(const LinArgs& a, hipStream_t st) {
         return n96 ? dispatch_nt_bk<T, 64, 96>(a, st) : dispatch_nt_bk<T, 64, 128>(a, st);
     }
     if constexpr (sizeof(T) == 2) {
+        if (ph_plan(a)) return launch_ph<2>(a, st);
         if (const int bn = p256_plan(a)) {
             // FMMT_NT_P256_RING: 1 (default) = K step 64, ring of 2 (3 for 128-wide tiles); 0 = K step 32, ring of 4.
             // Measured (profiles/r02_gemm_shapes.txt): the K-step-64 form wins on every shape by 3-17 % (half the barriers)
