@@ -203,14 +203,19 @@ def p256_tile(M, N, K, kw):
 
 
 def ph_takes(M, N, K, kw):
-    """mirror of csrc/gemm.hip::ph_plan (four-phase 256 x 256 kernel, csrc/gemm_ph.h): plain / bias launches whose tiles fill whole rounds of 256 workgroups"""
-    if kw.get("epi", 0) or any(kw.get(k) is not None for k in ("y_pre", "res", "aux", "rowscale")):
+    """mirror of csrc/gemm.hip::ph_plan (four-phase 256 x 256 kernel, csrc/gemm_ph.h)"""
+    if any(kw.get(k) is not None for k in ("res", "aux", "rowscale")):
         return False
-    if M < 16384 or M % 8 or N % 256 or K % 64 or K < 128:
+    gelu_pre = False and kw.get("epi", 0) == 1 and kw.get("y_pre") is not None       # FMMT_NT_PH_GELU = 0
+    if not gelu_pre and (kw.get("epi", 0) or kw.get("y_pre") is not None):
+        return False
+    if M <= 4096 or M % 8 or N % 256 or K % 64 or K < 128:
         return False
     tiles = ((M + 255) // 256) * (N // 256)
+    if M < 16384:
+        return tiles >= 150
     rounds = (tiles + 255) // 256
-    return tiles >= 256 and tiles * 100 >= rounds * 256 * 85
+    return (not gelu_pre) and tiles >= 256 and tiles * 100 >= rounds * 256 * 85
 
 
 def tn_dma_tile(M, N, K, scaled, rows_per_scale, x_gelu):

@@ -1129,17 +1129,27 @@ int dispatch_nt_bk(const LinArgs& a, hipStream_t st) {
     }
 }
 
-// The four-phase kernel (gemm_ph.h) takes the plain / bias launches whose 256 x 256 tiles fill whole rounds of 256 workgroups: measured against the
-// persistent kernel above (tools/probes/nt_ph_probe.hip, same call): 31360 x 3072 x 768 143 -> 131 us, x 2304 x 768 113 -> 102, 125440 x 1536 x 384
-// 190 -> 135 (without bias), 31360 x 768 x K (369 tiles = 1.44 rounds) 137 -> 138: no gain where the last round is half empty.
+// The four-phase kernel (gemm_ph.h).  Measured against the kernels below (tools/probes/nt_ph_probe.hip, same call, us per launch):
+//   * 16384+ tokens (the persistent 256-row kernel's ground), plain / bias: 31360 x 3072 x 768 143 -> 131, x 2304 x 768 113 -> 102, 125440 x 1536 x 384 190 -> 135
+//     (no bias); 31360 x 768 x K (369 tiles = 1.44 rounds of 256 workgroups) 137 -> 138: only where the tiles fill whole rounds.  GELU + pre-activation loses
+//     there (203 -> 231: its polynomial runs behind the MFMAs of a phase, on the workgroup's critical path) and stays on the persistent kernel;
+//   * 4096-16383 tokens (Swin stage 3: 7840 tokens, so far on the 128 x 128-tile kernels): 7840 x 6144 x 1536 186 -> 118, x 1536 x 6144 168 -> 132, GELU + pre-activation
+//     206 -> 170 / 174 -> 146: taken from 150 tiles.
 bool ph_plan(const LinArgs& a) {
     static const int on = fmmt_const("FMMT_NT_PH", 1);
-    if (!on || a.ksplit || a.part || a.epi || a.y_pre || a.res || a.aux || a.rowscale) return false;
-    if (a.M < 16384 || a.M % 8 || a.N % 256 || a.K % 64 || a.K < 128 || a.ldx % 8 || a.ldw % 8 || a.ldy % 8) return false;
+    if (!on || a.ksplit || a.part || a.res || a.aux || a.rowscale) return false;
+    // GELU + pre-activation (launch_ph<3>: GELU of the bf16-ROUNDED pre-activation on the epilogue's read-back side) is faster at stage 3 (206 -> 170 us) but
+    // moved the whole-Swin bf16 gradient statistics against the fp32 oracle (worst relative L2 0.089 -> 0.116, tests/test_gpu_swin.py's bar is 0.10): the
+    // persistent kernel applies GELU to the fp32 accumulator.  FMMT_NT_PH_GELU = 0 until the four-phase kernel does the same.
+    static const int ph_gelu = fmmt_const("FMMT_NT_PH_GELU", 0);
+    const bool gelu_pre = ph_gelu && a.epi == FMMT_EPI_GELU && a.y_pre;
+    if (!gelu_pre && (a.epi != 0 || a.y_pre)) return false;      // plain / bias
+    if (a.M < 4096 || a.M % 8 || a.N % 256 || a.K % 64 || a.K < 128 || a.ldx % 8 || a.ldw % 8 || a.ldy % 8) return false;
     if ((unsigned long long)a.M * a.ldx >= (1ull << 31) || (unsigned long long)a.N * a.ldw >= (1ull << 31) || (unsigned long long)a.M * a.ldy >= (1ull << 31)) return false;
     const long long tiles = (long long)((a.M + 255) / 256) * (a.N / 256);
+    if (a.M < 16384) return tiles >= 150;
     const long long rounds = (tiles + 255) / 256;
-    return tiles >= 256 && tiles * 100 >= rounds * 256 * 85;    // the last round at least ~85 % full on average
+    return !gelu_pre && tiles >= 256 && tiles * 100 >= rounds * 256 * 85;    // the last round at least ~85 % full on average
 }
 
 template <typename T>
@@ -1177,7 +1187,7 @@ int dispatch_nt(const LinArgs& a, hipStream_t st) {
         return n96 ? dispatch_nt_bk<T, 64, 96>(a, st) : dispatch_nt_bk<T, 64, 128>(a, st);
     }
     if constexpr (sizeof(T) == 2) {
-        if (ph_plan(a)) return launch_ph<2>(a, st);
+        if (ph_plan(a)) return a.epi == FMMT_EPI_GELU ? launch_ph<3>(a, st) : launch_ph<2>(a, st);
         if (const int bn = p256_plan(a)) {
             // FMMT_NT_P256_RING: 1 (default) = K step 64, ring of 2 (3 for 128-wide tiles); 0 = K step 32, ring of 4.
             // Measured (profiles/r02_gemm_shapes.txt): the K-step-64 form wins on every shape by 3-17 % (half the barriers)

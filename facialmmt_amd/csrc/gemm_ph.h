@@ -20,7 +20,7 @@
 //     ONE counted vmcnt per K step (in P4: everything but P4's own two instructions has landed);
 //   * the pipeline is flat over (tile, K step): the staging cursor runs into the workgroup's next tile while the current one is still being multiplied.
 // EPI 0: no output (main loop alone); 1: bias + bf16, whole 128-byte lines through wave-private LDS slabs, all at the tile boundary;
-// 2: the same rows spread over the phases around the tile boundary (drip; no bias yet).
+// 2: the same rows spread over the phases around the tile boundary (drip), non-temporal; 3: drip with GELU, the bf16 pre-activation to y_pre.
 // Requirements: N % 256 == 0, K % 64 == 0, K >= 128, M % 8 == 0, 32-bit byte offsets into x and w.
 #pragma once
 #include <type_traits>
@@ -212,6 +212,7 @@ __global__ __launch_bounds__(512) void linear_nt_ph_kernel(LinArgs p) {
     // instruction is issued (and counted by vmcnt) whatever the row, which the counted waits rely on
     const auto yrs = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (unsigned)p.M * (unsigned)p.ldy * 2u, 0x00020000);
     const auto nullrs = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, 0u, 0x00020000);
+    const auto prs = __builtin_amdgcn_make_buffer_rsrc(p.y_pre ? p.y_pre : p.y, 0, p.y_pre ? (unsigned)p.M * (unsigned)p.ldy * 2u : 0u, 0x00020000);
     const unsigned lane_off = ((unsigned)rr * (unsigned)p.ldy + (unsigned)(rc * 8)) * 2u;     // this lane's 16 bytes inside an 8-row block
     auto store_pair = [&](int a0) {
         // address = descriptor base + SCALAR offset of the 8-row block + lane_off: one address register for the whole kernel (per-row-block
@@ -222,16 +223,43 @@ __global__ __launch_bounds__(512) void linear_nt_ph_kernel(LinArgs p) {
         // store's registers must not be re-used right behind it (see convert_pair).
         // non-temporal: the output streams to memory once; as ordinary write-allocating stores each tile round fills the XCD's L2 with dirty lines and
         // evicts the operand panels the next K steps re-read (125440 x 1536 x 384: 190 -> 135 us, 8192^3: 842 -> 769; `nt sc1` the same, `sc0 sc1` no gain)
+        // two 8-row blocks at a time (EPI 3: their GELU in two more registers each), then a pause before anything may overwrite the stores' data
+        // registers (see convert_pair)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m_blk = em0 + (a0 + (i >> 1)) * 16 + (i & 1) * 8;                          // wave-uniform
-            const unsigned soff = ((unsigned)m_blk * (unsigned)p.ldy + (unsigned)en0) * 2u;
-            if (m_blk < p.M) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rb[i]), yrs, lane_off, soff, 2);
-            else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rb[i]), nullrs, lane_off, 0u, 2);
+        for (int j = 0; j < 2; ++j) {
+            bf16x8 gv[2];
+            if constexpr (EPI == 3) {
+                // GELU (+ the pre-activation as a second tensor, same leading dimension): applied to the bf16-rounded pre-activation on the read-back
+                // side -- whole rows, every lane 8 consecutive channels -- which is the value the backward differentiates at
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    float t[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) t[e] = (float)rb[2 * j + i][e];
+                    gelu_inplace<bf16, 2>(t, 8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) gv[i][e] = (bf16)t[e];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int m_blk = em0 + (a0 + j) * 16 + i * 8;                                   // wave-uniform
+                const unsigned soff = ((unsigned)m_blk * (unsigned)p.ldy + (unsigned)en0) * 2u;
+                const bool ok = m_blk < p.M;
+                if constexpr (EPI == 3) {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rb[2 * j + i]), ok ? prs : nullrs, lane_off, ok ? soff : 0u, 2);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, gv[i]), ok ? yrs : nullrs, lane_off, ok ? soff : 0u, 2);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rb[2 * j + i]), ok ? yrs : nullrs, lane_off, ok ? soff : 0u, 2);
+                }
+            }
+            if (EPI == 3 || j == 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_sleep(2);                   // ~128 cycles
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (EPI == 3) asm volatile("" ::"v"(gv[0]), "v"(gv[1]));
         }
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_sleep(2);                           // ~128 cycles before anything may overwrite the stores' data registers (see convert_pair)
-        __builtin_amdgcn_sched_barrier(0);
     };
 
     // ---- prologue: step 0 complete, W0 of step 1 on the way ----
@@ -248,14 +276,14 @@ __global__ __launch_bounds__(512) void linear_nt_ph_kernel(LinArgs p) {
     // branch behind the MFMAs is on the workgroup's critical path (measured: the same epilogue behind run-time conditions cost the main loop 10 %).
     int ct = first;
     auto step = [&](auto ZERO_, auto FIRST_, auto LAST_, int s) {
-        constexpr bool FIRST = decltype(FIRST_)::value && EPI == 2, LAST = decltype(LAST_)::value && EPI == 2;
+        constexpr bool FIRST = decltype(FIRST_)::value && EPI >= 2, LAST = decltype(LAST_)::value && EPI >= 2;
         const unsigned base = (unsigned)(s & 1) * (unsigned)BUF;
         const int nb = (s + 1) & 1;                            // buffer of the step being staged (cursor = s + 1 during P1-P3)
         // ---- P1 ----
         read_chans(base, 0);
         __builtin_amdgcn_sched_barrier(0);
         read_tokens(base, 0);
-        if constexpr (decltype(ZERO_)::value && EPI == 2) stage_bias(ct, bpar);
+        if constexpr (decltype(ZERO_)::value && EPI >= 2) stage_bias(ct, bpar);
         stage(2, nb);
         bar();
         landed();
@@ -295,7 +323,8 @@ __global__ __launch_bounds__(512) void linear_nt_ph_kernel(LinArgs p) {
         stage(0, s & 1);                                       // W0 of step s + 2 into the buffer whose channel half-tiles were last read in P2
         // everything of step s + 1 has landed (this wave's part); younger and allowed in flight: P4's own two DMA instructions and, in the
         // steps around a tile boundary, the four stores of this step's P3
-        if constexpr (FIRST || LAST) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if constexpr ((FIRST || LAST) && EPI == 3) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      // eight stores in this step's P3
+        else if constexpr (FIRST || LAST) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         bar();
         quadrant(1, 0, ZERO_);
@@ -352,7 +381,7 @@ __global__ __launch_bounds__(512) void linear_nt_ph_kernel(LinArgs p) {
         ct += G;
         bpar ^= 1;
     }
-    if constexpr (EPI == 2) {                                  // the job's last tile: pairs C, D
+    if constexpr (EPI >= 2) {                                  // the job's last tile: pairs C, D
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         store_pair(4);
         convert_pair(std::integral_constant<int, 6>{}, bpar ^ 1);

@@ -83,6 +83,7 @@ def t_linear_large():
                       (65536 + 77, 192, 192), (70000, 576, 192), (65600, 96, 384), (65536, 96, 288), (66000, 288, 768),
                       (65536 + 77, 384, 96), (70000, 288, 96), (65600, 96, 96),
                       (31360, 768, 3072), (31360 + 16, 2304, 768), (20000, 1536, 384), (125440, 1152, 384), (31360, 384, 1536),   # persistent 256-row-tile kernel: partial rounds, ragged panel
+                      (7840, 1536, 1536), (7840 + 8, 6144, 1536), (7840, 4608, 1536), (7848, 1536, 6144), (4104, 2304, 768),   # Swin stage 3 (and a 153-tile case): four-phase kernel (gemm_ph.h), plain / bias and GELU + pre-activation, ragged last panel
                       (640, 37632, 512), (300, 16384, 64)]:   # few rows, very wide output (input gradient of the embedding head): 128-row tiles
         x = rnd("x", (M, K), 1, dtype=dt)
         w = rnd("w", (N, K), 2, K ** -0.5, dtype=dt)

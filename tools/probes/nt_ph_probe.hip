@@ -71,7 +71,7 @@ int main(int argc, char** argv) {
     linear_fwd_t prod = h ? (linear_fwd_t)dlsym(h, "fmmt_linear_fwd") : nullptr;
     if (!prod) printf("(production library not loaded: %s)\n", dlerror());
     struct Shape { int M, N, K; };
-    const Shape shapes[] = {{125440, 1536, 384}, {31360, 3072, 768}, {31360, 768, 3072}, {31360, 2304, 768}, {31360, 768, 768}, {7840, 1536, 6144}, {8192, 8192, 8192}};
+    const Shape shapes[] = {{125440, 1536, 384}, {31360, 3072, 768}, {31360, 2304, 768}, {7840, 6144, 1536}, {7840, 1536, 6144}, {8192, 8192, 8192}};
     const size_t maxMK = 125440ull * 1536, maxNK = 8192ull * 8192, maxMN = 501760ull * 768;
     bf16 *x, *w, *y, *y2; float *bias, *ref; int* rows;
     CK(hipMalloc(&x, maxMK * 2)); CK(hipMalloc(&w, maxNK * 2 + 4096)); CK(hipMalloc(&y, maxMN * 2)); CK(hipMalloc(&y2, maxMN * 2));
@@ -148,6 +148,27 @@ int main(int argc, char** argv) {
             screen([&](const LinArgs& q) { return launch_ph<1>(q, 0); }, "burst bias");
             screen([&](const LinArgs& q) { return launch_ph<2, false>(q, 0); }, "drip bias lockstep");
             CK(hipFree(dbad));
+        }
+        if (prod) {                                             // GELU + pre-activation: both tensors against the production kernel's
+            bf16* ypre2; CK(hipMalloc(&ypre2, (size_t)M * N * 2));
+            bf16* ypre1; CK(hipMalloc(&ypre1, (size_t)M * N * 2));
+            auto pf = [&]() { return prod(1, M, N, K, x, K, w, K, bias, y2, N, ypre2, 1, nullptr, 0, nullptr, 0, nullptr, 1, nullptr); };
+            pf(); CK(hipDeviceSynchronize());
+            const float msp = time_ms([&] { pf(); });
+            a.epi = FMMT_EPI_GELU; a.y_pre = ypre1;
+            unsigned long long* dbad; CK(hipMalloc(&dbad, 8));
+            unsigned long long tot = 0, totp = 0;
+            for (int rep = 0; rep < 4; ++rep) {
+                CK(hipMemset(y, 0xff, (size_t)M * N * 2)); CK(hipMemset(ypre1, 0xff, (size_t)M * N * 2));
+                launch_ph<3>(a, 0);
+                unsigned long long hb;
+                CK(hipMemset(dbad, 0, 8)); cmp_kernel<<<1024, 256>>>(y, y2, (size_t)M * N, dbad); CK(hipMemcpy(&hb, dbad, 8, hipMemcpyDeviceToHost)); tot += hb;
+                CK(hipMemset(dbad, 0, 8)); cmp_kernel<<<1024, 256>>>(ypre1, ypre2, (size_t)M * N, dbad); CK(hipMemcpy(&hb, dbad, 8, hipMemcpyDeviceToHost)); totp += hb;
+            }
+            const float msg = time_ms([&] { launch_ph<3>(a, 0); });
+            printf("  gelu+pre: production %8.1f us, ph %8.1f us; vs production over 4 launches: y %llu, y_pre %llu elements differ\n", msp * 1e3, msg * 1e3, tot, totp);
+            a.epi = 0; a.y_pre = nullptr;
+            CK(hipFree(dbad)); CK(hipFree(ypre1)); CK(hipFree(ypre2));
         }
         a.bias = nullptr;
         run([&](const LinArgs& q) { return launch_ph<2>(q, 0); }, "ph drip nt nobias (time)", false);
