@@ -203,19 +203,33 @@ def p256_tile(M, N, K, kw):
 
 
 def ph_takes(M, N, K, kw):
-    """mirror of csrc/gemm.hip::ph_plan (four-phase 256 x 256 kernel, csrc/gemm_ph.h)"""
-    if any(kw.get(k) is not None for k in ("res", "aux", "rowscale")):
-        return False
-    gelu_pre = False and kw.get("epi", 0) == 1 and kw.get("y_pre") is not None       # FMMT_NT_PH_GELU = 0
+    """mirror of csrc/gemm.hip::ph_plan: "" (none), "ph256" (csrc/gemm_ph.h) or "ph192" (csrc/gemm_ph3.h)"""
+    if kw.get("aux") is not None:
+        return ""
+    gelu_pre = kw.get("epi", 0) == 1 and kw.get("y_pre") is not None
+    has_op = kw.get("res") is not None or kw.get("rowscale") is not None
     if not gelu_pre and (kw.get("epi", 0) or kw.get("y_pre") is not None):
-        return False
-    if M <= 4096 or M % 8 or N % 256 or K % 64 or K < 128:
-        return False
-    tiles = ((M + 255) // 256) * (N // 256)
-    if M < 16384:
-        return tiles >= 150
-    rounds = (tiles + 255) // 256
-    return (not gelu_pre) and tiles >= 256 and tiles * 100 >= rounds * 256 * 85
+        return ""
+    if gelu_pre and (has_op or K < 1536):
+        return ""
+    if M < 4096 or M % 8 or N % 128 or K % 64 or K < 192:
+        return ""
+    if N % 256:
+        if gelu_pre or K > 512:
+            return ""
+        t384 = ((M + 383) // 384) * (N // 128)
+        r384 = (t384 + 255) // 256
+        return "ph384" if (t384 >= 256 and t384 * 100 >= r384 * 256 * 85) else ""
+    t256, t192 = ((M + 255) // 256) * (N // 256), ((M + 191) // 192) * (N // 256)
+    r256, r192 = (t256 + 255) // 256, (t192 + 255) // 256
+    min_tiles = 150 if M < 16384 else 256
+    ok256 = t256 >= min_tiles and (M < 16384 or t256 * 100 >= r256 * 256 * 85)
+    ok192 = t192 >= min_tiles and (M < 16384 or t192 * 100 >= r192 * 256 * 85)
+    if gelu_pre or has_op:
+        return "ph192" if ok192 else ""
+    if ok192 and (not ok256 or r192 * 192 * 103 < r256 * 256 * 100):
+        return "ph192"
+    return "ph256" if ok256 else ""
 
 
 def tn_dma_tile(M, N, K, scaled, rows_per_scale, x_gelu):
@@ -281,8 +295,9 @@ class KernelTimer:
                 hasop = kw.get("res") is not None or kw.get("rowscale") is not None or kw.get("aux") is not None
                 isop = p256 != 256 and (hasop or (plainop and (K > 1536 or plainop > 1)))
                 bn = f"p256x{p256}" + ("op" if isop else "pipe" if K >= 384 else "")      # launch_p256: pipelined K loop from K = 384
-            if ph_takes(M, N, K, kw):
-                bn = "ph256x256"
+            ph = ph_takes(M, N, K, kw)
+            if ph:
+                bn = ph
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             y = raw(x2, w, bias, **kw)
@@ -1037,8 +1052,12 @@ def kernel_symbol(bn):
                  "fmmt_batchnorm1d_bwd": "bn1d_bwd_kernel", "fmmt_linear_wgrad_finish": "reduce_partials_kernel", "fmmt_colsum": "colsum_kernel",
                  "fmmt_layernorm_bwd_bf16": "lnp_bwd_kernel", "fmmt_linear_fwd_splitk": "linear_splitk_kernel", "fmmt_linear_wgrad": "linear_tn_few_kernel"}
         return names.get(base, base) + ("<" + rest if rest else "")
-    if bn == "ph256x256":
-        return "linear_nt_ph_kernel<drip epilogue>"
+    if bn == "ph256":
+        return "linear_nt_ph_kernel<256x256>"
+    if bn == "ph192":
+        return "linear_nt_ph3_kernel<192x256>"
+    if bn == "ph384":
+        return "linear_nt_ph3_kernel<384x128>"
     if bn.startswith("p256x"):
         op, pipe = bn.endswith("op"), bn.endswith("pipe")
         w = bn[5:-2] if op else bn[5:-4] if pipe else bn[5:]

@@ -8,6 +8,7 @@
 // epilogue (bias, GELU, residual, DropPath scale) works on contiguous vectors and stores rows.
 #include "gemm_common.h"
 #include "gemm_ph.h"
+#include "gemm_ph3.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -1129,27 +1130,50 @@ int dispatch_nt_bk(const LinArgs& a, hipStream_t st) {
     }
 }
 
-// The four-phase kernel (gemm_ph.h).  Measured against the kernels below (tools/probes/nt_ph_probe.hip, same call, us per launch):
-//   * 16384+ tokens (the persistent 256-row kernel's ground), plain / bias: 31360 x 3072 x 768 143 -> 131, x 2304 x 768 113 -> 102, 125440 x 1536 x 384 190 -> 135
-//     (no bias); 31360 x 768 x K (369 tiles = 1.44 rounds of 256 workgroups) 137 -> 138: only where the tiles fill whole rounds.  GELU + pre-activation loses
-//     there (203 -> 231: its polynomial runs behind the MFMAs of a phase, on the workgroup's critical path) and stays on the persistent kernel;
-//   * 4096-16383 tokens (Swin stage 3: 7840 tokens, so far on the 128 x 128-tile kernels): 7840 x 6144 x 1536 186 -> 118, x 1536 x 6144 168 -> 132, GELU + pre-activation
-//     206 -> 170 / 174 -> 146: taken from 150 tiles.
-bool ph_plan(const LinArgs& a) {
+// The phase-structured kernels (gemm_ph.h: 256 x 256 tiles, four phases; gemm_ph3.h: 192 x 256 tiles, three phases, all epilogues but GELU').
+// Returns 0 (none), 1 (gemm_ph.h, plain / bias), 3 (gemm_ph3.h, 192 x 256 tiles) or 4 (gemm_ph3.h, 384 x 128 tiles); *epi3 = gemm_ph3.h's EPI template value:
+// 2 plain / bias, 3 GELU + pre-activation, 5 residual / row scale.
+// Measured against the kernels below and each other (tools/probes/nt_ph_probe.hip, same call, us per launch, production -> ph / ph3):
+//   plain / bias     31360 x 768 x 3072 136 -> 139 / 110 (369 tiles of 256 x 256 = 1.44 rounds of 256 workgroups, 492 of 192 x 256 = 1.92), x 768 x 768 42 -> 44 / 35,
+//                    x 2304 x 768 113 -> 101 / 100, x 3072 x 768 143 -> 129 / 132, 125440 x 1536 x 384 190 -> 154 / 167, 7840 x 1536 x 6144 168 -> 134 / 106,
+//                    7840 x 6144 x 1536 186 -> 116 / 123, 7840 x 1536 x 1536 38.5 (128-row kernels) -> 38 / 31: the tile whose rounds waste less wins;
+//   res + row scale  31360 x 768 x 3072 156 -> 117, x 768 x 768 56 -> 42, x 3072 x 768 235 -> 161, 125440 x 1536 x 384 318 -> 242, 7840 x 1536 x 6144 169 -> 110 (ph3 only);
+//   GELU + pre       wins from K = 1536 (7840 x 6144 x 1536 211 -> 184, 31360 x 768 x 3072 159 -> 141), loses below (31360 x 3072 x 768 195 -> 254: the polynomial runs
+//                    behind the MFMAs of a phase, on the workgroup's critical path, and a short K loop has few phases to amortise it);
+//   GELU'            loses everywhere (262 -> 828): stays on the persistent kernel.
+int ph_plan(const LinArgs& a, int* epi3) {
     static const int on = fmmt_const("FMMT_NT_PH", 1);
-    if (!on || a.ksplit || a.part || a.res || a.aux || a.rowscale) return false;
-    // GELU + pre-activation (launch_ph<3>: GELU of the bf16-ROUNDED pre-activation on the epilogue's read-back side) is faster at stage 3 (206 -> 170 us) but
-    // moved the whole-Swin bf16 gradient statistics against the fp32 oracle (worst relative L2 0.089 -> 0.116, tests/test_gpu_swin.py's bar is 0.10): the
-    // persistent kernel applies GELU to the fp32 accumulator.  FMMT_NT_PH_GELU = 0 until the four-phase kernel does the same.
-    static const int ph_gelu = fmmt_const("FMMT_NT_PH_GELU", 0);
-    const bool gelu_pre = ph_gelu && a.epi == FMMT_EPI_GELU && a.y_pre;
-    if (!gelu_pre && (a.epi != 0 || a.y_pre)) return false;      // plain / bias
-    if (a.M < 4096 || a.M % 8 || a.N % 256 || a.K % 64 || a.K < 128 || a.ldx % 8 || a.ldw % 8 || a.ldy % 8) return false;
-    if ((unsigned long long)a.M * a.ldx >= (1ull << 31) || (unsigned long long)a.N * a.ldw >= (1ull << 31) || (unsigned long long)a.M * a.ldy >= (1ull << 31)) return false;
-    const long long tiles = (long long)((a.M + 255) / 256) * (a.N / 256);
-    if (a.M < 16384) return tiles >= 150;
-    const long long rounds = (tiles + 255) / 256;
-    return !gelu_pre && tiles >= 256 && tiles * 100 >= rounds * 256 * 85;    // the last round at least ~85 % full on average
+    if (!on || a.ksplit || a.part || a.aux) return 0;
+    const bool gelu_pre = a.epi == FMMT_EPI_GELU && a.y_pre, has_op = a.res || a.rowscale;
+    if (!gelu_pre && (a.epi != 0 || a.y_pre)) return 0;
+    if (gelu_pre && (has_op || a.K < 1536)) return 0;
+    if (a.M < 4096 || a.M % 8 || a.N % 128 || a.K % 64 || a.K < 192 || a.ldx % 8 || a.ldw % 8 || a.ldy % 8) return 0;
+    if (a.res && a.ldres % 8) return 0;
+    if (a.rowscale && a.rows_per_scale <= 0) return 0;
+    if ((unsigned long long)a.M * a.ldx >= (1ull << 31) || (unsigned long long)a.N * a.ldw >= (1ull << 31) || (unsigned long long)a.M * a.ldy >= (1ull << 31) ||
+        (a.res && (unsigned long long)a.M * a.ldres >= (1ull << 31)))
+        return 0;
+    if (a.N % 256) {
+        // channel counts that are multiples of 128 only (Swin stage 2: 384, 1152): gemm_ph3.h's 384-token x 128-channel layout (returns 4).  Measured at 125440 tokens
+        // (production -> ph3): x 1152 x 384 134 -> 129, x 384 x 384 45.5 -> 43.6, with residual + row scale 240 -> 204 / 79 -> 58, row scale alone 59 -> 54.5;
+        // at K = 1152 / 1536 it loses (164 -> 166, with residual 181 -> 196: three channel tiles per token panel, 96 FLOP per staged byte): K <= 512 only.
+        if (gelu_pre || a.K > 512) return 0;
+        const long long t384 = (long long)((a.M + 383) / 384) * (a.N / 128), r384 = (t384 + 255) / 256;
+        if (t384 < 256 || t384 * 100 < r384 * 256 * 85) return 0;
+        *epi3 = has_op ? 5 : 2;
+        return 4;
+    }
+    const long long t256 = (long long)((a.M + 255) / 256) * (a.N / 256), t192 = (long long)((a.M + 191) / 192) * (a.N / 256);
+    const long long r256 = (t256 + 255) / 256, r192 = (t192 + 255) / 256;
+    const long long min_tiles = a.M < 16384 ? 150 : 256;        // 16384+ tokens: the persistent 256-row kernel's ground, taken only with (nearly) full rounds
+    const bool ok256 = t256 >= min_tiles && (a.M < 16384 || t256 * 100 >= r256 * 256 * 85);
+    const bool ok192 = t192 >= min_tiles && (a.M < 16384 || t192 * 100 >= r192 * 256 * 85);
+    *epi3 = gelu_pre ? 3 : has_op ? 5 : 2;
+    if (gelu_pre || has_op) return ok192 ? 3 : 0;
+    // plain / bias: rows of MFMA work per workgroup over the launch; the 192-row tile is charged 3 % (shorter phases per byte staged)
+    const long long c256 = r256 * 256 * 100, c192 = r192 * 192 * 103;
+    if (ok192 && (!ok256 || c192 < c256)) return 3;
+    return ok256 ? 1 : 0;
 }
 
 template <typename T>
@@ -1187,7 +1211,12 @@ int dispatch_nt(const LinArgs& a, hipStream_t st) {
         return n96 ? dispatch_nt_bk<T, 64, 96>(a, st) : dispatch_nt_bk<T, 64, 128>(a, st);
     }
     if constexpr (sizeof(T) == 2) {
-        if (ph_plan(a)) return a.epi == FMMT_EPI_GELU ? launch_ph<3>(a, st) : launch_ph<2>(a, st);
+        int epi3 = 2;
+        if (const int ph = ph_plan(a, &epi3)) {
+            if (ph == 1) return launch_ph<2>(a, st);
+            if (ph == 4) return epi3 == 5 ? launch_ph3<5, true, 4>(a, st) : launch_ph3<2, true, 4>(a, st);
+            return epi3 == 3 ? launch_ph3<3>(a, st) : epi3 == 5 ? launch_ph3<5>(a, st) : launch_ph3<2>(a, st);
+        }
         if (const int bn = p256_plan(a)) {
             // FMMT_NT_P256_RING: 1 (default) = K step 64, ring of 2 (3 for 128-wide tiles); 0 = K step 32, ring of 4.
             // Measured (profiles/r02_gemm_shapes.txt): the K-step-64 form wins on every shape by 3-17 % (half the barriers)

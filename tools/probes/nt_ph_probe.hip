@@ -2,6 +2,7 @@
 // same bf16 operands, and timed with HIP events beside the production kernel (fmmt_linear_fwd of the in-tree libfmmt_hip.so, dlopen-ed).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I facialmmt_amd/csrc -o /tmp/nt_ph_probe tools/probes/nt_ph_probe.hip -ldl && /tmp/nt_ph_probe
 #include "gemm_ph.h"
+#include "gemm_ph3.h"
 #include <dlfcn.h>
 #include <cstdio>
 #include <cstdlib>
@@ -71,7 +72,7 @@ int main(int argc, char** argv) {
     linear_fwd_t prod = h ? (linear_fwd_t)dlsym(h, "fmmt_linear_fwd") : nullptr;
     if (!prod) printf("(production library not loaded: %s)\n", dlerror());
     struct Shape { int M, N, K; };
-    const Shape shapes[] = {{125440, 1536, 384}, {31360, 3072, 768}, {31360, 2304, 768}, {7840, 6144, 1536}, {7840, 1536, 6144}, {8192, 8192, 8192}};
+    const Shape shapes[] = {{125440, 1152, 384}, {125440, 384, 1536}, {125440, 384, 384}, {125440, 384, 1152}, {125440, 1536, 384}, {31360, 768, 3072}, {31360, 2304, 768}};
     const size_t maxMK = 125440ull * 1536, maxNK = 8192ull * 8192, maxMN = 501760ull * 768;
     bf16 *x, *w, *y, *y2; float *bias, *ref; int* rows;
     CK(hipMalloc(&x, maxMK * 2)); CK(hipMalloc(&w, maxNK * 2 + 4096)); CK(hipMalloc(&y, maxMN * 2)); CK(hipMalloc(&y2, maxMN * 2));
@@ -124,56 +125,57 @@ int main(int argc, char** argv) {
             const float ms = time_ms([&] { pf(); });
             printf("  production plain                                   %8.1f us %7.1f TF/s\n", ms * 1e3, 2.0 * M * N * K / ms / 1e9);
         }
-        run([&](const LinArgs& q) { return launch_ph<1>(q, 0); }, "ph burst", true);
-        run([&](const LinArgs& q) { return launch_ph<2>(q, 0); }, "ph drip nt bias", true);
-        if (prod) {                                             // whole-output comparison with the production kernel's result, several launches (race screen)
+        const bool n256 = N % 256 == 0;
+        if (n256) run([&](const LinArgs& q) { return launch_ph<2>(q, 0); }, "ph drip nt bias", true);
+        if (n256) run([&](const LinArgs& q) { return launch_ph3<2>(q, 0); }, "ph3 (192 x 256) drip bias", true);
+        if (n256) run([&](const LinArgs& q) { return launch_ph3<0>(q, 0); }, "ph3 (192 x 256) nostore", false);
+        run([&](const LinArgs& q) { return launch_ph3<2, true, 4>(q, 0); }, "ph3 (384 x 128) drip bias", true);
+        run([&](const LinArgs& q) { return launch_ph3<0, true, 4>(q, 0); }, "ph3 (384 x 128) nostore", false);
+        if (prod) {
             unsigned long long* dbad; CK(hipMalloc(&dbad, 8));
-            auto screen = [&](auto fn, const char* tag) {
-                unsigned long long tot = 0;
-                for (int rep = 0; rep < 8; ++rep) {
-                    CK(hipMemset(y, 0xff, (size_t)M * N * 2)); CK(hipMemset(dbad, 0, 8));
-                    fn(a);
-                    cmp_kernel<<<1024, 256>>>(y, y2, (size_t)M * N, dbad);
-                    unsigned long long hb; CK(hipMemcpy(&hb, dbad, 8, hipMemcpyDeviceToHost));
-                    tot += hb;
-                }
-                printf("    screen %-34s: %llu elements differ over 8 launches\n", tag, tot);
-            };
-            screen([&](const LinArgs& q) { return launch_ph<2>(q, 0); }, "drip bias");
-            a.bias = nullptr;
-            { auto pf = [&]() { return prod(1, M, N, K, x, K, w, K, nullptr, y2, N, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 1, nullptr); }; pf(); CK(hipDeviceSynchronize()); }
-            screen([&](const LinArgs& q) { return launch_ph<2>(q, 0); }, "drip, no bias");
-            a.bias = bias;
             { auto pf = [&]() { return prod(1, M, N, K, x, K, w, K, bias, y2, N, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 1, nullptr); }; pf(); CK(hipDeviceSynchronize()); }
-            screen([&](const LinArgs& q) { return launch_ph<1>(q, 0); }, "burst bias");
-            screen([&](const LinArgs& q) { return launch_ph<2, false>(q, 0); }, "drip bias lockstep");
+            unsigned long long tot = 0;
+            for (int rep = 0; rep < 8; ++rep) {
+                CK(hipMemset(y, 0xff, (size_t)M * N * 2)); CK(hipMemset(dbad, 0, 8));
+                launch_ph3<2, true, 4>(a, 0);
+                cmp_kernel<<<1024, 256>>>(y, y2, (size_t)M * N, dbad);
+                unsigned long long hb; CK(hipMemcpy(&hb, dbad, 8, hipMemcpyDeviceToHost));
+                tot += hb;
+            }
+            printf("    screen ph3 (384 x 128) drip bias      : %llu elements differ over 8 launches\n", tot);
             CK(hipFree(dbad));
         }
-        if (prod) {                                             // GELU + pre-activation: both tensors against the production kernel's
-            bf16* ypre2; CK(hipMalloc(&ypre2, (size_t)M * N * 2));
-            bf16* ypre1; CK(hipMalloc(&ypre1, (size_t)M * N * 2));
-            auto pf = [&]() { return prod(1, M, N, K, x, K, w, K, bias, y2, N, ypre2, 1, nullptr, 0, nullptr, 0, nullptr, 1, nullptr); };
-            pf(); CK(hipDeviceSynchronize());
-            const float msp = time_ms([&] { pf(); });
-            a.epi = FMMT_EPI_GELU; a.y_pre = ypre1;
+        if (prod) {                                             // ph3's other epilogues against the production kernels: whole outputs, 4 launches each
+            bf16 *t1, *t2, *opd; float* rsd;
+            CK(hipMalloc(&t1, (size_t)M * N * 2)); CK(hipMalloc(&t2, (size_t)M * N * 2)); CK(hipMalloc(&opd, (size_t)M * N * 2)); CK(hipMalloc(&rsd, (size_t)(M / 49 + 2) * 4));
+            fill_kernel<<<2048, 256>>>(opd, (size_t)M * N, 5u, 1.0f);
+            fillf_kernel<<<64, 256>>>(rsd, (size_t)(M / 49 + 2), 9u);
             unsigned long long* dbad; CK(hipMalloc(&dbad, 8));
-            unsigned long long tot = 0, totp = 0;
-            for (int rep = 0; rep < 4; ++rep) {
-                CK(hipMemset(y, 0xff, (size_t)M * N * 2)); CK(hipMemset(ypre1, 0xff, (size_t)M * N * 2));
-                launch_ph<3>(a, 0);
-                unsigned long long hb;
-                CK(hipMemset(dbad, 0, 8)); cmp_kernel<<<1024, 256>>>(y, y2, (size_t)M * N, dbad); CK(hipMemcpy(&hb, dbad, 8, hipMemcpyDeviceToHost)); tot += hb;
-                CK(hipMemset(dbad, 0, 8)); cmp_kernel<<<1024, 256>>>(ypre1, ypre2, (size_t)M * N, dbad); CK(hipMemcpy(&hb, dbad, 8, hipMemcpyDeviceToHost)); totp += hb;
-            }
-            const float msg = time_ms([&] { launch_ph<3>(a, 0); });
-            printf("  gelu+pre: production %8.1f us, ph %8.1f us; vs production over 4 launches: y %llu, y_pre %llu elements differ\n", msp * 1e3, msg * 1e3, tot, totp);
-            a.epi = 0; a.y_pre = nullptr;
-            CK(hipFree(dbad)); CK(hipFree(ypre1)); CK(hipFree(ypre2));
+            auto cmp = [&](const bf16* u, const bf16* v) { unsigned long long hb; CK(hipMemset(dbad, 0, 8)); cmp_kernel<<<1024, 256>>>(u, v, (size_t)M * N, dbad); CK(hipMemcpy(&hb, dbad, 8, hipMemcpyDeviceToHost)); return hb; };
+            auto variant = [&](const char* tag, auto pf, auto qf, bool two) {
+                pf(); CK(hipDeviceSynchronize());
+                const float msp = time_ms([&] { pf(); });
+                unsigned long long tot = 0, totp = 0;
+                for (int rep = 0; rep < 4; ++rep) {
+                    CK(hipMemset(y, 0xff, (size_t)M * N * 2)); CK(hipMemset(t1, 0xff, (size_t)M * N * 2));
+                    int rc = qf(); if (rc) { printf("  %s: rc %d\n", tag, rc); return; }
+                    tot += cmp(y, y2);
+                    if (two) totp += cmp(t1, t2);
+                }
+                const float msq = time_ms([&] { qf(); });
+                printf("  ph3 %-18s production %8.1f us, ph3 %8.1f us; over 4 launches: y %llu%s elements differ\n", tag, msp * 1e3, msq * 1e3, tot, two ? (std::string(", y_pre ") + std::to_string(totp)).c_str() : "");
+            };
+            LinArgs q = a;
+            q.epi = FMMT_EPI_GELU; q.y_pre = t1;
+            variant("gelu+pre", [&] { return prod(1, M, N, K, x, K, w, K, bias, y2, N, t2, 1, nullptr, 0, nullptr, 0, nullptr, 1, nullptr); }, [&] { return launch_ph3<3, true, 4>(q, 0); }, true);
+            q = a; q.bias = nullptr; q.epi = FMMT_EPI_GELU_BWD; q.aux = opd; q.ldaux = N;
+            variant("gelu'", [&] { return prod(1, M, N, K, x, K, w, K, nullptr, y2, N, nullptr, 2, opd, N, nullptr, 0, nullptr, 1, nullptr); }, [&] { return launch_ph3<4, true, 4>(q, 0); }, false);
+            q = a; q.res = opd; q.ldres = N; q.rowscale = rsd; q.rows_per_scale = 49;
+            variant("res+rowscale", [&] { return prod(1, M, N, K, x, K, w, K, bias, y2, N, nullptr, 0, nullptr, 0, opd, N, rsd, 49, nullptr); }, [&] { return launch_ph3<5, true, 4>(q, 0); }, false);
+            q = a; q.bias = nullptr; q.rowscale = rsd; q.rows_per_scale = 49;
+            variant("rowscale only", [&] { return prod(1, M, N, K, x, K, w, K, nullptr, y2, N, nullptr, 0, nullptr, 0, nullptr, 0, rsd, 49, nullptr); }, [&] { return launch_ph3<5, true, 4>(q, 0); }, false);
+            CK(hipFree(dbad)); CK(hipFree(t1)); CK(hipFree(t2)); CK(hipFree(opd)); CK(hipFree(rsd));
         }
-        a.bias = nullptr;
-        run([&](const LinArgs& q) { return launch_ph<2>(q, 0); }, "ph drip nt nobias (time)", false);
-        a.bias = bias;
-        run([&](const LinArgs& q) { return launch_ph<0>(q, 0); }, "ph nostore", false);
         fflush(stdout);
     }
     return 0;
