@@ -30,6 +30,7 @@ Rank 0 prints ONE JSON line: metric utterances/s (whole job), plus
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -643,7 +644,7 @@ def main():
             aux_step = GraphedAuxStep(swin, aopt, torch.optim.lr_scheduler.LambdaLR(aopt, lr_of), cfg, *aux_batch, averager=aflat)
         # N > 1: where the backward graph is cut follows from the exchange time MEASURED alone on this communicator (three blocking
         # exchanges of the real buckets after one warm-up, max over ranks), never from a nominal link rate (round-3 ADVICE / VERDICT)
-        swin_cut, cut_ms = max(args.swin_cut, 0), None
+        swin_cut, cut_ms, tail_ms = max(args.swin_cut, 0), None, None
         if ddp and flat.active:
             from facialmmt_amd.train_step import pick_swin_cut
             flat.exchange_all()
@@ -660,7 +661,11 @@ def main():
             cut_ms = float(tx.item())
             flat.zero_grad()
             if args.swin_cut < 0:
-                swin_cut = pick_swin_cut(cut_ms, args.utts * args.frames)
+                # the window behind each cut, timed on THIS device with this batch (was a table from one box's profile)
+                from facialmmt_amd.train_step import measure_swin_tail_ms
+                with torch.autocast("cuda", dtype=act) if act is not None else contextlib.nullcontext():
+                    tail_ms = measure_swin_tail_ms(swin, batch[8])
+                swin_cut = pick_swin_cut(cut_ms, args.utts * args.frames, tail_ms)
         pipelined = bool(args.pipeline_swin) and not (ddp and flat.active) and not args.aux_images and args.discarded_swin_gradients == "compute"
         step = GraphedTargetStep(swin, mm, opt, sched, cfg, batch, autocast_dtype=act, overlap_text=bool(args.overlap_text),
                                  parallel_fusion=bool(args.parallel_fusion), averager=flat, masters=masters,
@@ -755,7 +760,8 @@ def main():
         xchg = {"ranks": dist.get_world_size(), "backend": dist.get_backend(), "wire_dtype": args.grad_comm, "bytes_per_rank": nbytes,
                 "buckets": len(flat.buckets), "ms_issue_to_done": round(total_ms, 3), "ms_exposed_after_swin_backward": round(exposed_ms, 3),
                 "ms_alone": round(alone_ms, 3), "ms_alone_before_capture": (round(cut_ms, 3) if cut_ms is not None else None),
-                "swin_cut": step.SWIN_CUT, "swin_cut_from": ("--swin-cut" if args.swin_cut >= 0 else "exchange measured alone before capture (train_step.pick_swin_cut)"),
+                "swin_cut": step.SWIN_CUT, "swin_cut_from": ("--swin-cut" if args.swin_cut >= 0 else "exchange measured alone before capture against Swin's backward pieces timed on this device (train_step.pick_swin_cut, measure_swin_tail_ms)"),
+                "swin_tail_ms": tail_ms if (ddp and flat.active and args.swin_cut < 0) else None,
                 "rccl_tuning": args.rccl_tuning, "rccl_env": {k: os.environ.get(k) for k in RCCL_KNOBS},
                 "bus_GB_per_s_alone": round(2.0 * (world - 1) / max(world, 1) * nbytes / (alone_ms * 1e-3) / 1e9, 1) if world > 1 else None}
 

@@ -123,14 +123,15 @@ def test_affwild_logits_and_gradients(golden, dev, S):
     xin = frames[:3].clone().requires_grad_(True)
     probe = synth.tensor("probe7", (3, 7), seed=3).to(dev)
     (aff(xin, is_trg_task=False) * probe).sum().backward()
-    golden.check("swin_full", "grad/input", xin.grad, atol=2e-5, rtol=5e-3, sum_rtol=1e-3)
+    # (round 5: gradient goldens at the north-star 1e-3 class -- they were held at rtol 5e-3 while the measured error was 2e-4 of the tensor's scale)
+    golden.check("swin_full", "grad/input", xin.grad, atol=2e-5, rtol=1e-3, sum_rtol=1e-3)
     params = dict(aff.named_parameters())
     z = golden.files["swin_full"]
     names = sorted({k.split("/")[1] for k in z.files if k.startswith("grad/") and k.split("/")[1] not in ("input", "swin.output_layer.2.bias")})
     assert len(names) >= 20
     for n in names:
         ref, _ = golden.expected("swin_full", f"grad/{n}")
-        golden.check("swin_full", f"grad/{n}", params[n].grad, atol=1e-3 * float(np.abs(ref).max()) + 1e-7, rtol=5e-3, sum_rtol=2e-3)
+        golden.check("swin_full", f"grad/{n}", params[n].grad, atol=3e-4 * float(np.abs(ref).max()) + 1e-7, rtol=1e-3, sum_rtol=1e-3)
 
 
 def _diverse_frames(n, seed=1):

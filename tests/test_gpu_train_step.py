@@ -364,3 +364,20 @@ def test_replayed_benchmark_step_is_reproducible():
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "support_replay_step.py")], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "12 replays, 0 with differences" in r.stdout, r.stdout[-2000:]
+
+
+def test_measured_swin_backward_pieces_and_cut_choice():
+    """train_step.measure_swin_tail_ms: the GPU time of Swin's backward below each cut, from HIP events in stage backward hooks -- positive, growing with
+    the cut, smaller than the whole backward; pick_swin_cut takes the lowest cut whose piece holds the exchange (measured table or the profiled one)."""
+    from facialmmt_amd import models
+    from facialmmt_amd.config import default_args
+    from facialmmt_amd.train_step import measure_swin_tail_ms, pick_swin_cut
+    dev = torch.device("cuda:0")
+    aff = models.SwinForAffwildClassification(default_args()).to(dev).train()
+    frames = torch.randn(16, 3, 224, 224, device=dev)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        t = measure_swin_tail_ms(aff, frames)
+    assert set(t) == {0, 1, 2} and 0 < t[0] < t[1] < t[2]
+    assert all(p.grad is None for p in aff.parameters())
+    assert pick_swin_cut(t[0] * 0.5, 16, t) == 0 and pick_swin_cut((t[0] + t[1]) / 2, 16, t) == 1 and pick_swin_cut(t[2] * 2, 16, t) == 2
+    assert pick_swin_cut(9.0) == 0 and pick_swin_cut(12.0) == 1 and pick_swin_cut(100.0) == 2          # the profiled table at 640 frames
