@@ -639,7 +639,7 @@ def main():
         opt = HFAdamW(params, lr=torch.tensor(cfg.trg_lr, device=dev), weight_decay=cfg.weight_decay)
         sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_of)
         if args.aux_images:
-            aflat = GradientAverager(swin.parameters(), hooks=False, comm_dtype=comm)
+            aflat = GradientAverager(swin.parameters(), hooks=False, comm_dtype=comm, always=args.force_ddp)
             aopt = HFAdamW(swin.parameters(), lr=torch.tensor(cfg.aux_lr, device=dev))       # train.py:333: no weight decay on the Swin model
             aux_step = GraphedAuxStep(swin, aopt, torch.optim.lr_scheduler.LambdaLR(aopt, lr_of), cfg, *aux_batch, averager=aflat)
         # N > 1: where the backward graph is cut follows from the exchange time MEASURED alone on this communicator (three blocking
@@ -764,6 +764,32 @@ def main():
                 "swin_tail_ms": tail_ms if (ddp and flat.active and args.swin_cut < 0) else None,
                 "rccl_tuning": args.rccl_tuning, "rccl_env": {k: os.environ.get(k) for k in RCCL_KNOBS},
                 "bus_GB_per_s_alone": round(2.0 * (world - 1) / max(world, 1) * nbytes / (alone_ms * 1e-3) / 1e9, 1) if world > 1 else None}
+        if args.aux_images and aux_step is not None and getattr(aflat, "active", False):
+            # the auxiliary-task step's own exchange (train.py:15-41: the Swin model's 46.8 M gradients, every `aux_every` target steps): alone, and the
+            # whole auxiliary step (graph replays) after the timed region -- not part of `value`
+            abytes = sum(b[0].numel() for b in aflat.buckets) * (2 if comm is not None else 4)
+            aflat.exchange_all()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            t4 = time.perf_counter()
+            for _ in range(2):
+                aflat.exchange_all()
+            torch.cuda.synchronize()
+            a_alone = (time.perf_counter() - t4) / 2 * 1e3
+            aflat.zero_grad()
+            aux_step(*aux_batch)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            t5 = time.perf_counter()
+            for _ in range(3):
+                aux_step(*aux_batch)
+            torch.cuda.synchronize()
+            a_step = (time.perf_counter() - t5) / 3 * 1e3
+            xchg["aux_step"] = {"bytes_per_rank": abytes, "buckets": len(aflat.buckets), "ms_alone": round(a_alone, 3), "aux_step_ms": round(a_step, 2),
+                                "aux_images": args.aux_images,
+                                "bus_GB_per_s_alone": round(2.0 * (world - 1) / max(world, 1) * abytes / (a_alone * 1e-3) / 1e9, 1) if world > 1 else None}
 
     # host cost of issuing one step into an IDLE queue (during the timed loop the host mostly waits for the previous replay
     # of the same graph to drain, so the enqueue time above is back-pressure, not cost)
