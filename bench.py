@@ -91,6 +91,7 @@ def parse():
     ap.add_argument("--plm-dtype", default="bf16", choices=["bf16", "fp32"], help="parameter dtype of the text encoder in --graphs 2: bf16 with fp32 master weights in the optimizer, or fp32 under autocast")
     ap.add_argument("--grad-comm", default="bf16", choices=["fp32", "bf16"], help="element type of the gradient all-reduce (N > 1): bf16 halves the bytes on the xGMI links (0.87 GB instead of 1.74 GB per step)")
     ap.add_argument("--other-configs", type=int, default=1, help="N = 1 only: after the timed region also run 4 steps of configs[3] and configs[4] (per-GPU legs, own processes) and report them under `other_configs`")
+    ap.add_argument("--branch-graphs", type=int, default=0, help="1 (one rank, --graphs 2, no gradient exchange): text encoder forward / backward and Swin forward / backward as graphs of their own on two streams, events at the data dependencies (GraphedTargetStep branch_graphs)")
     ap.add_argument("--pipeline-swin", type=int, default=0, help="1 (one rank, --graphs 2, no auxiliary task): Swin's forward of step i + 1 as a graph of its own, replayed on a second stream beside step i (GraphedTargetStep pipeline_swin); every timed step still runs exactly one Swin forward.  Round 5, same call, alternating: 63.2 / 63.3 ms per step with it, 62.35 / 62.37 without -- the chip-filling Swin kernels (one persistent workgroup per CU) leave the other stream's small launches no CU to run on, so the two graphs time-slice; default off")
     ap.add_argument("--parallel-fusion", type=int, default=0, help="1: capture independent halves of the fusion stack as parallel graph branches (round 4, same call: 64.9-65.0 ms per step against 63.5-63.7 without -- a fork / join pair of the replayed graph costs more than the 50-250-workgroup launches it lets overlap)")
     ap.add_argument("--discarded-swin-gradients", choices=["compute", "skip"], default="compute",
@@ -667,9 +668,11 @@ def main():
                     tail_ms = measure_swin_tail_ms(swin, batch[8])
                 swin_cut = pick_swin_cut(cut_ms, args.utts * args.frames, tail_ms)
         pipelined = bool(args.pipeline_swin) and not (ddp and flat.active) and not args.aux_images and args.discarded_swin_gradients == "compute"
+        branched = bool(args.branch_graphs) and not pipelined and not (ddp and flat.active) and args.discarded_swin_gradients == "compute"
         step = GraphedTargetStep(swin, mm, opt, sched, cfg, batch, autocast_dtype=act, overlap_text=bool(args.overlap_text),
                                  parallel_fusion=bool(args.parallel_fusion), averager=flat, masters=masters,
-                                 discarded_swin_gradients=args.discarded_swin_gradients, swin_cut=swin_cut, pipeline_swin=pipelined)
+                                 discarded_swin_gradients=args.discarded_swin_gradients, swin_cut=swin_cut, pipeline_swin=pipelined,
+                                 branch_graphs=branched)
     else:
         if args.graphs == 1:
             from facialmmt_amd.train_step import graph_multimodal, select_frames
@@ -957,7 +960,7 @@ def main():
                        "parallelism": f"dp{world}", "kept_frame_fraction": round(float(kept.mean().item()), 3),
                        "model_tflops_per_s_per_gpu": round(flops_step / (ms * 1e-3) / 1e12, 1),
                        "host_enqueue_ms_per_step": round(issue_s / args.steps * 1e3, 1), "host_issue_ms_into_idle_queue": round(idle_issue_ms, 1),
-                       "hip_graphs": {2: ("whole step: 3 graphs (fwd + multimodal bwd | Swin bwd | clip+optimizer), gradient exchange beside the second" if ddp else ("whole step: 3 graphs (Swin fwd of the NEXT step on a second stream | everything else of this step | clip+optimizer)" if getattr(step, "pipeline", False) else "whole step: 2 graphs (fwd+bwd | clip+optimizer)")), 1: "multimodal model only (Swin eager)", 0: "none"}[args.graphs],
+                       "hip_graphs": {2: ("whole step: 3 graphs (fwd + multimodal bwd | Swin bwd | clip+optimizer), gradient exchange beside the second" if ddp else ("whole step: 3 graphs (Swin fwd of the NEXT step on a second stream | everything else of this step | clip+optimizer)" if getattr(step, "pipeline", False) else ("whole step: 6 graphs on two streams (text fwd || Swin fwd -> filter + fusion + loss fwd/bwd -> text bwd + hand-over + clip+optimizer || Swin bwd)" if getattr(step, "branches", False) else "whole step: 2 graphs (fwd+bwd | clip+optimizer)"))), 1: "multimodal model only (Swin eager)", 0: "none"}[args.graphs],
                        "text_encoder_concurrent_with_swin": bool(args.graphs and args.overlap_text),
                        "swin_forward_pipelined_across_steps": bool(getattr(step, "pipeline", False)),
                        "text_encoder_parameters": "bf16 with fp32 master weights in the optimizer" if (args.graphs == 2 and args.plm_dtype == "bf16" and args.dtype == "bf16") else "fp32 under bf16 autocast",

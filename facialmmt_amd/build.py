@@ -3,6 +3,7 @@
 hipcc cross-compiles without a GPU; the .so is git-ignored but travels with gpurun snapshots."""
 from __future__ import annotations
 
+import glob
 import os
 import subprocess
 import sys
@@ -28,7 +29,7 @@ def build(force: bool = False, verbose: bool = True, tag: str = "") -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     tag = tag or os.environ.get("FMMT_BUILD_TAG", "")
     csrc = os.environ.get("FMMT_CSRC_DIR", CSRC) if tag else CSRC      # a tagged build may come from another source tree (an earlier commit)
-    headers = [os.path.join(csrc, "fmmt_common.h"), os.path.join(csrc, "gemm_common.h"), os.path.join(csrc, "wattn_args.h"), os.path.join(csrc, "wattn_geom.h"), os.path.join(csrc, "mha_args.h"), os.path.join(csrc, "wblock_common.h"), os.path.join(csrc, "mlp_args.h"), os.path.join(csrc, "gelu_poly_data.h"), os.path.join(csrc, "..", "..", "include", "fmmt.h")]
+    headers = sorted(glob.glob(os.path.join(csrc, "*.h"))) + [os.path.join(csrc, "..", "..", "include", "fmmt.h")]
     objdir = os.path.join(HERE, "build_" + tag if tag else "build")
     out = os.path.join(HERE, f"libfmmt_hip_{tag}.so") if tag else OUT
     os.makedirs(objdir, exist_ok=True)

@@ -636,9 +636,17 @@ extern "C" int fmmt_window_attn_bwd(int dtype, int n_img, int H, int W, int C, i
                                     const float* table, const int32_t* index, const float* mask, int nW_mask,
                                     int mask_is_shift, float scale, void* dqkv, float* dtable,
                                     void* workspace, size_t workspace_bytes, void* stream) {
+    // parity instantiations (wattn_bwd_ref.hip, operands read instead of recomputed): FMMT_F32 with no mask or the standard SW-MSA mask, and
+    // FMMT_BF16 | FMMT_GENERIC (the bf16 instantiation of the same template, for the test that holds it against the production kernel).
+    // fp32 with an explicit mask tensor stays on the VALU kernel below (a different algorithm; tests use it as a cross-check).
+    const bool want_generic = (dtype & FMMT_GENERIC) != 0;
+    dtype &= 0xff;
     if (int e = wa_check(dtype, n_img, H, W, C, num_heads, shift)) return e;
     if (mask && nW_mask <= 0) return FMMT_EINVAL;
     if (workspace_bytes < fmmt_window_attn_bwd_workspace(num_heads)) return FMMT_EWORKSPACE;
+    const bool generic_ok = !mask || (mask_is_shift && shift > 0);
+    if (want_generic && !generic_ok) return FMMT_EINVAL;
+    const bool generic = want_generic || (dtype == FMMT_F32 && generic_ok);
     WaArgs a{};
     a.n_img = n_img; a.H = H; a.W = W; a.C = C; a.nH = num_heads; a.shift = shift; a.qkv = qkv; a.table = table;
     a.index = index; a.mask = mask; a.nW_mask = nW_mask; a.mask_is_shift = mask_is_shift; a.scale = scale; a.out = const_cast<void*>(out);
@@ -648,6 +656,12 @@ extern "C" int fmmt_window_attn_bwd(int dtype, int n_img, int H, int W, int C, i
     a.groups_per_head = wa_groups_per_head(B_, num_heads, true, dtype == FMMT_BF16);
     a.xcd_grouped = wa_xcd_grouped(a.groups_per_head, dtype == FMMT_BF16);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (generic) {
+        a.groups_per_head = fmmt_wattn_bwd_groups(B_, num_heads, 1);                    // one pair of waves (one window at a time) per workgroup
+        a.xcd_grouped = 0;
+        if (int rc = fmmt_wattn_bwd_ref_launch(dtype, a, num_heads * a.groups_per_head, st)) return rc;
+        return fmmt_wattn_dtable_finish(a.part, num_heads, a.groups_per_head, index, dtable, st);
+    }
     dim3 grid(num_heads * a.groups_per_head);
     if (dtype == FMMT_BF16) {
         if (int rc = fmmt_wattn_mfma_bwd_launch(a, (int)grid.x, st)) return rc;

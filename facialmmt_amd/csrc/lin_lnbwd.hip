@@ -17,12 +17,13 @@
 // accumulators over the persistent tile loop, summed over the row's 16 tokens by DPP, over the waves through LDS, one row of partial
 // sums per workgroup, finished in fixed order by mlp_ln_part_reduce_kernel's twin below.
 #include "gemm_common.h"
+#include "elem_trait.h"
 
 namespace {
 
 struct DlArgs {
     int M, tiles;
-    const bf16* dz;        // [M][K]
+    const bf16* dz;        // [M][K]            (the generic twin below reads these five as its own element type)
     const bf16* wt;        // [C][K] = W^T
     const bf16* x;         // [M][C] LayerNorm input
     const float* mean;
@@ -206,6 +207,113 @@ __global__ __launch_bounds__(512) void lin_lnbwd_kernel(DlArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// The same kernel restated over an ELEMENT-TYPE TRAIT, for parity (the companion of mlp_ref.hip / wblock_ref.hip / wattn_bwd_ref.hip):
+// same decomposition and index arithmetic -- 256-token tiles, wave w owns tokens [32 w, 32 w + 32), dz rows as the B fragments, W^T rows
+// chan_of<CW2> as the A fragments, the accumulator tile = d(LN out) with a token's C channels in the four lanes li + 16 g, LayerNorm' as
+// in-lane sums + two cross-lane steps, d(gamma) / d(beta) as per-lane sums over the tile loop -> DPP row sum -> per-wave LDS slots ->
+// one partial row per workgroup.  What the trait replaces: fragments of 8 fp32 and the 32-deep product as 8 x v_mfma_f32_16x16x4_f32;
+// and the weight fragments are read straight from memory (how operands reach the CU is not part of the algorithm being checked).
+// fp32: nothing is rounded -- held to the reference's block goldens at 1e-3.  bf16 | FMMT_GENERIC: held against the kernel above.
+template <typename T, int C, int K, bool HASRES>
+__global__ __launch_bounds__(512) void lin_lnbwd_ref_kernel(DlArgs p) {
+    using E = ElemTrait<T>;
+    using F = typename E::frag;
+    constexpr int KB = K / 32, KS = C / 32, NT2 = C / 16, CW2 = 4 * NT2;
+    constexpr int NV = KS * 8, NOWN = 2 * NV / 16;
+    __shared__ float slot_s[8 * 4 * 2 * NV];
+    const T* dzg = reinterpret_cast<const T*>(p.dz);
+    const T* wtg = reinterpret_cast<const T*>(p.wt);
+    const T* xg = reinterpret_cast<const T*>(p.x);
+    const T* drg = reinterpret_cast<const T*>(p.dres);
+    T* dxg = reinterpret_cast<T*>(p.dx);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    float dga[NV], dba[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) dga[i] = dba[i] = 0.f;
+    for (int tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
+        const int t0 = tile * 256 + wave * 32;
+        f32x4 acc[2][NT2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT2; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int kb = 0; kb < KB; ++kb) {
+            F zf[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) zf[mt] = E::ld(dzg + (size_t)min(t0 + mt * 16 + li, p.M - 1) * K + kb * 32 + lg * 8);
+#pragma unroll
+            for (int nt = 0; nt < NT2; ++nt) {
+                const F wf = E::ld(wtg + (size_t)chan_of<CW2>(nt, li >> 2, li & 3) * K + kb * 32 + lg * 8);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = E::mma(wf, zf[mt], acc[mt][nt]);
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int tok = t0 + mt * 16 + li, tokc = min(tok, p.M - 1);
+            const bool valid = tok < p.M;
+            const float mean = p.mean[tokc], rstd = p.rstd[tokc];
+            F lx[KS], dr[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                lx[ks] = E::ld(xg + (size_t)tokc * C + ks * 32 + lg * 8);
+                if constexpr (HASRES) dr[ks] = E::ld(drg + (size_t)tokc * C + ks * 32 + lg * 8);
+            }
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int c = 0; c < KS; ++c)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = acc[mt][2 * c + (e >> 2)][e & 3];
+                    const float xh = ((float)lx[c][e] - mean) * rstd;
+                    const float gm = d * p.gamma[c * 32 + lg * 8 + e];
+                    s1 += gm;
+                    s2 += gm * xh;
+                }
+            s1 = swap_sum(s1) * (1.0f / (float)C);
+            s2 = swap_sum(s2) * (1.0f / (float)C);
+#pragma unroll
+            for (int c = 0; c < KS; ++c) {
+                F o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int v = c * 8 + e;
+                    const float d = acc[mt][2 * c + (e >> 2)][e & 3];
+                    const float xh = ((float)lx[c][e] - mean) * rstd;
+                    const float gm = d * p.gamma[c * 32 + lg * 8 + e];
+                    o[e] = E::cv(rstd * (gm - s1 - xh * s2) + (HASRES ? (float)dr[c][e] : 0.f));
+                    const float dv = valid ? d : 0.f;
+                    dga[v] += dv * xh;
+                    dba[v] += dv;
+                }
+                if (valid) E::st(dxg + (size_t)tok * C + c * 32 + lg * 8, o);
+            }
+        }
+    }
+    float own[NOWN];
+#pragma unroll
+    for (int i = 0; i < NOWN; ++i) own[i] = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const float sg = dl_row16_sum(dga[v]), sb = dl_row16_sum(dba[v]);
+        if (li == (v & 15)) own[v >> 4] = sg;
+        if (li == ((v + NV) & 15)) own[(v + NV) >> 4] = sb;
+    }
+#pragma unroll
+    for (int k = 0; k < NOWN; ++k) slot_s[(wave * 4 + lg) * (2 * NV) + k * 16 + li] = own[k];
+    __syncthreads();
+    if (tid < 2 * C) {
+        const int kind = tid / C, ch = tid % C;
+        const int v = kind * NV + (ch >> 5) * 8 + (ch & 7), lgc = (ch >> 3) & 3;
+        float a = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) a += slot_s[(w * 4 + lgc) * (2 * NV) + v];
+        p.part[(size_t)blockIdx.x * 2 * C + tid] = a;
+    }
+}
+
 // rows of per-workgroup partial sums [nblocks][2 C] -> d(gamma) [C], d(beta) [C]; fixed order
 __global__ __launch_bounds__(1024) void lin_ln_part_reduce_kernel(const float* __restrict__ part, int nblocks, int C, float* dgamma, float* dbeta) {
     __shared__ float red[16][64];
@@ -234,7 +342,9 @@ extern "C" size_t fmmt_linear_ln_bwd_workspace(int C) { return (size_t)256 * 2 *
 extern "C" int fmmt_linear_ln_bwd(int dtype, int M, int C, int K, const void* dz, const void* wt, const void* x, const float* mean, const float* rstd,
                                   const float* ln_gamma, const void* dres, void* dx, float* dgamma, float* dbeta, void* workspace,
                                   size_t workspace_bytes, void* stream) {
-    if (dtype != FMMT_BF16 || M <= 0 || C != 96 || K != 288) return FMMT_EINVAL;           // other shapes: fmmt_linear_fwd + fmmt_layernorm_bwd
+    const int el = dtype & 0xff;
+    const bool generic = (dtype & FMMT_GENERIC) || el == FMMT_F32;                          // parity instantiations (lin_lnbwd_ref_kernel)
+    if ((el != FMMT_BF16 && el != FMMT_F32) || M <= 0 || C != 96 || K != 288) return FMMT_EINVAL;   // other shapes: fmmt_linear_fwd + fmmt_layernorm_bwd
     if (!dz || !wt || !x || !mean || !rstd || !ln_gamma || !dx || !dgamma || !dbeta || !workspace) return FMMT_EINVAL;
     if (workspace_bytes < fmmt_linear_ln_bwd_workspace(C)) return FMMT_EWORKSPACE;
     if (!al16(dz) || !al16(wt) || !al16(x) || !al16(dx) || (dres && !al16(dres)) || !al16(workspace)) return FMMT_EALIGN;
@@ -245,7 +355,15 @@ extern "C" int fmmt_linear_ln_bwd(int dtype, int M, int C, int K, const void* dz
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     constexpr int lds = (288 / 32) * 96 * 32 * 2 + 96 * 4 + 8 * 4 * 2 * 24 * 4;
     const int grid = a.tiles < 256 ? a.tiles : 256;
-    if (dres) {
+    if (generic) {
+        if (el == FMMT_F32) {
+            if (dres) hipLaunchKernelGGL((lin_lnbwd_ref_kernel<float, 96, 288, true>), dim3(grid), dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((lin_lnbwd_ref_kernel<float, 96, 288, false>), dim3(grid), dim3(512), 0, st, a);
+        } else {
+            if (dres) hipLaunchKernelGGL((lin_lnbwd_ref_kernel<bf16, 96, 288, true>), dim3(grid), dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((lin_lnbwd_ref_kernel<bf16, 96, 288, false>), dim3(grid), dim3(512), 0, st, a);
+        }
+    } else if (dres) {
         static FmmtLdsOnce lds_once;
         if (int rc_ = lds_once.set(reinterpret_cast<const void*>(&lin_lnbwd_kernel<96, 288, true>), lds)) return rc_;
         hipLaunchKernelGGL((lin_lnbwd_kernel<96, 288, true>), dim3(grid), dim3(512), lds, st, a);

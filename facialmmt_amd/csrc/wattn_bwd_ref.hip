@@ -84,7 +84,7 @@ template <typename T, int RC> struct WrLds {
     static constexpr int TILE = 64 * TP * (int)sizeof(T);
     static constexpr int TILES = 4 * TILE, STATS = 2 * 64 * 4, BIAS = 64 * BPM * 4;
     static constexpr int WP = RC + 8;
-    static constexpr int WGT = 128 * WP * (int)sizeof(T) + 96 * 4;
+    static constexpr int WGT = RC ? 128 * WP * (int)sizeof(T) + 96 * 4 : 0;              // RC = 0: q / k / v / d(out) are read, no weights
     static constexpr int TOTAL = TILES + STATS + BIAS + WGT;
 };
 
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(128) void wattn_bwd_ref_kernel(WaArgs p) {
         const int q = t / BPM, k = t - q * BPM;
         Bs[t] = (q < TOK && k < TOK) ? p.table[p.index[q * TOK + k] * p.nH + head] : NEG_BIG;
     }
-    {
+    if constexpr (RC > 0) {
         // rows in FRAGMENT order: (part * 2 + nt) * 16 + i <-> Wqkv row part * C + head * 32 + (i >> 2) * 8 + nt * 4 + (i & 3);
         // 96 + nt * 16 + i <-> COLUMN head * 32 + (i >> 2) * 8 + nt * 4 + (i & 3) of Wproj (row c of Wproj -> LDS column c)
         const T* wq = reinterpret_cast<const T*>(p.wqkv);
@@ -154,7 +154,20 @@ __global__ __launch_bounds__(128) void wattn_bwd_ref_kernel(WaArgs p) {
         F qf[2], kf[2], gf[2], vv[2];
         float ls[2], dl[2];
         __syncthreads();
-        {
+        if constexpr (RC == 0) {
+            // the materialised form (fmmt_window_attn_bwd; production: wattn_mfma_bwd_kernel<MM, 2, 0>): this head's q / k / v rows of the
+            // qkv tensor and d(attention output) ARE the fragments -- token li of the tile, head dims lg * 8 .. + 7
+            const T* qkvg = reinterpret_cast<const T*>(p.qkv);
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                tok[a] = tok_of(p, P, own[a].di, own[a].dj);
+                const T* row = qkvg + tok[a] * 3 * p.C + head * HD + lg * 8;
+                qf[a] = E::ld(row);
+                kf[a] = E::ld(row + p.C);
+                vv[a] = E::ld(row + 2 * p.C);
+                gf[a] = E::ld(dog + tok[a] * p.C + head * HD + lg * 8);
+            }
+        } else {
             F xf[2][KS], yf[2][KS];
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
@@ -357,8 +370,17 @@ int wr_launch(const WaArgs& a, int grid, hipStream_t st) {
 
 }  // namespace
 
-// generic restatement of the recompute backward, C = 96; head-major grid of num_heads * a.groups_per_head workgroups (one pair each)
+// generic restatement of the backward; head-major grid of num_heads * a.groups_per_head workgroups (one pair each).
+//   a.xn != nullptr   the recompute form behind fmmt_window_block_attn_bwd, C = 96
+//   a.xn == nullptr   the materialised form behind fmmt_window_attn_bwd (q / k / v / d(out) read from a.qkv / a.dout), any width of 32-wide
+//                     heads; mask none or the standard SW-MSA mask (an explicit mask tensor: FMMT_EINVAL, the caller keeps its other path)
 int fmmt_wattn_bwd_ref_launch(int dtype, const WaArgs& a, int grid, hipStream_t st) {
+    if (!a.xn) {
+        if (a.mask && !a.mask_is_shift) return FMMT_EINVAL;
+        const bool masked = a.mask != nullptr && a.shift > 0;
+        if (dtype == FMMT_F32) return masked ? wr_launch<float, 1, 0>(a, grid, st) : wr_launch<float, 0, 0>(a, grid, st);
+        return masked ? wr_launch<bf16, 1, 0>(a, grid, st) : wr_launch<bf16, 0, 0>(a, grid, st);
+    }
     const bool masked = a.shift > 0;
     if (a.C != 96) return FMMT_EINVAL;
     if (dtype == FMMT_F32) return masked ? wr_launch<float, 1, 96>(a, grid, st) : wr_launch<float, 0, 96>(a, grid, st);

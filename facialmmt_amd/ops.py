@@ -733,7 +733,8 @@ class PatchProjLnFn(Function):
 
 
 def patch_proj_ln_fusable(cols, weight, norm):
-    return (_PATCH_LN and norm is not None and cols.is_cuda and cols.dtype == torch.bfloat16 and tuple(weight.shape) == (96, 48)
+    # (fp32: the same kernel template over 8 x mfma_f32_16x16x4 per 32-deep block -- the parity instantiation, csrc/patch_ln.hip)
+    return (_PATCH_LN and norm is not None and cols.is_cuda and cols.dtype in (torch.bfloat16, torch.float32) and tuple(weight.shape) == (96, 48)
             and tuple(norm.weight.shape) == (96,))
 
 
@@ -958,8 +959,9 @@ def window_block_backward(dy, x2, xn, o, mean, rstd, lse, g, wqkv, bqkv, wproj, 
     dx = torch.empty_like(x2)
     dg = torch.empty(C, dtype=torch.float32, device=x2.device)
     db = torch.empty(C, dtype=torch.float32, device=x2.device)
-    if _WBLOCK_LNBWD and dt == torch.bfloat16 and C == 96:
+    if _WBLOCK_LNBWD and (dt == torch.bfloat16 or (_WBLOCK_F32 and dt == torch.float32)) and C == 96:
         # d(LN out) = dqkv . Wqkv, LayerNorm' and the residual gradient in one launch (fmmt_linear_ln_bwd): d(LN out) is never written
+        # (fp32: the generic instantiation of the same kernel, lin_lnbwd_ref_kernel -- what the gradient goldens of the fp32 model check)
         nb2 = lib.fmmt_linear_ln_bwd_workspace(C)
         ws2 = _ws(nb2, x2.device)
         rc = lib.fmmt_linear_ln_bwd(dtype_code(dt), x2.shape[0], C, 3 * C, _p(dqkv), _p(_lp(wqkv, dt, transpose=True)), _p(x2), _p(mean), _p(rstd), _p(g),

@@ -857,9 +857,13 @@ class GraphedTargetStep:
     `accumulation_steps` > 1 replays A that many times per B (gradients accumulate in the flat buffers).
     Parity: tests/test_gpu_train_step.py walks this against the eager TargetStep (same losses, same parameters)."""
 
+    # where the text branch's launches enter the capture order: "start" (in front of Swin's forward), "pe" (behind PatchEmbed), "s<i>"
+    # (behind Swin stage i).  Development switch FMMT_TEXT_FORK; measured in NOTES.md R5.3.
+    TEXT_FORK_AT = __import__("os").environ.get("FMMT_TEXT_FORK", "start")
+
     def __init__(self, swin_model, multimodal_model, optimizer, scheduler, args, batch, autocast_dtype=None,
                  overlap_text=True, parallel_fusion=False, averager=None, warmup_iters=2, masters=None, discarded_swin_gradients="compute",
-                 swin_cut: int = 0, pipeline_swin: bool = False):
+                 swin_cut: int = 0, pipeline_swin: bool = False, branch_graphs: bool = False):
         """`averager`: GradientAverager(hooks=False) over the parameters the optimizer steps (default: the multimodal
         model's); `swin_cut`: with an exchange to hide (N > 1), the Swin stage behind which the backward graph is cut (0: the second
         piece is stage 0's backward, ~10 ms; 1: stages 1 + 0, ~17 ms) -- the caller picks it from a MEASURED exchange time
@@ -878,6 +882,7 @@ class GraphedTargetStep:
             raise ValueError("discarded_swin_gradients: 'compute' or 'skip'")
         self.skip_swin_bwd = discarded_swin_gradients == "skip"
         self.pipeline = bool(pipeline_swin)
+        self.branches = bool(branch_graphs)                 # BRANCH_NOTE below
         if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "") != "0":
             raise RuntimeError("GraphedTargetStep: DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 must be in the environment before the HIP "
                                "runtime initialises (see facialmmt_amd/__init__.py)")
@@ -948,6 +953,8 @@ class GraphedTargetStep:
         self.SWIN_CUT = int(swin_cut)                      # the window behind the cut has to hold the exchange: see pick_swin_cut
         if self.pipeline and (self.split or self.skip_swin_bwd):
             raise ValueError("pipeline_swin: one rank without a gradient exchange, Swin's backward computed")
+        if self.branches and (self.split or self.skip_swin_bwd or self.pipeline):
+            raise ValueError("branch_graphs: one rank without a gradient exchange, Swin's backward computed, not together with pipeline_swin")
         self.graph_a, self.graph_a2, self.graph_b = torch.cuda.CUDAGraph(), (torch.cuda.CUDAGraph() if self.split else None), torch.cuda.CUDAGraph()
         self.sets, self.side_stream, self.cur, self.prefetched = [], None, 0, None
         if self.pipeline:
@@ -970,6 +977,37 @@ class GraphedTargetStep:
                 with torch.cuda.graph(self.graph_b, stream=cap):
                     self._update()
             self.loss, self.new_mask = self.sets[0].loss, self.sets[0].mask
+        elif self.branches:
+            # BRANCH_NOTE.  Inside ONE graph the text encoder and Swin are two branches, but the replay does not run them side by side: the
+            # runtime enqueues a graph branch by branch, and a branch that continues on another queue waits for EVERYTHING the first branch
+            # has enqueued so far, not for the node it depends on (profiles/r05_timeline.txt: the text encoder's forward runs alone for
+            # ~4 ms in front of Swin's forward -- behind it when the capture order is swapped, FMMT_TEXT_FORK --, its backward starts ~12 ms
+            # into Swin's backward and ends ~5 ms after it).  Here every branch is a graph of its own, launched on one of two streams with
+            # events between them -- dependencies exactly where the data flow has them:
+            #     side:  T  text encoder forward ............................ TB text encoder backward, hand-over | B update
+            #     main:  S  Swin forward -> [T] F  frame filter, fusion stack, loss, its backward -> SB Swin backward
+            # Autograd crosses the graph boundaries on detached copies of the two branch outputs (F differentiates down to them, TB / SB
+            # continue from their gradients).  Pools: graphs that may run at the same time never share one (T, TB, B | S, SB | F).
+            self.side_stream = distinct_stream(dev, (cap,))
+            self.swin_shadows, self.mm_shadows = _pin_shadows([self.swin]), _pin_shadows([self.mm])
+            g = types.SimpleNamespace(T=torch.cuda.CUDAGraph(), S=torch.cuda.CUDAGraph(), F=torch.cuda.CUDAGraph(), TB=torch.cuda.CUDAGraph(),
+                                      SB=torch.cuda.CUDAGraph(), ev_t=torch.cuda.Event(), ev_f=torch.cuda.Event())
+            with capture_window(), _ops_pinned_scope(self.shadows):
+                with torch.cuda.graph(g.T, stream=cap):
+                    feat, tmask = self._text_forward()
+                with torch.cuda.graph(g.S, stream=cap):
+                    preds = self._swin_forward(self.static[8])
+                with torch.cuda.graph(g.F, stream=cap):
+                    self.loss, self.new_mask, dfeat, dpreds = self._fusion_fwd_bwd(feat, tmask, preds)
+                with torch.cuda.graph(g.TB, pool=g.T.pool(), stream=cap):
+                    self._text_backward(feat, dfeat)
+                with torch.cuda.graph(g.SB, pool=g.S.pool(), stream=cap):
+                    self._bwd_swin((preds, dpreds))
+                del feat, tmask, preds, dfeat, dpreds
+                with torch.cuda.graph(self.graph_b, pool=g.T.pool(), stream=cap):
+                    self._update()
+            self.bg = g
+            _KEEP_GRAPHS.append((g.T, g.S, g.F, g.TB, g.SB))
         else:
           with capture_window(), _ops_pinned_scope(self.shadows):
             if self.split:
@@ -993,6 +1031,84 @@ class GraphedTargetStep:
         loss, new_mask, _ = self._fwd_bwd_multimodal(whole=True)
         return loss, new_mask
 
+    def _text_forward(self):
+        """branch_graphs, graph T: the multimodal model's bf16 shadows (text encoder AND fusion stack: one launch), then the text branch"""
+        (ids, attn_mask, sep_mask, _a, _am, _v, _vm, _l, _f, _n, utt_idx) = self.static
+        if self.mm_shadows is not None:
+            self.mm_shadows.refresh()
+        import contextlib
+        ac = (lambda: torch.autocast("cuda", dtype=self.autocast_dtype)) if self.autocast_dtype is not None else contextlib.nullcontext
+        with ac():
+            return self.mm.text_branch(ids, attn_mask, sep_mask, torch.as_tensor(utt_idx, device=ids.device))
+
+    def _fusion_fwd_bwd(self, feat, tmask, preds):
+        """branch_graphs, graph F: frame filter, fusion stack, loss and their backward, down to detached copies of the two branch outputs;
+        returns (loss, kept-frame mask, d(text features), d(Swin output)).  The fusion stack's parameter gradients are complete here."""
+        (_i, _m, _s, audio, audio_mask, vision_inputs, vision_mask, labels, _f, num_imgs, _u) = self.static
+        import contextlib
+        ac = (lambda: torch.autocast("cuda", dtype=self.autocast_dtype)) if self.autocast_dtype is not None else contextlib.nullcontext
+        feat_d = feat.detach().requires_grad_(True)
+        preds_d = preds.detach().requires_grad_(True)
+        vis_concat, new_mask = select_frames(preds_d.float(), vision_inputs, vision_mask, num_imgs, self.args.FacialEmoImpor_threshold)
+        with ac():
+            logits = self.mm.fusion_branch(feat_d, tmask, audio, audio_mask, vis_concat, new_mask)
+        loss = F.cross_entropy(logits.float(), labels) / self.args.trg_accumulation_steps
+        leaves = [l for l, _ in self.pairs if l.requires_grad]
+        got = torch.autograd.grad(loss, [feat_d, preds_d] + leaves, allow_unused=True)
+        for l, gr in zip(leaves, got[2:]):
+            l.grad = gr
+        return loss.detach(), new_mask, got[0], got[1]
+
+    def _text_backward(self, feat, dfeat):
+        """branch_graphs, graph TB: the text branch's backward from the gradient of its output, then the hand-over of EVERY multimodal gradient
+        (graph F's included) to the optimizer's flat buffers with the clip norm in the same pass"""
+        leaves = [l for l, _ in self.pairs if l.requires_grad]
+        if dfeat is not None:
+            got = torch.autograd.grad(feat, leaves, dfeat, allow_unused=True)
+            for l, gr in zip(leaves, got):
+                if gr is not None:
+                    l.grad = gr if l.grad is None else l.grad + gr      # (a parameter both pieces use: none in this model)
+        if self.handover is not None and self.handover(self.pairs, self.flat_view_of, self.accumulate, self.fused.norm):
+            self.fused.norm_ready = True
+        else:
+            _hand_over_gradients(self.pairs, self.flat_view_of, self.accumulate)
+            if self.fused is not None:
+                self.fused.norm_ready = False
+
+    def _call_branches(self, batch):
+        g, main, side = self.bg, torch.cuda.current_stream(), self.side_stream
+        main.wait_stream(side)                              # the previous step's side-stream work read the static inputs
+        with torch.no_grad():
+            for i, (dst, src) in enumerate(zip(self.static, batch)):
+                if dst is src:
+                    continue
+                src = src if torch.is_tensor(src) else torch.as_tensor(src)
+                if tuple(src.shape) != tuple(dst.shape):
+                    raise ValueError(f"GraphedTargetStep: batch entry {i} has shape {tuple(src.shape)}, the captured graphs are for {tuple(dst.shape)}")
+                dst.copy_(src, non_blocking=True)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            g.T.replay()
+            g.ev_t.record(side)
+        g.S.replay()
+        main.wait_event(g.ev_t)
+        g.F.replay()
+        g.ev_f.record(main)
+        side.wait_event(g.ev_f)
+        self.i_batch += 1
+        last = self.i_batch % self.args.trg_accumulation_steps == 0
+        with torch.cuda.stream(side):
+            g.TB.replay()
+            if last:
+                self.graph_b.replay()
+        g.SB.replay()
+        main.wait_stream(side)                              # what follows this call on the current stream sees the finished step
+        if last:
+            _bump_versions(self.flat.params)
+            if self.sched is not None:
+                self.sched.step()
+        return self.loss, self.new_mask
+
     def _swin_forward(self, frames):
         """pipeline_swin, graph S: Swin's forward alone (its bf16 shadows refreshed at the head: an auxiliary step may have moved the weights)"""
         if self.swin_shadows is not None:
@@ -1015,10 +1131,31 @@ class GraphedTargetStep:
                 self.mm_shadows.refresh()                   # Swin's shadows belong to graph S
         elif self.shadows is not None:
             self.shadows.refresh()                          # every bf16 weight shadow of the step, one launch (ops.PinnedShadows)
+        fork_hook = None
         if self.text_stream is not None:
-            self.text_stream.wait_stream(main)             # fork: the text branch does not depend on the visual path
-            with torch.cuda.stream(self.text_stream), ac():
-                pending = mm.text_branch(ids, attn_mask, sep_mask, torch.as_tensor(utt_idx, device=ids.device))
+            # fork: the text branch does not depend on the visual path.  WHERE its launches sit in the capture order decides when the
+            # replay lets the other branch start (TEXT_FORK_AT below)
+            fork_ev = torch.cuda.Event()
+            fork_ev.record(main)
+            box = {}
+
+            def launch_text(*_):
+                self.text_stream.wait_event(fork_ev)
+                with torch.cuda.stream(self.text_stream), ac():
+                    box["out"] = mm.text_branch(ids, attn_mask, sep_mask, torch.as_tensor(utt_idx, device=ids.device))
+
+            where = self.TEXT_FORK_AT if preds is None and not self.skip_swin_bwd else "start"
+            sw = getattr(self.swin, "swin", None)
+            mod = None
+            if where == "pe":
+                mod = getattr(sw, "patch_embed", None)
+            elif where.startswith("s") and where[1:].isdigit() and getattr(sw, "layers", None) is not None:
+                mod = sw.layers[int(where[1:])]
+            if mod is None:
+                launch_text()
+                pending = box["out"]
+            else:
+                fork_hook = mod.register_forward_hook(launch_text)
         cut, hook = {}, None
         if preds is not None:
             pass
@@ -1037,6 +1174,11 @@ class GraphedTargetStep:
             preds = self.swin(frames, is_trg_task=True)
             if hook is not None:
                 hook.remove()
+            if fork_hook is not None:
+                fork_hook.remove()
+                if "out" not in box:                        # the hooked module was not called through __call__ on this path
+                    launch_text()
+                pending = box["out"]
         vis_concat, new_mask = select_frames(preds.float(), vision_inputs, vision_mask, num_imgs, args.FacialEmoImpor_threshold)
         with ac():
             if pending is None:
@@ -1172,6 +1314,8 @@ class GraphedTargetStep:
             raise ValueError(f"GraphedTargetStep: batch of {len(batch)} entries, captured with {len(self.static)}")
         if self.pipeline:
             return self._call_pipelined(batch, next_batch)
+        if self.branches:
+            return self._call_branches(batch)
         with torch.no_grad():
             for i, (dst, src) in enumerate(zip(self.static, batch)):
                 if dst is src:

@@ -252,7 +252,9 @@ int fmmt_window_block_attn_bwd(int dtype, int n_img, int H, int W, int C, int nu
  *   dx[M,C] = LayerNorm'( dz[M,K] . w ; x, mean, rstd, ln_gamma ) + dres[M,C]         (dres: the residual stream's gradient, or NULL)
  * plus d(gamma) / d(beta) of the LayerNorm (per-workgroup partial sums in `workspace`, summed in fixed order by a second small launch).
  * wt = w^T [C, K] (the transposed bf16 copy the two-launch form also reads); mean / rstd: the statistics the forward saved.
- * bf16, C = 96, K = 288 (FMMT_EINVAL otherwise: the two launches).  d(LN out) is never written. */
+ * C = 96, K = 288 (FMMT_EINVAL otherwise: the two launches).  d(LN out) is never written.  dtype FMMT_BF16: the production kernel;
+ * FMMT_F32 (all five matrices fp32) and FMMT_BF16 | FMMT_GENERIC: the same kernel restated over an element-type trait
+ * (lin_lnbwd_ref_kernel; fp32 = 8 x mfma_f32_16x16x4 per 32-deep block, nothing rounded) -- the parity instantiations. */
 size_t fmmt_linear_ln_bwd_workspace(int C);
 int fmmt_linear_ln_bwd(int dtype, int M, int C, int K, const void* dz, const void* wt, const void* x, const float* mean, const float* rstd,
                        const float* ln_gamma, const void* dres, void* dx, float* dgamma, float* dbeta, void* workspace,
@@ -442,7 +444,8 @@ int fmmt_patch_embed_u8(int dtype, int mode, int n_img, int in_size, const void*
 /* PatchEmbed's projection + bias + LayerNorm in one launch (Swin_Transformer.py:392-422: proj, flatten, norm) on the patch matrix
  * fmmt_patch_embed_u8 / fmmt_patch_im2col produced: cols (M, K = 48) bf16, w (C = 96, 48) bf16 (Conv2d weight viewed as a matrix), bias /
  * ln_gamma / ln_beta fp32.  y (M, 96) = LayerNorm(x_pre), x_pre = bf16(cols . w^T + bias); x_pre, mean, rstd (or NULL at inference) are
- * what fmmt_layernorm_bwd needs.  bf16, C = 96, K = 48 only (FMMT_EINVAL otherwise: fmmt_linear_fwd + fmmt_layernorm_fwd). */
+ * what fmmt_layernorm_bwd needs.  C = 96, K = 48 only (FMMT_EINVAL otherwise: fmmt_linear_fwd + fmmt_layernorm_fwd).  FMMT_F32 (cols, w,
+ * x_pre, y fp32): the same kernel template with fp32 fragments, nothing rounded -- the parity instantiation. */
 int fmmt_patch_embed_ln_fwd(int dtype, int M, int C, int K, const void* cols, const void* w, const float* bias, const float* ln_gamma,
                             const float* ln_beta, float eps, void* x_pre, void* y, float* mean, float* rstd, void* stream);
 

@@ -179,6 +179,78 @@ def test_generic_backward_template_in_bf16_reproduces_the_production_kernel(dev,
     assert (t0 - t1).abs().max().item() <= 1e-4 * max(1e-6, t1.abs().max().item())
 
 
+MATERIALISED_CASES = [(192, 6, 2, 28, 0), (192, 6, 3, 28, 3), (384, 12, 2, 14, 3), (768, 24, 3, 7, 0), (96, 3, 1, 56, 3)]
+
+
+@pytest.mark.parametrize("C,nh,n_img,H,shift", MATERIALISED_CASES)
+def test_generic_twin_of_the_materialised_window_attention_backward(dev, C, nh, n_img, H, shift):
+    """fmmt_window_attn_bwd (q / k / v / d(out) READ from the qkv tensor: Swin stages 1-3, Swin_Transformer.py:113-144) has the same generic
+    twin as the recompute form -- wattn_bwd_ref_kernel<T, MM, 0> -- reachable with FMMT_BF16 | FMMT_GENERIC and run by default for FMMT_F32:
+      * its bf16 instantiation against the production kernel wattn_mfma_bwd_kernel<MM, 2, 0>: dqkv to one bf16 rounding step, almost
+        everywhere identical; d(table) to fp32 summation order;
+      * its fp32 instantiation against fp64 autograd of the oracle's attention core at 1e-4, and against the VALU fp32 kernel (a different
+        algorithm, reached by handing the same mask over as an explicit tensor)."""
+    from facialmmt_amd import _lib
+    from oracle import swin as OS
+    lib = _lib.load()
+    g = torch.Generator(device=dev).manual_seed(700 + C + shift)
+    rnd = lambda *sh: torch.randn(*sh, device=dev, generator=g)
+    M, nW = n_img * H * H, (H // 7) ** 2
+    qkv = rnd(M, 3 * C)
+    dout = rnd(M, C)
+    table = (rnd(169, nh) * 0.5).contiguous()
+    index = OS.relative_position_index(7).to(dev).int().contiguous()
+    mask = OS.shift_mask(H, H, 7, shift).to(dev).float().contiguous() if shift > 0 else None
+    scale = 32 ** -0.5
+    st = lambda: torch.cuda.current_stream().cuda_stream
+    nbytes = lib.fmmt_window_attn_bwd_workspace(nh)
+
+    def run(code, dt, explicit_mask=False):
+        q, do = qkv.to(dt).contiguous(), dout.to(dt).contiguous()
+        out = torch.empty(M, C, dtype=dt, device=dev)
+        lse = torch.empty(n_img * nW * nh * 49, device=dev)
+        mp = mask.data_ptr() if mask is not None else None
+        is_shift = 0 if explicit_mask else (1 if mask is not None else 0)
+        rc = lib.fmmt_window_attn_fwd(code & 0xff, n_img, H, H, C, nh, shift, q.data_ptr(), table.data_ptr(), index.data_ptr(), mp, nW if mask is not None else 0,
+                                      is_shift, scale, out.data_ptr(), lse.data_ptr(), st())
+        assert rc == 0
+        dqkv = torch.zeros(M, 3 * C, dtype=dt, device=dev)
+        dtab = torch.empty_like(table)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        rc = lib.fmmt_window_attn_bwd(code, n_img, H, H, C, nh, shift, q.data_ptr(), out.data_ptr(), do.data_ptr(), lse.data_ptr(), table.data_ptr(), index.data_ptr(),
+                                      mp, nW if mask is not None else 0, is_shift, scale, dqkv.data_ptr(), dtab.data_ptr(), ws.data_ptr(), nbytes, st())
+        assert rc == 0, rc
+        torch.cuda.synchronize()
+        return dqkv.float(), dtab
+
+    d0, t0 = run(_lib.BF16, torch.bfloat16)
+    d1, t1 = run(_lib.BF16 | _lib.GENERIC, torch.bfloat16)
+    sc = d1.abs().max().item()
+    assert (d0 - d1).abs().max().item() <= 2.0 ** -7 * sc and (d0 != d1).float().mean().item() <= 0.03, ((d0 - d1).abs().max().item(), sc, (d0 != d1).float().mean().item())
+    assert (t0 - t1).abs().max().item() <= 2e-4 * max(1e-6, t1.abs().max().item())
+    # fp32 instantiation: fp64 autograd through the plain attention core
+    d32, t32 = run(_lib.F32, torch.float32)
+    q64 = qkv.double().requires_grad_(True)
+    tab64 = table.double().requires_grad_(True)
+    tok = OS.window_token_index(H, H, 7, shift).to(dev)                      # (nW, 49): roll + window_partition as a gather
+    xw = q64.reshape(n_img, H * H, 3 * C)[:, tok].reshape(n_img * nW, 49, 3, nh, 32)
+    q_, k_, v_ = xw[:, :, 0].transpose(1, 2) * scale, xw[:, :, 1].transpose(1, 2), xw[:, :, 2].transpose(1, 2)
+    s_ = q_ @ k_.transpose(-1, -2) + tab64[index.long().reshape(-1)].reshape(49, 49, nh).permute(2, 0, 1)
+    if mask is not None:
+        s_ = (s_.reshape(n_img, nW, nh, 49, 49) + mask.double()[None, :, None]).reshape(n_img * nW, nh, 49, 49)
+    ow = (torch.softmax(s_, -1) @ v_).transpose(1, 2).reshape(n_img, nW * 49, C)
+    o64 = torch.zeros(n_img, H * H, C, dtype=torch.float64, device=dev).index_add(1, tok.reshape(-1), ow).reshape(M, C)
+    gq, gt = torch.autograd.grad(o64, [q64, tab64], dout.double())
+    assert _rel(d32, gq) <= 1e-4 and _rel(t32, gt) <= 1e-4
+    if mask is not None:                                     # the VALU kernel on the same problem (explicit mask tensor)
+        dv, tv = run(_lib.F32, torch.float32, explicit_mask=True)
+        assert _rel(d32, dv) <= 1e-5 and _rel(t32, tv) <= 1e-4
+        # the bf16 twin does not take an explicit mask: refused, not mis-computed
+        q = qkv.bfloat16()
+        assert lib.fmmt_window_attn_bwd(_lib.BF16 | _lib.GENERIC, n_img, H, H, C, nh, shift, q.data_ptr(), q.data_ptr(), q.data_ptr(), t0.data_ptr(), table.data_ptr(),
+                                        index.data_ptr(), mask.data_ptr(), nW, 0, scale, q.data_ptr(), t0.data_ptr(), q.data_ptr(), nbytes, st()) == -1
+
+
 @pytest.mark.parametrize("n_img,H,shift,use_rs", GENERIC_CASES)
 def test_fp32_instantiation_of_the_fused_block_against_fp64(dev, n_img, H, shift, use_rs):
     """The fp32 instantiation of the same template (fp32 fragments, 8 x v_mfma_f32_16x16x4_f32 per 32-deep block, nothing rounded to bf16):
@@ -374,6 +446,13 @@ def test_generic_mlp_templates_in_bf16_reproduce_the_production_kernels(dev, C, 
                                            dh.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), nb, st())
             assert rc == 0
             res += [("dh", dh), ("dx", dx), ("dgamma", dg), ("dbeta", db)]
+        else:                                                # C = 192 in production: the input gradient without the LayerNorm epilogue (mlp_fused_bwd_kernel<192>)
+            dy = torch.randn(M, C, device=dev, generator=torch.Generator(device=dev).manual_seed(3)).bfloat16()
+            dh, dx = torch.empty(M, 4 * C, dtype=x.dtype, device=dev), torch.empty_like(x)
+            rc = lib.fmmt_mlp_bwd_input(code, M, C, dy.data_ptr(), outs[0][2][1].data_ptr() if outs else hp.data_ptr(), w2t.data_ptr(), w1t.data_ptr(),
+                                        rs.data_ptr() if rs is not None else None, rps, dh.data_ptr(), dx.data_ptr(), st())
+            assert rc == 0
+            res += [("dh", dh), ("dx", dx)]
         torch.cuda.synchronize()
         outs.append(res)
     for (name, a), (_, b) in zip(*outs):
@@ -478,6 +557,46 @@ def test_patch_embed_projection_and_layernorm_in_one_launch(dev, monkeypatch, go
         assert _rel(a, c) <= 4e-2 and _rel(b, c) <= 4e-2
 
 
+def test_fp32_patch_embed_reaches_the_golden_through_the_fused_kernel(dev, golden, monkeypatch):
+    """`patch_embed` (output of the reference's PatchEmbed, Swin_Transformer.py:392-422) at 1e-3 through the fp32 module, which must have
+    been ONE call of fmmt_patch_embed_ln_fwd with dtype F32 (patch_embed_ln_kernel<float>: the production template, fp32 fragments); the
+    two-launch fp32 form agrees with it; gradients of the fp32 instantiation against fp64 at 1e-4 (ragged last tile: 5 images)."""
+    from facialmmt_amd import _lib, synth
+    from facialmmt_amd.modules.SwinTransformer import Swin_Transformer as S
+    pe = S.PatchEmbed(224, 4, 3, 96, torch.nn.LayerNorm)
+    synth.fill_state_dict(pe, seed=30, prefix="pe.")
+    pe.to(dev)
+    lib = _lib.load()
+    calls = []
+    real = lib.fmmt_patch_embed_ln_fwd
+    monkeypatch.setattr(lib, "fmmt_patch_embed_ln_fwd", lambda *a: (calls.append(a[0]), real(*a))[1])
+    frames = synth.tensor("frames", (2, 3, 224, 224), seed=1).to(dev)
+    with torch.no_grad():
+        y = pe(frames)
+    assert calls == [_lib.F32]
+    golden.check("swin_parts", "patch_embed", y, atol=1e-3, rtol=1e-3)
+    monkeypatch.setattr(ops, "_PATCH_LN", False)
+    with torch.no_grad():
+        y2 = pe(frames)
+    assert len(calls) == 1 and (y2 - y).abs().max().item() <= 2e-5 * max(1.0, y.abs().max().item())
+    monkeypatch.setattr(ops, "_PATCH_LN", True)
+    f5 = synth.tensor("frames5", (5, 3, 224, 224), seed=2).to(dev).requires_grad_(True)
+    params = list(pe.parameters())
+    y5 = pe(f5)
+    w = torch.randn(y5.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(4))
+    g1 = torch.autograd.grad(y5, [f5] + params, w)
+    assert calls == [_lib.F32, _lib.F32]
+    f64 = f5.detach().double().requires_grad_(True)
+    p64 = [p.detach().double().requires_grad_(True) for p in params]
+    named = dict(zip([k for k, _ in pe.named_parameters()], p64))
+    x64 = torch.nn.functional.conv2d(f64, named["proj.weight"], named["proj.bias"], stride=4).flatten(2).transpose(1, 2)
+    r64 = torch.nn.functional.layer_norm(x64, (96,), named["norm.weight"], named["norm.bias"], 1e-5)
+    g64 = torch.autograd.grad(r64, [f64] + p64, w.double())
+    assert _rel(y5, r64) <= 1e-5
+    for a, c in zip(g1, g64):
+        assert _rel(a, c) <= 1e-4
+
+
 @pytest.mark.parametrize("M,with_res", [(8192 + 77, True), (3136 * 2, False), (300, True)])
 def test_linear_and_layernorm_backward_in_one_launch(dev, M, with_res):
     """fmmt_linear_ln_bwd (d(LN out) = dz . W, LayerNorm', residual gradient, d(gamma) / d(beta): the tail of the stage-0 attention
@@ -530,5 +649,57 @@ def test_linear_and_layernorm_backward_in_one_launch(dev, M, with_res):
     # shapes the kernel does not cover are refused, not mis-computed
     assert lib.fmmt_linear_ln_bwd(1, M, 192, 576, dz.data_ptr(), wt.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
                                   None, dx.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), nb, st) == -1
-    assert lib.fmmt_linear_ln_bwd(0, M, C, K, dz.data_ptr(), wt.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+    assert lib.fmmt_linear_ln_bwd(2, M, C, K, dz.data_ptr(), wt.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
                                   None, dx.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), nb, st) == -1
+
+
+@pytest.mark.parametrize("M,with_res", [(8192 + 77, True), (3136 * 2, False), (300, True)])
+def test_linear_and_layernorm_backward_generic_instantiations(dev, M, with_res):
+    """lin_lnbwd_ref_kernel -- fmmt_linear_ln_bwd's kernel restated over an element-type trait (same tiles, fragments, accumulator layout,
+    LayerNorm' epilogue and d(gamma) / d(beta) reduction tree): the fp32 instantiation (8 x mfma_f32_16x16x4 per 32-deep block, nothing
+    rounded) against fp64 autograd at 1e-4, and its bf16 instantiation (dtype FMMT_BF16 | FMMT_GENERIC) against the production kernel --
+    which is what ties the production kernel to the fp32 parity evidence (Swin_Transformer.py:239-243)."""
+    from facialmmt_amd import _lib
+    C, K = 96, 288
+    g = torch.Generator(device=dev).manual_seed(190 + M % 7)
+    rnd = lambda *s: torch.randn(*s, device=dev, generator=g)
+    x = rnd(M, C) * 1.5 + 0.3
+    dz = rnd(M, K)
+    w = rnd(K, C) * C ** -0.5
+    gamma = 1.0 + 0.2 * rnd(C)
+    dres = rnd(M, C) if with_res else None
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    nb = lib.fmmt_linear_ln_bwd_workspace(C)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+
+    def run(code, dt):
+        xx, zz, wt = x.to(dt), dz.to(dt), w.to(dt).t().contiguous()
+        rr = dres.to(dt) if with_res else None
+        xf = xx.float()
+        mean = xf.mean(1)
+        rstd = (xf.var(1, unbiased=False) + 1e-5).rsqrt()
+        dx = torch.empty_like(xx)
+        dg = torch.empty(C, device=dev)
+        db = torch.empty(C, device=dev)
+        rc = lib.fmmt_linear_ln_bwd(code, M, C, K, zz.data_ptr(), wt.data_ptr(), xx.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                                    rr.data_ptr() if with_res else None, dx.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), nb, st)
+        assert rc == 0
+        return dx, dg, db
+
+    dx, dg, db = run(_lib.F32, torch.float32)
+    x64 = x.double().requires_grad_(True)
+    g64 = gamma.double().requires_grad_(True)
+    b64 = torch.zeros(C, dtype=torch.float64, device=dev, requires_grad=True)
+    y64 = torch.nn.functional.layer_norm(x64, (C,), g64, b64, 1e-5)
+    gx, gg, gb = torch.autograd.grad(y64, [x64, g64, b64], dz.double() @ w.double())
+    if with_res:
+        gx = gx + dres.double()
+    assert _rel(dx, gx) <= 1e-4 and _rel(dg, gg) <= 1e-4 and _rel(db, gb) <= 1e-4
+    # bf16: generic instantiation == production kernel up to the accumulation order inside a 32-deep block (none here: same MFMA, same order)
+    pa = run(_lib.BF16, torch.bfloat16)
+    ga = run(_lib.BF16 | _lib.GENERIC, torch.bfloat16)
+    same = (pa[0] == ga[0]).float().mean().item()
+    step = (pa[0].float() - ga[0].float()).abs().max().item()
+    assert same >= 0.98 and step <= 2.0 ** -6 * max(1.0, ga[0].float().abs().max().item()), (same, step)
+    assert _rel(pa[1], ga[1]) <= 1e-4 and _rel(pa[2], ga[2]) <= 1e-4
