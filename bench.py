@@ -362,6 +362,8 @@ class KernelTimer:
             "fmmt_mlp_bwd_input": lambda a: (f"<C={a[2]}>", 16.0 * a[1] * a[2] * a[2], a[1] * a[2] * 2.0 * 2 + a[1] * 4 * a[2] * 2.0 * 2),
             "fmmt_mlp_ln_bwd_input": lambda a: (f"<C={a[2]}>", 16.0 * a[1] * a[2] * a[2], a[1] * a[2] * 2.0 * 3 + a[1] * 4 * a[2] * 2.0 * 2),
             "fmmt_patch_embed_u8": lambda a: ("", 0.0, a[2] * a[3] * a[3] * 3.0 + a[2] * 3136 * 48 * es(a)),
+            # args: dtype, mode, n_img, in_size, img, tab, lut, w, bias, gamma, beta, eps, cols, x_pre, y, mean, rstd: u8 in, y out, cols + x_pre out in training
+            "fmmt_patch_embed_u8_ln_fwd": lambda a: ("", 2.0 * a[2] * 3136 * 96 * 48, a[2] * a[3] * a[3] * 3.0 + a[2] * 3136 * es(a) * (96.0 + 48.0 * nz(a[12]) + 96.0 * nz(a[13]))),
             "fmmt_patch_embed_ln_fwd": lambda a: ("", 2.0 * a[1] * a[2] * a[3], a[1] * a[3] * 2.0 + a[1] * a[2] * 2.0 * (1 + nz(a[10]))),
             "fmmt_patch_im2col": lambda a: ("", 0.0, a[1] * 3 * 224 * 224 * es(a) * 2.0),
             "fmmt_patch_col2im": lambda a: ("", 0.0, a[1] * 3 * 224 * 224 * es(a) * 2.0),
@@ -1082,7 +1084,7 @@ def kernel_symbol(bn):
                  "fmmt_window_attn_bwd": "wattn_mfma_bwd_kernel", "fmmt_mlp_fwd": "mlp_fused_fwd_kernel", "fmmt_window_block_fwd": "wblock_fwd_kernel",
                  "fmmt_mlp_ln_fwd": "mlp_fused_fwd_kernel<LN>", "fmmt_mlp_bwd_input": "mlp_fused_bwd_kernel", "fmmt_mlp_ln_bwd_input": "mlp_fused_bwd_kernel<LN'>",
                  "fmmt_window_block_attn_bwd": "wattn_mfma_bwd_kernel<recompute>", "fmmt_patch_embed_ln_fwd": "patch_embed_ln_kernel",
-                 "fmmt_patch_embed_u8": "patch_embed_u8_kernel", "fmmt_mha_fwd": "mha_mfma_fwd_kernel", "fmmt_mha_bwd": "mha_mfma_bwd_kernel",
+                 "fmmt_patch_embed_u8": "patch_embed_u8_kernel", "fmmt_patch_embed_u8_ln_fwd": "patch_embed_u8_kernel<fused projection + LayerNorm>", "fmmt_mha_fwd": "mha_mfma_fwd_kernel", "fmmt_mha_bwd": "mha_mfma_bwd_kernel",
                  "fmmt_adamw_batch": "adamw_batch_kernel", "fmmt_cast_batch": "cast_batch_kernel", "fmmt_grad_handover": "grad_handover_kernel", "fmmt_linear_ln_bwd": "lin_lnbwd_kernel", "fmmt_batchnorm1d_fwd": "bn1d_fwd_kernel",
                  "fmmt_batchnorm1d_bwd": "bn1d_bwd_kernel", "fmmt_linear_wgrad_finish": "reduce_partials_kernel", "fmmt_colsum": "colsum_kernel",
                  "fmmt_layernorm_bwd_bf16": "lnp_bwd_kernel", "fmmt_linear_fwd_splitk": "linear_splitk_kernel", "fmmt_linear_wgrad": "linear_tn_few_kernel"}

@@ -73,6 +73,7 @@ SIGNATURES = {
     "fmmt_resize_band_rows": (_i, [_p, _i]),
     "fmmt_patch_embed_u8": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p]),
     "fmmt_patch_embed_ln_fwd": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p]),
+    "fmmt_patch_embed_u8_ln_fwd": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p]),
 }
 
 FMMT_EINVAL, FMMT_EALIGN, FMMT_EWORKSPACE = -1, -2, -3

@@ -13,8 +13,7 @@
 // The kernel is written over the element-type trait of elem_trait.h: T = bf16 is the production instantiation (the trait's members are the
 // instructions the round-4 kernel spelled out), T = float the parity instantiation -- 8 x mfma_f32_16x16x4 per 32-deep block, nothing
 // rounded -- that the fp32 module runs and the reference's `patch_embed` golden is held to at 1e-3.
-#include "gemm_common.h"
-#include "elem_trait.h"
+#include "patch_ln_core.h"
 
 namespace {
 
@@ -38,26 +37,11 @@ template <typename T>
 __global__ __launch_bounds__(512) void patch_embed_ln_kernel(PlArgs<T> p) {
     using E = ElemTrait<T>;
     using F = typename E::frag;
-    constexpr int C = 96, K = 48, NT = C / 16, KS = C / 32;
+    constexpr int K = 48;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lg = lane >> 4;
-    F wf[NT][2];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int ch = chan_of<4 * NT>(nt, li >> 2, li & 3);          // the channel that row li of accumulator tile nt holds
-        wf[nt][0] = E::ld(p.w + (size_t)ch * K + lg * 8);
-        wf[nt][1] = lg < 2 ? E::ld(p.w + (size_t)ch * K + 32 + lg * 8) : E::zero();
-    }
-    float bia[KS * 8], gam[KS * 8], bet[KS * 8];
-#pragma unroll
-    for (int c = 0; c < KS; ++c)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int ch = c * 32 + lg * 8 + e;
-            bia[c * 8 + e] = p.bias ? p.bias[ch] : 0.f;
-            gam[c * 8 + e] = p.gamma[ch];
-            bet[c * 8 + e] = p.beta[ch];
-        }
+    PatchLnParams<T> P;
+    patch_ln_load<T>(P, p.w, p.bias, p.gamma, p.beta, li, lg);
     for (int tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
         const int t0 = tile * 256 + wave * 32;
 #pragma unroll
@@ -66,45 +50,7 @@ __global__ __launch_bounds__(512) void patch_embed_ln_kernel(PlArgs<T> p) {
             const int tk = min(tok, p.M - 1);
             const F c0 = E::ld(p.cols + (size_t)tk * K + lg * 8);
             const F c1 = lg < 2 ? E::ld(p.cols + (size_t)tk * K + 32 + lg * 8) : E::zero();
-            f32x4 acc[NT];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                acc[nt] = E::mma(wf[nt][0], c0, f32x4{0.f, 0.f, 0.f, 0.f});
-                acc[nt] = E::mma(wf[nt][1], c1, acc[nt]);
-            }
-            float v[KS * 8], sum = 0.f;
-#pragma unroll
-            for (int c = 0; c < KS; ++c) {
-                F o;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    o[e] = E::cv(acc[2 * c + (e >> 2)][e & 3] + bia[c * 8 + e]);
-                    v[c * 8 + e] = (float)o[e];
-                    sum += v[c * 8 + e];
-                }
-                if (p.x_pre && tok < p.M) E::st(p.x_pre + (size_t)tok * C + c * 32 + lg * 8, o);
-            }
-            const float mean = swap_sum(sum) * (1.0f / (float)C);
-            float q = 0.f;
-#pragma unroll
-            for (int i = 0; i < KS * 8; ++i) {
-                v[i] -= mean;
-                q += v[i] * v[i];
-            }
-            const float rstd = rsqrtf(swap_sum(q) * (1.0f / (float)C) + p.eps);
-            if (tok < p.M) {
-#pragma unroll
-                for (int c = 0; c < KS; ++c) {
-                    F o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = E::cv(v[c * 8 + e] * rstd * gam[c * 8 + e] + bet[c * 8 + e]);
-                    E::st(p.y + (size_t)tok * C + c * 32 + lg * 8, o);
-                }
-                if (p.mean && lg == 0) {
-                    p.mean[tok] = mean;
-                    p.rstd[tok] = rstd;
-                }
-            }
+            patch_ln_tile<T>(P, c0, c1, p.eps, (size_t)tok, tok < p.M, lg, p.x_pre, p.y, p.mean, p.rstd);
         }
     }
 }

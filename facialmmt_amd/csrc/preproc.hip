@@ -13,6 +13,7 @@
 // the library's own, and uploaded once per (flavour, size) by the caller.
 #include "fmmt_common.h"
 #include "../../include/fmmt.h"
+#include "patch_ln_core.h"
 #include <math.h>
 
 namespace {
@@ -33,15 +34,35 @@ double pil_cubic(double x) {
 //   1. stage the source rows [ymin, ymax] of the band as bytes            (coalesced 4-byte loads)
 //   2. horizontal pass into LDS: H[r][x*3+c]  (PIL: uint8-rounded; cv2: raw int32 sums)
 //   3. vertical pass, rounding, byte -> float through the ToTensor/Normalize table, store in patch-column order
-template <typename T, bool PIL>
+//   FUSE (fmmt_patch_embed_u8_ln_fwd): 4. the band's 56 patch rows stay in LDS as well, and the four waves run PatchEmbed's projection + bias +
+//      LayerNorm on them (patch_ln_core.h: 16 patches per wave, the tile arithmetic of patch_embed_ln_kernel) -- the patch matrix is written
+//      for the backward (weight gradient of the projection) or not at all (inference), never read back.
+template <typename T>
+struct PeTail {                                             // the projection + LayerNorm behind the gather (FUSE)
+    const T* w;
+    const float* bias;
+    const float* gamma;
+    const float* beta;
+    float eps;
+    T* x_pre;
+    T* y;
+    float* mean;
+    float* rstd;
+};
+constexpr int CPITCH = 56;                                  // LDS pitch of a patch row (48 values): 112 / 224 bytes, 16-byte aligned fragments
+
+template <typename T, bool PIL, bool FUSE>
 __global__ __launch_bounds__(256) void patch_embed_u8_kernel(const uint8_t* __restrict__ img, int S, const int32_t* __restrict__ tab,
-                                                            const float* __restrict__ lut, T* __restrict__ cols) {
+                                                            const float* __restrict__ lut, T* __restrict__ cols, PeTail<T> tail) {
     __shared__ __attribute__((aligned(16))) uint8_t src[RMAX * SMAX * 3];
+    __shared__ __attribute__((aligned(16))) T colsl[FUSE ? 64 * CPITCH : 8];
     __shared__ int32_t H[RMAX][OUT * 3];
     __shared__ int32_t tx[OUT * 8];
     __shared__ int32_t ty[4][8];
     __shared__ float slut[256];
     const int p = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+    PatchLnParams<T> P;
+    if constexpr (FUSE) patch_ln_load<T>(P, tail.w, tail.bias, tail.gamma, tail.beta, tid & 15, (tid & 63) >> 4);   // requested now, used in step 4
     if (tid < 32) ty[tid >> 3][tid & 7] = tab[(4 * p + (tid >> 3)) * 8 + (tid & 7)];
     slut[tid] = lut[tid];
     for (int i = tid; i < OUT * 8; i += 256) tx[i] = tab[i];
@@ -94,7 +115,19 @@ __global__ __launch_bounds__(256) void patch_embed_u8_kernel(const uint8_t* __re
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc += H[ty[dy][k] - ymin][col] * ty[dy][4 + k];
         const int v = min(max(acc >> 22, 0), 255);
-        out[e] = from_f32<T>(slut[v]);
+        const T val = from_f32<T>(slut[v]);
+        if (!FUSE || cols) out[e] = val;
+        if constexpr (FUSE) colsl[patch * CPITCH + kk] = val;
+    }
+    if constexpr (FUSE) {
+        for (int e = tid; e < 8 * KPATCH; e += 256) colsl[(GRID + e / KPATCH) * CPITCH + e % KPATCH] = from_f32<T>(0.f);   // rows 56-63 of the last wave's tile
+        __syncthreads();
+        using E = ElemTrait<T>;
+        const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+        const int patch = wave * 16 + li;
+        const typename E::frag c0 = E::ld(colsl + patch * CPITCH + lg * 8);
+        const typename E::frag c1 = lg < 2 ? E::ld(colsl + patch * CPITCH + 32 + lg * 8) : E::zero();
+        patch_ln_tile<T>(P, c0, c1, tail.eps, ((size_t)n * GRID + p) * GRID + patch, patch < GRID, lg, tail.x_pre, tail.y, tail.mean, tail.rstd);
     }
 }
 
@@ -183,11 +216,35 @@ extern "C" int fmmt_patch_embed_u8(int dtype, int mode, int n_img, int in_size, 
     dim3 grid(GRID, n_img);
     const uint8_t* img = reinterpret_cast<const uint8_t*>(img_u8);
     if (dtype == FMMT_BF16) {
-        if (mode == FMMT_RESIZE_PIL) hipLaunchKernelGGL((patch_embed_u8_kernel<bf16, true>), grid, dim3(256), 0, st, img, in_size, table_dev, lut_dev, (bf16*)cols);
-        else hipLaunchKernelGGL((patch_embed_u8_kernel<bf16, false>), grid, dim3(256), 0, st, img, in_size, table_dev, lut_dev, (bf16*)cols);
+        if (mode == FMMT_RESIZE_PIL) hipLaunchKernelGGL((patch_embed_u8_kernel<bf16, true, false>), grid, dim3(256), 0, st, img, in_size, table_dev, lut_dev, (bf16*)cols, PeTail<bf16>{});
+        else hipLaunchKernelGGL((patch_embed_u8_kernel<bf16, false, false>), grid, dim3(256), 0, st, img, in_size, table_dev, lut_dev, (bf16*)cols, PeTail<bf16>{});
     } else {
-        if (mode == FMMT_RESIZE_PIL) hipLaunchKernelGGL((patch_embed_u8_kernel<float, true>), grid, dim3(256), 0, st, img, in_size, table_dev, lut_dev, (float*)cols);
-        else hipLaunchKernelGGL((patch_embed_u8_kernel<float, false>), grid, dim3(256), 0, st, img, in_size, table_dev, lut_dev, (float*)cols);
+        if (mode == FMMT_RESIZE_PIL) hipLaunchKernelGGL((patch_embed_u8_kernel<float, true, false>), grid, dim3(256), 0, st, img, in_size, table_dev, lut_dev, (float*)cols, PeTail<float>{});
+        else hipLaunchKernelGGL((patch_embed_u8_kernel<float, false, false>), grid, dim3(256), 0, st, img, in_size, table_dev, lut_dev, (float*)cols, PeTail<float>{});
+    }
+    FMMT_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int fmmt_patch_embed_u8_ln_fwd(int dtype, int mode, int n_img, int in_size, const void* img_u8, const int32_t* table_dev, const float* lut_dev,
+                                          const void* w, const float* bias, const float* ln_gamma, const float* ln_beta, float eps,
+                                          void* cols, void* x_pre, void* y, float* mean, float* rstd, void* stream) {
+    if ((dtype != FMMT_BF16 && dtype != FMMT_F32) || (mode != FMMT_RESIZE_PIL && mode != FMMT_RESIZE_CV2)) return FMMT_EINVAL;
+    if (n_img <= 0 || n_img > 65535 || in_size < 4 || in_size > SMAX || !img_u8 || !table_dev || !lut_dev) return FMMT_EINVAL;
+    if (!w || !ln_gamma || !ln_beta || !y || (mean == nullptr) != (rstd == nullptr)) return FMMT_EINVAL;
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (!al16(w) || !al16(y) || (x_pre && !al16(x_pre)) || (cols && !al16(cols))) return FMMT_EALIGN;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid(GRID, n_img);
+    const uint8_t* img = reinterpret_cast<const uint8_t*>(img_u8);
+    if (dtype == FMMT_BF16) {
+        const PeTail<bf16> t{(const bf16*)w, bias, ln_gamma, ln_beta, eps, (bf16*)x_pre, (bf16*)y, mean, rstd};
+        if (mode == FMMT_RESIZE_PIL) hipLaunchKernelGGL((patch_embed_u8_kernel<bf16, true, true>), grid, dim3(256), 0, st, img, in_size, table_dev, lut_dev, (bf16*)cols, t);
+        else hipLaunchKernelGGL((patch_embed_u8_kernel<bf16, false, true>), grid, dim3(256), 0, st, img, in_size, table_dev, lut_dev, (bf16*)cols, t);
+    } else {
+        const PeTail<float> t{(const float*)w, bias, ln_gamma, ln_beta, eps, (float*)x_pre, (float*)y, mean, rstd};
+        if (mode == FMMT_RESIZE_PIL) hipLaunchKernelGGL((patch_embed_u8_kernel<float, true, true>), grid, dim3(256), 0, st, img, in_size, table_dev, lut_dev, (float*)cols, t);
+        else hipLaunchKernelGGL((patch_embed_u8_kernel<float, false, true>), grid, dim3(256), 0, st, img, in_size, table_dev, lut_dev, (float*)cols, t);
     }
     FMMT_CHECK_LAUNCH();
     return 0;

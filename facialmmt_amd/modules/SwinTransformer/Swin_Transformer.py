@@ -316,8 +316,11 @@ class PatchEmbed(nn.Module):
         _require(tuple(self.img_size) == (224, 224) and tuple(self.patch_size) == (4, 4) and self.in_chans == 3,
                  "PatchEmbed kernel is built for 3x224x224 images and 4x4 patches")
         B = x.shape[0]
-        cols = ops.patch_embed_u8(x, resize, dtype or self.proj.weight.dtype)
         w2d = self.proj.weight.view(self.embed_dim, -1)
+        dt = dtype or self.proj.weight.dtype
+        if ops.patch_embed_u8_ln_fusable(x, w2d, self.norm, dt):   # pre-step, projection, bias and LayerNorm: one launch
+            return ops.patch_embed_u8_ln(x, resize, w2d, self.proj.bias, self.norm.weight, self.norm.bias, self.norm.eps, dt).view(B, self.num_patches, self.embed_dim)
+        cols = ops.patch_embed_u8(x, resize, dt)
         if ops.patch_proj_ln_fusable(cols, w2d, self.norm):    # projection + bias + LayerNorm: one launch
             return ops.patch_proj_ln(cols, w2d, self.proj.bias, self.norm.weight, self.norm.bias, self.norm.eps).view(B, self.num_patches, self.embed_dim)
         y = ops.linear(cols, w2d, self.proj.bias).view(B, self.num_patches, self.embed_dim)

@@ -1370,6 +1370,66 @@ def patch_embed_u8(img_u8: torch.Tensor, mode: str, dtype) -> torch.Tensor:
     return cols
 
 
+_PATCH_U8_LN = True          # False: the uint8 pre-step and the projection + LayerNorm as two launches (patch matrix written, then read back)
+
+
+class PatchEmbedU8LnFn(Function):
+    """uint8 crops -> LayerNorm(PatchEmbed projection) in ONE launch (fmmt_patch_embed_u8_ln_fwd): the bicubic resize / ToTensor / Normalize / 4x4
+    gather of the reference's host pre-step (utils/util.py:43-52, utils/dataset.py:47-69) feeds the projection's MFMA operand out of LDS
+    (Swin_Transformer.py:392-422).  The patch matrix is written only when a backward will need it (the projection's weight gradient);
+    backward = PatchProjLnFn's (the input is integer data: no input gradient)."""
+
+    @staticmethod
+    def forward(ctx, img_u8, mode, weight, bias, gamma, beta, eps, dtype, grad_on=True):
+        _need_cuda(img_u8, "patch_embed_u8_ln")
+        if img_u8.dtype != torch.uint8 or img_u8.dim() != 4 or img_u8.shape[1] != img_u8.shape[2] or img_u8.shape[3] != 3:
+            raise ValueError(f"patch_embed_u8 expects (n, S, S, 3) uint8 crops, got {tuple(img_u8.shape)} {img_u8.dtype}")
+        img_u8 = img_u8.contiguous()
+        n, S = img_u8.shape[0], img_u8.shape[1]
+        code, tab, lut = resize_tables(mode, S, img_u8.device)
+        M, C = n * 3136, weight.shape[0]
+        train = grad_on and any(ctx.needs_input_grad)
+        dev = img_u8.device
+        g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        y = torch.empty((M, C), dtype=dtype, device=dev)
+        cols = torch.empty((M, 48), dtype=dtype, device=dev) if train else None
+        x_pre = torch.empty_like(y) if train else None
+        mean = torch.empty(M, dtype=torch.float32, device=dev) if train else None
+        rstd = torch.empty(M, dtype=torch.float32, device=dev) if train else None
+        rc = _lib.load().fmmt_patch_embed_u8_ln_fwd(dtype_code(dtype), code, n, S, _p(img_u8), _p(tab), _p(lut), _p(_lp(weight, dtype)),
+                                                    _p(bias.detach().float().contiguous() if bias is not None else None), _p(g), _p(b), float(eps),
+                                                    _p(cols), _p(x_pre), _p(y), _p(mean), _p(rstd), _st())
+        check(rc, f"fmmt_patch_embed_u8_ln_fwd(n={n},S={S},{mode})")
+        ctx.save_for_backward(cols, weight, x_pre, mean, rstd, g)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        cols, weight, x_pre, mean, rstd, g = ctx.saved_tensors
+        M, C = x_pre.shape
+        lib = _lib.load()
+        dy = dy.contiguous()
+        dxp = torch.empty_like(x_pre)
+        dg = torch.empty(C, dtype=torch.float32, device=dy.device)
+        db = torch.empty(C, dtype=torch.float32, device=dy.device)
+        nbytes = lib.fmmt_layernorm_bwd_workspace(C)
+        ws = _ws(nbytes, dy.device)
+        check(lib.fmmt_layernorm_bwd(dtype_code(dy.dtype), M, C, _p(dy), _p(x_pre), _p(mean), _p(rstd), _p(g), None, _p(dxp), _p(dg), _p(db), 0,
+                                     _p(ws), nbytes, _st()), f"fmmt_layernorm_bwd(patch embed, M={M})")
+        dw, dbias = wgrad_raw(dxp, cols, ctx.has_bias)
+        return None, None, dw.view_as(weight), dbias, dg, db, None, None, None
+
+
+def patch_embed_u8_ln_fusable(img_u8, weight, norm, dtype):
+    return (_PATCH_U8_LN and _PATCH_LN and norm is not None and img_u8.is_cuda and dtype in (torch.bfloat16, torch.float32)
+            and tuple(weight.shape) == (96, 48) and tuple(norm.weight.shape) == (96,))
+
+
+def patch_embed_u8_ln(img_u8, mode, weight, bias, gamma, beta, eps, dtype):
+    return PatchEmbedU8LnFn.apply(img_u8, mode, weight, bias, gamma, beta, eps, dtype, torch.is_grad_enabled())
+
+
 def batch_norm_1d_fwd_raw(x, g, b, running_mean, running_var, momentum, eps, training):
     n, C = x.shape
     y = torch.empty_like(x)

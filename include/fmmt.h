@@ -449,6 +449,16 @@ int fmmt_patch_embed_u8(int dtype, int mode, int n_img, int in_size, const void*
 int fmmt_patch_embed_ln_fwd(int dtype, int M, int C, int K, const void* cols, const void* w, const float* bias, const float* ln_gamma,
                             const float* ln_beta, float eps, void* x_pre, void* y, float* mean, float* rstd, void* stream);
 
+/* The two launches above as one (SURVEY 8f rank 3 "fused into PatchEmbed's load"; utils/dataset.py:47-69, utils/util.py:43-52 ->
+ * Swin_Transformer.py:392-422): uint8 crops (n_img, in_size, in_size, 3) -> bicubic resize / ToTensor / Normalize / 4x4 gather of one patch
+ * row per workgroup in LDS -> projection + bias + LayerNorm from there.  y (n_img * 3136, 96); x_pre / mean / rstd as in
+ * fmmt_patch_embed_ln_fwd (NULL at inference); cols (n_img * 3136, 48): the patch matrix, written for the projection's weight gradient, or
+ * NULL (inference: it is never materialised).  table_dev / lut_dev: fmmt_resize_table's tables on the device.  FMMT_BF16 / FMMT_F32 (the
+ * parity instantiation: same template, fp32 fragments). */
+int fmmt_patch_embed_u8_ln_fwd(int dtype, int mode, int n_img, int in_size, const void* img_u8, const int32_t* table_dev, const float* lut_dev,
+                               const void* w, const float* bias, const float* ln_gamma, const float* ln_beta, float eps,
+                               void* cols, void* x_pre, void* y, float* mean, float* rstd, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

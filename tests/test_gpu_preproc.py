@@ -97,3 +97,57 @@ def test_full_size_batch_is_chunk_independent(dev):
     want = torch.from_numpy(P.patch_cols_from_u8(img[pick].numpy(), "pil")).bfloat16()
     got = torch.cat([full[i * 3136:(i + 1) * 3136] for i in pick]).cpu()
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("mode,S,dtype", [("pil", 112, torch.bfloat16), ("cv2", 160, torch.bfloat16), ("pil", 57, torch.float32), ("cv2", 224, torch.float32)])
+def test_pre_step_projection_and_layernorm_in_one_launch(dev, monkeypatch, mode, S, dtype):
+    """fmmt_patch_embed_u8_ln_fwd (uint8 crops -> LayerNorm(PatchEmbed projection), the patch matrix fed to the MFMA out of LDS): the patch matrix it
+    writes is the oracle's, bit for bit; y / x_pre / statistics equal the two launches it replaces bit for bit (same tile arithmetic on the same
+    values: patch_ln_core.h); at inference the patch matrix is not written and y is unchanged; parameter gradients equal the two-launch
+    form's (same backward on the same saved tensors)."""
+    from facialmmt_amd import _lib
+    from facialmmt_amd.modules.SwinTransformer import Swin_Transformer as SW
+    img = _crops("crop_fused", 3, S, seed=S + 3)
+    img[0, :3] = 255
+    img[0, -3:] = 0
+    x = torch.from_numpy(img).to(dev)
+    pe = SW.PatchEmbed(224, 4, 3, 96, torch.nn.LayerNorm)
+    synth.fill_state_dict(pe, seed=31, prefix="pe.")
+    pe.to(dev)
+    lib = _lib.load()
+    calls = []
+    real = lib.fmmt_patch_embed_u8_ln_fwd
+    monkeypatch.setattr(lib, "fmmt_patch_embed_u8_ln_fwd", lambda *a: (calls.append(a[12]), real(*a))[1])
+    outs = []
+    for fused in (True, False):
+        monkeypatch.setattr(ops, "_PATCH_U8_LN", fused)
+        pe.zero_grad(set_to_none=True)
+        y = pe.forward_u8(x, mode, dtype)
+        w = torch.randn(y.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(9)).to(dtype)
+        grads = torch.autograd.grad(y, list(pe.parameters()), w)
+        outs.append((y.detach(), grads))
+    assert len(calls) == 1 and calls[0] is not None          # one fused call, training: the patch matrix pointer was handed over
+    assert torch.equal(outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(a, b)
+    monkeypatch.setattr(ops, "_PATCH_U8_LN", True)
+    with torch.no_grad():
+        y_inf = pe.forward_u8(x, mode, dtype)
+    assert len(calls) == 2 and calls[1] is None and torch.equal(y_inf, outs[0][0])
+    # the raw entry point: patch matrix against the oracle, bit-exact
+    code, tab, lut = ops.resize_tables(mode, S, dev)
+    cols = torch.empty(3 * 3136, 48, dtype=dtype, device=dev)
+    y2 = torch.empty(3 * 3136, 96, dtype=dtype, device=dev)
+    w2d = pe.proj.weight.detach().view(96, 48).to(dtype).contiguous()
+    rc = real(_lib.BF16 if dtype == torch.bfloat16 else _lib.F32, code, 3, S, x.data_ptr(), tab.data_ptr(), lut.data_ptr(), w2d.data_ptr(),
+              pe.proj.bias.detach().float().data_ptr(), pe.norm.weight.detach().float().data_ptr(), pe.norm.bias.detach().float().data_ptr(), 1e-5,
+              cols.data_ptr(), None, y2.data_ptr(), None, None, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    want = torch.from_numpy(P.patch_cols_from_u8(img, mode))
+    assert torch.equal(cols.cpu(), want.to(dtype))
+    assert torch.equal(y2.view_as(y_inf), y_inf)
+    # refused, not mis-computed
+    assert real(2, code, 3, S, x.data_ptr(), tab.data_ptr(), lut.data_ptr(), w2d.data_ptr(), None, pe.norm.weight.data_ptr(), pe.norm.bias.data_ptr(), 1e-5,
+                None, None, y2.data_ptr(), None, None, 0) == -1
+    assert real(1, code, 3, 300, x.data_ptr(), tab.data_ptr(), lut.data_ptr(), w2d.data_ptr(), None, pe.norm.weight.data_ptr(), pe.norm.bias.data_ptr(), 1e-5,
+                None, None, y2.data_ptr(), None, None, 0) == -1

@@ -12,6 +12,8 @@ dev = torch.device("cuda:0")
 vendor = "--vendor" in sys.argv
 SHAPES = [(501760, 576, 192), (501760, 768, 192), (501760, 192, 768), (125440, 1152, 384), (125440, 1536, 384), (125440, 384, 384),
           (125440, 384, 1536), (125440, 384, 1152), (31360, 2304, 768), (31360, 3072, 768), (31360, 768, 3072), (31360, 768, 768)]
+if os.environ.get("NT_PROBE_SHAPES"):                         # "M,N,K;M,N,K;..." instead of the Swin list
+    SHAPES = [tuple(int(v) for v in t.split(",")) for t in os.environ["NT_PROBE_SHAPES"].split(";") if t]
 
 
 def ev(fn, n=10, reps=3):
@@ -37,7 +39,7 @@ for (M, N, K) in SHAPES:
         pre = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
         t4 = ev(lambda: ops.linear_raw(x, w, b, epi=EPI_GELU, y_pre=pre)); tot += t4
         line += f" | gelu+pre {t4*1e3:7.1f} us"
-    rps = 196 if M == 125440 else 49
+    rps = 196 if M == 125440 else (49 if M % 49 == 0 else 64)
     rs = torch.full((M // rps,), 1.0 / 0.9, device=dev)
     if N == 4 * K:                                             # fc2 input gradient: GELU' operand
         aux = torch.randn(M, N, device=dev, dtype=torch.bfloat16)
