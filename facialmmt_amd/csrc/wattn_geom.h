@@ -8,7 +8,7 @@ namespace {
 
 constexpr int TOK = 49, WS = 7, HD = 32;
 constexpr int TP = 40;       // LDS tile pitch in bf16 (80 B rows: 16-byte aligned, spreads banks)
-constexpr int BPM = 64;      // LDS bias pitch (floats)
+constexpr int BPM = 68;      // LDS bias pitch (floats): 272-byte rows -- at 64 the 16 query rows of an f32x4 bias read sat on the same 4 banks (round 5: SQ_LDS_BANK_CONFLICT 55 % of SQ_LDS_IDX_ACTIVE)
 constexpr float NEG_BIG = -1.0e30f;
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;

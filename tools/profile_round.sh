@@ -2,6 +2,7 @@
 # Collect the evidence committed under profiles/ (run on the GPU box through gpurun):
 #   tools/profile_round.sh TAG        -> gpurun_out/summ_TAG/{bench.json, bench_config3.json, bench_config4.json, kernel_stats*.md,
 #                                        launch_census.md, pmc_*.md, timeline.txt, gemm_shapes.txt, nt_shapes.txt, tn_shapes.txt, few_shapes.txt}
+# then, here: bash tools/copy_profiles.sh TAG   (-> profiles/TAG_*, profiles/traffic.json)
 # PMC passes run WITHOUT HIP graphs (counter collection under graph replay crashes rocprofv3 on this image) and
 # each under its own timeout.
 TAG=${1:-x}
@@ -44,4 +45,5 @@ timeout 200 python tools/probes/few_probe.py > $S/few_shapes.txt 2>&1
 timeout 300 python tools/probes/time_swin.py 640 > $S/swin_time.txt 2>&1
 bash tools/prof_swin.sh > /dev/null 2>&1; cp $O/swin_kernel_stats.md $S/swin_kernel_stats.md
 timeout 300 python tests/support_wblock_cases.py --speed > $S/wblock_speed.txt 2>&1
+python tools/make_traffic_json.py $S $TAG > $O/traffic_$TAG.json 2>/dev/null
 cut -c1-300 $S/bench.json
