@@ -1741,7 +1741,8 @@ bool tn_few_ok(int M, int N, int K, int dtype) {
 //    row starts on bank 0; with 384-byte rows on bank 0 / 32 alternately, which the same g() absorbs;
 //  * bias gradient without a register pass: one extra MFMA against a B fragment of ones at fixed fragment positions;
 //  * partial sums leave in fragment order (1 KB per store); reduce_partials_kernel undoes the permutation;
-//  * DropPath scale: the SCALED instantiation rescales the dy stage in LDS one stage ahead;
+//  * DropPath scale: the SCALED instantiation zeroes a dropped image's rows of the dy stage in LDS where the stage is consumed and applies the
+//    common factor of a two-valued scale vector to the accumulators (any other vector: every stage rescaled in LDS);
 //  * token counts are multiples of 64 (every Swin launch is); anything else, a recomputed activation, fewer than four tiles:
 //    the register-staged kernel.
 // ---------------------------------------------------------------------------------------------
@@ -1789,11 +1790,11 @@ __device__ __forceinline__ void tn_read12(s16x4 (&o)[24], const unsigned (&ad)[1
 }
 
 // TNn x TKk output tile, 32 tokens per stage, NBUF stages, waves WN x (8 / WN), 12 fragments per wave.
-// SCALED: DropPath row scale s[token / rows_per_scale] on dy.  The DMA image of a dy stage is scaled IN LDS, one stage ahead of
-// the fragment reads (each element once per workgroup; on the fragments it would be once per wave that reads it): at step s
-// the waves scale stage s + 1 -- 512 threads x 16 (12) elements, fp32 multiply, RNE back to bf16 -- and then contract stage s;
-// the barrier of step s + 1 publishes it.  Two stages stay in flight instead of three.  The slice of the scale vector a
-// token split needs sits in LDS behind the ring (host side: at most 1024 samples per split, else the register-staged kernel).
+// SCALED: DropPath row scale s[token / rows_per_scale] on dy (rows_per_scale >= 32: a 32-token stage touches at most two images).  The DMA image of a
+// dy stage is rescaled IN LDS (each element once per workgroup; on the fragments it would be once per wave that reads it) where the stage is consumed,
+// between two barriers of its own -- 512 threads x 16 (12) elements, fp32 multiply, RNE back to bf16.  DropPath's vectors are two-valued (0 / 1 / keep):
+// then only the stages holding a dropped image's tokens are touched (rows zeroed) and the common factor multiplies the accumulators once, exactly.
+// The slice of the scale vector a token split needs sits in LDS behind the ring (host side: at most 1024 samples per split, else the register-staged kernel).
 template <int TNn, int TKk, int NBUF, int WN, bool SCALED = false>
 __global__ __launch_bounds__(512) void linear_tn_dma_kernel(TnArgs p) {
     using T = bf16;
@@ -1825,28 +1826,35 @@ __global__ __launch_bounds__(512) void linear_tn_dma_kernel(TnArgs p) {
 
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
-    auto issue_one = [&](T* base, int j, int mb) {
-        const T* src;
-        T* dst;
+    // source address of a DMA instruction = a workgroup-uniform 64-bit base that moves with the stage (scalar registers) + this lane's loop-invariant
+    // 32-bit byte offset (one VGPR per instruction; as 64-bit per-lane pointers the five of them were the registers the scaled kernel ran out of)
+    constexpr int NISS = CNT + (REM != 0 ? 1 : 0);
+    unsigned goff[NISS];
+#pragma unroll
+    for (int i = 0; i < NISS; ++i) {
+        const int j = i * 8 + wave;
         if (j < NIA) {
             const int q = j * 64 + lane, row = q / CPRA, pos = q - row * CPRA;          // LDS slot (row, pos) of this lane
             const int gpos = (tn_sigma<TNn>(row, pos >> 1) << 1) | (pos & 1);           // the global chunk that belongs there
-            src = dyg + (size_t)(mb + row) * p.lddy + n0 + gpos * 8;
-            dst = base + j * 512;
+            goff[i] = (unsigned)(row * p.lddy + n0 + gpos * 8) * 2u;
         } else {
             const int q = (j - NIA) * 64 + lane, row = q / CPRB, pos = q - row * CPRB;
             const int gpos = (tn_sigma<TKk>(row, pos >> 1) << 1) | (pos & 1);
-            src = xg + (size_t)(mb + row) * p.ldx + k0 + gpos * 8;
-            dst = base + A_EL + (j - NIA) * 512;
+            goff[i] = (unsigned)(row * p.ldx + k0 + gpos * 8) * 2u;
         }
-        __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)dst, 16, 0, 0);
+    }
+    auto issue_one = [&](T* base, int i, int mb) {
+        const int j = i * 8 + wave;                                                     // wave-uniform instruction index
+        const char* sb = j < NIA ? reinterpret_cast<const char*>(dyg) + (size_t)mb * p.lddy * 2 : reinterpret_cast<const char*>(xg) + (size_t)mb * p.ldx * 2;
+        T* dst = j < NIA ? base + j * 512 : base + A_EL + (j - NIA) * 512;
+        __builtin_amdgcn_global_load_lds((gptr_t*)(sb + goff[i]), (lptr_t*)dst, 16, 0, 0);
     };
     auto issue = [&](int slot, int mb) {
         T* base = S + slot * STAGE;
 #pragma unroll
-        for (int i = 0; i < CNT; ++i) issue_one(base, i * 8 + wave, mb);                // wave-uniform instruction index
+        for (int i = 0; i < CNT; ++i) issue_one(base, i, mb);
         if constexpr (REM != 0)
-            if (extra) issue_one(base, CNT * 8 + wave, mb);
+            if (extra) issue_one(base, CNT, mb);
     };
     // the stage about to be consumed has landed when at most (NBUF - 2) later stages of this wave are still in flight
     auto wait_landed = [&](bool steady) {
@@ -1924,6 +1932,16 @@ __global__ __launch_bounds__(512) void linear_tn_dma_kernel(TnArgs p) {
     };
 
     const int nsteps = (mend - mbeg) / BT;                   // whole steps only (M % 64 == 0, chunk % 64 == 0)
+    // SCALED: this thread's (at most two) entries of the split's scale slice are requested BEFORE the first stages, so that they return first and the
+    // DMA prologue stays in flight while the slice is examined (requested behind it, their wait was a wait for the whole prologue: +4-8 us per workgroup)
+    // (inline asm: the compiler's own wait for a global load it tracks is vmcnt(0) once DMA instructions follow; here the wait is counted, below)
+    float rsv0 = 0.f, rsv1 = 0.f;
+    if constexpr (SCALED) {
+        const int samp0_ = mbeg / p.rows_per_scale, nsamp_ = (mend - 1) / p.rows_per_scale - samp0_ + 1;
+        const float* a0 = p.rowscale + samp0_ + min(tid, nsamp_ - 1);
+        const float* a1 = p.rowscale + samp0_ + min(tid + 512, nsamp_ - 1);
+        asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off" : "=&v"(rsv0), "=&v"(rsv1) : "v"(a0), "v"(a1) : "memory");
+    }
     int islot = 0, im = mbeg;
 #pragma unroll
     for (int s = 0; s < NBUF - 1; ++s)
@@ -1933,6 +1951,7 @@ __global__ __launch_bounds__(512) void linear_tn_dma_kernel(TnArgs p) {
             im += BT;
         }
     int cslot = 0;
+    float post = 1.0f;                                       // SCALED, two-valued scale vector: the common non-zero value, applied to the accumulators
     if constexpr (!SCALED) {
         for (int s = 0; s < nsteps; ++s) {
             wait_landed(s + NBUF - 2 < nsteps);              // steady: NBUF - 2 later stages have been issued
@@ -1952,9 +1971,42 @@ __global__ __launch_bounds__(512) void linear_tn_dma_kernel(TnArgs p) {
         const int rps = p.rows_per_scale;
         float* sc = reinterpret_cast<float*>(smem + (size_t)NBUF * STAGE * sizeof(T));
         const int samp0 = mbeg / rps, nsamp = (mend - 1) / rps - samp0 + 1;
-        for (int i = tid; i < nsamp; i += 512) sc[i] = p.rowscale[samp0 + i];
-        const int srow = tid >> 4;
-        int sidx = (mbeg + srow) / rps - samp0, srem = (mbeg + srow) % rps;
+        // DropPath hands over a TWO-VALUED vector (0 for a dropped image, 1 / keep for the others).  Then the non-zero value is a factor of the whole
+        // sum: it goes onto the accumulators once, and a stage is touched in LDS only if one of its (at most two) images is dropped -- zeroing its
+        // rows; the other ~90 % of the stages skip the pass.  Any other vector takes the general pass (every stage rescaled).
+        // the two slice loads were issued in front of the prologue's stages: wait for them by count (everything issued since stays in flight)
+        if (nsteps >= NBUF - 1) {
+            if constexpr (REM != 0) {
+                if (extra) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(rsv0), "+v"(rsv1) : "n"((NBUF - 1) * (CNT + 1)) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(rsv0), "+v"(rsv1) : "n"((NBUF - 1) * CNT) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(%2)" : "+v"(rsv0), "+v"(rsv1) : "n"((NBUF - 1) * CNT) : "memory");
+            }
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(rsv0), "+v"(rsv1) : : "memory");
+        }
+        float vmx = 0.f, vmn = 3.0e38f;
+        if (tid < nsamp) {
+            sc[tid] = rsv0;
+            vmx = rsv0;
+            if (rsv0 != 0.f) vmn = rsv0;
+        }
+        if (tid + 512 < nsamp) {
+            sc[tid + 512] = rsv1;
+            vmx = fmaxf(vmx, rsv1);
+            if (rsv1 != 0.f) vmn = fminf(vmn, rsv1);
+        }
+#pragma unroll
+        for (int o = 32; o; o >>= 1) {
+            vmx = fmaxf(vmx, __shfl_xor(vmx, o, 64));
+            vmn = fminf(vmn, __shfl_xor(vmn, o, 64));
+        }
+        float* red = sc + 1024;
+        if ((tid & 63) == 0) {
+            red[tid >> 6] = vmx;
+            red[8 + (tid >> 6)] = vmn;
+        }
+        const int srow = tid >> 4;                          // (rows_per_scale >= 32, host-checked: a 32-token stage touches at most two images)
         const unsigned sc0 = (unsigned)(uintptr_t)(lptr_t*)sc;
         const unsigned soff = lds0 + (unsigned)((srow * TNn + (tid & 15) * EPT) * 2);
         auto scale2 = [](unsigned w, float sv) -> unsigned {  // two bf16 in a dword -> scaled, rounded to nearest even
@@ -1964,7 +2016,9 @@ __global__ __launch_bounds__(512) void linear_tn_dma_kernel(TnArgs p) {
             r.v = bf16x2_t{(__bf16)lo, (__bf16)hi};
             return r.u;
         };
-        auto scale_stage = [&](int slot) {
+        bool binary = false;                                 // set behind the prologue barrier below
+        auto scale_stage = [&](int slot, int step) {        // (runs on the few touched stages: the division is off the common path)
+            const int sidx = min((mbeg + step * BT + srow) / rps - samp0, nsamp - 1);
             const unsigned a = soff + (unsigned)slot * (unsigned)(STAGE * 2), sa = sc0 + (unsigned)sidx * 4u;
             u32x4 v0;
             float sv;
@@ -1972,6 +2026,7 @@ __global__ __launch_bounds__(512) void linear_tn_dma_kernel(TnArgs p) {
                 u32x4 v1;
                 asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b32 %2, %4\n\ts_waitcnt lgkmcnt(0)"
                              : "=&v"(v0), "=&v"(v1), "=&v"(sv) : "v"(a), "v"(sa) : "memory");
+                if (binary) sv = sv != 0.f ? 1.0f : 0.f;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v0[e] = scale2(v0[e], sv); v1[e] = scale2(v1[e], sv); }
                 asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:16" ::"v"(a), "v"(v0), "v"(v1) : "memory");
@@ -1979,50 +2034,59 @@ __global__ __launch_bounds__(512) void linear_tn_dma_kernel(TnArgs p) {
                 u32x2 v1;
                 asm volatile("ds_read_b128 %0, %3\n\tds_read_b64 %1, %3 offset:16\n\tds_read_b32 %2, %4\n\ts_waitcnt lgkmcnt(0)"
                              : "=&v"(v0), "=&v"(v1), "=&v"(sv) : "v"(a), "v"(sa) : "memory");
+                if (binary) sv = sv != 0.f ? 1.0f : 0.f;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v0[e] = scale2(v0[e], sv);
                 v1[0] = scale2(v1[0], sv);
                 v1[1] = scale2(v1[1], sv);
                 asm volatile("ds_write_b128 %0, %1\n\tds_write_b64 %0, %2 offset:16" ::"v"(a), "v"(v0), "v"(v1) : "memory");
             }
-            srem += BT;
-            while (srem >= rps) {
-                srem -= rps;
-                ++sidx;
-            }
         };
-        // stages issued beyond the one that has to have landed: `later`
-        auto wait_later = [&](int later) {
-            if (later <= 0) { wait_vm<0>(); return; }
-            if constexpr (REM != 0) {
-                if (extra) wait_vm<CNT + 1>();
-                else wait_vm<CNT>();
-            } else {
-                wait_vm<CNT>();
-            }
-        };
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // prologue: the scale slice and the first stages (once)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slice and the per-wave extrema are in LDS (the first stages may still be in flight)
         __builtin_amdgcn_s_barrier();
-        if (nsteps > 0) scale_stage(0);
-        // 192 x 384: the two waves of a SIMD (w and w + 4) take the two jobs of a step in opposite order, one scales while the
-        // other's MFMAs run (measured +3-8 % on the stage-2 shapes, -8 % with the 256 x 256 tile, which keeps one order)
-        const bool scale_first = TNn == 192 ? wave < 4 : true;
+        {
+            float mx = red[0], mn = red[8];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) {
+                mx = fmaxf(mx, red[w]);
+                mn = fminf(mn, red[8 + w]);
+            }
+            // (a negative entry makes mn < mx: general pass); both values are workgroup-uniform: kept in scalar registers
+            binary = __builtin_amdgcn_readfirstlane((rps >= BT && (mx == 0.f || mn == mx)) ? 1 : 0) != 0;
+            if (binary) post = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, mx)));
+        }
+        // ONE schedule -- the unscaled kernel's (NBUF - 1 stages in flight).  A stage is rescaled in LDS where it is consumed, between two barriers of
+        // its own: with a two-valued vector only the stages that hold a dropped image's tokens (one in ten at DropPath's largest rate; the rows are
+        // zeroed, the common factor goes onto the accumulators), with any other vector every stage (the pass is then exposed: that form is for
+        // callers outside the model -- round 4 scaled one stage ahead inside a shallower ring and paid +30-40 % on every launch).
+        // "does the stage hold a token of a dropped image?" is looked up one step ahead (the LDS read sits behind the previous step's MFMAs)
+        // which stages hold a token of a dropped image: one bit per stage in four 64-bit scalar masks, built once (lane l looks at stages l, l + 64, ...);
+        // the loop tests a bit -- no LDS access, no wait, no per-step image arithmetic.  More than 256 stages per split: every stage is touched.
+        unsigned long long tm[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+        if (binary && nsteps <= 256) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int st = k * 64 + lane, m0 = mbeg + st * BT;
+                const int i0 = min(m0 / rps - samp0, nsamp - 1), i1 = min((m0 + BT - 1) / rps - samp0, nsamp - 1);
+                tm[k] = __ballot(st < nsteps && (sc[max(i0, 0)] == 0.f || sc[max(i1, 0)] == 0.f));
+            }
+        }
         for (int s = 0; s < nsteps; ++s) {
-            // stage s + 1 has to have landed; issued so far: up to stage s + NBUF - 2
-            if (s + 1 < nsteps) wait_later(NBUF >= 4 && s + 2 < nsteps ? 1 : 0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's scaled rows are in LDS before anyone passes the barrier
+            wait_landed(s + NBUF - 2 < nsteps);
             __builtin_amdgcn_s_barrier();
             if (s + NBUF - 1 < nsteps) {
                 issue(islot, im);
                 islot = islot + 1 == NBUF ? 0 : islot + 1;
                 im += BT;
             }
-            const int nslot = cslot + 1 == NBUF ? 0 : cslot + 1;
-            const bool more = s + 1 < nsteps;
-            if (more && scale_first) scale_stage(nslot);
+            const unsigned long long word = s < 64 ? tm[0] : s < 128 ? tm[1] : s < 192 ? tm[2] : tm[3];
+            if ((s >= 256) || ((word >> (s & 63)) & 1ull)) {
+                scale_stage(cslot, s);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
             compute(cslot);
-            if (more && !scale_first) scale_stage(nslot);
-            cslot = nslot;
+            cslot = cslot + 1 == NBUF ? 0 : cslot + 1;
         }
     }
 
@@ -2030,6 +2094,14 @@ __global__ __launch_bounds__(512) void linear_tn_dma_kernel(TnArgs p) {
     // (row-major order would be 4-byte stores to four rows per instruction); the finish pass undoes the permutation while it
     // sums (reduce_partials_kernel, layout id in the workspace header)
     float* pw = p.part_w + (size_t)split * p.N * p.K + (size_t)tile * (TNn * TKk) + (size_t)wave * (FA * FB * 256) + lane * 4;
+    if constexpr (SCALED) {
+#pragma unroll
+        for (int a = 0; a < FA; ++a)
+#pragma unroll
+            for (int b = 0; b < FB; ++b) acc[a][b] *= post;
+        accb0 *= post;
+        accb1 *= post;
+    }
 #pragma unroll
     for (int a = 0; a < FA; ++a)
 #pragma unroll
@@ -2047,7 +2119,7 @@ __global__ __launch_bounds__(512) void linear_tn_dma_kernel(TnArgs p) {
 
 template <int TNn, int TKk, int NBUF, int WN, bool SCALED = false>
 int launch_tn_dma(const TnArgs& a, int grid, hipStream_t st) {
-    constexpr size_t lds = (size_t)NBUF * 32 * (TNn + TKk) * 2 + (SCALED ? 4096 : 0);
+    constexpr size_t lds = (size_t)NBUF * 32 * (TNn + TKk) * 2 + (SCALED ? 4096 + 64 : 0);
     static_assert(lds <= 160 * 1024, "LDS");
     static FmmtLdsOnce lds_once;
     if (int rc_ = lds_once.set(reinterpret_cast<const void*>(&linear_tn_dma_kernel<TNn, TKk, NBUF, WN, SCALED>), (int)lds)) return rc_;
@@ -2292,7 +2364,7 @@ int launch_tn_plan(int dtype, int M, int N, int K, const void* dy, int lddy, con
         const TnPlan pd = tn_plan_dma(M, N, K);
         // scaled launches: the split's slice of the scale vector has to fit the 4 KB behind the ring
         static const int dma_scaled = fmmt_const("FMMT_TN_DMA_SCALED", 1);
-        const bool scaled_ok = !rowscale || (dma_scaled && rows_per_scale > 0 && pd.tn && pd.chunk / rows_per_scale + 2 <= 1024);
+        const bool scaled_ok = !rowscale || (dma_scaled && rows_per_scale >= 32 && pd.tn && pd.chunk / rows_per_scale + 2 <= 1024);
         if (pd.tn && scaled_ok) {
             TnArgs a{M, N, K, dy, lddy, x, ldx, part_w, part_b, rowscale, rows_per_scale, pd.tiles_k, pd.chunk, pd.tiles_n, tn_xcd, 0, hdr, pd.splits};
             const int grid = pd.tiles_n * pd.tiles_k * pd.splits;

@@ -150,6 +150,21 @@ def t_wgrad_large():
         sdy = dy.float() * rs.repeat_interleave(196)[:M, None]
         report(f"wgrad large rowscale dw {M}x{N}x{K}", dw, sdy.t() @ x.float(), 5e-3)      # s * dy is rounded to bf16 before the MFMA
         report(f"wgrad large rowscale db {M}x{N}x{K}", db, sdy.sum(0), 5e-3)
+        # what DropPath hands over: 0 for a dropped image, 1 / keep for the others (two-valued: the DMA-staged kernel zeroes the dropped images'
+        # rows and applies the common factor to its accumulators -- nothing is rounded, so the fp32 product of the bf16 operands is exact to 1e-3);
+        # images of 196 and of 49 tokens (stage 2 / 3), first and last image dropped, and the all-dropped vector
+        for rps in (196, 49):
+            nimg = (M + rps - 1) // rps
+            rs2 = torch.full((nimg,), 1.0 / 0.9, device=dy.device)
+            rs2[torch.arange(0, nimg, 7, device=dy.device)] = 0.0
+            rs2[-1] = 0.0
+            dw, db = ops.wgrad_raw(dy, x, True, rs2, rps)
+            s2 = rs2.repeat_interleave(rps)[:M, None]
+            tol2 = tol if M in (125440, 31360, 15680) and (N, K) != (768, 768) else 5e-3      # the register-staged kernel rounds s * dy to bf16
+            report(f"wgrad large droppath dw {M}x{N}x{K} rps={rps}", dw, (dy.float() * s2).t() @ x.float(), tol2)
+            report(f"wgrad large droppath db {M}x{N}x{K} rps={rps}", db, (dy.float() * s2).sum(0), tol2)
+        dw, db = ops.wgrad_raw(dy, x, True, torch.zeros_like(rs2), 49)
+        RES.append((f"wgrad large all-dropped {M}x{N}x{K}", bool((dw == 0).all()) and bool((db == 0).all())))
         del dy, x, dw, db, dw2, sdy
 
 

@@ -41,7 +41,8 @@ for (M, N, K) in SHAPES:
     tot += full
     rps = 196 if M > 100000 else 49
     rs = torch.full((M // rps,), 1.0 / 0.9, device=dev)
-    rs[::7] = 0.0
+    if int(os.environ.get('TN_PROBE_DROP', '10')):
+        rs[::int(os.environ.get('TN_PROBE_DROP', '10'))] = 0.0    # DropPath's largest rate in Swin-T (0.1): one image in ten dropped (TN_PROBE_DROP=0: none)
     ops.wgrad_partials_raw(dy, x, True, ws, nbytes, rs, rps); torch.cuda.synchronize()
     bs = 1e9
     for rep in range(3):
