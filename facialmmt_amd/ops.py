@@ -539,7 +539,7 @@ class MlpFn(Function):
 _MLP_BWD_FUSED = True        # False = GELU' GEMM + input-gradient GEMM as two launches
 # "192" adds stage 1 (one token tile per wave there: no spill, all tests pass, and 0.1 ms SLOWER per Swin forward + backward than the two
 # GEMM launches + LayerNorm backward it replaces: 43.69 against 43.57 ms, same call) -- off
-_MLP_BWD_WIDTHS = (96,)      # (96, 192) adds stage 1 (one token tile per wave: no spill, all tests pass, measured 0.1 ms slower than the launches it replaces)
+_MLP_BWD_WIDTHS = (96, 192)  # stage 0 and stage 1 (round 4: stage 1 measured 0.1 ms slower than the GELU' GEMM + input-gradient GEMM it replaces and stayed off; round 5, same-call A/B of whole steps: 57.56 / 57.57 against 57.67 / 57.63 ms -- on)
 _MLP_BWD_LN = True           # False = fmmt_mlp_bwd_input + fmmt_layernorm_bwd
 
 
