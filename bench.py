@@ -92,6 +92,7 @@ def parse():
     ap.add_argument("--grad-comm", default="bf16", choices=["fp32", "bf16"], help="element type of the gradient all-reduce (N > 1): bf16 halves the bytes on the xGMI links (0.87 GB instead of 1.74 GB per step)")
     ap.add_argument("--other-configs", type=int, default=1, help="N = 1 only: after the timed region also run 4 steps of configs[3] and configs[4] (per-GPU legs, own processes) and report them under `other_configs`")
     ap.add_argument("--branch-graphs", type=int, default=0, help="1 (one rank, --graphs 2, no gradient exchange): text encoder forward / backward and Swin forward / backward as graphs of their own on two streams, events at the data dependencies (GraphedTargetStep branch_graphs)")
+    ap.add_argument("--fork-streams", type=int, default=0, help="1 (one rank, --graphs 2, no gradient exchange): one graph whose fork node's first child is a tick on the launch queue, text encoder and Swin each on a stream of their own, forward and backward (GraphedTargetStep fork_streams)")
     ap.add_argument("--pipeline-swin", type=int, default=0, help="1 (one rank, --graphs 2, no auxiliary task): Swin's forward of step i + 1 as a graph of its own, replayed on a second stream beside step i (GraphedTargetStep pipeline_swin); every timed step still runs exactly one Swin forward.  Round 5, same call, alternating: 63.2 / 63.3 ms per step with it, 62.35 / 62.37 without -- the chip-filling Swin kernels (one persistent workgroup per CU) leave the other stream's small launches no CU to run on, so the two graphs time-slice; default off")
     ap.add_argument("--parallel-fusion", type=int, default=0, help="1: capture independent halves of the fusion stack as parallel graph branches (round 4, same call: 64.9-65.0 ms per step against 63.5-63.7 without -- a fork / join pair of the replayed graph costs more than the 50-250-workgroup launches it lets overlap)")
     ap.add_argument("--discarded-swin-gradients", choices=["compute", "skip"], default="compute",
@@ -674,7 +675,8 @@ def main():
         step = GraphedTargetStep(swin, mm, opt, sched, cfg, batch, autocast_dtype=act, overlap_text=bool(args.overlap_text),
                                  parallel_fusion=bool(args.parallel_fusion), averager=flat, masters=masters,
                                  discarded_swin_gradients=args.discarded_swin_gradients, swin_cut=swin_cut, pipeline_swin=pipelined,
-                                 branch_graphs=branched)
+                                 branch_graphs=branched,
+                                 fork_streams=bool(args.fork_streams) and not branched and not pipelined and not (ddp and flat.active) and args.discarded_swin_gradients == "compute")
     else:
         if args.graphs == 1:
             from facialmmt_amd.train_step import graph_multimodal, select_frames

@@ -863,7 +863,7 @@ class GraphedTargetStep:
 
     def __init__(self, swin_model, multimodal_model, optimizer, scheduler, args, batch, autocast_dtype=None,
                  overlap_text=True, parallel_fusion=False, averager=None, warmup_iters=2, masters=None, discarded_swin_gradients="compute",
-                 swin_cut: int = 0, pipeline_swin: bool = False, branch_graphs: bool = False):
+                 swin_cut: int = 0, pipeline_swin: bool = False, branch_graphs: bool = False, fork_streams: bool = False):
         """`averager`: GradientAverager(hooks=False) over the parameters the optimizer steps (default: the multimodal
         model's); `swin_cut`: with an exchange to hide (N > 1), the Swin stage behind which the backward graph is cut (0: the second
         piece is stage 0's backward, ~10 ms; 1: stages 1 + 0, ~17 ms) -- the caller picks it from a MEASURED exchange time
@@ -883,6 +883,7 @@ class GraphedTargetStep:
         self.skip_swin_bwd = discarded_swin_gradients == "skip"
         self.pipeline = bool(pipeline_swin)
         self.branches = bool(branch_graphs)                 # BRANCH_NOTE below
+        self.forked = bool(fork_streams)                    # FORK_NOTE at _fwd_bwd_forked
         if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "") != "0":
             raise RuntimeError("GraphedTargetStep: DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 must be in the environment before the HIP "
                                "runtime initialises (see facialmmt_amd/__init__.py)")
@@ -920,6 +921,11 @@ class GraphedTargetStep:
         self.shadows = None                                 # set after the warm-up passes, before capture
         self.text_stream = distinct_stream(dev, (cap,)) if overlap_text else None
         self.mm.pair_stream = distinct_stream(dev, (cap, self.text_stream)) if parallel_fusion else None
+        if self.forked:
+            if self.text_stream is None:
+                self.text_stream = distinct_stream(dev, (cap,))
+            self.swin_stream = distinct_stream(dev, tuple(x for x in (cap, self.text_stream, self.mm.pair_stream) if x is not None))
+            self._tick = torch.zeros(1, device=dev)
         # -- warm-up on a side stream (lazy initialisations: kernel attributes, shadow caches, optimizer state), undone below
         snap = [(t, t.detach().clone()) for m in (self.swin, self.mm) for t in list(m.parameters()) + list(m.buffers())]
         if masters is not None:
@@ -955,6 +961,8 @@ class GraphedTargetStep:
             raise ValueError("pipeline_swin: one rank without a gradient exchange, Swin's backward computed")
         if self.branches and (self.split or self.skip_swin_bwd or self.pipeline):
             raise ValueError("branch_graphs: one rank without a gradient exchange, Swin's backward computed, not together with pipeline_swin")
+        if self.forked and (self.split or self.skip_swin_bwd or self.pipeline or self.branches):
+            raise ValueError("fork_streams: one rank without a gradient exchange, Swin's backward computed, not together with pipeline_swin / branch_graphs")
         self.graph_a, self.graph_a2, self.graph_b = torch.cuda.CUDAGraph(), (torch.cuda.CUDAGraph() if self.split else None), torch.cuda.CUDAGraph()
         self.sets, self.side_stream, self.cur, self.prefetched = [], None, 0, None
         if self.pipeline:
@@ -1028,13 +1036,59 @@ class GraphedTargetStep:
 
     # one micro-step: forward + backward (runs eagerly during warm-up, once more under capture), in the two pieces the graphs hold
     def _fwd_bwd(self):
+        if getattr(self, "forked", False):
+            return self._fwd_bwd_forked()
         loss, new_mask, _ = self._fwd_bwd_multimodal(whole=True)
         return loss, new_mask
 
-    def _text_forward(self):
+    def _fwd_bwd_forked(self):
+        """FORK_NOTE.  ONE graph whose two branches really start together.  The replay enqueues a graph branch by branch; the branch that CONTINUES on
+        the launch queue (the fork node's first-created child) goes first and whole, and a branch that moves to another queue waits for the launch
+        queue's tail as of then -- so with the text encoder (or Swin) as that first child the other branch starts when it has finished
+        (profiles/r05_timeline*.txt).  Here the fork node's first child is a one-element tick on the launch queue that leads straight to the join; the
+        text encoder and Swin are its second and third child, each on a stream of its own, and wait for a tail that ends at the tick.  Forward and
+        backward are forked the same way (the backward by hand: the fusion stack is differentiated down to detached branch outputs, as branch_graphs)."""
+        cap, ts, ss = torch.cuda.current_stream(), self.text_stream, self.swin_stream
+        frames = self.static[8]
+        if self.shadows is not None:
+            self.shadows.refresh()
+        ev = torch.cuda.Event()
+        ev.record(cap)
+        self._tick.add_(1.0)                                # first child of the fork: the launch queue's own continuation
+        ts.wait_event(ev)
+        ss.wait_event(ev)
+        with torch.cuda.stream(ts):
+            feat, tmask = self._text_forward(refresh=False)
+        with torch.cuda.stream(ss):
+            preds = self.swin(frames, is_trg_task=True)
+        cap.wait_stream(ts)
+        cap.wait_stream(ss)
+        for t in (feat, tmask, preds):
+            if torch.is_tensor(t):
+                t.record_stream(cap)
+        loss, new_mask, dfeat, dpreds = self._fusion_fwd_bwd(feat, tmask, preds)
+        ev2 = torch.cuda.Event()
+        ev2.record(cap)
+        self._tick.add_(1.0)
+        ts.wait_event(ev2)
+        ss.wait_event(ev2)
+        if dfeat is not None:
+            dfeat.record_stream(ts)
+        if dpreds is not None:
+            dpreds.record_stream(ss)
+        with torch.cuda.stream(ts):
+            self._text_backward(feat, dfeat, handover=False)
+        with torch.cuda.stream(ss):
+            self._bwd_swin((preds, dpreds))
+        cap.wait_stream(ts)
+        cap.wait_stream(ss)
+        self._hand_over()
+        return loss, new_mask
+
+    def _text_forward(self, refresh=True):
         """branch_graphs, graph T: the multimodal model's bf16 shadows (text encoder AND fusion stack: one launch), then the text branch"""
         (ids, attn_mask, sep_mask, _a, _am, _v, _vm, _l, _f, _n, utt_idx) = self.static
-        if self.mm_shadows is not None:
+        if refresh and self.mm_shadows is not None:
             self.mm_shadows.refresh()
         import contextlib
         ac = (lambda: torch.autocast("cuda", dtype=self.autocast_dtype)) if self.autocast_dtype is not None else contextlib.nullcontext
@@ -1059,7 +1113,7 @@ class GraphedTargetStep:
             l.grad = gr
         return loss.detach(), new_mask, got[0], got[1]
 
-    def _text_backward(self, feat, dfeat):
+    def _text_backward(self, feat, dfeat, handover=True):
         """branch_graphs, graph TB: the text branch's backward from the gradient of its output, then the hand-over of EVERY multimodal gradient
         (graph F's included) to the optimizer's flat buffers with the clip norm in the same pass"""
         leaves = [l for l, _ in self.pairs if l.requires_grad]
@@ -1068,6 +1122,10 @@ class GraphedTargetStep:
             for l, gr in zip(leaves, got):
                 if gr is not None:
                     l.grad = gr if l.grad is None else l.grad + gr      # (a parameter both pieces use: none in this model)
+        if handover:
+            self._hand_over()
+
+    def _hand_over(self):
         if self.handover is not None and self.handover(self.pairs, self.flat_view_of, self.accumulate, self.fused.norm):
             self.fused.norm_ready = True
         else:
