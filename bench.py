@@ -1,6 +1,6 @@
 """Benchmark of the FacialMMT hot path on MI355X (contract: see the task prompt / DESIGN.md section 6).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: re-executes itself as the line below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -109,6 +109,7 @@ def parse():
     ap.add_argument("--shape-report", default=None, help="write a per-GEMM-shape timing table to this file (development aid)")
     ap.add_argument("--host-input-leg", type=int, default=1, help="after the timed region, also time the steps with the batch handed over in pinned host memory (PCIe-inclusive rate; reported, never `value`)")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames in the CPU-baseline Swin sample")
+    ap.add_argument("--rendezvous-check", action="store_true", help="only bring up the process group (one all-reduce of ones), have rank 0 print {\"rendezvous_check\": ..., \"ranks_seen\": N} and exit -- needs no GPU with FMMT_BENCH_BACKEND=gloo; what tests/test_host_cpu.py uses to run `python bench.py --gpus 2` as typed")
     a = ap.parse_args()
     if a.config == 3:
         a.plm = a.plm or "bert-large"
@@ -581,11 +582,42 @@ def cpu_baseline(args, cfg):
                       f"encoders ({t_meld:.2f} s [{f_meld:.2f} s]) + {args.plm} 512 tokens (HF, {'%.2f s [%.2f s]' % (t_plm, f_plm) if t_plm else 'skipped'}); optimizer excluded"}
 
 
+def spawn_command(argv, gpus, port=None):
+    """`python bench.py --gpus N` typed without a launcher (WORLD_SIZE unset, N > 1): the command this process re-executes itself as --
+    one rank per GPU under torch.distributed.run on 127.0.0.1 (the container's hostname may not resolve), the same line the driver uses"""
+    port = port or int(os.environ.get("FMMT_BENCH_PORT", "0")) or 29500 + os.getpid() % 2000
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+            os.path.abspath(__file__)] + list(argv)
+
+
+def rendezvous_check(args, world, rank, backend):
+    """--rendezvous-check: the process group alone.  Every rank contributes a one; rank 0 prints what the sum says"""
+    if world > 1:
+        if not dist.is_initialized():
+            dist.init_process_group(backend)
+        t = torch.ones(1, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t)
+        seen = int(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        seen = 1
+    if rank == 0:
+        print(json.dumps({"rendezvous_check": seen == args.gpus, "n_gpus": args.gpus, "world_size": world, "ranks_seen": seen, "backend": backend}), flush=True)
+    return 0 if seen == args.gpus else 1
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # typed as `python bench.py --gpus N`: become the launcher (round-5 VERDICT item 6: this used to die on the assertion below)
+        os.execv(sys.executable, spawn_command(sys.argv[1:], args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus"
+    if args.rendezvous_check:
+        sys.exit(rendezvous_check(args, world, rank, os.environ.get("FMMT_BENCH_BACKEND", "nccl")))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the hot path has no CPU fallback)"
     # FMMT_BENCH_DEVICE / FMMT_BENCH_BACKEND: dry-run switches for exercising the N>1 code path on a one-GPU box (all
     # ranks on device 0, gloo instead of RCCL, which refuses two ranks per device); never set by the driver
@@ -609,7 +641,6 @@ def main():
             os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT")
             os.environ.setdefault("NCCL_DEBUG_FILE", rccl_log)
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
     from facialmmt_amd.config import default_args
     from facialmmt_amd.parallel import GradientAverager, broadcast_parameters

@@ -289,6 +289,32 @@ def test_bench_contract_flags_and_loud_failure_without_gpu():
     assert not r.stdout.strip().startswith("{")            # no metric line from a run that measured nothing
 
 
+def test_bench_gpus_n_runs_as_typed():
+    """`python bench.py --gpus 2` with no launcher around it (WORLD_SIZE unset) re-executes itself under torch.distributed.run, one rank per
+    GPU on 127.0.0.1, instead of dying on an assertion (round-5 VERDICT item 6).  --rendezvous-check stops behind the process group (gloo
+    here: no GPU), rank 0 prints the one JSON line with the number of ranks the all-reduce saw."""
+    import json
+    import subprocess
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    cmd = bench.spawn_command(["--gpus", "8", "--steps", "3"], 8, port=29555)
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=8" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "8", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(FMMT_BENCH_BACKEND="gloo", FMMT_BENCH_DEVICE="0", FMMT_BENCH_PORT=str(29600 + os.getpid() % 300))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-check"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["rendezvous_check"] is True and line["ranks_seen"] == 2 and line["world_size"] == 2 and line["n_gpus"] == 2
+    # a launcher whose --nproc-per-node disagrees with --gpus is still refused
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-check"], capture_output=True, text=True, env=env2, timeout=300)
+    assert r2.returncode != 0 and "--nproc-per-node must equal --gpus" in r2.stderr
+
+
 def test_capture_window_fences_the_cyclic_collector():
     """train_step.capture_window: collect before a graph capture, collector off inside, previous state restored after
     (also when the body raises, and when the collector was already off)."""
