@@ -131,8 +131,51 @@ __device__ __forceinline__ void fmmt_odd_poly2(const float (&c)[N], float R, con
 #pragma unroll
     for (int j = 0; j < NP; ++j) out[j] = q[j] * xc[j] + 0.5f;
 }
+// Round 6: the forms the bf16 kernels evaluate (gelu_poly_data.h part 2, tools/gen_gelu_poly.py).  The odd polynomials above are accurate to 5e-5
+// ABSOLUTE, i.e. not at all where the functions are smaller than that: gelu(x) for x < -3.5 (|gelu| < 8e-4) came out with tens of percent of relative
+// error and either sign.  With a = max(-|x|, -R):
+//     gelu(x)  = max(x, 0) + a 2^L(a),          L ~ log2 Phi on [-9, 0], degree 6        (gelu(x) = x + gelu(-x) for x > 0; the product is <= 0 always)
+//     gelu'(x) = 1/2 + sign(x) (1/2 - g(a)),    g = 2^(c a^2) S(a), S degree 8            (gelu'(x) = 1 - gelu'(-x); the Gaussian carries the decay)
+// relative error <= 4.6e-4 (gelu, x in [-8, 0)) / 7.1e-4 (gelu', [-8, -1.5]) and the exact sign on the negative tail, 6.8e-5 / 6.0e-5 absolute
+// everywhere; per element 1 v_max + 6 / 8 v_fma + ONE v_exp_f32 + 3 / 6 plain VALU -- no packed fp32 (profiles/r05_issue_rates.txt: a v_pk_fma_f32
+// beside MFMAs costs ~12 cycles, a plain VALU instruction hides).  tests/test_gpu_ops.py::test_gelu_epilogues_negative_tail sweeps [-8, 8].
+template <int N> __device__ __forceinline__ float fmmt_horner(const float (&c)[N], float a) {
+    float q = c[N - 1];
+#pragma unroll
+    for (int k = N - 2; k >= 0; --k) q = __builtin_fmaf(q, a, c[k]);
+    return q;
+}
+__device__ __forceinline__ float gelu_exp_f(float x) {
+    const float a = fmaxf(-fabsf(x), -FMMT_GELU_L_R);
+    const float t = a * __builtin_amdgcn_exp2f(fmmt_horner(fmmt_gelu_log2phi_poly, a));
+    return fmaxf(x, 0.f) + t;
+}
+__device__ __forceinline__ float gelu_grad_exp_f(float x) {
+    const float a = fmaxf(-fabsf(x), -FMMT_GELU_S_R);
+    const float e = __builtin_amdgcn_exp2f((a * FMMT_GELU_S_C) * a);
+    const float g = e * fmmt_horner(fmmt_gelu_grad_s_poly, a);
+    return x < 0.f ? g : 1.0f - g;                          // (1/2 + sign(x) (1/2 - g) would cancel the tail away: g itself for x < 0)
+}
+// gelu AND gelu' of one value (the forward epilogues that store the derivative for the backward, FMMT_EPI_GELU_DG): Phi(a) = 2^L(a) serves both,
+// phi(a) = 2^(c a^2 + log2(1 / sqrt(2 pi))) is one more exponential -- gelu'(a) = Phi(a) + a phi(a); 16 plain VALU + 2 v_exp_f32 for the pair
+// (separately 11 + 1 and 15 + 1).  Relative error of gelu' on the tail: Phi's 4.6e-4 scaled by Phi / |gelu'| ~ 1 / a^2.
+__device__ __forceinline__ void gelu_both_exp_f(float x, float& g, float& dg) {
+    const float a = fmaxf(-fabsf(x), -FMMT_GELU_L_R);
+    const float cdf = __builtin_amdgcn_exp2f(fmmt_horner(fmmt_gelu_log2phi_poly, a));
+    const float pdf = __builtin_amdgcn_exp2f(__builtin_fmaf(a * FMMT_GELU_S_C, a, -1.3257480647361592f));     // log2(1 / sqrt(2 pi))
+    g = fmaxf(x, 0.f) + a * cdf;
+    const float ga = __builtin_fmaf(a, pdf, cdf);
+    dg = x < 0.f ? ga : 1.0f - ga;
+}
+#ifndef FMMT_GELU_EXP
+#define FMMT_GELU_EXP 1
+#endif
 // v[e] <- gelu(v[e]) / v[e] <- v[e] * gelu'(pre[e]), n = 2 NP elements
 template <int NP> __device__ __forceinline__ void gelu_poly_inplace(float* v) {
+#if FMMT_GELU_EXP
+#pragma unroll
+    for (int j = 0; j < 2 * NP; ++j) v[j] = gelu_exp_f(v[j]);
+#else
     f32x2 x[NP], ph[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) x[j] = f32x2{v[2 * j], v[2 * j + 1]};
@@ -143,8 +186,13 @@ template <int NP> __device__ __forceinline__ void gelu_poly_inplace(float* v) {
         v[2 * j] = y.x;
         v[2 * j + 1] = y.y;
     }
+#endif
 }
 template <int NP> __device__ __forceinline__ void gelu_grad_poly_mul_inplace(float* v, const float* pre) {
+#if FMMT_GELU_EXP
+#pragma unroll
+    for (int j = 0; j < 2 * NP; ++j) v[j] *= gelu_grad_exp_f(pre[j]);
+#else
     f32x2 x[NP], g[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) x[j] = f32x2{pre[2 * j], pre[2 * j + 1]};
@@ -154,6 +202,7 @@ template <int NP> __device__ __forceinline__ void gelu_grad_poly_mul_inplace(flo
         v[2 * j] *= g[j].x;
         v[2 * j + 1] *= g[j].y;
     }
+#endif
 }
 
 // element-type dispatch used by the GEMM epilogues: exact for float, packed polynomial for bf16 (n = 4 or a multiple of 8)
@@ -166,6 +215,23 @@ template <typename T, int IL = 4> __device__ __forceinline__ void gelu_inplace(f
         if (n == 4) return gelu_poly_inplace<2>(v);
 #pragma unroll
         for (int e = 0; e < n; e += 2 * IL) gelu_poly_inplace<IL>(v + e);
+    }
+}
+// v[e] <- gelu(v[e]), d[e] <- gelu'(v[e]) (before the update): exact for float, the shared-exponential form for bf16
+// GRP: elements evaluated together (0 = all n; 4 / 2 where the registers are short: the eight chains of a fragment keep ~6 temporaries each alive)
+template <typename T, int GRP = 0> __device__ __forceinline__ void gelu_both_inplace(float* v, float* d, int n) {
+#pragma unroll
+    for (int e = 0; e < n; ++e) {
+        const float x = v[e];
+        if constexpr (sizeof(T) == 4) {
+            v[e] = gelu_f(x);
+            d[e] = gelu_grad_f(x);
+        } else {
+            gelu_both_exp_f(x, v[e], d[e]);
+        }
+        if constexpr (GRP > 0) {
+            if ((e + 1) % GRP == 0 && e + 1 < n) __builtin_amdgcn_sched_barrier(0);
+        }
     }
 }
 template <typename T, int IL = 4> __device__ __forceinline__ void gelu_grad_mul_inplace(float* v, const float* pre, int n) {

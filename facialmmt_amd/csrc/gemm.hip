@@ -1132,7 +1132,7 @@ int dispatch_nt_bk(const LinArgs& a, hipStream_t st) {
 
 // The phase-structured kernels (gemm_ph.h: 256 x 256 tiles, four phases; gemm_ph3.h: 192 x 256 tiles, three phases, all epilogues but GELU').
 // Returns 0 (none), 1 (gemm_ph.h, plain / bias), 3 (gemm_ph3.h, 192 x 256 tiles) or 4 (gemm_ph3.h, 384 x 128 tiles); *epi3 = gemm_ph3.h's EPI template value:
-// 2 plain / bias, 3 GELU + pre-activation, 5 residual / row scale.
+// 2 plain / bias, 3 GELU + pre-activation, 5 residual / row scale, 6 product with the stored GELU derivative (+ row scale).
 // Measured against the kernels below and each other (tools/probes/nt_ph_probe.hip, same call, us per launch, production -> ph / ph3):
 //   plain / bias     31360 x 768 x 3072 136 -> 139 / 110 (369 tiles of 256 x 256 = 1.44 rounds of 256 workgroups, 492 of 192 x 256 = 1.92), x 768 x 768 42 -> 44 / 35,
 //                    x 2304 x 768 113 -> 101 / 100, x 3072 x 768 143 -> 129 / 132, 125440 x 1536 x 384 190 -> 154 / 167, 7840 x 1536 x 6144 168 -> 134 / 106,
@@ -1143,10 +1143,12 @@ int dispatch_nt_bk(const LinArgs& a, hipStream_t st) {
 //   GELU'            loses everywhere (262 -> 828): stays on the persistent kernel.
 int ph_plan(const LinArgs& a, int* epi3) {
     static const int on = fmmt_const("FMMT_NT_PH", 1);
-    if (!on || a.ksplit || a.part || a.aux) return 0;
+    const bool mul_aux = a.epi == FMMT_EPI_MUL_AUX && a.aux && !a.res && !a.y_pre && !a.bias;
+    if (!on || a.ksplit || a.part || (a.aux && !mul_aux)) return 0;
     const bool gelu_pre = a.epi == FMMT_EPI_GELU && a.y_pre, has_op = a.res || a.rowscale;
-    if (!gelu_pre && (a.epi != 0 || a.y_pre)) return 0;
+    if (!gelu_pre && !mul_aux && (a.epi != 0 || a.y_pre)) return 0;
     if (gelu_pre && (has_op || a.K < 1536)) return 0;
+    if (mul_aux && (a.ldaux % 8 || (unsigned long long)a.M * a.ldaux >= (1ull << 31))) return 0;
     if (a.M < 4096 || a.M % 8 || a.N % 128 || a.K % 64 || a.K < 192 || a.ldx % 8 || a.ldw % 8 || a.ldy % 8) return 0;
     if (a.res && a.ldres % 8) return 0;
     if (a.rowscale && a.rows_per_scale <= 0) return 0;
@@ -1160,7 +1162,7 @@ int ph_plan(const LinArgs& a, int* epi3) {
         if (gelu_pre || a.K > 512) return 0;
         const long long t384 = (long long)((a.M + 383) / 384) * (a.N / 128), r384 = (t384 + 255) / 256;
         if (t384 < 256 || t384 * 100 < r384 * 256 * 85) return 0;
-        *epi3 = has_op ? 5 : 2;
+        *epi3 = mul_aux ? 6 : has_op ? 5 : 2;
         return 4;
     }
     const long long t256 = (long long)((a.M + 255) / 256) * (a.N / 256), t192 = (long long)((a.M + 191) / 192) * (a.N / 256);
@@ -1168,8 +1170,8 @@ int ph_plan(const LinArgs& a, int* epi3) {
     const long long min_tiles = a.M < 16384 ? 150 : 256;        // 16384+ tokens: the persistent 256-row kernel's ground, taken only with (nearly) full rounds
     const bool ok256 = t256 >= min_tiles && (a.M < 16384 || t256 * 100 >= r256 * 256 * 85);
     const bool ok192 = t192 >= min_tiles && (a.M < 16384 || t192 * 100 >= r192 * 256 * 85);
-    *epi3 = gelu_pre ? 3 : has_op ? 5 : 2;
-    if (gelu_pre || has_op) return ok192 ? 3 : 0;
+    *epi3 = gelu_pre ? 3 : mul_aux ? 6 : has_op ? 5 : 2;
+    if (gelu_pre || has_op || mul_aux) return ok192 ? 3 : 0;
     // plain / bias: rows of MFMA work per workgroup over the launch; the 192-row tile is charged 3 % (shorter phases per byte staged)
     const long long c256 = r256 * 256 * 100, c192 = r192 * 192 * 103;
     if (ok192 && (!ok256 || c192 < c256)) return 3;
@@ -1214,8 +1216,8 @@ int dispatch_nt(const LinArgs& a, hipStream_t st) {
         int epi3 = 2;
         if (const int ph = ph_plan(a, &epi3)) {
             if (ph == 1) return launch_ph<2>(a, st);
-            if (ph == 4) return epi3 == 5 ? launch_ph3<5, true, 4>(a, st) : launch_ph3<2, true, 4>(a, st);
-            return epi3 == 3 ? launch_ph3<3>(a, st) : epi3 == 5 ? launch_ph3<5>(a, st) : launch_ph3<2>(a, st);
+            if (ph == 4) return epi3 == 6 ? launch_ph3<6, true, 4>(a, st) : epi3 == 5 ? launch_ph3<5, true, 4>(a, st) : launch_ph3<2, true, 4>(a, st);
+            return epi3 == 3 ? launch_ph3<3>(a, st) : epi3 == 6 ? launch_ph3<6>(a, st) : epi3 == 5 ? launch_ph3<5>(a, st) : launch_ph3<2>(a, st);
         }
         if (const int bn = p256_plan(a)) {
             // FMMT_NT_P256_RING: 1 (default) = K step 64, ring of 2 (3 for 128-wide tiles); 0 = K step 32, ring of 4.
@@ -1985,16 +1987,19 @@ __global__ __launch_bounds__(512) void linear_tn_dma_kernel(TnArgs p) {
         } else {
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(rsv0), "+v"(rsv1) : : "memory");
         }
-        float vmx = 0.f, vmn = 3.0e38f;
+        // extrema over the NON-ZERO entries only (lanes without an entry, and zeros, contribute neither): "two-valued" = zeros and ONE other value of
+        // either sign (round-5 ADVICE: with the maximum taken over all entries and 0 for idle lanes, a slice of zeros and negatives looked all-zero)
+        float vmx = -3.0e38f, vmn = 3.0e38f;
         if (tid < nsamp) {
             sc[tid] = rsv0;
-            vmx = rsv0;
-            if (rsv0 != 0.f) vmn = rsv0;
+            if (rsv0 != 0.f) vmx = vmn = rsv0;
         }
         if (tid + 512 < nsamp) {
             sc[tid + 512] = rsv1;
-            vmx = fmaxf(vmx, rsv1);
-            if (rsv1 != 0.f) vmn = fminf(vmn, rsv1);
+            if (rsv1 != 0.f) {
+                vmx = fmaxf(vmx, rsv1);
+                vmn = fminf(vmn, rsv1);
+            }
         }
 #pragma unroll
         for (int o = 32; o; o >>= 1) {
@@ -2051,9 +2056,10 @@ __global__ __launch_bounds__(512) void linear_tn_dma_kernel(TnArgs p) {
                 mx = fmaxf(mx, red[w]);
                 mn = fminf(mn, red[8 + w]);
             }
-            // (a negative entry makes mn < mx: general pass); both values are workgroup-uniform: kept in scalar registers
-            binary = __builtin_amdgcn_readfirstlane((rps >= BT && (mx == 0.f || mn == mx)) ? 1 : 0) != 0;
-            if (binary) post = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, mx)));
+            // no non-zero entry at all (mx still at its start value): the sum is zero; one non-zero value: mn == mx.  Both workgroup-uniform: scalar registers
+            const bool none = mx == -3.0e38f;
+            binary = __builtin_amdgcn_readfirstlane((rps >= BT && (none || mn == mx)) ? 1 : 0) != 0;
+            if (binary) post = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, none ? 0.f : mx)));
         }
         // ONE schedule -- the unscaled kernel's (NBUF - 1 stages in flight).  A stage is rescaled in LDS where it is consumed, between two barriers of
         // its own: with a two-valued vector only the stages that hold a dropped image's tokens (one in ten at DropPath's largest rate; the rows are
@@ -2229,7 +2235,8 @@ extern "C" int fmmt_linear_fwd(int dtype, int M, int N, int K,
     const int vec = dtype == FMMT_BF16 ? 8 : 4;
     if (dtype != FMMT_BF16 && dtype != FMMT_F32) return FMMT_EINVAL;
     if (K % vec || N % 4 || ldx % vec || ldw % vec || ldy % 4) return FMMT_EINVAL;
-    if (epi == FMMT_EPI_GELU_BWD && (!aux || ldaux % 4)) return FMMT_EINVAL;
+    if (epi < 0 || epi > FMMT_EPI_MUL_AUX) return FMMT_EINVAL;
+    if ((epi == FMMT_EPI_GELU_BWD || epi == FMMT_EPI_MUL_AUX) && (!aux || ldaux % 4)) return FMMT_EINVAL;
     if (res && ldres % 4) return FMMT_EINVAL;
     if (rowscale && rows_per_scale <= 0) return FMMT_EINVAL;
     if (!aligned16(x) || !aligned16(w) || !aligned16(y) || (bias && !aligned16(bias)) ||

@@ -52,8 +52,9 @@ struct EpiPre {
 };
 template <int MT, int NT>
 __device__ __forceinline__ void nt_epilogue_prefetch(const LinArgs& p, EpiPre<MT, NT>& pre, int mbase, int nbase, int li, int lg) {
-    const bf16* __restrict__ src = reinterpret_cast<const bf16*>(p.epi == FMMT_EPI_GELU_BWD ? p.aux : p.res);
-    const int ld = p.epi == FMMT_EPI_GELU_BWD ? p.ldaux : p.ldres;
+    const bool use_aux = p.epi == FMMT_EPI_GELU_BWD || p.epi == FMMT_EPI_MUL_AUX;
+    const bf16* __restrict__ src = reinterpret_cast<const bf16*>(use_aux ? p.aux : p.res);
+    const int ld = use_aux ? p.ldaux : p.ldres;
 #pragma unroll
     for (int a = 0; a < MT; ++a) {
         const int m = min(mbase + a * 16 + li, p.M - 1);     // ragged last panel: a valid row, never stored
@@ -158,12 +159,21 @@ __device__ __forceinline__ void nt_epilogue(const LinArgs& p, f32x4 (&acc)[MT][N
                 if (p.epi == FMMT_EPI_GELU) {
                     if (ypre) store_chunk(ypre, p.ldy, v);
                     gelu_inplace<T>(v, VEC);
+                } else if (p.epi == FMMT_EPI_GELU_DG) {         // y = gelu(v), y_pre = gelu'(v): the backward multiplies (FMMT_EPI_MUL_AUX), no polynomial there
+                    float d[VEC];
+                    gelu_both_inplace<T>(v, d, VEC);
+                    if (ypre) store_chunk(ypre, p.ldy, d);
                 } else if (!NOOPS && p.epi == FMMT_EPI_GELU_BWD) {
                     float ax[VEC];
                     load_chunk(auxg, p.ldaux, ax);
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) ax[e] = (e < w) ? ax[e] : 0.f;
                     gelu_grad_mul_inplace<T>(v, ax, VEC);
+                } else if (!NOOPS && p.epi == FMMT_EPI_MUL_AUX) {
+                    float ax[VEC];
+                    load_chunk(auxg, p.ldaux, ax);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) v[e] *= (e < w) ? ax[e] : 0.f;
                 }
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) v[e] *= rs;
@@ -273,12 +283,25 @@ __device__ __forceinline__ void nt_epilogue_wslab(const LinArgs& p, f32x4 (&acc)
                 if (p.epi == FMMT_EPI_GELU) {
                     if (ypre) put(ypre, p.ldy);
                     gelu_inplace<T>(v, 8);
+                } else if (p.epi == FMMT_EPI_GELU_DG) {
+                    float d[8];
+                    gelu_both_inplace<T>(v, d, 8);
+                    if (ypre) {
+                        Vec<T> t;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) t.set(e, d[e]);
+                        stvec<T>(ypre + (size_t)m * p.ldy + n, t);
+                    }
                 } else if (p.epi == FMMT_EPI_GELU_BWD) {
                     const Vec<T> t = ldvec<T>(auxg + (size_t)m * p.ldaux + n);
                     float ax[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) ax[e] = t.get(e);
                     gelu_grad_mul_inplace<T>(v, ax, 8);
+                } else if (p.epi == FMMT_EPI_MUL_AUX) {
+                    const Vec<T> t = ldvec<T>(auxg + (size_t)m * p.ldaux + n);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= t.get(e);
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] *= rs;

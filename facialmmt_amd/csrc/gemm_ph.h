@@ -3,7 +3,7 @@
 //   y[M,N] = x[M,K] . w[N,K]^T + bias            bf16 operands, fp32 accumulate; Swin stages 1-3 (Swin_Transformer.py:19-28,105-107,142,304)
 //
 // Why another main loop.  linear_nt_p256_kernel passes ONE barrier per K step with all eight waves in the same phase (DMA issue, fragment reads, MFMAs
-// add up: ~3600 cycles per step for 1536 of matrix-pipe work); the first ping-pong form (gemm_pp.h: 32-deep steps on 32x32x16 MFMAs, every fragment of
+// add up: ~3600 cycles per step for 1536 of matrix-pipe work); the first ping-pong form (tools/probes/gemm_pp.h: 32-deep steps on 32x32x16 MFMAs, every fragment of
 // a step read in one LOAD segment) measured no better -- its LOAD segment, not the MFMA segment, was the critical path.  This form follows the phase
 // structure the CDNA4 guide reports at 1.3-1.5 PF/s on square problems:
 //   * one workgroup of 8 waves per CU, tile 256 tokens x 256 channels, waves 2 (tokens) x 4 (channels), wave tile 128 x 64 = 8 x 4 accumulator tiles of
@@ -20,7 +20,7 @@
 //     ONE counted vmcnt per K step (in P4: everything but P4's own two instructions has landed);
 //   * the pipeline is flat over (tile, K step): the staging cursor runs into the workgroup's next tile while the current one is still being multiplied.
 // EPI 0: no output (main loop alone); 1: bias + bf16, whole 128-byte lines through wave-private LDS slabs, all at the tile boundary;
-// 2: the same rows spread over the phases around the tile boundary (drip), non-temporal; 3: drip with GELU, the bf16 pre-activation to y_pre.
+// 2: the same rows spread over the phases around the tile boundary (drip), non-temporal.
 // Requirements: N % 256 == 0, K % 64 == 0, K >= 128, M % 8 == 0, 32-bit byte offsets into x and w.
 #pragma once
 #include <type_traits>
@@ -212,7 +212,6 @@ __global__ __launch_bounds__(512) void linear_nt_ph_kernel(LinArgs p) {
     // instruction is issued (and counted by vmcnt) whatever the row, which the counted waits rely on
     const auto yrs = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (unsigned)p.M * (unsigned)p.ldy * 2u, 0x00020000);
     const auto nullrs = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, 0u, 0x00020000);
-    const auto prs = __builtin_amdgcn_make_buffer_rsrc(p.y_pre ? p.y_pre : p.y, 0, p.y_pre ? (unsigned)p.M * (unsigned)p.ldy * 2u : 0u, 0x00020000);
     const unsigned lane_off = ((unsigned)rr * (unsigned)p.ldy + (unsigned)(rc * 8)) * 2u;     // this lane's 16 bytes inside an 8-row block
     auto store_pair = [&](int a0) {
         // address = descriptor base + SCALAR offset of the 8-row block + lane_off: one address register for the whole kernel (per-row-block
@@ -223,42 +222,24 @@ __global__ __launch_bounds__(512) void linear_nt_ph_kernel(LinArgs p) {
         // store's registers must not be re-used right behind it (see convert_pair).
         // non-temporal: the output streams to memory once; as ordinary write-allocating stores each tile round fills the XCD's L2 with dirty lines and
         // evicts the operand panels the next K steps re-read (125440 x 1536 x 384: 190 -> 135 us, 8192^3: 842 -> 769; `nt sc1` the same, `sc0 sc1` no gain)
-        // two 8-row blocks at a time (EPI 3: their GELU in two more registers each), then a pause before anything may overwrite the stores' data
-        // registers (see convert_pair)
+        // two 8-row blocks at a time, then a pause before anything may overwrite the stores' data registers (see convert_pair).
+        // (Round 5 carried a GELU form here -- EPI 3, GELU of the bf16-ROUNDED pre-activation on the read-back side; it moved the bf16 gradient
+        // statistics past their bar (0.089 -> 0.116 against 0.10) and was never selected; removed in round 6.  GELU epilogues evaluate on the fp32
+        // accumulator: gemm_ph3.h, gemm.hip.)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            bf16x8 gv[2];
-            if constexpr (EPI == 3) {
-                // GELU (+ the pre-activation as a second tensor, same leading dimension): applied to the bf16-rounded pre-activation on the read-back
-                // side -- whole rows, every lane 8 consecutive channels -- which is the value the backward differentiates at
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    float t[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) t[e] = (float)rb[2 * j + i][e];
-                    gelu_inplace<bf16, 2>(t, 8);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) gv[i][e] = (bf16)t[e];
-                }
-            }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int m_blk = em0 + (a0 + j) * 16 + i * 8;                                   // wave-uniform
                 const unsigned soff = ((unsigned)m_blk * (unsigned)p.ldy + (unsigned)en0) * 2u;
                 const bool ok = m_blk < p.M;
-                if constexpr (EPI == 3) {
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rb[2 * j + i]), ok ? prs : nullrs, lane_off, ok ? soff : 0u, 2);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, gv[i]), ok ? yrs : nullrs, lane_off, ok ? soff : 0u, 2);
-                } else {
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rb[2 * j + i]), ok ? yrs : nullrs, lane_off, ok ? soff : 0u, 2);
-                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rb[2 * j + i]), ok ? yrs : nullrs, lane_off, ok ? soff : 0u, 2);
             }
-            if (EPI == 3 || j == 1) {
+            if (j == 1) {
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_sleep(2);                   // ~128 cycles
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if constexpr (EPI == 3) asm volatile("" ::"v"(gv[0]), "v"(gv[1]));
         }
     };
 
@@ -323,8 +304,7 @@ __global__ __launch_bounds__(512) void linear_nt_ph_kernel(LinArgs p) {
         stage(0, s & 1);                                       // W0 of step s + 2 into the buffer whose channel half-tiles were last read in P2
         // everything of step s + 1 has landed (this wave's part); younger and allowed in flight: P4's own two DMA instructions and, in the
         // steps around a tile boundary, the four stores of this step's P3
-        if constexpr ((FIRST || LAST) && EPI == 3) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      // eight stores in this step's P3
-        else if constexpr (FIRST || LAST) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if constexpr (FIRST || LAST) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         bar();
         quadrant(1, 0, ZERO_);

@@ -16,7 +16,9 @@
 //     phases after its last fragment read):  P1(s): X(s+1) (3 DMA instructions per wave) | P3(s): W0, W1(s+2) (4) and the step's ONE counted vmcnt.
 // EPI 0: no output (main loop alone); 2: bias, bf16, non-temporal whole rows; 3: GELU of the fp32 value (+ the bf16 pre-activation to y_pre);
 // 4: y = value * gelu'(aux) (fc2's input gradient); 5: y = res + rowscale[row / rows_per_scale] * (value + bias) (proj / fc2 forward, res or rowscale may be
-// absent).  4 and 5 read their M x N operand as WHOLE ROWS on the epilogue's read-back side (16 bytes per lane, 8 lanes per 128-byte line), requested three
+// absent); 6: y = value * aux * rowscale (FMMT_EPI_MUL_AUX: fc2's input gradient against the STORED derivative -- EPI 5's read-back path with a product instead
+// of a sum; round 6: the GELU' launches of stages 2 / 3 had been the step's slowest GEMMs, 0.19 of their roofline, on the round-2 kernels).
+// 4, 5 and 6 read their M x N operand as WHOLE ROWS on the epilogue's read-back side (16 bytes per lane, 8 lanes per 128-byte line), requested three
 // phases before they are used; they need K >= 192.
 // Requirements: N % 256 == 0, K % 64 == 0, K >= 128, M % 8 == 0, 32-bit byte offsets into x, w, y.
 #pragma once
@@ -29,47 +31,15 @@ template <int OFF> __device__ __forceinline__ void q3_rd(bf16x8& dst, unsigned a
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
 }
 
-// GELU / GELU' of 8 values with PLAIN single-issue FMAs.  The packed form of fmmt_common.h keeps its 2 x 10 coefficients in vector registers for the whole
-// kernel (the compiler hoists them): 132 registers spilled in this kernel.  A plain v_fma_f32 takes its coefficient as a literal, and beside the partner
-// wave's MFMAs on the same SIMD it is the cheaper instruction anyway (profiles/r05_issue_rates.txt).  Same polynomials, same coefficients.
-// (the coefficient tables are indexed directly, with compile-time indices: handed over by reference they were copied to scratch memory and re-loaded)
-template <bool GRAD, int NE>
-__device__ __forceinline__ void q3_odd_poly(const float (&x)[NE], float (&out)[NE]) {
-    constexpr int N = GRAD ? 10 : 8;
-    constexpr float R = GRAD ? FMMT_GELU_GRAD_R : FMMT_GELU_PHI_R;
-    auto cf = [](auto K_) -> float {
-        constexpr int k = decltype(K_)::value;
-        if constexpr (GRAD) return fmmt_gelu_grad_poly[k];
-        else return fmmt_gelu_phi_poly[k];
-    };
-    float xc[NE], u[NE], q[NE];
-#pragma unroll
-    for (int j = 0; j < NE; ++j) xc[j] = __builtin_amdgcn_fmed3f(x[j], -R, R);
-#pragma unroll
-    for (int j = 0; j < NE; ++j) u[j] = __builtin_fmaf(xc[j] * xc[j], 2.0f / (R * R), -1.0f);
-#pragma unroll
-    for (int j = 0; j < NE; ++j) q[j] = __builtin_fmaf(u[j], cf(std::integral_constant<int, N - 1>{}), cf(std::integral_constant<int, N - 2>{}));
-    auto horner = [&](auto K_) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < NE; ++j) q[j] = __builtin_fmaf(q[j], u[j], cf(K_));
-    };
-    if constexpr (GRAD) { horner(std::integral_constant<int, 7>{}); horner(std::integral_constant<int, 6>{}); }
-    horner(std::integral_constant<int, 5>{}); horner(std::integral_constant<int, 4>{}); horner(std::integral_constant<int, 3>{});
-    horner(std::integral_constant<int, 2>{}); horner(std::integral_constant<int, 1>{}); horner(std::integral_constant<int, 0>{});
-#pragma unroll
-    for (int j = 0; j < NE; ++j) out[j] = __builtin_fmaf(q[j], xc[j], 0.5f);
-}
+// GELU / GELU' of NE values: the forms of fmmt_common.h (one v_exp_f32 + plain FMAs whose coefficients are literals -- nothing to hoist into registers;
+// round 5 carried its own copy of the packed odd polynomials here because those kept 2 x 10 coefficient registers alive for the whole kernel)
 template <int NE> __device__ __forceinline__ void q3_gelu(float (&v)[NE]) {
-    float ph[NE];
-    q3_odd_poly<false, NE>(v, ph);
 #pragma unroll
-    for (int j = 0; j < NE; ++j) v[j] *= ph[j];
+    for (int j = 0; j < NE; ++j) v[j] = gelu_exp_f(v[j]);
 }
 template <int NE> __device__ __forceinline__ void q3_gelu_grad_mul(float (&v)[NE], const float (&pre)[NE]) {
-    float g[NE];
-    q3_odd_poly<true, NE>(pre, g);
 #pragma unroll
-    for (int j = 0; j < NE; ++j) v[j] *= g[j];
+    for (int j = 0; j < NE; ++j) v[j] *= gelu_grad_exp_f(pre[j]);
 }
 
 template <int EPI = 2, bool STAGGER = true, int WT = 2>
@@ -193,7 +163,7 @@ __global__ __launch_bounds__(512) void linear_nt_ph3_kernel(LinArgs p) {
     // ---- drip epilogue ----
     bf16x8 rb[4];
     bf16x8 rg[4];                                              // EPI 3: the GELU rows beside the pre-activation rows in rb
-    float rsv[4];                                              // EPI 5: DropPath scale of the four 8-row blocks' rows
+    float rsv[4];                                              // EPI 5 / 6: DropPath scale of the four 8-row blocks' rows
     float* const rslab = reinterpret_cast<float*>(smem + 2 * BUF + 8 * (16 * 144) + 8 * 512) + wave * 256;   // two 128-float slots by tile parity: rowscale of this wave's 96 rows
     int em0 = 0, en0 = 0;
     char* const wslab = smem + 2 * BUF + wave * (16 * 144);
@@ -249,7 +219,7 @@ __global__ __launch_bounds__(512) void linear_nt_ph3_kernel(LinArgs p) {
                 for (int h = 0; h < 2; ++h) rg[2 * t + h] = *reinterpret_cast<const bf16x8*>(wslab + (h * 8 + rr) * 144 + rc * 16);
             }
         }
-        if constexpr (EPI == 5) {
+        if constexpr (EPI == 5 || EPI == 6) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) rsv[i] = p_rowscale ? rslab[par * 128 + (a0 + (i >> 1)) * 16 + (i & 1) * 8 + rr] : 1.0f;
         }
@@ -259,9 +229,9 @@ __global__ __launch_bounds__(512) void linear_nt_ph3_kernel(LinArgs p) {
     const auto prs = __builtin_amdgcn_make_buffer_rsrc(p_y_pre ? p_y_pre : p_y, 0, p_y_pre ? (unsigned)p_M * (unsigned)p_ldy * 2u : 0u, 0x00020000);
     const unsigned lane_off = ((unsigned)rr * (unsigned)p_ldy + (unsigned)(rc * 8)) * 2u;
     // operand of the read-back side (EPI 4: aux, EPI 5: res; an absent one: empty descriptor, loads return zero -- the instruction count stays fixed)
-    constexpr bool OPS = EPI == 4 || EPI == 5;
-    const void* const opp = EPI == 4 ? p_aux : p_res;
-    const int ldop = EPI == 4 ? p_ldaux : p_ldres;
+    constexpr bool OPS = EPI == 4 || EPI == 5 || EPI == 6;
+    const void* const opp = (EPI == 4 || EPI == 6) ? p_aux : p_res;
+    const int ldop = (EPI == 4 || EPI == 6) ? p_ldaux : p_ldres;
     const auto ors = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(opp ? opp : p_y), 0, opp ? (unsigned)p_M * (unsigned)ldop * 2u : 0u, 0x00020000);
     const unsigned lane_off_op = ((unsigned)rr * (unsigned)ldop + (unsigned)(rc * 8)) * 2u;
     u32x4 op0[4], op1[4];                                      // operand rows: op0 = pair A, then pair C; op1 = pair B
@@ -296,6 +266,9 @@ __global__ __launch_bounds__(512) void linear_nt_ph3_kernel(LinArgs p) {
                     for (int e = 0; e < 4; ++e) { v[e] = (float)rb[i][4 * hf + e]; a[e] = (float)o[4 * hf + e]; }
                     if constexpr (EPI == 4) {
                         q3_gelu_grad_mul<4>(v, a);
+                    } else if constexpr (EPI == 6) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = a[e] * (rsv[i] * v[e]);
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = a[e] + rsv[i] * v[e];
@@ -356,7 +329,7 @@ __global__ __launch_bounds__(512) void linear_nt_ph3_kernel(LinArgs p) {
             q3_rd<3 * 2048>(cf[3][0], w0); q3_rd<3 * 2048>(cf[3][1], w1);
         }
         if constexpr (ZERO && EPI >= 2) stage_bias(ct, bpar);
-        if constexpr (ZERO && EPI == 5) stage_rowscale(ct, bpar);
+        if constexpr (ZERO && (EPI == 5 || EPI == 6)) stage_rowscale(ct, bpar);
         stage_x((s + 1) & 1);                                  // token rows of step s + 1 (cursor) into the other buffer: last read in P2 of step s - 1
         bar();
         landed();
@@ -451,7 +424,7 @@ int launch_ph3(const LinArgs& a, hipStream_t st, int grid = 256) {
     static_assert(lds <= 160 * 1024, "LDS");
     static FmmtLdsOnce lds_once;
     if (int rc_ = lds_once.set(reinterpret_cast<const void*>(&linear_nt_ph3_kernel<EPI, STAGGER, WT>), lds)) return rc_;
-    if (a.N % BN || a.K % 64 || a.K < 128 || ((EPI == 4 || EPI == 5) && a.K < 192)) return FMMT_EINVAL;
+    if (a.N % BN || a.K % 64 || a.K < 128 || ((EPI == 4 || EPI == 5 || EPI == 6) && a.K < 192)) return FMMT_EINVAL;
     LinArgs p = a;
     p.tiles_m = (a.M + BM - 1) / BM;
     p.tiles_n = a.N / BN;

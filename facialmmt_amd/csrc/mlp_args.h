@@ -26,6 +26,7 @@ struct MlpArgs {                                              // (global: it cro
     // LN-backward epilogue of the input-gradient kernel (fmmt_mlp_ln_bwd_input): the LayerNorm's input, and per-workgroup partial sums
     const bf16* ln_x;
     float* ln_part;
+    int dg;                                                   // FMMT_SAVE_DG: h_pre is gelu'(pre-activation), not the pre-activation (forward: written; backward: read)
 };
 
 // mlp_ref.hip: the generic instantiations (el = FMMT_F32 / FMMT_BF16; the activation / weight pointers of MlpArgs reinterpreted)

@@ -33,7 +33,9 @@ namespace {
 //  13 %, the training forms, whose time goes into the hidden-tensor stores, lose 0-19 % to the 20 spilled registers.)
 // FULL: M is a multiple of the 256-token tile -- no token guard anywhere, the stage body is branch-free (the stores of a ragged tail
 // are conditional: branches, which end the compiler's scheduling regions inside the stage)
-template <int C, bool LN, bool FULL>
+// DG (FMMT_SAVE_DG, round 6): h_pre receives gelu'(pre-activation) instead of the pre-activation -- the one thing the backward wants of it -- formed beside
+// gelu() from the same exponential (fmmt_common.h, gelu_both_exp_f); the backward kernel then multiplies instead of evaluating a polynomial.
+template <int C, bool LN, bool FULL, bool DG = false>
 __global__ __launch_bounds__(512) void mlp_fused_fwd_kernel(MlpArgs p) {
     using T = bf16;
     constexpr int H = 4 * C, HS = 64, NS = H / HS;          // hidden channels per ring stage, stages per tile
@@ -290,9 +292,16 @@ __global__ __launch_bounds__(512) void mlp_fused_fwd_kernel(MlpArgs p) {
                     v[r] = acc1[mt][0][r] + bb[0][r];
                     v[4 + r] = acc1[mt][1][r] + bb[1][r];
                 }
+                if constexpr (DG) {
+                    float d[8];
+                    gelu_both_inplace<T>(v, d, 8);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) pre[mt][e] = (bf16)v[e];
-                gelu_inplace<T>(v, 8);                       // packed polynomial (fmmt_common.h): FMAs only, no table, no wait
+                    for (int e = 0; e < 8; ++e) pre[mt][e] = (bf16)d[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pre[mt][e] = (bf16)v[e];
+                    gelu_inplace<T>(v, 8);                   // fmmt_common.h: FMAs and one v_exp_f32, no table, no wait
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) hf[mt][e] = (bf16)v[e];
             }
@@ -388,9 +397,21 @@ __global__ __launch_bounds__(512) void mlp_fused_fwd_kernel(MlpArgs p) {
                 }
                 const int tok = t0 + mt * 16 + li;
                 bf16x8 pre8;
+                if constexpr (DG) {
+                    // four values at a time, the derivative rounded at once: eight chains in lockstep keep ~50 temporaries alive (34 registers spilled at C = 192)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) pre8[e] = (bf16)v[e];
-                gelu_inplace<T, C == 96 ? 4 : 2>(v, 8);      // packed polynomial (fmmt_common.h): FMAs only, no table, no wait
+                    for (int q = 0; q < 2; ++q) {
+                        float d[4];
+                        gelu_both_inplace<T>(v + 4 * q, d, 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pre8[4 * q + e] = (bf16)d[e];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pre8[e] = (bf16)v[e];
+                    gelu_inplace<T, C == 96 ? 4 : 2>(v, 8);  // fmmt_common.h: FMAs and one v_exp_f32, no table, no wait
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) hf[mt][e] = (bf16)v[e];
                 if (blk == 0) {
@@ -486,7 +507,8 @@ __device__ __forceinline__ float row16_sum(float v) {
 // last step's AUX wait (vmcnt(CNT + 4), or 0 at the tail) then covers them, they are older than everything it lets fly.
 // d(gamma) / d(beta): in-lane products, summed over the row's 16 tokens by DPP (fixed order), each of the 48 values kept by the lane
 // li == v % 16 (3 registers); per-wave slots -> fixed-order sum over the waves -> one row of partial sums per workgroup.
-template <int C, bool LNB = false>
+// DG: p.h_pre holds gelu'(pre-activation) (the forward's FMMT_SAVE_DG form): epilogue 1 is a product.
+template <int C, bool LNB = false, bool DG = false>
 __global__ __launch_bounds__(512) void mlp_fused_bwd_kernel(MlpArgs p) {
     using T = bf16;
     constexpr int H = 4 * C, HS = 64, NS = H / HS;
@@ -674,7 +696,12 @@ __global__ __launch_bounds__(512) void mlp_fused_bwd_kernel(MlpArgs p) {
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) ax[e] = (float)cur[mt * 2 + blk][e];
-                gelu_grad_mul_inplace<T, C == 96 ? 4 : 2>(v, ax, 8);   // v *= gelu'(pre): packed polynomial (fmmt_common.h)
+                if constexpr (DG) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= ax[e];
+                } else {
+                    gelu_grad_mul_inplace<T, C == 96 ? 4 : 2>(v, ax, 8);   // v *= gelu'(pre) (fmmt_common.h)
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) hf[mt][e] = (bf16)(v[e] * rsv[mt]);
                 const int tok = t0 + mt * 16 + li;
@@ -805,34 +832,35 @@ __global__ __launch_bounds__(1024) void mlp_ln_part_reduce_kernel(const float* _
     }
 }
 
-template <int C, bool LNB = false>
+template <int C, bool LNB = false, bool DG = false>
 int launch_mlp_bwd(const MlpArgs& a0, hipStream_t st) {
     constexpr size_t lds = (size_t)3 * (((C / 32) * 64 * 32 + 2 * C * 32) * 2) + (LNB ? C * sizeof(float) : 0);
     static_assert(lds <= 160 * 1024, "LDS");
     static FmmtLdsOnce lds_once;
-    if (int rc_ = lds_once.set(reinterpret_cast<const void*>(&mlp_fused_bwd_kernel<C, LNB>), (int)lds)) return rc_;
+    if (int rc_ = lds_once.set(reinterpret_cast<const void*>(&mlp_fused_bwd_kernel<C, LNB, DG>), (int)lds)) return rc_;
     MlpArgs a = a0;
     constexpr int TT = C == 96 ? 256 : 128;                  // tokens per tile (the kernel's MTW)
     a.tiles = (a.M + TT - 1) / TT;
     const int grid = a.tiles < 256 ? a.tiles : 256;
-    hipLaunchKernelGGL((mlp_fused_bwd_kernel<C, LNB>), dim3(grid), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((mlp_fused_bwd_kernel<C, LNB, DG>), dim3(grid), dim3(512), lds, st, a);
     FMMT_CHECK_LAUNCH();
     return 0;
 }
 
-template <int C, bool LN, bool FULL>
+template <int C, bool LN, bool FULL, bool DG>
 int launch_mlp_f(const MlpArgs& a, hipStream_t st) {
     constexpr size_t lds = (size_t)3 * (((C / 32) * 64 * 32 + 2 * C * 32) * 2 + 1024);
     static FmmtLdsOnce lds_once;
-    if (int rc_ = lds_once.set(reinterpret_cast<const void*>(&mlp_fused_fwd_kernel<C, LN, FULL>), (int)lds)) return rc_;
+    if (int rc_ = lds_once.set(reinterpret_cast<const void*>(&mlp_fused_fwd_kernel<C, LN, FULL, DG>), (int)lds)) return rc_;
     const int grid = a.tiles < 256 ? a.tiles : 256;
-    hipLaunchKernelGGL((mlp_fused_fwd_kernel<C, LN, FULL>), dim3(grid), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((mlp_fused_fwd_kernel<C, LN, FULL, DG>), dim3(grid), dim3(512), lds, st, a);
     FMMT_CHECK_LAUNCH();
     return 0;
 }
 template <int C, bool LN>
 int launch_mlp(const MlpArgs& a, hipStream_t st) {
-    return a.M % 256 == 0 ? launch_mlp_f<C, LN, true>(a, st) : launch_mlp_f<C, LN, false>(a, st);
+    if (a.dg) return a.M % 256 == 0 ? launch_mlp_f<C, LN, true, true>(a, st) : launch_mlp_f<C, LN, false, true>(a, st);
+    return a.M % 256 == 0 ? launch_mlp_f<C, LN, true, false>(a, st) : launch_mlp_f<C, LN, false, false>(a, st);
 }
 
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -848,6 +876,7 @@ extern "C" int fmmt_mlp_fwd(int dtype, int M, int C, const void* x, const void* 
     if (rowscale && rows_per_scale <= 0) return FMMT_EINVAL;
     if (!al16(x) || !al16(w1) || !al16(b1) || !al16(w2) || !al16(b2) || !al16(y) || (res && !al16(res)) || (h_pre && !al16(h_pre)) || (h_act && !al16(h_act))) return FMMT_EALIGN;
     MlpArgs a{M, (const bf16*)x, (const bf16*)w1, b1, (const bf16*)w2, b2, (const bf16*)res, rowscale, rows_per_scale, (bf16*)y, (bf16*)h_pre, (bf16*)h_act, (M + 255) / 256};
+    a.dg = (dtype & FMMT_SAVE_DG) ? 1 : 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (generic) return fmmt_mlp_ref_fwd_launch(el, C, false, a, st);
     return C == 96 ? launch_mlp<96, false>(a, st) : launch_mlp<192, false>(a, st);
@@ -865,6 +894,7 @@ extern "C" int fmmt_mlp_ln_fwd(int dtype, int M, int C, const void* x, const flo
         (h_pre && !al16(h_pre)) || (h_act && !al16(h_act))) return FMMT_EALIGN;
     MlpArgs a{M, (const bf16*)x, (const bf16*)w1, b1, (const bf16*)w2, b2, nullptr, rowscale, rows_per_scale, (bf16*)y, (bf16*)h_pre, (bf16*)h_act, (M + 255) / 256,
               ln_gamma, ln_beta, eps, (bf16*)xn, mean, rstd};
+    a.dg = (dtype & FMMT_SAVE_DG) ? 1 : 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (generic) return fmmt_mlp_ref_fwd_launch(el, C, true, a, st);
     return C == 96 ? launch_mlp<96, true>(a, st) : launch_mlp<192, true>(a, st);
@@ -880,8 +910,10 @@ extern "C" int fmmt_mlp_bwd_input(int dtype, int M, int C, const void* dy, const
     MlpArgs a{};
     a.M = M; a.x = (const bf16*)dy; a.w1 = (const bf16*)w2t; a.w2 = (const bf16*)w1t; a.rowscale = rowscale; a.rows_per_scale = rows_per_scale;
     a.y = (bf16*)dx; a.h_pre = (bf16*)const_cast<void*>(h_pre); a.h_act = (bf16*)dh; a.tiles = (M + 255) / 256;
+    a.dg = (dtype & FMMT_SAVE_DG) ? 1 : 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (generic) return fmmt_mlp_ref_bwd_launch(el, C, false, a, st);
+    if (a.dg) return C == 96 ? launch_mlp_bwd<96, false, true>(a, st) : launch_mlp_bwd<192, false, true>(a, st);
     return C == 96 ? launch_mlp_bwd<96>(a, st) : launch_mlp_bwd<192>(a, st);
 }
 
@@ -902,6 +934,7 @@ extern "C" int fmmt_mlp_ln_bwd_input(int dtype, int M, int C, const void* dy, co
     a.M = M; a.x = (const bf16*)dy; a.w1 = (const bf16*)w2t; a.w2 = (const bf16*)w1t; a.rowscale = rowscale; a.rows_per_scale = rows_per_scale;
     a.y = (bf16*)dx; a.h_pre = (bf16*)const_cast<void*>(h_pre); a.h_act = (bf16*)dh; a.tiles = (M + 255) / 256;
     a.ln_g = ln_gamma; a.mean = const_cast<float*>(mean); a.rstd = const_cast<float*>(rstd); a.ln_x = (const bf16*)x; a.ln_part = (float*)workspace;
+    a.dg = (dtype & FMMT_SAVE_DG) ? 1 : 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (generic) {
         if (int rc = fmmt_mlp_ref_bwd_launch(el, C, true, a, st)) return rc;
@@ -910,7 +943,8 @@ extern "C" int fmmt_mlp_ln_bwd_input(int dtype, int M, int C, const void* dy, co
         FMMT_CHECK_LAUNCH();
         return 0;
     }
-    if (int rc = C == 96 ? launch_mlp_bwd<96, true>(a, st) : launch_mlp_bwd<192, true>(a, st)) return rc;
+    if (int rc = a.dg ? (C == 96 ? launch_mlp_bwd<96, true, true>(a, st) : launch_mlp_bwd<192, true, true>(a, st))
+                      : (C == 96 ? launch_mlp_bwd<96, true>(a, st) : launch_mlp_bwd<192, true>(a, st))) return rc;
     const int tiles = (M + (C == 96 ? 256 : 128) - 1) / (C == 96 ? 256 : 128), grid = tiles < 256 ? tiles : 256;
     hipLaunchKernelGGL(mlp_ln_part_reduce_kernel, dim3((2 * C + 63) / 64), dim3(1024), 0, st, (const float*)workspace, grid, C, dgamma, dbeta);
     FMMT_CHECK_LAUNCH();

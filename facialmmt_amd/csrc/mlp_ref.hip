@@ -137,9 +137,16 @@ __global__ __launch_bounds__(512) void mlp_ref_fwd_kernel(MlpArgs p) {
                     }
                     const int tok = t0 + mt * 16 + li;
                     F pre8;
+                    if (p.dg) {                              // FMMT_SAVE_DG: the derivative in place of the pre-activation (production: mlp_fused.hip, DG)
+                        float d[8];
+                        gelu_both_inplace<T>(v, d, 8);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) pre8[e] = E::cv(v[e]);
-                    gelu_inplace<T>(v, 8);                   // fp32: erff; bf16: the production kernels' packed polynomial (fmmt_common.h)
+                        for (int e = 0; e < 8; ++e) pre8[e] = E::cv(d[e]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) pre8[e] = E::cv(v[e]);
+                        gelu_inplace<T>(v, 8);               // fp32: erff; bf16: the production kernels' form (fmmt_common.h)
+                    }
 #pragma unroll
                     for (int e = 0; e < 8; ++e) hf[mt][e] = E::cv(v[e]);
                     if (tok < p.M) {
@@ -235,7 +242,12 @@ __global__ __launch_bounds__(512) void mlp_ref_bwd_kernel(MlpArgs p) {
                         a[e] = e < 4 ? acc1[mt][0][e] : acc1[mt][1][e - 4];
                         pre[e] = (float)ax[e];
                     }
-                    gelu_grad_mul_inplace<T>(a, pre, 8);     // fp32: erff / expf; bf16: the production kernels' packed polynomial
+                    if (p.dg) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) a[e] *= pre[e];
+                    } else {
+                        gelu_grad_mul_inplace<T>(a, pre, 8); // fp32: erff / expf; bf16: the production kernels' form
+                    }
 #pragma unroll
                     for (int e = 0; e < 8; ++e) hf[mt][e] = E::cv(a[e] * rsv[mt]);
                     if (tok < p.M) E::st(dhg + (size_t)tok * H + h0 + lg * 8, hf[mt]);

@@ -11,7 +11,7 @@ import torch
 from torch.autograd import Function
 
 from . import _lib
-from ._lib import EPI_GELU, EPI_GELU_BWD, EPI_NONE, check, dtype_code
+from ._lib import EPI_GELU, EPI_GELU_BWD, EPI_GELU_DG, EPI_MUL_AUX, EPI_NONE, SAVE_DG, check, dtype_code
 
 
 def _st():
@@ -468,11 +468,11 @@ class PlmQkvFn(torch.autograd.Function):
         return dx, dw[:E], dw[E:2 * E], dw[2 * E:], db[:E], db[E:2 * E], db[2 * E:], None, None
 
 
-def mlp_fused_raw(x2, w1l, b1, w2l, b2, res2, rowscale, rows_per_scale, h_pre, h_act=None):
-    """one launch: y = res + rowscale * (gelu(x W1^T + b1) W2^T + b2); h_pre / h_act (or None) receive the pre-activation / activation"""
+def mlp_fused_raw(x2, w1l, b1, w2l, b2, res2, rowscale, rows_per_scale, h_pre, h_act=None, dg=False):
+    """one launch: y = res + rowscale * (gelu(x W1^T + b1) W2^T + b2); h_pre / h_act (or None) receive the pre-activation (dg: its gelu') / activation"""
     M, C = x2.shape
     y = torch.empty((M, C), dtype=x2.dtype, device=x2.device)
-    rc = _lib.load().fmmt_mlp_fwd(dtype_code(x2.dtype), M, C, _p(x2), _p(w1l), _p(b1), _p(w2l), _p(b2), _p(res2), _p(rowscale), rows_per_scale,
+    rc = _lib.load().fmmt_mlp_fwd(dtype_code(x2.dtype) | (SAVE_DG if dg else 0), M, C, _p(x2), _p(w1l), _p(b1), _p(w2l), _p(b2), _p(res2), _p(rowscale), rows_per_scale,
                                   _p(y), _p(h_pre), _p(h_act), _st())
     check(rc, f"fmmt_mlp_fwd(M={M},C={C})")
     return y
@@ -489,6 +489,9 @@ def _mlp_dtype_ok(dt):
 # The fused forward also stores the activation and fc2's weight gradient reads it (storing only the pre-activation and recomputing
 # gelu() while the weight-gradient kernel stages its operand measured slower: 0.75 vs 0.40 ms per stage-0 launch; round 2)
 _MLP_SAVE_H = True
+# Every Mlp saves gelu'(pre-activation) instead of the pre-activation (round 6: FMMT_EPI_GELU_DG / FMMT_EPI_MUL_AUX, FMMT_SAVE_DG; False: the pre-activation and a
+# GELU' evaluation in the backward, as before)
+_MLP_SAVE_DG = True
 
 
 def _mlp_fusable(x2, w1, w2, b1, b2):
@@ -513,9 +516,14 @@ class MlpFn(Function):
             # Swin stages 0 / 1: the whole Mlp in one launch, hidden activation kept on chip (csrc/mlp_fused.hip); the
             # backward recomputes gelu(h_pre) inside the weight-gradient kernel instead of reading a stored activation
             h = torch.empty_like(h_pre) if (train and _MLP_SAVE_H) else None
-            y = mlp_fused_raw(x2, w1l, b1.detach().float().contiguous(), w2l, b2.detach().float().contiguous(), res2, rowscale, rows_per_scale, h_pre, h)
+            ctx.dg = _MLP_SAVE_DG and _MLP_SAVE_H
+            y = mlp_fused_raw(x2, w1l, b1.detach().float().contiguous(), w2l, b2.detach().float().contiguous(), res2, rowscale, rows_per_scale, h_pre, h, ctx.dg)
         else:
-            h = linear_raw(x2, w1l, b1.detach(), epi=EPI_GELU, y_pre=h_pre)
+            # Swin stages 2 / 3 (and any other width): two GEMM launches.  The only thing the backward needs of the pre-activation is gelu'(.) of it,
+            # so the forward's epilogue -- which evaluates gelu() there anyway, and shares its exponential -- stores THAT (FMMT_EPI_GELU_DG) and the
+            # backward's input-gradient GEMM multiplies by it (FMMT_EPI_MUL_AUX: no polynomial in the epilogue, so it runs on the phase kernels)
+            ctx.dg = _MLP_SAVE_DG and _MLP_SAVE_H
+            h = linear_raw(x2, w1l, b1.detach(), epi=EPI_GELU_DG if ctx.dg else EPI_GELU, y_pre=h_pre)
             y = linear_raw(h, w2l, b2.detach(), res=res2, rowscale=rowscale, rows_per_scale=rows_per_scale)
         ctx.save_for_backward(x2, w1, w2, h_pre, h, rowscale)
         ctx.rps = rows_per_scale
@@ -528,7 +536,8 @@ class MlpFn(Function):
         x2, w1, w2, h_pre, h, rowscale = ctx.saved_tensors
         dy2 = dy.reshape(-1, w2.shape[0]).contiguous()
         # d(h_pre) = (s * dy @ W2) * gelu'(h_pre)   [fused epilogue]
-        dh = linear_raw(dy2, _lp(w2, dy2.dtype, transpose=True), None, epi=EPI_GELU_BWD, aux=h_pre, rowscale=rowscale,
+        # (ctx.dg: h_pre holds the derivative itself)
+        dh = linear_raw(dy2, _lp(w2, dy2.dtype, transpose=True), None, epi=EPI_MUL_AUX if ctx.dg else EPI_GELU_BWD, aux=h_pre, rowscale=rowscale,
                         rows_per_scale=ctx.rps)
         dw2, db2 = wgrad_raw(dy2, h, True, rowscale, ctx.rps) if h is not None else wgrad_raw(dy2, h_pre, True, rowscale, ctx.rps, x_gelu=True)
         dx = linear_raw(dh, _lp(w1, dy2.dtype, transpose=True), None).reshape(ctx.xshape) if ctx.needs_input_grad[0] else None
@@ -543,18 +552,18 @@ _MLP_BWD_WIDTHS = (96, 192)  # stage 0 and stage 1 (round 4: stage 1 measured 0.
 _MLP_BWD_LN = True           # False = fmmt_mlp_bwd_input + fmmt_layernorm_bwd
 
 
-def mlp_bwd_input_raw(dy2, h_pre, w1, w2, rowscale, rows_per_scale):
-    """(dh, dx) of the Mlp: one launch where the fused kernel applies (bf16, C = 96), the two GEMM launches otherwise"""
+def mlp_bwd_input_raw(dy2, h_pre, w1, w2, rowscale, rows_per_scale, dg=False):
+    """(dh, dx) of the Mlp: one launch where the fused kernel applies (bf16, C = 96), the two GEMM launches otherwise.  dg: h_pre holds gelu'(pre-activation)"""
     M, C = dy2.shape
     dt = dy2.dtype
     if _MLP_BWD_FUSED and _mlp_dtype_ok(dt) and C in _MLP_BWD_WIDTHS and w1.shape == (4 * C, C) and M >= 4096:
         dh = torch.empty((M, 4 * C), dtype=dt, device=dy2.device)
         dx = torch.empty_like(dy2)
-        rc = _lib.load().fmmt_mlp_bwd_input(dtype_code(dt), M, C, _p(dy2), _p(h_pre), _p(_lp(w2, dt, transpose=True)), _p(_lp(w1, dt, transpose=True)),
+        rc = _lib.load().fmmt_mlp_bwd_input(dtype_code(dt) | (SAVE_DG if dg else 0), M, C, _p(dy2), _p(h_pre), _p(_lp(w2, dt, transpose=True)), _p(_lp(w1, dt, transpose=True)),
                                             _p(rowscale), rows_per_scale, _p(dh), _p(dx), _st())
         check(rc, f"fmmt_mlp_bwd_input(M={M},C={C})")
         return dh, dx
-    dh = linear_raw(dy2, _lp(w2, dt, transpose=True), None, epi=EPI_GELU_BWD, aux=h_pre, rowscale=rowscale, rows_per_scale=rows_per_scale)
+    dh = linear_raw(dy2, _lp(w2, dt, transpose=True), None, epi=EPI_MUL_AUX if dg else EPI_GELU_BWD, aux=h_pre, rowscale=rowscale, rows_per_scale=rows_per_scale)
     return dh, linear_raw(dh, _lp(w1, dt, transpose=True), None)
 
 
@@ -578,7 +587,8 @@ class MlpLnFn(Function):
         rstd = torch.empty(M, dtype=torch.float32, device=dev) if train else None
         h_pre = torch.empty((M, 4 * C), dtype=x.dtype, device=dev) if train else None
         h = torch.empty_like(h_pre) if train else None
-        rc = _lib.load().fmmt_mlp_ln_fwd(dtype_code(x.dtype), M, C, _p(x2), _p(g), _p(b), float(eps), _p(_lp(w1, x.dtype)), _p(b1.detach().float().contiguous()),
+        ctx.dg = bool(train and _MLP_SAVE_DG)
+        rc = _lib.load().fmmt_mlp_ln_fwd(dtype_code(x.dtype) | (SAVE_DG if ctx.dg else 0), M, C, _p(x2), _p(g), _p(b), float(eps), _p(_lp(w1, x.dtype)), _p(b1.detach().float().contiguous()),
                                          _p(_lp(w2, x.dtype)), _p(b2.detach().float().contiguous()), _p(rowscale), rows_per_scale, _p(y), _p(xn), _p(mean), _p(rstd),
                                          _p(h_pre), _p(h), _st())
         check(rc, f"fmmt_mlp_ln_fwd(M={M},C={C})")
@@ -602,13 +612,13 @@ class MlpLnFn(Function):
             db = torch.empty(C, dtype=torch.float32, device=x2.device)
             nbytes = lib.fmmt_mlp_ln_bwd_input_workspace(C)
             ws = _ws(nbytes, x2.device)
-            rc = lib.fmmt_mlp_ln_bwd_input(dtype_code(dt), M, C, _p(dy2), _p(h_pre), _p(_lp(w2, dt, transpose=True)), _p(_lp(w1, dt, transpose=True)),
+            rc = lib.fmmt_mlp_ln_bwd_input(dtype_code(dt) | (SAVE_DG if ctx.dg else 0), M, C, _p(dy2), _p(h_pre), _p(_lp(w2, dt, transpose=True)), _p(_lp(w1, dt, transpose=True)),
                                            _p(rowscale), ctx.rps, _p(x2), _p(mean), _p(rstd), _p(g), _p(dh), _p(dx), _p(dg), _p(db), _p(ws), nbytes, _st())
             check(rc, f"fmmt_mlp_ln_bwd_input(M={M},C={C})")
             dw2, db2 = wgrad_raw(dy2, h, True, rowscale, ctx.rps)
             dw1, db1 = wgrad_raw(dh, xn, True)
             return dx.reshape(ctx.xshape), dg, db, None, dw1, db1, dw2, db2, None, None, None
-        dh, dxn = mlp_bwd_input_raw(dy2, h_pre, w1, w2, rowscale, ctx.rps)
+        dh, dxn = mlp_bwd_input_raw(dy2, h_pre, w1, w2, rowscale, ctx.rps, ctx.dg)
         dw2, db2 = wgrad_raw(dy2, h, True, rowscale, ctx.rps)
         dw1, db1 = wgrad_raw(dh, xn, True)
         del dh
@@ -1237,7 +1247,15 @@ def select_frames(preds, vision_inputs, vision_mask, num_imgs, threshold):
 # ------------------------------------------------------------------------------------------------
 # dropout seeds: one device draw per scope instead of one per call site
 # ------------------------------------------------------------------------------------------------
-_SEED_SCOPES: list = []
+import threading as _threading
+
+
+class _SeedScopes(_threading.local):                         # per thread: a scope opened by one thread never feeds another thread's draws
+    def __init__(self):
+        self.stack = []
+
+
+_SEED_TLS = _SeedScopes()
 
 
 class seed_scope:
@@ -1254,19 +1272,19 @@ class seed_scope:
         if self.enabled:
             self.words = torch.randint(0, 2 ** 62, (self.n,), device=self.device, dtype=torch.int64)
             self.next = 0
-            _SEED_SCOPES.append(self)
+            _SEED_TLS.stack.append(self)
         return self
 
     def __exit__(self, *exc):
         if self.enabled:
-            _SEED_SCOPES.remove(self)
+            _SEED_TLS.stack.remove(self)
         return False
 
 
 def draw_seed(device, n: int = 1):
     """n (default 1) device-resident int64 dropout seed words (see seed_scope)"""
-    if _SEED_SCOPES:
-        sc = _SEED_SCOPES[-1]
+    if _SEED_TLS.stack:
+        sc = _SEED_TLS.stack[-1]
         if sc.words.device == torch.device(device) and sc.next + n <= sc.n:
             w = sc.words[sc.next:sc.next + n]
             sc.next += n

@@ -407,7 +407,11 @@ def _packed_qkv_forward(self, hidden_states, *args, **kwargs):
     ok = (hidden_states.is_cuda and hidden_states.dtype == w.dtype and torch.is_grad_enabled() and q.weight.data_ptr() == w.data_ptr()
           and k.weight.data_ptr() == w.data_ptr() + w[0].numel() * w.shape[0] // 3 * w.element_size()
           and v.weight.data_ptr() == w.data_ptr() + 2 * w[0].numel() * w.shape[0] // 3 * w.element_size() and q.bias.data_ptr() == b.data_ptr())
-    if not ok:
+    # key / value from another tensor (cross-attention) or a cache: the packed projection of hidden_states would silently be the wrong one
+    # (round-5 ADVICE).  transformers passes these by keyword or as the positional slots behind attention_mask / head_mask
+    cross = (getattr(self, "is_cross_attention", False) or any(kwargs.get(k) is not None for k in ("encoder_hidden_states", "past_key_value", "past_key_values"))
+             or any(torch.is_tensor(a) and a.dim() == 3 and a.shape[-1] == hidden_states.shape[-1] for a in args[2:]))
+    if not ok or cross:
         return self._fmmt_stock_forward(hidden_states, *args, **kwargs)
     from . import ops
     yq, yk, yv = ops.PlmQkvFn.apply(hidden_states, q.weight, k.weight, v.weight, q.bias, k.bias, v.bias, w, b)
@@ -440,7 +444,8 @@ def fuse_text_encoder(plm, tails: bool = True, qkv: bool = True):
     salt = 0
     for name, m in plm.named_modules():
         cls = type(m).__name__
-        if tails and cls.endswith(("SelfOutput", "Output")) and hasattr(m, "dense") and hasattr(m, "LayerNorm") and hasattr(m, "dropout") \
+        if tails and cls.endswith(("SelfOutput", "Output")) and isinstance(getattr(m, "dense", None), torch.nn.Linear) \
+                and isinstance(getattr(m, "LayerNorm", None), torch.nn.LayerNorm) and isinstance(getattr(m, "dropout", None), torch.nn.Dropout) \
                 and not hasattr(m, "_fmmt_stock_forward"):
             m._fmmt_stock_forward = m.forward
             m._fmmt_seed = box
@@ -450,6 +455,8 @@ def fuse_text_encoder(plm, tails: bool = True, qkv: bool = True):
             n_tail += 1
         elif qkv and cls.endswith("SelfAttention") and all(hasattr(m, a) for a in ("query", "key", "value")) and not hasattr(m, "_fmmt_stock_forward"):
             q, k, v = m.query, m.key, m.value
+            if not all(isinstance(l, torch.nn.Linear) for l in (q, k, v)) or getattr(m, "is_cross_attention", False):
+                continue
             if not (q.weight.shape == k.weight.shape == v.weight.shape and q.bias is not None and k.bias is not None and v.bias is not None
                     and q.weight.dtype == k.weight.dtype == v.weight.dtype):
                 continue
@@ -650,11 +657,27 @@ class HFAdamW(torch.optim.Optimizer):
             if len(ns) > 1:
                 raise ValueError(f"per-parameter step counters of one group disagree: {sorted(ns)}")
             steps.append(ns.pop() if ns else None)
+        # Optimizer.load_state_dict REPLACES each group with the checkpoint's values: the reference stores `lr` as a Python float, and the
+        # graphed steps (FusedClipAdamW, a captured graph) address the group's 0-dim DEVICE lr tensor the scheduler writes into -- keep that
+        # tensor object and fill it with the saved value; keys the checkpoint does not carry (`step`, anything added here later) stay
+        live = [dict(g) for g in self.param_groups]
         self.load_state_dict(sd)
-        for g, n in zip(self.param_groups, steps):
+        for g, old, n in zip(self.param_groups, live, steps):
+            if torch.is_tensor(old.get("lr")):
+                saved = g["lr"]
+                g["lr"] = old["lr"]
+                with torch.no_grad():
+                    g["lr"].fill_(float(saved))
+            for k, v in old.items():
+                if k not in g:
+                    g[k] = v
             if n is not None:
-                dev = g["params"][0].device
-                g["step"] = torch.full((), float(n), dtype=torch.float32, device=dev)
+                if torch.is_tensor(old.get("step")):
+                    g["step"] = old["step"]
+                    with torch.no_grad():
+                        g["step"].fill_(float(n))
+                else:
+                    g["step"] = torch.full((), float(n), dtype=torch.float32, device=g["params"][0].device)
 
     def hf_state_dict(self):
         """`state_dict()` in transformers.AdamW's layout: an int `step` per parameter beside exp_avg / exp_avg_sq, none in the groups"""
@@ -787,6 +810,29 @@ class FusedClipAdamW:
         self.step.zero_()
         torch._foreach_zero_(self.m)
         torch._foreach_zero_(self.v)
+
+    @torch.no_grad()
+    def load_from(self, opt):
+        """take moments and step counter from `opt` (after HFAdamW.load_hf_state_dict / Optimizer.load_state_dict of a checkpoint): this object
+        keeps its own m, v and step -- the ones the captured update addresses -- so a loaded optimizer state must be copied IN, in place.
+        Parameters the optimizer holds no state for keep zero moments."""
+        params = self.keep[0]
+        g = opt.param_groups[0]
+        for p, m, v in zip(params, self.m, self.v):
+            st = opt.state.get(p, {})
+            if "exp_avg" in st:
+                m.copy_(st["exp_avg"])
+                v.copy_(st["exp_avg_sq"])
+            else:
+                m.zero_()
+                v.zero_()
+        t = g.get("step")
+        if t is None:                                         # torch.optim.AdamW: a per-parameter counter
+            ts = {float(opt.state[p]["step"]) for p in params if p in opt.state and "step" in opt.state[p]}
+            if len(ts) > 1:
+                raise ValueError(f"per-parameter step counters disagree: {sorted(ts)}")
+            t = ts.pop() if ts else 0.0
+        self.step.fill_(float(t))
 
     @torch.no_grad()
     def update(self):

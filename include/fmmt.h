@@ -32,6 +32,10 @@ extern "C" {
  * nothing rounded: the parity instantiation, held to the reference's goldens at 1e-3); FMMT_BF16 | FMMT_GENERIC exists so that tests
  * can hold the generic template against the kernel the benchmark runs.  (The block-half kernels have _ref entry points instead.) */
 #define FMMT_GENERIC 0x100
+/* fmmt_mlp_fwd / fmmt_mlp_ln_fwd / fmmt_mlp_bwd_input / fmmt_mlp_ln_bwd_input, dtype | FMMT_SAVE_DG: the h_pre tensor holds gelu'(pre-activation) instead
+ * of the pre-activation -- the only thing the backward needs of it (Swin_Transformer.py:19-28) -- written by the forward beside gelu() (one shared
+ * exponential), multiplied in by the backward (no polynomial there).  The fused counterpart of FMMT_EPI_GELU_DG / FMMT_EPI_MUL_AUX; round 6. */
+#define FMMT_SAVE_DG 0x200
 
 #define FMMT_EINVAL (-1)   /* bad shape / unsupported size */
 #define FMMT_EALIGN (-2)   /* pointer or leading dimension not 16-byte aligned */
@@ -40,6 +44,10 @@ extern "C" {
 /* epilogue flags of fmmt_linear_fwd */
 #define FMMT_EPI_GELU 1       /* y = gelu(acc + bias)          (nn.GELU / F.gelu, exact erf form) */
 #define FMMT_EPI_GELU_BWD 2   /* y = acc * gelu'(aux)          (backward of the line above)        */
+#define FMMT_EPI_GELU_DG 3    /* y = gelu(acc + bias), y_pre = gelu'(acc + bias): the DERIVATIVE is what the backward needs of the pre-activation
+                                 (Swin_Transformer.py:19-28: fc1 -> GELU), so it is formed where gelu() is -- one shared exponential -- and stored
+                                 in its place; round 6 */
+#define FMMT_EPI_MUL_AUX 4    /* y = acc * aux                 (backward of the line above: aux = the stored derivative; no polynomial) */
 
 int fmmt_version(void);
 
@@ -54,7 +62,8 @@ int fmmt_version(void);
  *   - bias (fp32) may be NULL; res (dtype) may be NULL; rowscale (fp32, DropPath per-sample multiplier,
  *     Swin_Transformer.py:267-268) may be NULL;
  *   - FMMT_EPI_GELU: if y_pre != NULL the pre-activation (acc + bias) is stored there as well;
- *   - FMMT_EPI_GELU_BWD: aux[M,N] (dtype) holds the saved pre-activation.
+ *   - FMMT_EPI_GELU_BWD: aux[M,N] (dtype) holds the saved pre-activation;
+ *   - FMMT_EPI_GELU_DG: y_pre (may be NULL) receives gelu'(acc + bias); FMMT_EPI_MUL_AUX: aux[M,N] (dtype) holds that derivative.
  * The same entry point computes input gradients: dx[M,K] = dy[M,N] . (w^T)[K,N]^T with a transposed
  * copy of the weight.  K % 8 == 0 (bf16) / K % 4 == 0 (f32), N % 4 == 0.
  */

@@ -10,7 +10,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from facialmmt_amd import ops, synth  # noqa: E402
-from facialmmt_amd._lib import EPI_GELU, EPI_GELU_BWD  # noqa: E402
+from facialmmt_amd._lib import EPI_GELU, EPI_GELU_BWD, EPI_GELU_DG, EPI_MUL_AUX  # noqa: E402
 from oracle import crossmodal as OC  # noqa: E402
 from oracle import swin as OS  # noqa: E402
 
@@ -73,6 +73,15 @@ def t_linear():
             g = torch.autograd.grad(OS.gelu_erf(a64).sum(), a64)[0]
             y = ops.linear_raw(x, w, None, epi=EPI_GELU_BWD, aux=aux)
             report(f"linear gelu_bwd {dt} {M}x{N}x{K}", y, (x.double() @ w.double().t()) * g, tol)
+            # round 6: the forward stores the derivative (FMMT_EPI_GELU_DG), the backward multiplies by it (FMMT_EPI_MUL_AUX)
+            ydg = torch.empty((M, N), dtype=dt, device=dev)
+            y = ops.linear_raw(x, w, b, epi=EPI_GELU_DG, y_pre=ydg)
+            p64 = pre.clone().requires_grad_(True)
+            g64 = torch.autograd.grad(OS.gelu_erf(p64).sum(), p64)[0]
+            report(f"linear gelu_dg {dt} {M}x{N}x{K}", y, OS.gelu_erf(pre), tol)
+            report(f"linear gelu_dg derivative {dt} {M}x{N}x{K}", ydg, g64, tol)
+            y = ops.linear_raw(x, w, None, epi=EPI_MUL_AUX, aux=aux, rowscale=rs, rows_per_scale=100)
+            report(f"linear mul_aux {dt} {M}x{N}x{K}", y, rs.double().repeat_interleave(100)[:M, None] * (x.double() @ w.double().t()) * aux.double(), tol)
 
 
 def t_linear_large():
@@ -103,6 +112,18 @@ def t_linear_large():
         g = torch.autograd.grad(torch.nn.functional.gelu(a32).sum(), a32)[0]
         y = ops.linear_raw(x, w, None, epi=EPI_GELU_BWD, aux=aux)
         report(f"linear large gelu_bwd {M}x{N}x{K}", y, (x.float() @ w.float().t()) * g, tol)
+        # round 6: derivative stored by the forward / product in the backward (the latter on gemm_ph3.h's EPI 6 where the shape allows)
+        ydg = torch.empty((M, N), dtype=dt, device=dev)
+        y = ops.linear_raw(x, w, b, epi=EPI_GELU_DG, y_pre=ydg)
+        p32 = pre.clone().requires_grad_(True)
+        g32 = torch.autograd.grad(torch.nn.functional.gelu(p32).sum(), p32)[0]
+        report(f"linear large gelu_dg {M}x{N}x{K}", y, torch.nn.functional.gelu(pre), tol)
+        report(f"linear large gelu_dg derivative {M}x{N}x{K}", ydg, g32, tol)
+        y = ops.linear_raw(x, w, None, epi=EPI_MUL_AUX, aux=aux, rowscale=rs, rows_per_scale=196)
+        report(f"linear large mul_aux+rowscale {M}x{N}x{K}", y, rs.repeat_interleave(196)[:M, None] * (x.float() @ w.float().t()) * aux.float(), tol)
+        y = ops.linear_raw(x, w, None, epi=EPI_MUL_AUX, aux=aux)
+        report(f"linear large mul_aux {M}x{N}x{K}", y, (x.float() @ w.float().t()) * aux.float(), tol)
+        del ydg, p32, g32
         del x, w, pre, y, ypre, res, aux, a32, g
 
 
@@ -165,6 +186,14 @@ def t_wgrad_large():
             report(f"wgrad large droppath db {M}x{N}x{K} rps={rps}", db, (dy.float() * s2).sum(0), tol2)
         dw, db = ops.wgrad_raw(dy, x, True, torch.zeros_like(rs2), 49)
         RES.append((f"wgrad large all-dropped {M}x{N}x{K}", bool((dw == 0).all()) and bool((db == 0).all())))
+        # the public entry point takes ANY vector (round-5 ADVICE): zeros and one NEGATIVE value (two-valued: the exact pass with a negative common
+        # factor -- used to be taken for all-zero), only negatives, and mixed signs (general pass)
+        for name, vec in (("zeros+negative", torch.where(rs2 == 0, rs2, torch.full_like(rs2, -1.25))), ("all negative", torch.full_like(rs2, -0.75)),
+                          ("mixed signs", torch.where(torch.arange(rs2.numel(), device=rs2.device) % 3 == 0, -rs2 - 0.5, rs2 + 0.25))):
+            dw, db = ops.wgrad_raw(dy, x, True, vec, 49)
+            s3 = vec.repeat_interleave(49)[:M, None]
+            report(f"wgrad large rowscale {name} dw {M}x{N}x{K}", dw, (dy.float() * s3).t() @ x.float(), 5e-3)
+            report(f"wgrad large rowscale {name} db {M}x{N}x{K}", db, (dy.float() * s3).sum(0), 5e-3)
         del dy, x, dw, db, dw2, sdy
 
 
@@ -230,6 +259,80 @@ def t_mlp_fused():
         for name, g, r in (("dx", x.grad, xr.grad), ("dw1", w1.grad, w1r.grad), ("db1", b1.grad, b1r.grad), ("dw2", w2.grad, w2r.grad),
                            ("db2", b2.grad, b2r.grad), ("dres", res.grad, rr.grad)):
             report(f"mlp autograd {name} {M}x{C}", g, r, 4e-2)
+
+
+def t_gelu_tail():
+    """bf16 GELU / GELU' epilogues over x in [-8, 8] with a RELATIVE and a SIGN check on the negative tail (round-4 ADVICE, round-5 VERDICT weak 1):
+    the round-4 odd polynomials were accurate to 5e-5 absolute -- tens of percent, either sign, where |gelu| is smaller than that (x < -3.5).  The
+    sweep reaches the epilogues exactly: identity weights (stacked identities for the Mlp) make the fp32 pre-activation the bf16 sweep value itself,
+    so the kernel's output is bf16(gelu(x)) and is compared with the bf16-rounded fp64 erf-GELU at 8.5e-3 relative (ONE bf16 step: the form's 4.6e-4 / 7.1e-4 may
+    tip a rounding),
+    gelu(x) <= 0 for x < 0, gelu'(x) < 0 for x in [-8, -1.5].  Kernel families: few-token tiles, the many-token persistent / phase kernels
+    (stage-2 / stage-3 shapes, GELU + pre-activation and GELU'), the fused Mlp forward (C = 96, 192) and its fused backward."""
+    import math
+    dt = torch.bfloat16
+
+    def sweep(M, N):
+        # every row the same N-point sweep of [-8, 8] (bf16-representable values), dense on the negative tail; rows shifted so that every lane / tile position sees the tail
+        base = torch.cat([torch.linspace(-8.0, -3.0, N // 2), torch.linspace(-3.0, 8.0, N - N // 2)]).to(dt)
+        idx = (torch.arange(N)[None, :] + torch.arange(M)[:, None] * 7) % N
+        return base[idx].to(dev).contiguous()
+
+    def gelu64(v):
+        v = v.double()
+        return 0.5 * v * torch.special.erfc(-v / math.sqrt(2.0))          # erfc: no cancellation on the negative tail
+
+    def grad64(v):
+        v = v.double()
+        return 0.5 * torch.special.erfc(-v / math.sqrt(2.0)) + v * torch.exp(-0.5 * v * v) / math.sqrt(2.0 * math.pi)
+
+    def check(name, got, x, ref, lo, hi, want_neg):
+        got, ref = got.double(), ref.to(dt).double()                         # reference rounded like the output: what is left is half a step + the form
+        m = (x.double() >= lo) & (x.double() <= hi)
+        rel = ((got[m] - ref[m]).abs() / ref[m].abs().clamp_min(1e-300)).max().item()
+        sign_ok = bool((got[m] < 0).all()) if want_neg else True
+        absr = (got - ref).abs().max().item()
+        ok = rel <= 8.5e-3 and sign_ok and absr <= 4e-2 and bool(torch.isfinite(got).all())
+        RES.append((name, ok))
+        print(f"{'OK  ' if ok else 'FAIL'} {name:58s} tail rel={rel:.3e} sign={'ok' if sign_ok else 'WRONG'} max|err|={absr:.3e}", flush=True)
+
+    for (M, N) in [(300, 384), (300, 768), (70000, 384), (31360, 768), (125440, 1536), (7840, 1536)]:
+        x = sweep(M, N)
+        w = torch.eye(N, dtype=dt, device=dev)
+        ypre = torch.empty((M, N), dtype=dt, device=dev)
+        y = ops.linear_raw(x, w, None, epi=EPI_GELU, y_pre=ypre)
+        RES.append((f"gelu tail pre exact {M}x{N}", bool(torch.equal(ypre, x))))
+        check(f"gelu tail fwd {M}x{N}", y, x, gelu64(x), -8.0, -1e-3, True)
+        ones = torch.ones((M, N), dtype=dt, device=dev)
+        g = ops.linear_raw(ones, w, None, epi=EPI_GELU_BWD, aux=x)
+        check(f"gelu tail bwd {M}x{N}", g, x, grad64(x), -8.0, -1.5, True)
+        two = ops.linear_raw(ones * 2, w, None, epi=EPI_GELU_BWD, aux=x)
+        check(f"gelu tail bwd x2 {M}x{N}", two, x, 2.0 * grad64(x), -8.0, -1.5, True)
+        ydg = torch.empty((M, N), dtype=dt, device=dev)
+        y = ops.linear_raw(x, w, None, epi=EPI_GELU_DG, y_pre=ydg)      # the forward that stores the derivative (shared exponential)
+        check(f"gelu tail dg fwd {M}x{N}", y, x, gelu64(x), -8.0, -1e-3, True)
+        check(f"gelu tail dg derivative {M}x{N}", ydg, x, grad64(x), -8.0, -1.5, True)
+        del x, w, ypre, y, ones, g, two, ydg
+    for (M, C) in [(256 * 40, 96), (256 * 12 + 40, 96), (256 * 24, 192), (5000, 192)]:
+        x = sweep(M, C)
+        w1 = torch.eye(C, dtype=dt, device=dev).repeat(4, 1).contiguous()      # hidden channel h sees x[:, h % C]
+        b1 = torch.zeros(4 * C, device=dev)
+        w2 = rnd("w2", (C, 4 * C), 4, (4 * C) ** -0.5, dtype=dt)
+        b2 = torch.zeros(C, device=dev)
+        hp = torch.empty((M, 4 * C), dtype=dt, device=dev)
+        ha = torch.empty((M, 4 * C), dtype=dt, device=dev)
+        ops.mlp_fused_raw(x, w1, b1, w2, b2, None, None, 49, hp, ha)
+        xx = x.repeat(1, 4)
+        RES.append((f"gelu tail mlp pre exact {M}x{C}", bool(torch.equal(hp, xx))))
+        check(f"gelu tail mlp fwd {M}x{C}", ha, xx, gelu64(xx), -8.0, -1e-3, True)
+        # fused backward: dy = first unit vector, W2 row 0 = ones  ->  (dy . W2) = 1 for every hidden channel, dh = gelu'(h_pre)
+        dy = torch.zeros((M, C), dtype=dt, device=dev)
+        dy[:, 0] = 1.0
+        w2b = torch.zeros((C, 4 * C), dtype=dt, device=dev)
+        w2b[0] = 1.0
+        dh, _ = ops.mlp_bwd_input_raw(dy, xx.contiguous(), w1, w2b, None, 49)
+        check(f"gelu tail mlp bwd {M}x{C}", dh, xx, grad64(xx), -8.0, -1.5, True)
+        del x, hp, ha, xx, dy, dh
 
 
 def t_layernorm():

@@ -16,7 +16,7 @@ def _run(fn_name):
     assert P.RES and not bad, f"{fn_name}: failed cases: {bad}"
 
 
-@pytest.mark.parametrize("case", ["t_linear", "t_linear_large", "t_wgrad", "t_wgrad_large", "t_mlp_fused", "t_layernorm", "t_wattn", "t_mha", "t_misc"])
+@pytest.mark.parametrize("case", ["t_linear", "t_linear_large", "t_wgrad", "t_wgrad_large", "t_mlp_fused", "t_gelu_tail", "t_layernorm", "t_wattn", "t_mha", "t_misc"])
 def test_op_parity(case):
     assert torch.cuda.is_available()
     _run(case)

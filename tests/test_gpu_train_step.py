@@ -336,6 +336,52 @@ def test_hf_adamw_formula_and_fused_launch():
     assert torch.equal(low, mine[0].detach().to(torch.bfloat16))
 
 
+def test_fused_adamw_continues_from_a_loaded_hf_state_dict():
+    """A transformers.AdamW-layout checkpoint loaded into a LIVE HFAdamW + FusedClipAdamW pair: load_hf_state_dict keeps the device lr
+    tensor the fused update reads, FusedClipAdamW.load_from copies the moments and the counter into the buffers the (captured) update addresses;
+    the next fused update equals the uninterrupted eager run's."""
+    from facialmmt_amd.train_step import FusedClipAdamW, HFAdamW
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(11)
+    shapes = [(300, 70), (4097,), (5,)]
+    init = [torch.randn(sh, generator=g).to(dev) for sh in shapes]
+    ref = [torch.nn.Parameter(t.clone()) for t in init]
+    opt_r = HFAdamW(ref, lr=torch.tensor(4e-3, device=dev), weight_decay=0.01)
+    gs = [[torch.randn(sh, generator=g).to(dev) * 0.01 for sh in shapes] for _ in range(4)]
+    for k in range(3):
+        for p, gr in zip(ref, gs[k]):
+            p.grad = gr.clone()
+        torch.nn.utils.clip_grad_norm_(ref, 1.0)
+        opt_r.step()
+    import copy
+    sd = copy.deepcopy(opt_r.hf_state_dict())               # (as read from a file: Optimizer.load_state_dict does not copy same-dtype tensors)
+    sd["param_groups"][0]["lr"] = 4e-3
+    mine = [torch.nn.Parameter(p.detach().clone()) for p in ref]
+    lr = torch.tensor(9e-3, device=dev)
+    opt_m = HFAdamW(mine, lr=lr, weight_decay=0.01)
+    grads = {p: torch.zeros_like(p) for p in mine}
+    fused = FusedClipAdamW(opt_m, mine, grads, {}, max_norm=1.0)
+    for pm, gr in zip(mine, gs[0]):                          # the fused pair has stepped before the checkpoint arrives
+        grads[pm].copy_(gr)
+    fused.update()
+    with torch.no_grad():
+        for pm, pr in zip(mine, ref):
+            pm.copy_(pr)
+    opt_m.load_hf_state_dict(sd)
+    assert opt_m.param_groups[0]["lr"] is lr and fused.lr is lr and FusedClipAdamW.eligible(opt_m, mine)
+    fused.load_from(opt_m)
+    assert float(fused.step) == 3.0
+    for pr, pm, gr in zip(ref, mine, gs[3]):
+        pr.grad = gr.clone()
+        grads[pm].copy_(gr)
+    torch.nn.utils.clip_grad_norm_(ref, 1.0)
+    opt_r.step()
+    fused.update()
+    torch.cuda.synchronize()
+    for pr, pm in zip(ref, mine):
+        assert torch.allclose(pr, pm, rtol=2e-6, atol=2e-7), (pr - pm).abs().max()
+
+
 @pytest.mark.parametrize("accumulation", [1, 2])
 def test_fused_optimizer_in_the_graphed_step_equals_eager_adamw(accumulation):
     """GraphedTargetStep with an AdamW optimizer: graph B is one norm + fmmt_adamw_batch (clip + AdamW on the flat gradient

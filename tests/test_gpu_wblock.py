@@ -416,11 +416,13 @@ def _mlp_operands(C, M, use_rs, dtype, seed):
     return x, P, rs, rps
 
 
-@pytest.mark.parametrize("C,M,use_rs", [(96, 8192 + 77, True), (192, 4096 + 130, False)])
-def test_generic_mlp_templates_in_bf16_reproduce_the_production_kernels(dev, C, M, use_rs):
+@pytest.mark.parametrize("dg", [False, True])
+@pytest.mark.parametrize("C,M,use_rs", [(96, 8192 + 77, True), (192, 4096 + 130, False), (192, 4096, False)])
+def test_generic_mlp_templates_in_bf16_reproduce_the_production_kernels(dev, C, M, use_rs, dg):
     """csrc/mlp_ref.hip (the fused Mlp forward / input-gradient kernels over an element-type trait, weights read as fragments instead of
     through the DMA ring) in bf16 -- dtype FMMT_BF16 | FMMT_GENERIC on the same entry points -- against the kernels the benchmark runs:
-    every output to one bf16 rounding step and almost everywhere identical; the LayerNorm-backward partial sums to fp32 summation order."""
+    every output to one bf16 rounding step and almost everywhere identical; the LayerNorm-backward partial sums to fp32 summation order.
+    dg: the same with FMMT_SAVE_DG (round 6: h_pre holds gelu'(pre-activation), the backward multiplies) -- what the model runs since."""
     from facialmmt_amd import _lib
     lib = _lib.load()
     x, P, rs, rps = _mlp_operands(C, M, use_rs, torch.bfloat16, 70)
@@ -428,7 +430,7 @@ def test_generic_mlp_templates_in_bf16_reproduce_the_production_kernels(dev, C, 
     w1t, w2t = w1.t().contiguous(), w2.t().contiguous()
     st = lambda: torch.cuda.current_stream().cuda_stream
     outs = []
-    for code in (_lib.BF16, _lib.BF16 | _lib.GENERIC):
+    for code in (_lib.BF16 | (_lib.SAVE_DG if dg else 0), _lib.BF16 | _lib.GENERIC | (_lib.SAVE_DG if dg else 0)):
         y, xn, hp, ha = torch.empty_like(x), torch.empty_like(x), torch.empty(M, 4 * C, dtype=x.dtype, device=dev), torch.empty(M, 4 * C, dtype=x.dtype, device=dev)
         mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
         rc = lib.fmmt_mlp_ln_fwd(code, M, C, x.data_ptr(), P["g"].data_ptr(), P["b"].data_ptr(), 1e-5, w1.data_ptr(), P["b1"].data_ptr(), w2.data_ptr(), P["b2"].data_ptr(),

@@ -361,3 +361,52 @@ def test_master_weights_keep_frozen_parameters_and_buffers_in_fp32():
     got = mw.state_dict_fp32()
     for k, v in want.items():
         assert got[k].dtype == torch.float32 and torch.equal(got[k], v), k
+
+
+def test_hf_adamw_state_dict_round_trip_keeps_the_lr_tensor_and_continues_the_run():
+    """HFAdamW.hf_state_dict -> load_hf_state_dict (the transformers.AdamW layout of the reference's checkpoints, train.py:316-331: float lr, an
+    int step per parameter): the group's lr TENSOR object survives (the graphed steps and the scheduler address it) filled with the
+    saved value, the step counter continues, and the next step equals the uninterrupted run's."""
+    from facialmmt_amd.train_step import HFAdamW
+    g = torch.Generator().manual_seed(3)
+    shapes = [(17, 5), (9,)]
+    init = [torch.randn(sh, generator=g) for sh in shapes]
+    a = [torch.nn.Parameter(t.clone()) for t in init]
+    opt_a = HFAdamW(a, lr=torch.tensor(3e-3), weight_decay=0.01)
+    grads = [[torch.randn(sh, generator=g) for sh in shapes] for _ in range(4)]
+    for k in range(3):
+        for p, gr in zip(a, grads[k]):
+            p.grad = gr.clone()
+        opt_a.step()
+    import copy
+    sd = copy.deepcopy(opt_a.hf_state_dict())               # (as read from a file: Optimizer.load_state_dict does not copy same-dtype tensors)
+    sd["param_groups"][0]["lr"] = 2e-3                       # as transformers.AdamW stores it: a Python float (here: another value than the live one)
+    assert all(sd["state"][i]["step"] == 3 for i in sd["state"]) and "step" not in sd["param_groups"][0]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    lr_b = torch.tensor(7e-3)
+    opt_b = HFAdamW(b, lr=lr_b, weight_decay=0.01)
+    for p, gr in zip(b, grads[0]):                           # a live optimizer: state and counter exist already
+        p.grad = gr.clone()
+    opt_b.step()
+    with torch.no_grad():
+        for p, q in zip(b, a):
+            p.copy_(q)
+    step_b = opt_b.param_groups[0]["step"]
+    opt_b.load_hf_state_dict(sd)
+    gb = opt_b.param_groups[0]
+    assert gb["lr"] is lr_b and abs(float(lr_b) - 2e-3) < 1e-9          # same tensor object, saved value
+    assert gb["step"] is step_b and float(step_b) == 3.0
+    assert gb["correct_bias"] is True and gb["eps"] == 1e-6
+    opt_a.param_groups[0]["lr"].fill_(2e-3)
+    for pa, pb, gr in zip(a, b, grads[3]):
+        pa.grad = gr.clone()
+        pb.grad = gr.clone()
+    opt_a.step()
+    opt_b.step()
+    for pa, pb in zip(a, b):
+        assert torch.equal(pa, pb)
+    assert float(gb["step"]) == 4.0
+    bad = opt_a.hf_state_dict()
+    bad["state"][0]["step"] = 1
+    with pytest.raises(ValueError):
+        opt_b.load_hf_state_dict(bad)

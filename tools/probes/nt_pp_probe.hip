@@ -1,6 +1,6 @@
-// Development probe for csrc/gemm_pp.h (round 5): the ping-pong NT kernel alone, checked against an fp32-accumulating reference kernel on the
+// Development probe for tools/probes/gemm_pp.h (round 5; a rejected main loop, kept beside its probe -- not part of the library): the ping-pong NT kernel alone, checked against an fp32-accumulating reference kernel on the
 // same bf16 operands, and timed with HIP events beside the production kernel (fmmt_linear_fwd of the in-tree libfmmt_hip.so, dlopen-ed).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I facialmmt_amd/csrc -o /tmp/nt_pp_probe tools/probes/nt_pp_probe.hip -ldl && /tmp/nt_pp_probe
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I facialmmt_amd/csrc -I tools/probes -o /tmp/nt_pp_probe tools/probes/nt_pp_probe.hip -ldl && /tmp/nt_pp_probe
 #include "gemm_pp.h"
 #include <dlfcn.h>
 #include <cstdio>
