@@ -101,44 +101,21 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     return cdf + x * pdf;
 }
 
-// Throughput (bf16) mode: Phi(x) and gelu'(x) = Phi(x) + x phi(x) as ODD POLYNOMIALS around 1/2, two elements at a time in packed
-// fp32 math and nothing but FMAs:
-//     xc = clamp(x, -R, R);  u = 2 (xc / R)^2 - 1;  f(x) ~ 1/2 + xc * P(u)          (gelu_poly_data.h, tools/gen_gelu_poly.py)
-// Phi: R = 4, 8 terms, |error| <= 4.9e-5; gelu': R = 4.5, 10 terms, <= 6.4e-5 (measured with this fp32 Horner form over [-10, 10]) --
-// 1/40 of the bf16 rounding of what is stored; the fp32 (parity) kernels keep erff.  Per PAIR of elements: 2 v_med3 + 1 v_pk_mul
-// + 9 / 11 v_pk_fma (+ the product with x or dy) = 6.5 / 7.5 issue slots per element, no transcendental, no LDS, no wait.
-// History.  Round 1: libm erff, ~32 VALU instructions per element.  Round 2: Abramowitz-Stegun 7.1.26 with v_rcp + v_exp (quarter rate),
-// ~20 issue slots per element: 57 % of the fused Mlp's cycles.  Round 3: a (value, slope) table in LDS, 6 VALU + 1 ds_read_b64 per element --
-// fewer instructions, but each lookup is a dependent LDS round trip and the compiler waits for them four at a time (eight exposed LDS
-// latencies per 32-element stage; the fused Mlp forward's waves spent 45 % of their cycles parked on s_waitcnt, 31 % issue-stalled:
-// profiles/r03_pmc_mlp_fused_fwd_sq1.md) plus three register moves per pair to un-interleave the pairs for the packed FMA.
+// Throughput (bf16) mode.  History.  Round 1: libm erff, ~32 VALU instructions per element.  Round 2: Abramowitz-Stegun 7.1.26 with v_rcp + v_exp (quarter rate),
+// ~20 issue slots per element: 57 % of the fused Mlp's cycles.  Round 3: a (value, slope) table in LDS, 6 VALU + 1 ds_read_b64 per element -- each lookup a
+// dependent LDS round trip (the fused Mlp forward's waves spent 45 % of their cycles parked on s_waitcnt: profiles/r03_pmc_mlp_fused_fwd_sq1.md).  Round 4: Phi and
+// gelu' as odd polynomials around 1/2 in packed fp32 math (8 / 10 terms, argument clamped to +-4 / +-4.5; tools/gen_gelu_poly.py still prints them):
+// |error| <= 5e-5 ABSOLUTE -- i.e. no accuracy at all where the functions are smaller than that: gelu(x) for x < -3.5 (|gelu| < 8e-4) came out with tens of
+// percent of relative error and either sign (round-4 ADVICE, round-5 VERDICT).
 typedef __attribute__((ext_vector_type(2))) float f32x2;
-// NP pairs in lockstep: consecutive instructions belong to different pairs, so no packed FMA consumes its predecessor's result (a
-// dependent v_pk_fma_f32 pair costs the compiler an s_nop between them, and a lone Horner chain exposes the VALU latency)
-template <int N, int NP>
-__device__ __forceinline__ void fmmt_odd_poly2(const float (&c)[N], float R, const f32x2 (&x)[NP], f32x2 (&out)[NP]) {
-    f32x2 xc[NP], u[NP], q[NP];
-#pragma unroll
-    for (int j = 0; j < NP; ++j) xc[j] = f32x2{__builtin_amdgcn_fmed3f(x[j].x, -R, R), __builtin_amdgcn_fmed3f(x[j].y, -R, R)};
-#pragma unroll
-    for (int j = 0; j < NP; ++j) u[j] = xc[j] * xc[j] * (2.0f / (R * R)) - 1.0f;
-#pragma unroll
-    for (int j = 0; j < NP; ++j) q[j] = u[j] * c[N - 1] + c[N - 2];
-#pragma unroll
-    for (int k = N - 3; k >= 0; --k)
-#pragma unroll
-        for (int j = 0; j < NP; ++j) q[j] = q[j] * u[j] + c[k];
-#pragma unroll
-    for (int j = 0; j < NP; ++j) out[j] = q[j] * xc[j] + 0.5f;
-}
-// Round 6: the forms the bf16 kernels evaluate (gelu_poly_data.h part 2, tools/gen_gelu_poly.py).  The odd polynomials above are accurate to 5e-5
-// ABSOLUTE, i.e. not at all where the functions are smaller than that: gelu(x) for x < -3.5 (|gelu| < 8e-4) came out with tens of percent of relative
-// error and either sign.  With a = max(-|x|, -R):
+// Round 6: the forms the bf16 kernels evaluate (gelu_poly_data.h, tools/gen_gelu_poly.py).  With a = max(-|x|, -R):
 //     gelu(x)  = max(x, 0) + a 2^L(a),          L ~ log2 Phi on [-9, 0], degree 6        (gelu(x) = x + gelu(-x) for x > 0; the product is <= 0 always)
-//     gelu'(x) = 1/2 + sign(x) (1/2 - g(a)),    g = 2^(c a^2) S(a), S degree 8            (gelu'(x) = 1 - gelu'(-x); the Gaussian carries the decay)
+//     gelu'(x) = x < 0 ? g(a) : 1 - g(a),       g = 2^(c a^2) S(a), S degree 8            (gelu'(x) = 1 - gelu'(-x); the Gaussian carries the decay)
 // relative error <= 4.6e-4 (gelu, x in [-8, 0)) / 7.1e-4 (gelu', [-8, -1.5]) and the exact sign on the negative tail, 6.8e-5 / 6.0e-5 absolute
-// everywhere; per element 1 v_max + 6 / 8 v_fma + ONE v_exp_f32 + 3 / 6 plain VALU -- no packed fp32 (profiles/r05_issue_rates.txt: a v_pk_fma_f32
-// beside MFMAs costs ~12 cycles, a plain VALU instruction hides).  tests/test_gpu_ops.py::test_gelu_epilogues_negative_tail sweeps [-8, 8].
+// everywhere; per element 1 v_max + 6 / 8 v_fmaak + ONE v_exp_f32 + 3 / 6 plain VALU -- no packed fp32 (profiles/r05_issue_rates.txt: a v_pk_fma_f32
+// beside MFMAs costs ~12 cycles, a plain VALU instruction hides).  tests/support_op_cases.py::t_gelu_tail sweeps [-8, 8] through every kernel family.
+// Measured against the round-4 forms (round 6, same call, profiles/r06_gelu_forms.txt): GELU epilogues and the fused Mlp forward unchanged (they are bound by
+// their two output streams), GELU' launches +4 % -- which is why the forward now STORES gelu' (gelu_both_exp_f below) and no bench kernel evaluates it alone.
 template <int N> __device__ __forceinline__ float fmmt_horner(const float (&c)[N], float a) {
     float q = c[N - 1];
 #pragma unroll
@@ -167,42 +144,14 @@ __device__ __forceinline__ void gelu_both_exp_f(float x, float& g, float& dg) {
     const float ga = __builtin_fmaf(a, pdf, cdf);
     dg = x < 0.f ? ga : 1.0f - ga;
 }
-#ifndef FMMT_GELU_EXP
-#define FMMT_GELU_EXP 1
-#endif
 // v[e] <- gelu(v[e]) / v[e] <- v[e] * gelu'(pre[e]), n = 2 NP elements
 template <int NP> __device__ __forceinline__ void gelu_poly_inplace(float* v) {
-#if FMMT_GELU_EXP
 #pragma unroll
     for (int j = 0; j < 2 * NP; ++j) v[j] = gelu_exp_f(v[j]);
-#else
-    f32x2 x[NP], ph[NP];
-#pragma unroll
-    for (int j = 0; j < NP; ++j) x[j] = f32x2{v[2 * j], v[2 * j + 1]};
-    fmmt_odd_poly2(fmmt_gelu_phi_poly, FMMT_GELU_PHI_R, x, ph);
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        const f32x2 y = x[j] * ph[j];
-        v[2 * j] = y.x;
-        v[2 * j + 1] = y.y;
-    }
-#endif
 }
 template <int NP> __device__ __forceinline__ void gelu_grad_poly_mul_inplace(float* v, const float* pre) {
-#if FMMT_GELU_EXP
 #pragma unroll
     for (int j = 0; j < 2 * NP; ++j) v[j] *= gelu_grad_exp_f(pre[j]);
-#else
-    f32x2 x[NP], g[NP];
-#pragma unroll
-    for (int j = 0; j < NP; ++j) x[j] = f32x2{pre[2 * j], pre[2 * j + 1]};
-    fmmt_odd_poly2(fmmt_gelu_grad_poly, FMMT_GELU_GRAD_R, x, g);
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        v[2 * j] *= g[j].x;
-        v[2 * j + 1] *= g[j].y;
-    }
-#endif
 }
 
 // element-type dispatch used by the GEMM epilogues: exact for float, packed polynomial for bf16 (n = 4 or a multiple of 8)

@@ -29,6 +29,10 @@
 
 namespace {
 
+// (round 6: the hidden tensors -- derivative / pre-activation, activation, dh -- written non-temporal, as the GEMM epilogues' whole-line stores are:
+//  Swin forward + backward 39.47 / 39.53 -> 39.43 / 39.52 ms, whole step 57.52 / 57.25 -> 57.26 / 57.69 ms, same call: nothing; plain stores stay)
+__device__ __forceinline__ void st_hidden(bf16* dst, const bf16x8& v) { *reinterpret_cast<bf16x8*>(dst) = v; }
+
 // (Two workgroups per CU at C = 96 -- 76.8 KB of LDS each, registers forced to 128 -- were measured: the inference form gains
 //  13 %, the training forms, whose time goes into the hidden-tensor stores, lose 0-19 % to the 20 spilled registers.)
 // FULL: M is a multiple of the 256-token tile -- no token guard anywhere, the stage body is branch-free (the stores of a ragged tail
@@ -348,12 +352,12 @@ __global__ __launch_bounds__(512) void mlp_fused_fwd_kernel(MlpArgs p) {
             if (FULL || tok < p.M) {
                 const size_t off = (size_t)tok * H + hs * HS + lg * 8;
                 if (p.h_pre) {
-                    *reinterpret_cast<bf16x8*>(p.h_pre + off) = pre0[mt];
-                    *reinterpret_cast<bf16x8*>(p.h_pre + off + 32) = pre1[mt];
+                    st_hidden(p.h_pre + off, pre0[mt]);
+                    st_hidden(p.h_pre + off + 32, pre1[mt]);
                 }
                 if (p.h_act) {
-                    *reinterpret_cast<bf16x8*>(p.h_act + off) = hf0[mt];
-                    *reinterpret_cast<bf16x8*>(p.h_act + off + 32) = hf1[mt];
+                    st_hidden(p.h_act + off, hf0[mt]);
+                    st_hidden(p.h_act + off + 32, hf1[mt]);
                 }
             }
         }
@@ -420,12 +424,12 @@ __global__ __launch_bounds__(512) void mlp_fused_fwd_kernel(MlpArgs p) {
                 } else if (FULL || tok < p.M) {
                     const size_t off = (size_t)tok * H + hs * HS + lg * 8;
                     if (p.h_pre) {
-                        *reinterpret_cast<bf16x8*>(p.h_pre + off) = keep_pre[mt];
-                        *reinterpret_cast<bf16x8*>(p.h_pre + off + 32) = pre8;
+                        st_hidden(p.h_pre + off, keep_pre[mt]);
+                        st_hidden(p.h_pre + off + 32, pre8);
                     }
                     if (p.h_act) {
-                        *reinterpret_cast<bf16x8*>(p.h_act + off) = keep_act[mt];
-                        *reinterpret_cast<bf16x8*>(p.h_act + off + 32) = hf[mt];
+                        st_hidden(p.h_act + off, keep_act[mt]);
+                        st_hidden(p.h_act + off + 32, hf[mt]);
                     }
                 }
             }
@@ -708,8 +712,8 @@ __global__ __launch_bounds__(512) void mlp_fused_bwd_kernel(MlpArgs p) {
                 if (blk == 0) keep[mt] = hf[mt];
                 else if (tok < p.M) {
                     const size_t off = (size_t)tok * H + hs * HS + lg * 8;
-                    *reinterpret_cast<bf16x8*>(p.h_act + off) = keep[mt];
-                    *reinterpret_cast<bf16x8*>(p.h_act + off + 32) = hf[mt];
+                    st_hidden(p.h_act + off, keep[mt]);
+                    st_hidden(p.h_act + off + 32, hf[mt]);
                 }
             }
 #pragma unroll

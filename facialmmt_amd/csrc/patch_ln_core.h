@@ -83,3 +83,67 @@ __device__ __forceinline__ void patch_ln_tile(const PatchLnParams<T>& P, const t
         }
     }
 }
+
+
+// The same tile with every per-channel constant loaded where it is used (weights -> products -> bias -> statistics -> gamma / beta) instead of held in a
+// PatchLnParams for the kernel's life: for a caller that runs ONE tile per wave (preproc.hip: the uint8 pre-step's workgroup) the 120 registers of the
+// parameter block only cost occupancy -- 172 registers, two workgroups per CU under a latency-bound gather.  Same operations in the same order as
+// patch_ln_load + patch_ln_tile: bit-identical results.
+template <typename T>
+__device__ __forceinline__ void patch_ln_tile_lean(const T* __restrict__ w, const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, const typename ElemTrait<T>::frag& c0, const typename ElemTrait<T>::frag& c1,
+                                                   float eps, size_t tok, bool valid, int li, int lg, T* __restrict__ x_pre, T* __restrict__ y,
+                                                   float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+    using E = ElemTrait<T>;
+    using F = typename E::frag;
+    constexpr int C = 96, NT = 6, KS = 3, K = 48;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int ch = chan_of<4 * NT>(nt, li >> 2, li & 3);
+        const F w0 = E::ld(w + (size_t)ch * K + lg * 8);
+        const F w1 = lg < 2 ? E::ld(w + (size_t)ch * K + 32 + lg * 8) : E::zero();
+        acc[nt] = E::mma(w0, c0, f32x4{0.f, 0.f, 0.f, 0.f});
+        acc[nt] = E::mma(w1, c1, acc[nt]);
+    }
+    float v[KS * 8], sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < KS; ++c) {
+        F o;
+        f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+        if (bias) {
+            b0 = *reinterpret_cast<const f32x4*>(bias + c * 32 + lg * 8);
+            b1 = *reinterpret_cast<const f32x4*>(bias + c * 32 + lg * 8 + 4);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            o[e] = E::cv(acc[2 * c + (e >> 2)][e & 3] + (e < 4 ? b0[e & 3] : b1[e & 3]));
+            v[c * 8 + e] = (float)o[e];
+            sum += v[c * 8 + e];
+        }
+        if (x_pre && valid) E::st(x_pre + tok * C + c * 32 + lg * 8, o);
+    }
+    const float mean = swap_sum(sum) * (1.0f / (float)C);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < KS * 8; ++i) {
+        v[i] -= mean;
+        q += v[i] * v[i];
+    }
+    const float rstd = rsqrtf(swap_sum(q) * (1.0f / (float)C) + eps);
+    if (valid) {
+#pragma unroll
+        for (int c = 0; c < KS; ++c) {
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c * 32 + lg * 8), g1 = *reinterpret_cast<const f32x4*>(gamma + c * 32 + lg * 8 + 4);
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(beta + c * 32 + lg * 8), t1 = *reinterpret_cast<const f32x4*>(beta + c * 32 + lg * 8 + 4);
+            F o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = E::cv(v[c * 8 + e] * rstd * (e < 4 ? g0[e & 3] : g1[e & 3]) + (e < 4 ? t0[e & 3] : t1[e & 3]));
+            E::st(y + tok * C + c * 32 + lg * 8, o);
+        }
+        if (mean_out && lg == 0) {
+            mean_out[tok] = mean;
+            rstd_out[tok] = rstd;
+        }
+    }
+}

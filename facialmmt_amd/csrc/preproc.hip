@@ -30,13 +30,17 @@ double pil_cubic(double x) {
     return 0.0;
 }
 
-// block = (patch row p, image n); 256 threads.
+// block = (patch row p, image n); 256 threads.  Round 6 form (the round-5 kernel kept the band's horizontal pass in a 21 KB LDS array, re-read its tap
+// tables from LDS for every element and ran at 0.19 of the HBM rate its 0.6 GB would allow -- instruction- and LDS-issue-bound):
 //   1. stage the source rows [ymin, ymax] of the band as bytes            (coalesced 4-byte loads)
-//   2. horizontal pass into LDS: H[r][x*3+c]  (PIL: uint8-rounded; cv2: raw int32 sums)
-//   3. vertical pass, rounding, byte -> float through the ToTensor/Normalize table, store in patch-column order
-//   FUSE (fmmt_patch_embed_u8_ln_fwd): 4. the band's 56 patch rows stay in LDS as well, and the four waves run PatchEmbed's projection + bias +
-//      LayerNorm on them (patch_ln_core.h: 16 patches per wave, the tile arithmetic of patch_embed_ln_kernel) -- the patch matrix is written
-//      for the backward (weight gradient of the projection) or not at all (inference), never read back.
+//   2. a thread OWNS output columns (x, c) = tid, tid + 256, tid + 512 of the band: its four horizontal taps (source offsets, weights) are two 16-byte
+//      table loads per column, its horizontal results for the band's <= 8 source rows stay in REGISTERS (PIL: uint8-rounded; cv2: raw int32 sums) --
+//   3. -- and feed the vertical pass directly: the band's 4 x 4 vertical taps are workgroup-uniform (scalar registers), folded once into a 4 x 8 matrix
+//      W[dy][r] of weights per staged row, so an output value is 8 integer multiply-adds on registers; rounding, byte -> float through the ToTensor /
+//      Normalize table, into the LDS patch tile (patch-column order).  Same integer sums as before (integer addition is exact: the order is free).
+//   4. the patch tile goes out as whole 16-byte chunks (training: the projection's weight gradient reads it);
+//   FUSE (fmmt_patch_embed_u8_ln_fwd): 5. the four waves run PatchEmbed's projection + bias + LayerNorm on the tile (patch_ln_core.h: 16 patches per wave,
+//      the tile arithmetic of patch_embed_ln_kernel) -- the patch matrix is written for the backward or not at all (inference), never read back.
 template <typename T>
 struct PeTail {                                             // the projection + LayerNorm behind the gather (FUSE)
     const T* w;
@@ -55,27 +59,33 @@ template <typename T, bool PIL, bool FUSE>
 __global__ __launch_bounds__(256) void patch_embed_u8_kernel(const uint8_t* __restrict__ img, int S, const int32_t* __restrict__ tab,
                                                             const float* __restrict__ lut, T* __restrict__ cols, PeTail<T> tail) {
     __shared__ __attribute__((aligned(16))) uint8_t src[RMAX * SMAX * 3];
-    __shared__ __attribute__((aligned(16))) T colsl[FUSE ? 64 * CPITCH : 8];
-    __shared__ int32_t H[RMAX][OUT * 3];
-    __shared__ int32_t tx[OUT * 8];
-    __shared__ int32_t ty[4][8];
+    __shared__ __attribute__((aligned(16))) T colsl[64 * CPITCH];
     __shared__ float slut[256];
     const int p = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
-    PatchLnParams<T> P;
-    if constexpr (FUSE) patch_ln_load<T>(P, tail.w, tail.bias, tail.gamma, tail.beta, tid & 15, (tid & 63) >> 4);   // requested now, used in step 4
-    if (tid < 32) ty[tid >> 3][tid & 7] = tab[(4 * p + (tid >> 3)) * 8 + (tid & 7)];
     slut[tid] = lut[tid];
-    for (int i = tid; i < OUT * 8; i += 256) tx[i] = tab[i];
-    __syncthreads();
+    // the band's vertical taps: the same for every thread (uniform addresses: scalar loads)
+    int tyi[4][4], tyw[4][4];
     int ymin = S, ymax = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            ymin = min(ymin, ty[j][k]);
-            ymax = max(ymax, ty[j][k]);
+            tyi[j][k] = tab[(4 * p + j) * 8 + k];
+            tyw[j][k] = tab[(4 * p + j) * 8 + 4 + k];
+            ymin = min(ymin, tyi[j][k]);
+            ymax = max(ymax, tyi[j][k]);
         }
     const int nr = ymax - ymin + 1;                          // <= RMAX (host-checked)
+    int W[4][RMAX];                                          // weight of staged row r in output row dy of the band
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+            int w = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w += (tyi[j][k] - ymin == r) ? tyw[j][k] : 0;
+            W[j][r] = w;
+        }
     const int rowb = S * 3;
     const uint8_t* base = img + ((size_t)n * S + ymin) * rowb;
     const int nbytes = nr * rowb;                            // the rows are contiguous in the image
@@ -94,40 +104,58 @@ __global__ __launch_bounds__(256) void patch_embed_u8_kernel(const uint8_t* __re
         src[o + 3] = (uint8_t)(v >> 24);
     }
     for (int i = head + 4 * words + tid; i < nbytes; i += 256) src[i] = base[i];
-    __syncthreads();
-    for (int e = tid; e < nr * OUT * 3; e += 256) {
-        const int r = e / (OUT * 3), rem = e - r * (OUT * 3);
-        const int x = rem / 3, c = rem - 3 * x;
-        const int32_t* t = tx + x * 8;
-        const uint8_t* s = src + r * rowb + c;
-        int32_t acc = PIL ? (1 << 21) : 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) acc += (int32_t)s[t[k] * 3] * t[4 + k];
-        H[r][rem] = PIL ? min(max(acc >> 22, 0), 255) : acc;
-    }
-    __syncthreads();
-    T* out = cols + ((size_t)n * GRID + p) * GRID * KPATCH;
-    for (int e = tid; e < GRID * KPATCH; e += 256) {
-        const int patch = e / KPATCH, kk = e - patch * KPATCH;
-        const int c = kk >> 4, dy = (kk >> 2) & 3, dx = kk & 3;
-        const int col = (patch * 4 + dx) * 3 + c;
-        int32_t acc = 1 << 21;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) acc += H[ty[dy][k] - ymin][col] * ty[dy][4 + k];
-        const int v = min(max(acc >> 22, 0), 255);
-        const T val = from_f32<T>(slut[v]);
-        if (!FUSE || cols) out[e] = val;
-        if constexpr (FUSE) colsl[patch * CPITCH + kk] = val;
-    }
     if constexpr (FUSE) {
         for (int e = tid; e < 8 * KPATCH; e += 256) colsl[(GRID + e / KPATCH) * CPITCH + e % KPATCH] = from_f32<T>(0.f);   // rows 56-63 of the last wave's tile
-        __syncthreads();
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int rem = tid + 256 * i;                       // output column: x = rem / 3, channel c = rem % 3
+        if (rem >= OUT * 3) break;
+        const int x = rem / 3, c = rem - 3 * x;
+        const int4 ti = *reinterpret_cast<const int4*>(tab + x * 8), tw = *reinterpret_cast<const int4*>(tab + x * 8 + 4);
+        const int o0 = ti.x * 3 + c, o1 = ti.y * 3 + c, o2 = ti.z * 3 + c, o3 = ti.w * 3 + c;
+        int h[RMAX];
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+            if (r < nr) {                                    // uniform
+                const uint8_t* s = src + r * rowb;
+                int32_t acc = PIL ? (1 << 21) : 0;
+                acc += (int32_t)s[o0] * tw.x + (int32_t)s[o1] * tw.y + (int32_t)s[o2] * tw.z + (int32_t)s[o3] * tw.w;
+                h[r] = PIL ? min(max(acc >> 22, 0), 255) : acc;
+            } else {
+                h[r] = 0;
+            }
+        }
+        const int patch = x >> 2, dx = x & 3;
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy) {
+            int32_t acc = 1 << 21;
+#pragma unroll
+            for (int r = 0; r < RMAX; ++r) acc += h[r] * W[dy][r];
+            const int v = min(max(acc >> 22, 0), 255);
+            colsl[patch * CPITCH + c * 16 + dy * 4 + dx] = from_f32<T>(slut[v]);
+        }
+    }
+    __syncthreads();
+    if (!FUSE || cols) {                                     // the patch matrix of the band: 56 rows of 48 values, whole 16-byte chunks
+        constexpr int CH = 16 / (int)sizeof(T), CPR = KPATCH / CH;
+        T* out = cols + ((size_t)n * GRID + p) * GRID * KPATCH;
+        for (int q = tid; q < GRID * CPR; q += 256) {
+            const int patch = q / CPR, ch = q - patch * CPR;
+            *reinterpret_cast<uint4*>(out + patch * KPATCH + ch * CH) = *reinterpret_cast<const uint4*>(colsl + patch * CPITCH + ch * CH);
+        }
+    }
+    if constexpr (FUSE) {
         using E = ElemTrait<T>;
         const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
         const int patch = wave * 16 + li;
         const typename E::frag c0 = E::ld(colsl + patch * CPITCH + lg * 8);
         const typename E::frag c1 = lg < 2 ? E::ld(colsl + patch * CPITCH + 32 + lg * 8) : E::zero();
-        patch_ln_tile<T>(P, c0, c1, tail.eps, ((size_t)n * GRID + p) * GRID + patch, patch < GRID, lg, tail.x_pre, tail.y, tail.mean, tail.rstd);
+        // (the projection's 9 KB of weights and the per-channel constants are loaded where they are used: held from the kernel's start -- round 5 -- they
+        //  made this a 172-register kernel, two workgroups per CU under the latency-bound gather above)
+        patch_ln_tile_lean<T>(tail.w, tail.bias, tail.gamma, tail.beta, c0, c1, tail.eps, ((size_t)n * GRID + p) * GRID + patch, patch < GRID, li, lg,
+                              tail.x_pre, tail.y, tail.mean, tail.rstd);
     }
 }
 
@@ -211,6 +239,7 @@ extern "C" int fmmt_patch_embed_u8(int dtype, int mode, int n_img, int in_size, 
                                    const float* lut_dev, void* cols, void* stream) {
     if ((dtype != FMMT_BF16 && dtype != FMMT_F32) || (mode != FMMT_RESIZE_PIL && mode != FMMT_RESIZE_CV2)) return FMMT_EINVAL;
     if (n_img <= 0 || n_img > 65535 || in_size < 4 || in_size > SMAX || !img_u8 || !table_dev || !lut_dev || !cols) return FMMT_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(table_dev) | reinterpret_cast<uintptr_t>(cols)) & 15) return FMMT_EALIGN;     // 16-byte table loads, 16-byte stores of the patch rows
     // a band of four output rows of an up-scaling (in_size <= 224) table touches at most 4 + 3 + 1 = 8 source rows
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid(GRID, n_img);
@@ -233,7 +262,8 @@ extern "C" int fmmt_patch_embed_u8_ln_fwd(int dtype, int mode, int n_img, int in
     if (n_img <= 0 || n_img > 65535 || in_size < 4 || in_size > SMAX || !img_u8 || !table_dev || !lut_dev) return FMMT_EINVAL;
     if (!w || !ln_gamma || !ln_beta || !y || (mean == nullptr) != (rstd == nullptr)) return FMMT_EINVAL;
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-    if (!al16(w) || !al16(y) || (x_pre && !al16(x_pre)) || (cols && !al16(cols))) return FMMT_EALIGN;
+    if (!al16(w) || !al16(y) || (x_pre && !al16(x_pre)) || (cols && !al16(cols)) || !al16(table_dev) || (bias && !al16(bias)) || !al16(ln_gamma) || !al16(ln_beta))
+        return FMMT_EALIGN;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid(GRID, n_img);
     const uint8_t* img = reinterpret_cast<const uint8_t*>(img_u8);

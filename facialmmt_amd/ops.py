@@ -492,6 +492,9 @@ _MLP_SAVE_H = True
 # Every Mlp saves gelu'(pre-activation) instead of the pre-activation (round 6: FMMT_EPI_GELU_DG / FMMT_EPI_MUL_AUX, FMMT_SAVE_DG; False: the pre-activation and a
 # GELU' evaluation in the backward, as before)
 _MLP_SAVE_DG = True
+# ... the FUSED kernels at these widths only.  C = 192: the forward kernel sits at the 256-register limit and the second output costs 34 spilled registers
+# (round 6, same call: forward 0.724 -> 1.123 ms, backward 0.892 -> 0.809); C = 96: forward 1.08 (unchanged), backward 1.135 -> 0.886 ms
+_MLP_FUSED_DG_WIDTHS = (96,)
 
 
 def _mlp_fusable(x2, w1, w2, b1, b2):
@@ -516,7 +519,7 @@ class MlpFn(Function):
             # Swin stages 0 / 1: the whole Mlp in one launch, hidden activation kept on chip (csrc/mlp_fused.hip); the
             # backward recomputes gelu(h_pre) inside the weight-gradient kernel instead of reading a stored activation
             h = torch.empty_like(h_pre) if (train and _MLP_SAVE_H) else None
-            ctx.dg = _MLP_SAVE_DG and _MLP_SAVE_H
+            ctx.dg = _MLP_SAVE_DG and _MLP_SAVE_H and K in _MLP_FUSED_DG_WIDTHS
             y = mlp_fused_raw(x2, w1l, b1.detach().float().contiguous(), w2l, b2.detach().float().contiguous(), res2, rowscale, rows_per_scale, h_pre, h, ctx.dg)
         else:
             # Swin stages 2 / 3 (and any other width): two GEMM launches.  The only thing the backward needs of the pre-activation is gelu'(.) of it,
@@ -587,7 +590,7 @@ class MlpLnFn(Function):
         rstd = torch.empty(M, dtype=torch.float32, device=dev) if train else None
         h_pre = torch.empty((M, 4 * C), dtype=x.dtype, device=dev) if train else None
         h = torch.empty_like(h_pre) if train else None
-        ctx.dg = bool(train and _MLP_SAVE_DG)
+        ctx.dg = bool(train and _MLP_SAVE_DG and C in _MLP_FUSED_DG_WIDTHS)
         rc = _lib.load().fmmt_mlp_ln_fwd(dtype_code(x.dtype) | (SAVE_DG if ctx.dg else 0), M, C, _p(x2), _p(g), _p(b), float(eps), _p(_lp(w1, x.dtype)), _p(b1.detach().float().contiguous()),
                                          _p(_lp(w2, x.dtype)), _p(b2.detach().float().contiguous()), _p(rowscale), rows_per_scale, _p(y), _p(xn), _p(mean), _p(rstd),
                                          _p(h_pre), _p(h), _st())

@@ -165,16 +165,12 @@ for ln in lines:
 here = os.path.dirname(os.path.abspath(__file__))
 with open(os.path.join(here, "..", "facialmmt_amd", "csrc", "gelu_poly_data.h"), "w") as f:
     f.write("// Generated by tools/gen_gelu_poly.py -- do not edit.\n"
-            "// (1) round 4, kept for the record and the A/B probe: monomial coefficients in u = 2 (x / R)^2 - 1 of the odd polynomials\n"
-            "//   Phi(x) ~ 0.5 + x P(u), gelu'(x) ~ 0.5 + x G(u); argument clamped to [-R, R].\n"
-            "// (2) round 6, what the kernels evaluate: a = clamp(-|x|, -R, 0); gelu(x) = max(x, 0) + a 2^L(a); gelu'(x) = x < 0 ? g : 1 - g, g = 2^(c a^2) S(a);\n"
-            "//   L, S plain polynomials in a (lowest power first).\n")
+            "// What the bf16 kernels evaluate (round 6): a = clamp(-|x|, -R, 0); gelu(x) = max(x, 0) + a 2^L(a); gelu'(x) = x < 0 ? g : 1 - g, g = 2^(c a^2) S(a);\n"
+            "//   L, S plain polynomials in a (lowest power first).  For the record, the first two lines: the round-4 odd polynomials these replaced\n"
+            "//   (Phi(x) ~ 0.5 + x P(u), gelu'(x) ~ 0.5 + x G(u), u = 2 (x / R)^2 - 1, argument clamped to [-R, R]; the script still fits and measures them).\n")
     for ln in lines:
         f.write("//   " + ln + "\n")
     f.write("#pragma once\n")
-    f.write(f"constexpr float FMMT_GELU_PHI_R = {RP}f, FMMT_GELU_GRAD_R = {RG}f;\n")
-    f.write(emit("fmmt_gelu_phi_poly", cp))
-    f.write(emit("fmmt_gelu_grad_poly", cg))
     f.write(f"constexpr float FMMT_GELU_L_R = {RL}f, FMMT_GELU_S_R = {RS}f, FMMT_GELU_S_C = {-0.5 / math.log(2.0):.9e}f;\n")
     f.write(emit("fmmt_gelu_log2phi_poly", pl))
     f.write(emit("fmmt_gelu_grad_s_poly", ps))

@@ -28,6 +28,7 @@ for (M, C) in [(2007040, 96), (501760, 192)]:
     dy = torch.randn(M, C, device=dev, dtype=dt)
     for dg in (False, True):
         ops._MLP_SAVE_DG = dg
+        ops._MLP_FUSED_DG_WIDTHS = (96, 192)
         xr = x.clone().requires_grad_(True)
         w1r, w2r = w1.float().requires_grad_(True), w2.float().requires_grad_(True)
         def fwd():
