@@ -1877,10 +1877,12 @@ __global__ __launch_bounds__(512) void linear_tn_dma_kernel(TnArgs p) {
     // order so that its first block sits at position 0 (and the second, which exists only for tiles_k == 1, at position WK):
     // the extra MFMA against a ones fragment then hangs off fixed positions behind loop-invariant flags -- selecting the
     // position at run time made the compiler copy accumulators around every MFMA row.
-    static_assert(FA > WK && FA <= 2 * WK, "positions 0 and WK");
+    // (384 x 192 tiles, waves 4 x 2, round 6: FA = 6 = 3 WK -- a third block at position 2 WK)
+    static_assert(FA > WK && FA <= 3 * WK, "positions 0, WK and 2 WK");
     const int o0 = wk * p.tiles_k + tile_k;
     const bool has0 = p.part_b != nullptr && o0 < FA;
     const bool has1 = has0 && p.tiles_k == 1 && o0 + WK < FA;
+    const bool has2 = has1 && FA > 2 * WK && o0 + 2 * WK < FA;
     const int rot = has0 ? o0 : 0;
     auto block_of = [&](int j) { const int a = j + rot; return a >= FA ? a - FA : a; };
     unsigned foff[12];
@@ -1904,7 +1906,7 @@ __global__ __launch_bounds__(512) void linear_tn_dma_kernel(TnArgs p) {
     for (int a = 0; a < FA; ++a)
 #pragma unroll
         for (int b = 0; b < FB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 accb0 = f32x4{0.f, 0.f, 0.f, 0.f}, accb1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 accb0 = f32x4{0.f, 0.f, 0.f, 0.f}, accb1 = f32x4{0.f, 0.f, 0.f, 0.f}, accb2 = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 ones;
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
@@ -1930,6 +1932,9 @@ __global__ __launch_bounds__(512) void linear_tn_dma_kernel(TnArgs p) {
             for (int b = 0; b < FB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[a], fr[FA + b], acc[a][b], 0, 0, 0);
             if (a == 0 && has0) accb0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[0], ones, accb0, 0, 0, 0);
             if (a == WK && has1) accb1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[WK], ones, accb1, 0, 0, 0);
+            if constexpr (FA > 2 * WK) {
+                if (a == 2 * WK && has2) accb2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[2 * WK], ones, accb2, 0, 0, 0);
+            }
         }
     };
 
@@ -2107,6 +2112,7 @@ __global__ __launch_bounds__(512) void linear_tn_dma_kernel(TnArgs p) {
             for (int b = 0; b < FB; ++b) acc[a][b] *= post;
         accb0 *= post;
         accb1 *= post;
+        accb2 *= post;
     }
 #pragma unroll
     for (int a = 0; a < FA; ++a)
@@ -2119,6 +2125,12 @@ __global__ __launch_bounds__(512) void linear_tn_dma_kernel(TnArgs p) {
         if (has1) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) pb[block_of(WK) * 16 + r] = accb1[r];
+        }
+        if constexpr (FA > 2 * WK) {
+            if (has2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pb[block_of(2 * WK) * 16 + r] = accb2[r];
+            }
         }
     }
 }
@@ -2137,10 +2149,11 @@ int launch_tn_dma(const TnArgs& a, int grid, hipStream_t st) {
 // out[i] = sum_s part[s][i] : 256 threads = 64 float4 outputs x 4 split groups, fixed-order tree (deterministic).
 // One launch finishes both the weight gradient (blocks [0, wblocks)) and, if present, the bias gradient.
 // hdr[0] = number of splits, hdr[1] = layout of the weight partials as written by the contraction kernel: 0 = row-major
-// [N][K]; 256 / 192 = fragment order of linear_tn_dma_kernel<256,256> / <192,384> (undone here, K = row length of dW).
+// [N][K]; 256 / 192 / 384 = fragment order of linear_tn_dma_kernel<256,256> / <192,384> / <384,192> (undone here, K = row length of dW).
 __device__ __forceinline__ size_t tn_frag_dest(int layout, size_t q, int K, int r) {
     // q = float4 index inside one split's partials: ((((tile * 8 + wave) * FA + a) * FB + b) * 64 + lane)
-    const int TNn = layout, TKk = layout == 256 ? 256 : 384, FA = layout == 256 ? 8 : 6, FB = layout == 256 ? 4 : 6;
+    const int TNn = layout, TKk = layout == 256 ? 256 : layout == 192 ? 384 : 192, FA = layout == 256 ? 8 : 6, FB = layout == 256 ? 4 : 6;
+    const int WK = layout == 384 ? 2 : 4, WN = 8 / WK;          // 384: linear_tn_dma_kernel<384,192>, waves 4 x 2
     const int lane = (int)(q & 63);
     size_t t = q >> 6;
     const int b = (int)(t % FB); t /= FB;
@@ -2148,9 +2161,9 @@ __device__ __forceinline__ size_t tn_frag_dest(int layout, size_t q, int K, int 
     const int wave = (int)(t & 7);
     const int tile = (int)(t >> 3);
     const int tiles_k = K / TKk, tile_n = tile / tiles_k, tile_k = tile - tile_n * tiles_k;
-    const int wn = wave >> 2, wk = wave & 3;                 // waves 2 x 4
-    const int n = tile_n * TNn + wn * (TNn / 2) + a * 16 + (lane >> 4) * 4 + r;
-    const int k = tile_k * TKk + wk * (TKk / 4) + b * 16 + (lane & 15);
+    const int wn = wave / WK, wk = wave % WK;
+    const int n = tile_n * TNn + wn * (TNn / WN) + a * 16 + (lane >> 4) * 4 + r;
+    const int k = tile_k * TKk + wk * (TKk / WK) + b * 16 + (lane & 15);
     return (size_t)n * K + k;
 }
 // 16 split groups x 64 float4 columns per workgroup (4 groups until round 3: a 96 x 96 weight gradient with 768 token splits is 36
@@ -2322,6 +2335,9 @@ TnPlan tn_plan_dma(int M, int N, int K) {
     int tn = 0, tk = 0;
     if (N % 256 == 0 && K % 256 == 0) tn = 256, tk = 256;
     else if (N % 192 == 0 && K % 384 == 0) tn = 192, tk = 384;
+    // round 6: the transposed tile for K = 192 (Swin stage 1's fc1 weight gradient, 768 x 192: it fell to the 128 x 128 register-staged kernel at 3.3 TB/s
+    // where its mirror image 192 x 768 runs at 4.7 on <192,384>); one k-tile only (the bias blocks' positions assume it), unscaled launches only
+    else if (N % 384 == 0 && K == 192) tn = 384, tk = 192;
     // (two or three tiles used to be refused -- > 64 splits, "the partial sums outweigh the operands" --; re-measured in round 4, same call:
     //  501760 x 192 x 768 with the DropPath scale 324 -> 233 us, 125440 x 384 x 384 70 -> 64 us with the finish pass, no shape slower.  One tile stays out.)
     if (tn && (N / tn) * (K / tk) < 2) tn = 0;
@@ -2371,11 +2387,12 @@ int launch_tn_plan(int dtype, int M, int N, int K, const void* dy, int lddy, con
         const TnPlan pd = tn_plan_dma(M, N, K);
         // scaled launches: the split's slice of the scale vector has to fit the 4 KB behind the ring
         static const int dma_scaled = fmmt_const("FMMT_TN_DMA_SCALED", 1);
-        const bool scaled_ok = !rowscale || (dma_scaled && rows_per_scale >= 32 && pd.tn && pd.chunk / rows_per_scale + 2 <= 1024);
+        const bool scaled_ok = !rowscale || (dma_scaled && rows_per_scale >= 32 && pd.tn && pd.tk != 192 && pd.chunk / rows_per_scale + 2 <= 1024);
         if (pd.tn && scaled_ok) {
             TnArgs a{M, N, K, dy, lddy, x, ldx, part_w, part_b, rowscale, rows_per_scale, pd.tiles_k, pd.chunk, pd.tiles_n, tn_xcd, 0, hdr, pd.splits};
             const int grid = pd.tiles_n * pd.tiles_k * pd.splits;
             if (rowscale) return pd.tk == 256 ? launch_tn_dma<256, 256, 4, 2, true>(a, grid, st) : launch_tn_dma<192, 384, 4, 2, true>(a, grid, st);
+            if (pd.tk == 192) return launch_tn_dma<384, 192, 4, 4>(a, grid, st);
             return pd.tk == 256 ? launch_tn_dma<256, 256, 4, 2>(a, grid, st) : launch_tn_dma<192, 384, 4, 2>(a, grid, st);
         }
     }

@@ -375,6 +375,10 @@ void wattn_mfma_bwd_kernel(WaArgs p) {
             float d = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) d += (float)gf[a][e] * (float)of[e];
+            // (Round 6, measured and not kept: the row statistics through the MFMAs' C operand -- S' = K.Q^T - lse / scale, dP' = V.dO^T - delta -- instead of
+            //  one v_sub per logit each, 2 of ~12 VALU slots: stage 0 / 1 backward 0.965 / 0.993 / 0.484 -> 0.951 / 0.937 / 0.470 ms, stage 2 0.256 -> 0.34,
+            //  Swin forward + backward 41.2 -> 41.1 ms, the step 58.3 -> 58.3: nothing.  A two-instruction mask (AND against a sign-extended bit field instead
+            //  of test + compare + select) spilled 15-44 registers: the sixteen masks of a tile are formed early.  profiles/r06_wattn_fold.txt)
             dl[a] = xor_sum(d);
             ls[a] = cur.ls[a] * WA_LOG2E;
             const int off = slot * TP + lg * 8;

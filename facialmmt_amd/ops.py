@@ -503,6 +503,13 @@ def _mlp_fusable(x2, w1, w2, b1, b2):
             and b1 is not None and b2 is not None and x2.shape[0] >= 4096)
 
 
+def mlp_saves_dg(x2, w1, w2, b1, b2) -> bool:
+    """does the Mlp of these operands save gelu'(pre-activation) in place of the pre-activation?  (one rule for ops.MlpFn and torch.ops.fmmt.mlp)"""
+    if not (_MLP_SAVE_DG and _MLP_SAVE_H):
+        return False
+    return x2.shape[1] in _MLP_FUSED_DG_WIDTHS if _mlp_fusable(x2, w1, w2, b1, b2) else True
+
+
 class MlpFn(Function):
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, res, rowscale, rows_per_scale, grad_on=True):
@@ -519,13 +526,13 @@ class MlpFn(Function):
             # Swin stages 0 / 1: the whole Mlp in one launch, hidden activation kept on chip (csrc/mlp_fused.hip); the
             # backward recomputes gelu(h_pre) inside the weight-gradient kernel instead of reading a stored activation
             h = torch.empty_like(h_pre) if (train and _MLP_SAVE_H) else None
-            ctx.dg = _MLP_SAVE_DG and _MLP_SAVE_H and K in _MLP_FUSED_DG_WIDTHS
+            ctx.dg = mlp_saves_dg(x2, w1, w2, b1, b2)
             y = mlp_fused_raw(x2, w1l, b1.detach().float().contiguous(), w2l, b2.detach().float().contiguous(), res2, rowscale, rows_per_scale, h_pre, h, ctx.dg)
         else:
             # Swin stages 2 / 3 (and any other width): two GEMM launches.  The only thing the backward needs of the pre-activation is gelu'(.) of it,
             # so the forward's epilogue -- which evaluates gelu() there anyway, and shares its exponential -- stores THAT (FMMT_EPI_GELU_DG) and the
             # backward's input-gradient GEMM multiplies by it (FMMT_EPI_MUL_AUX: no polynomial in the epilogue, so it runs on the phase kernels)
-            ctx.dg = _MLP_SAVE_DG and _MLP_SAVE_H
+            ctx.dg = mlp_saves_dg(x2, w1, w2, b1, b2)
             h = linear_raw(x2, w1l, b1.detach(), epi=EPI_GELU_DG if ctx.dg else EPI_GELU, y_pre=h_pre)
             y = linear_raw(h, w2l, b2.detach(), res=res2, rowscale=rowscale, rows_per_scale=rows_per_scale)
         ctx.save_for_backward(x2, w1, w2, h_pre, h, rowscale)

@@ -7,7 +7,8 @@ kernel is registered (device_types="cuda": a CPU tensor raises from the dispatch
 Registered (forward ops return what their backward needs as extra outputs, as custom ops must):
 
     fmmt::linear(x, weight, bias?, res?, rowscale?, rows_per_scale) -> y                  nn.Linear (+ residual, DropPath scale)
-    fmmt::mlp(x, w1, b1, w2, b2, res?, rowscale?, rows_per_scale) -> (y, h_pre, h_act)    Mlp of a Swin block (fused for C = 96 / 192)
+    fmmt::mlp(x, w1, b1, w2, b2, res?, rowscale?, rows_per_scale) -> (y, h_dg, h_act)     Mlp of a Swin block (fused for C = 96 / 192); h_dg = what the backward needs
+                                                                                           of the pre-activation: its gelu' (round 6; the pre-activation itself where ops.mlp_saves_dg says no)
     fmmt::layer_norm(x, gamma, beta, eps) -> (y, mean, rstd)                              nn.LayerNorm
     fmmt::window_attention(qkv, table, index, n_img, H, W, heads, shift, scale) -> (out, lse)   W-MSA / SW-MSA core on token-order qkv
     fmmt::patch_embed_u8(img_u8, flavour, bf16) -> cols                                    input pre-step + patch gather (no gradient)
@@ -29,7 +30,7 @@ import torch
 from torch import Tensor
 
 from . import ops
-from ._lib import EPI_GELU, EPI_GELU_BWD
+from ._lib import EPI_GELU, EPI_GELU_BWD, EPI_GELU_DG, EPI_MUL_AUX
 
 _LIB = "fmmt"
 
@@ -84,11 +85,12 @@ def mlp(x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, res: Optional
     w1l, w2l = _cast(w1, x.dtype), _cast(w2, x.dtype)
     res2 = res.reshape(-1, w2.shape[0]).contiguous() if res is not None else None
     h_pre = torch.empty((x2.shape[0], w1.shape[0]), dtype=x.dtype, device=x.device)
+    dg = ops.mlp_saves_dg(x2, w1, w2, b1, b2)
     if ops._mlp_fusable(x2, w1, w2, b1, b2):
         h = torch.empty_like(h_pre)
-        y = ops.mlp_fused_raw(x2, w1l, b1.float().contiguous(), w2l, b2.float().contiguous(), res2, rowscale, rows_per_scale, h_pre, h)
+        y = ops.mlp_fused_raw(x2, w1l, b1.float().contiguous(), w2l, b2.float().contiguous(), res2, rowscale, rows_per_scale, h_pre, h, dg)
     else:
-        h = ops.linear_raw(x2, w1l, b1, epi=EPI_GELU, y_pre=h_pre)
+        h = ops.linear_raw(x2, w1l, b1, epi=EPI_GELU_DG if dg else EPI_GELU, y_pre=h_pre)
         y = ops.linear_raw(h, w2l, b2, res=res2, rowscale=rowscale, rows_per_scale=rows_per_scale)
     return y.reshape(*x.shape[:-1], w2.shape[0]), h_pre, h
 
@@ -104,6 +106,7 @@ def _mlp_setup(ctx, inputs, output):
     _, h_pre, h = output
     ctx.save_for_backward(x, w1, w2, h_pre, h, rowscale)
     ctx.has_res, ctx.rps = res is not None, rps
+    ctx.dg = ops.mlp_saves_dg(x.reshape(-1, x.shape[-1]), w1, w2, b1, b2)
     ctx.set_materialize_grads(False)
 
 
@@ -111,7 +114,7 @@ def _mlp_backward(ctx, dy, _dpre, _dact):
     x, w1, w2, h_pre, h, rowscale = ctx.saved_tensors
     x2 = x.reshape(-1, x.shape[-1]).contiguous()
     dy2 = dy.reshape(-1, w2.shape[0]).contiguous()
-    dh = ops.linear_raw(dy2, _cast(w2, dy2.dtype, True), None, epi=EPI_GELU_BWD, aux=h_pre, rowscale=rowscale, rows_per_scale=ctx.rps)
+    dh = ops.linear_raw(dy2, _cast(w2, dy2.dtype, True), None, epi=EPI_MUL_AUX if ctx.dg else EPI_GELU_BWD, aux=h_pre, rowscale=rowscale, rows_per_scale=ctx.rps)
     dw2, db2 = ops.wgrad_raw(dy2, h, True, rowscale, ctx.rps)
     dx = ops.linear_raw(dh, _cast(w1, dy2.dtype, True), None).reshape(x.shape) if ctx.needs_input_grad[0] else None
     dw1, db1 = ops.wgrad_raw(dh, x2, True)

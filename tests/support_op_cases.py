@@ -157,7 +157,8 @@ def t_wgrad_large():
     for (M, N, K) in [(125440, 1536, 384), (125440, 384, 1536), (125440, 1152, 384), (125440, 384, 384), (31360, 768, 768),
                       (20008, 1536, 384), (17000, 384, 1536), (31360, 2304, 768), (501760, 192, 384), (62720, 768, 384),
                       (31360, 768, 3072), (125440, 384, 768), (31360, 768, 1536), (20480, 1024, 256),
-                      (15680, 2304, 768), (15680, 768, 3072), (12544, 3072, 768), (8256, 768, 768), (15680, 768, 768)]:      # 320-frame utterances (configs[4]): stage 3
+                      (15680, 2304, 768), (15680, 768, 3072), (12544, 3072, 768), (8256, 768, 768), (15680, 768, 768),      # 320-frame utterances (configs[4]): stage 3
+                      (125440, 768, 192), (62720, 1152, 192), (501760, 768, 192)]:      # round 6: the 384 x 192 tile of the DMA-staged kernel (K = 192: stage 1's fc1 weight gradient), three bias blocks per wave
         dy = rnd("dy", (M, N), 1, dtype=dt)
         x = rnd("x", (M, K), 2, dtype=dt)
         dw, db = ops.wgrad_raw(dy, x, True)

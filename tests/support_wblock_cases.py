@@ -9,6 +9,9 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from facialmmt_amd import _lib  # noqa: E402
+if os.environ.get("PROBE_LIB"):                                # --speed: same-call A/B of two builds
+    _lib.LIB_PATH = os.environ["PROBE_LIB"]
 from facialmmt_amd import ops, synth  # noqa: E402
 from oracle import swin as OS  # noqa: E402
 
