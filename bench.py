@@ -208,11 +208,12 @@ def p256_tile(M, N, K, kw):
 
 def ph_takes(M, N, K, kw):
     """mirror of csrc/gemm.hip::ph_plan: "" (none), "ph256" (csrc/gemm_ph.h) or "ph192" (csrc/gemm_ph3.h)"""
-    if kw.get("aux") is not None:
+    mul_aux = kw.get("epi", 0) == 4 and kw.get("aux") is not None and kw.get("res") is None and kw.get("y_pre") is None      # FMMT_EPI_MUL_AUX (round 6): gemm_ph3.h EPI 6
+    if kw.get("aux") is not None and not mul_aux:
         return ""
     gelu_pre = kw.get("epi", 0) == 1 and kw.get("y_pre") is not None
     has_op = kw.get("res") is not None or kw.get("rowscale") is not None
-    if not gelu_pre and (kw.get("epi", 0) or kw.get("y_pre") is not None):
+    if not gelu_pre and not mul_aux and (kw.get("epi", 0) or kw.get("y_pre") is not None):
         return ""
     if gelu_pre and (has_op or K < 1536):
         return ""
@@ -229,7 +230,7 @@ def ph_takes(M, N, K, kw):
     min_tiles = 150 if M < 16384 else 256
     ok256 = t256 >= min_tiles and (M < 16384 or t256 * 100 >= r256 * 256 * 85)
     ok192 = t192 >= min_tiles and (M < 16384 or t192 * 100 >= r192 * 256 * 85)
-    if gelu_pre or has_op:
+    if gelu_pre or has_op or mul_aux:
         return "ph192" if ok192 else ""
     if ok192 and (not ok256 or r192 * 192 * 103 < r256 * 256 * 100):
         return "ph192"
@@ -244,6 +245,8 @@ def tn_dma_tile(M, N, K, scaled, rows_per_scale, x_gelu):
         tn, tk = 256, 256
     elif N % 192 == 0 and K % 384 == 0:
         tn, tk = 192, 384
+    elif N % 384 == 0 and K == 192 and not scaled:                    # round 6: the transposed tile (stage 1's fc1 weight gradient), waves 4 x 2
+        tn, tk = 384, 192
     else:
         return None
     tiles = (N // tn) * (K // tk)
@@ -253,7 +256,7 @@ def tn_dma_tile(M, N, K, scaled, rows_per_scale, x_gelu):
     chunk = (-(-M // splits) + 63) // 64 * 64
     if chunk < 512 or (scaled and chunk // rows_per_scale + 2 > 1024):
         return None
-    return f"{tn},{tk}"
+    return f"{tn},{tk},4,{4 if tk == 192 else 2}"
 
 
 class KernelTimer:
@@ -306,7 +309,9 @@ class KernelTimer:
             s.record()
             y = raw(x2, w, bias, **kw)
             e.record()
-            timer.events.append((bn, 2.0 * M * N * K, (M * K + N * K + M * N) * 2.0, s, e,
+            # algorithmic bytes: operands once, the output once, plus every further M x N tensor the epilogue reads or writes (second output, GELU' / product operand, residual)
+            extra = sum(kw.get(k) is not None for k in ("y_pre", "aux", "res"))
+            timer.events.append((bn, 2.0 * M * N * K, (M * K + N * K + M * N * (1 + extra)) * 2.0, s, e,
                                  ("nt", M, N, K, kw.get("epi", 0), kw.get("y_pre") is not None, kw.get("res") is not None)))
             return y
 
@@ -326,7 +331,7 @@ class KernelTimer:
                 name = "linear_tn_few_kernel"
             dma = tn_dma_tile(M, N, K, rowscale is not None, rows_per_scale, x_gelu)
             if dma:
-                name = f"linear_tn_dma_kernel<{dma},4,2,{'true' if rowscale is not None else 'false'}>"
+                name = f"linear_tn_dma_kernel<{dma},{'true' if rowscale is not None else 'false'}>"
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             raw_w(dy2, x2, want_bias, ws, nbytes, rowscale, rows_per_scale, x_gelu)

@@ -883,8 +883,11 @@ __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
                     for (int a = 0; a < MT; ++a) acc[a][b] += bb;
                 }
             }
-            // (GELU + pre-activation through the same slabs: FMMT_NT_P256_LDSGELU=1; measured 281 -> 292 us, off)
-            if (BN == 256 && !HASOP && !p.part && !(p.reserved & 4) && !p.y_pre && (p.epi == 0 || (p.epi == FMMT_EPI_GELU && lds_gelu))) {
+            // (GELU + pre-activation through the block-wide slabs of the narrower tiles: FMMT_NT_P256_LDSGELU=1; measured 281 -> 292 us, off.)
+            // Round 6: the GELU launches (+ pre-activation or derivative: TWO output tensors) of the 256-wide tile take the wave-private slabs as well --
+            // straight from the accumulator layout they were 16-row x 64-byte partial-line stores, twice (FMMT_NT_P256_WAVEGELU=0: as before).
+            const bool gelu_any = p.epi == FMMT_EPI_GELU || p.epi == FMMT_EPI_GELU_DG;
+            if (BN == 256 && !HASOP && !p.part && !(p.reserved & 4) && ((p.epi == 0 && !p.y_pre) || (gelu_any && !(p.reserved & 128)))) {
                 // 256-wide tile: a wave's 64 channels are one 128-byte line, so the transposition is wave-private -- 16 token rows
                 // at a time through this wave's own 2.3 KB slab, no barrier -- and serves GELU + pre-activation (two tensors) too
                 if constexpr (BN == 256) {
@@ -914,11 +917,45 @@ __global__ __launch_bounds__(512) void linear_nt_p256_kernel(LinArgs p) {
                             if (m < p.M) __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(dst + (size_t)m * p.ldy + nw + rc * 8));
                         }
                     };
-                    const bool two = p.epi == FMMT_EPI_GELU && ypre != nullptr;
+                    // FMMT_EPI_GELU_DG: activation and derivative of a 16-row tile from ONE evaluation (shared exponential), through the slab one after the other
+                    // (a wave's LDS operations execute in order: write, read, write, read without waits between them)
+                    auto emit_dg = [&](int a) {
+                        bf16x8 dv[2];
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            float t[8], d[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) t[e] = acc[a][2 * c + (e >> 2)][e & 3];
+                            gelu_both_inplace<T>(t, d, 8);
+                            bf16x8 v;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) { v[e] = (bf16)t[e]; dv[c][e] = (bf16)d[e]; }
+                            *reinterpret_cast<bf16x8*>(ws + li * 144 + chan_of<CW>(2 * c, lg, 0) * 2) = v;
+                        }
+#pragma unroll
+                        for (int pass = 0; pass < 2; ++pass) {
+                            T* dst = pass == 0 ? yg : ypre;
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                const int m = mw + a * 16 + h * 8 + rr;
+                                const bf16x8 v = *reinterpret_cast<const bf16x8*>(ws + (h * 8 + rr) * 144 + rc * 16);
+                                if (m < p.M && dst) __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(dst + (size_t)m * p.ldy + nw + rc * 8));
+                            }
+                            if (pass == 0) {
+#pragma unroll
+                                for (int c = 0; c < 2; ++c) *reinterpret_cast<bf16x8*>(ws + li * 144 + chan_of<CW>(2 * c, lg, 0) * 2) = dv[c];
+                            }
+                        }
+                    };
+                    const bool two = gelu_any && ypre != nullptr;
 #pragma unroll
                     for (int a = 0; a < MT; ++a) {
-                        if (two) emit(a, ypre, false);
-                        emit(a, yg, p.epi == FMMT_EPI_GELU);
+                        if (p.epi == FMMT_EPI_GELU_DG) {
+                            emit_dg(a);
+                        } else {
+                            if (two) emit(a, ypre, false);
+                            emit(a, yg, p.epi == FMMT_EPI_GELU);
+                        }
                     }
                     if (!PIPE && mw + 128 <= p.M) st_prev = MT * 2 * (two ? 2 : 1);   // (PIPE: DMA pieces follow the stores, see issue_group)
                 }
@@ -1004,7 +1041,8 @@ int launch_p256_b(const LinArgs& a, hipStream_t st) {
     static const int lds_epi = fmmt_const("FMMT_NT_P256_LDSEPI", 1);
     static const int lds_gelu = fmmt_const("FMMT_NT_P256_LDSGELU", 0);   // measured slower (two tensors, 16-row passes: 32 barriers per tile): 273 -> 296 us
     static const int wrows = fmmt_const("FMMT_NT_P256_WROWS", 1);
-    p.reserved = (lds_epi ? 0 : 4) | (lds_gelu ? 0 : 8) | (wrows ? 0 : 64);
+    static const int wave_gelu = fmmt_const("FMMT_NT_P256_WAVEGELU", 1);   // round 6: the two-tensor GELU epilogues of the 256-wide tile through the wave-private slabs
+    p.reserved = (lds_epi ? 0 : 4) | (lds_gelu ? 0 : 8) | (wrows ? 0 : 64) | (wave_gelu ? 0 : 128);
     hipLaunchKernelGGL((linear_nt_p256_kernel<BN, BK, NBUF, BATCH, HASOP, PIPE>), dim3(256), dim3(512), lds, st, p);
     FMMT_CHECK_LAUNCH();
     return 0;

@@ -182,7 +182,7 @@ def t_wgrad_large():
             rs2[-1] = 0.0
             dw, db = ops.wgrad_raw(dy, x, True, rs2, rps)
             s2 = rs2.repeat_interleave(rps)[:M, None]
-            tol2 = tol if M in (125440, 31360, 15680) and (N, K) != (768, 768) else 5e-3      # the register-staged kernel rounds s * dy to bf16
+            tol2 = tol if M in (125440, 31360, 15680) and (N, K) != (768, 768) and K != 192 else 5e-3      # the register-staged kernel rounds s * dy to bf16 (K = 192: the <384,192> tile is unscaled-only)
             report(f"wgrad large droppath dw {M}x{N}x{K} rps={rps}", dw, (dy.float() * s2).t() @ x.float(), tol2)
             report(f"wgrad large droppath db {M}x{N}x{K} rps={rps}", db, (dy.float() * s2).sum(0), tol2)
         dw, db = ops.wgrad_raw(dy, x, True, torch.zeros_like(rs2), 49)

@@ -9,16 +9,19 @@ FAMILIES = {
     "linear_nt_p256_kernel<192,64,2,true,false,true>": ["linear_nt_p256_kernel<192, 64, 2, true, false, true>"],
     "linear_nt_p256_kernel<192,64,2,true,true,false>": ["linear_nt_p256_kernel<192, 64, 2, true, true, false>"],
     "linear_nt_p256_kernel<256,64,2,true,false,true>": ["linear_nt_p256_kernel<256, 64, 2, true, false, true>"],
-    "linear_nt_ph3_kernel<384x128>": ["linear_nt_ph3_kernel<2, true, 4>", "linear_nt_ph3_kernel<5, true, 4>"],
-    "linear_nt_ph3_kernel<192x256>": ["linear_nt_ph3_kernel<2, true, 2>", "linear_nt_ph3_kernel<5, true, 2>", "linear_nt_ph3_kernel<3, true, 2>"],
+    "linear_nt_ph3_kernel<384x128>": ["linear_nt_ph3_kernel<2, true, 4>", "linear_nt_ph3_kernel<5, true, 4>", "linear_nt_ph3_kernel<6, true, 4>"],
+    "linear_nt_ph3_kernel<192x256>": ["linear_nt_ph3_kernel<2, true, 2>", "linear_nt_ph3_kernel<5, true, 2>", "linear_nt_ph3_kernel<3, true, 2>", "linear_nt_ph3_kernel<6, true, 2>"],
     "linear_nt_ph_kernel<256x256>": ["linear_nt_ph_kernel<"],
     "linear_nt_deep32_kernel<0,128>": ["linear_nt_deep32_kernel<0, 128>"],
     "linear_nt_deep32_kernel<6,128>": ["linear_nt_deep32_kernel<6, 128>"],
     "linear_tn_dma_kernel<192,384,4,2,true>": ["linear_tn_dma_kernel<192, 384, 4, 2, true>"],
     "linear_tn_dma_kernel<192,384,4,2,false>": ["linear_tn_dma_kernel<192, 384, 4, 2, false>"],
+    "linear_tn_dma_kernel<384,192,4,4,false>": ["linear_tn_dma_kernel<384, 192, 4, 4, false>"],
+    "linear_tn_dma_kernel<256,256,4,2,false>": ["linear_tn_dma_kernel<256, 256, 4, 2, false>"],
+    "linear_tn_dma_kernel<256,256,4,2,true>": ["linear_tn_dma_kernel<256, 256, 4, 2, true>"],
     "mlp_fused_fwd_kernel<LN><C=96>": ["mlp_fused_fwd_kernel<96, true"],
     "mlp_fused_fwd_kernel<LN><C=192>": ["mlp_fused_fwd_kernel<192, true"],
-    "mlp_fused_bwd_kernel<LN'><C=96>": ["mlp_fused_bwd_kernel<96, true>"],
+    "mlp_fused_bwd_kernel<LN'><C=96>": ["mlp_fused_bwd_kernel<96, true"],
     "mlp_fused_bwd_kernel<C=192>": ["mlp_fused_bwd_kernel<192"],
     "wattn_mfma_bwd_kernel<recompute><C=96>": ["wattn_mfma_bwd_kernel<0, 4, 96>", "wattn_mfma_bwd_kernel<1, 4, 96>"],
     "wattn_mfma_bwd_kernel": ["wattn_mfma_bwd_kernel<0, 2, 0>", "wattn_mfma_bwd_kernel<1, 2, 0>"],
