@@ -245,11 +245,11 @@ def tn_dma_tile(M, N, K, scaled, rows_per_scale, x_gelu):
         tn, tk = 256, 256
     elif N % 192 == 0 and K % 384 == 0:
         tn, tk = 192, 384
-    elif N % 384 == 0 and K == 192 and not scaled:                    # round 6: the transposed tile (stage 1's fc1 weight gradient), waves 4 x 2
+    elif (N % 384 == 0 or (N % 384 == 192 and N >= 576)) and K == 192 and not scaled:      # round 6: the transposed tile (stage 1's fc1 / qkv weight gradients), waves 4 x 2
         tn, tk = 384, 192
     else:
         return None
-    tiles = (N // tn) * (K // tk)
+    tiles = -(-N // tn) * (K // tk)
     if tiles < 2 or tiles > 128:
         return None
     splits = 256 // tiles

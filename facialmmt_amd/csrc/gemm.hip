@@ -1369,6 +1369,7 @@ struct TnArgs {
     int x_gelu;         // 1: the x operand holds a pre-activation; contract with gelu(x) (recomputed activation of the fused Mlp)
     int* hdr;           // workspace header: hdr[0] receives the number of splits written (read by the finish pass); may be NULL
     int splits;
+    int npad;           // rows of one split's partials (stride of part_w / part_b); 0 = N.  > N: linear_tn_dma_kernel<384,192> on an N that is 192 short of a tile
 };
 
 __device__ __forceinline__ bf16x8 lds_tr_frag(const bf16* s, int pitch, int c0, int li, int lg) {
@@ -1436,7 +1437,7 @@ void linear_tn_kernel(TnArgs p) {
     const int tile_n = tile / p.tiles_k, tile_k = tile % p.tiles_k;
     const int n0 = tile_n * 128, k0 = tile_k * 128;
     const int mbeg = split * p.chunk, mend = min(p.M, mbeg + p.chunk);
-    if (p.hdr && blockIdx.x == 0 && tid == 0) { p.hdr[0] = p.splits; p.hdr[1] = 0; }
+    if (p.hdr && blockIdx.x == 0 && tid == 0) { p.hdr[0] = p.splits; p.hdr[1] = 0; p.hdr[2] = p.N; }
 
     const T* __restrict__ dyg = reinterpret_cast<const T*>(p.dy);
     const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
@@ -1633,7 +1634,7 @@ __global__ __launch_bounds__(512) void linear_tn_few_kernel(TnArgs p) {
     const int li = lane & 15, lg = lane >> 4;
     const int tile_n = blockIdx.x / p.tiles_k, tile_k = blockIdx.x % p.tiles_k;
     const int n0 = tile_n * 64, k0 = tile_k * 64;
-    if (p.hdr && blockIdx.x == 0 && tid == 0) { p.hdr[0] = 1; p.hdr[1] = 0; }
+    if (p.hdr && blockIdx.x == 0 && tid == 0) { p.hdr[0] = 1; p.hdr[1] = 0; p.hdr[2] = p.N; }
     const T* __restrict__ dyg = reinterpret_cast<const T*>(p.dy);
     const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
     const bool do_bias = p.part_b != nullptr && tile_k == 0;
@@ -1859,7 +1860,8 @@ __global__ __launch_bounds__(512) void linear_tn_dma_kernel(TnArgs p) {
     const int tile_n = tile / p.tiles_k, tile_k = tile % p.tiles_k;
     const int n0 = tile_n * TNn, k0 = tile_k * TKk;
     const int mbeg = split * p.chunk, mend = min(p.M, mbeg + p.chunk);
-    if (p.hdr && blockIdx.x == 0 && tid == 0) { p.hdr[0] = p.splits; p.hdr[1] = TNn; }     // TNn != 0: fragment-order partials
+    const int NP = p.npad ? p.npad : p.N;                    // rows of a split's partials (> N: the last tile's upper 192 channels do not exist)
+    if (p.hdr && blockIdx.x == 0 && tid == 0) { p.hdr[0] = p.splits; p.hdr[1] = TNn; p.hdr[2] = NP; }     // TNn != 0: fragment-order partials
     const T* __restrict__ dyg = reinterpret_cast<const T*>(p.dy);
     const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
     const bool extra = wave < REM;
@@ -1876,7 +1878,9 @@ __global__ __launch_bounds__(512) void linear_tn_dma_kernel(TnArgs p) {
         if (j < NIA) {
             const int q = j * 64 + lane, row = q / CPRA, pos = q - row * CPRA;          // LDS slot (row, pos) of this lane
             const int gpos = (tn_sigma<TNn>(row, pos >> 1) << 1) | (pos & 1);           // the global chunk that belongs there
-            goff[i] = (unsigned)(row * p.lddy + n0 + gpos * 8) * 2u;
+            int col = n0 + gpos * 8;
+            if (col >= p.N) col -= NP - p.N;                                            // padded tile: a valid column instead (its products are never read)
+            goff[i] = (unsigned)(row * p.lddy + col) * 2u;
         } else {
             const int q = (j - NIA) * 64 + lane, row = q / CPRB, pos = q - row * CPRB;
             const int gpos = (tn_sigma<TKk>(row, pos >> 1) << 1) | (pos & 1);
@@ -2142,7 +2146,7 @@ __global__ __launch_bounds__(512) void linear_tn_dma_kernel(TnArgs p) {
     // partial sums in FRAGMENT order: [split][tile][wave][block a][b][lane] x 4 floats -- one 1 KB store per accumulator tile
     // (row-major order would be 4-byte stores to four rows per instruction); the finish pass undoes the permutation while it
     // sums (reduce_partials_kernel, layout id in the workspace header)
-    float* pw = p.part_w + (size_t)split * p.N * p.K + (size_t)tile * (TNn * TKk) + (size_t)wave * (FA * FB * 256) + lane * 4;
+    float* pw = p.part_w + (size_t)split * NP * p.K + (size_t)tile * (TNn * TKk) + (size_t)wave * (FA * FB * 256) + lane * 4;
     if constexpr (SCALED) {
 #pragma unroll
         for (int a = 0; a < FA; ++a)
@@ -2157,7 +2161,7 @@ __global__ __launch_bounds__(512) void linear_tn_dma_kernel(TnArgs p) {
 #pragma unroll
         for (int b = 0; b < FB; ++b) *reinterpret_cast<f32x4*>(pw + (block_of(a) * FB + b) * 256) = acc[a][b];
     if (li == 0 && has0) {                                   // every column of the ones-product holds the row sum
-        float* pb = p.part_b + (size_t)split * p.N + n0 + wn * (TNn / WN) + lg * 4;
+        float* pb = p.part_b + (size_t)split * NP + n0 + wn * (TNn / WN) + lg * 4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) pb[block_of(0) * 16 + r] = accb0[r];
         if (has1) {
@@ -2198,7 +2202,7 @@ __device__ __forceinline__ size_t tn_frag_dest(int layout, size_t q, int K, int 
     const int a = (int)(t % FA); t /= FA;
     const int wave = (int)(t & 7);
     const int tile = (int)(t >> 3);
-    const int tiles_k = K / TKk, tile_n = tile / tiles_k, tile_k = tile - tile_n * tiles_k;
+    const int tiles_k = K / TKk, tile_n = tile / tiles_k, tile_k = tile - tile_n * tiles_k;      // (row n may be >= N for a padded last tile: the caller drops it)
     const int wn = wave / WK, wk = wave % WK;
     const int n = tile_n * TNn + wn * (TNn / WN) + a * 16 + (lane >> 4) * 4 + r;
     const int k = tile_k * TKk + wk * (TKk / WK) + b * 16 + (lane & 15);
@@ -2207,18 +2211,25 @@ __device__ __forceinline__ size_t tn_frag_dest(int layout, size_t q, int K, int 
 // 16 split groups x 64 float4 columns per workgroup (4 groups until round 3: a 96 x 96 weight gradient with 768 token splits is 36
 // workgroups, each thread a chain of 192 loads -- 58 us for 28 MB)
 constexpr int RP_GROUPS = 16;
+// n / n2: the true sizes N K and N of dW / db; a split's partials hold hdr[2] >= N rows (0: N) -- the stride, and for fragment-order partials the range walked.
 __global__ __launch_bounds__(64 * RP_GROUPS) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n, const int* __restrict__ hdr,
                                                               int wblocks, const float* __restrict__ part2, float* __restrict__ out2, size_t n2, int K) {
     __shared__ f32x4 red[RP_GROUPS][64];
     const int splits = hdr[0];                               // written by the contraction kernel that filled the partials
     int layout = hdr[1];
+    const size_t rows = hdr[2] > 0 ? (size_t)hdr[2] : n2;
+    const size_t n_true = n, n2_true = n2;
+    n = rows * (size_t)K;                                    // per-split stride / walked range of the weight partials
+    n2 = rows;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     int blk = blockIdx.x;
+    size_t limit = n_true;                                   // row-major partials: elements past the true size are padding
     if (blk >= wblocks) {                                  // bias gradient blocks
         blk -= wblocks;
         part = part2;
         out = out2;
         n = n2;
+        limit = n2_true;
         layout = 0;
     }
     const size_t q = (size_t)blk * 64 + tx;                  // float4 index; n % 4 == 0
@@ -2231,15 +2242,19 @@ __global__ __launch_bounds__(64 * RP_GROUPS) void reduce_partials_kernel(const f
         f32x4 v = red[0][tx];
 #pragma unroll
         for (int g = 1; g < RP_GROUPS; ++g) v += red[g][tx];
-        if (layout == 0) *reinterpret_cast<f32x4*>(out + q * 4) = v;
-        else {
+        if (layout == 0) {
+            if (q * 4 < limit) *reinterpret_cast<f32x4*>(out + q * 4) = v;      // (limit % 4 == 0)
+        } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) out[tn_frag_dest(layout, q, K, r)] = v[r];
+            for (int r = 0; r < 4; ++r) {
+                const size_t d = tn_frag_dest(layout, q, K, r);
+                if (d < n_true) out[d] = v[r];                                   // rows >= N of a padded last tile: dropped
+            }
         }
     }
 }
 
-struct TnPlan { int tiles_n, tiles_k, splits, chunk; size_t bytes; int tn, tk; };     // tn != 0: linear_tn_dma_kernel<tn>
+struct TnPlan { int tiles_n, tiles_k, splits, chunk; size_t bytes; int tn, tk; int npad; };     // tn != 0: linear_tn_dma_kernel<tn>; npad: rows of a split's partials (0 = N)
 
 // (An XCD-local decomposition -- tile shapes 192 x 96 / 96 x 192 / 128 x 128 chosen so that all tiles of a token split fill
 //  whole XCDs, every dy / x slab fetched into exactly one L2 -- was written, tested and measured: the stage-2/3 launches of the
@@ -2359,7 +2374,7 @@ extern "C" int fmmt_linear_fwd_splitk(int dtype, int M, int N, int K, const void
 namespace {
 // DMA-staged plan (linear_tn_dma_kernel): tile TNn x 128 with TNn = 256 / 192, one workgroup per CU, splits = 256 / tiles
 TnPlan tn_plan_dma(int M, int N, int K) {
-    TnPlan pl{0, 0, 0, 0, 0, 0, 0};
+    TnPlan pl{0, 0, 0, 0, 0, 0, 0, 0};
     // Default on (FMMT_TN_DMA=0: everything register-staged).  History: the first version of this kernel (256 / 192 x 128 tiles,
     // the builtin ds_read_tr) measured 3-9 % SLOWER than the register-staged kernel with 68 % of its wave cycles parked in
     // waits -- hipcc had put s_waitcnt vmcnt(0) in front of every stage's first fragment read, so the ring never had a second
@@ -2375,20 +2390,23 @@ TnPlan tn_plan_dma(int M, int N, int K) {
     else if (N % 192 == 0 && K % 384 == 0) tn = 192, tk = 384;
     // round 6: the transposed tile for K = 192 (Swin stage 1's fc1 weight gradient, 768 x 192: it fell to the 128 x 128 register-staged kernel at 3.3 TB/s
     // where its mirror image 192 x 768 runs at 4.7 on <192,384>); one k-tile only (the bias blocks' positions assume it), unscaled launches only
-    else if (N % 384 == 0 && K == 192) tn = 384, tk = 192;
+    // N = 576 (stage 1's qkv weight gradient) is 192 short of two tiles: the last tile's upper half re-reads valid columns and its products go to partial rows
+    // the finish pass drops (npad)
+    else if ((N % 384 == 0 || (N % 384 == 192 && N >= 576)) && K == 192) tn = 384, tk = 192;
     // (two or three tiles used to be refused -- > 64 splits, "the partial sums outweigh the operands" --; re-measured in round 4, same call:
     //  501760 x 192 x 768 with the DropPath scale 324 -> 233 us, 125440 x 384 x 384 70 -> 64 us with the finish pass, no shape slower.  One tile stays out.)
-    if (tn && (N / tn) * (K / tk) < 2) tn = 0;
+    const int npad = tn ? (N + tn - 1) / tn * tn : 0;
+    if (tn && (npad / tn) * (K / tk) < 2) tn = 0;
     if (!tn) return pl;
-    const int tiles = (N / tn) * (K / tk);
+    const int tiles = (npad / tn) * (K / tk);
     if (tiles > 128) return pl;
     int splits = 256 / tiles;
-    while (splits > 1 && (size_t)splits * N * K * 4 > ((size_t)512 << 20)) --splits;
+    while (splits > 1 && (size_t)splits * npad * K * 4 > ((size_t)512 << 20)) --splits;
     int chunk = (M + splits - 1) / splits;
     chunk = (chunk + 63) / 64 * 64;
     splits = (M + chunk - 1) / chunk;
     if (chunk < 512) return pl;
-    pl = TnPlan{N / tn, K / tk, splits, chunk, 0, tn, tk};
+    pl = TnPlan{npad / tn, K / tk, splits, chunk, 0, tn, tk, npad == N ? 0 : npad};
     return pl;
 }
 
@@ -2404,7 +2422,18 @@ int tn_smax(int M, int N, int K, int dtype) {
     }
     return smax;
 }
-size_t tn_ws_bytes(int M, int N, int K, int dtype) { return TN_HDR + (size_t)tn_smax(M, N, K, dtype) * ((size_t)N * K + N) * sizeof(float); }
+// rows of a split's partials the workspace is carved for: N, or the padded count of a DMA plan that may take the launch
+int tn_rows(int M, int N, int K, int dtype) {
+    if (dtype == FMMT_BF16) {
+        const TnPlan pd = tn_plan_dma(M, N, K);
+        if (pd.tn && pd.npad > N) return pd.npad;
+    }
+    return N;
+}
+size_t tn_ws_bytes(int M, int N, int K, int dtype) {
+    const size_t rows = (size_t)tn_rows(M, N, K, dtype);
+    return TN_HDR + (size_t)tn_smax(M, N, K, dtype) * (rows * K + rows) * sizeof(float);
+}
 
 }  // namespace
 
@@ -2427,7 +2456,7 @@ int launch_tn_plan(int dtype, int M, int N, int K, const void* dy, int lddy, con
         static const int dma_scaled = fmmt_const("FMMT_TN_DMA_SCALED", 1);
         const bool scaled_ok = !rowscale || (dma_scaled && rows_per_scale >= 32 && pd.tn && pd.tk != 192 && pd.chunk / rows_per_scale + 2 <= 1024);
         if (pd.tn && scaled_ok) {
-            TnArgs a{M, N, K, dy, lddy, x, ldx, part_w, part_b, rowscale, rows_per_scale, pd.tiles_k, pd.chunk, pd.tiles_n, tn_xcd, 0, hdr, pd.splits};
+            TnArgs a{M, N, K, dy, lddy, x, ldx, part_w, part_b, rowscale, rows_per_scale, pd.tiles_k, pd.chunk, pd.tiles_n, tn_xcd, 0, hdr, pd.splits, pd.npad};
             const int grid = pd.tiles_n * pd.tiles_k * pd.splits;
             if (rowscale) return pd.tk == 256 ? launch_tn_dma<256, 256, 4, 2, true>(a, grid, st) : launch_tn_dma<192, 384, 4, 2, true>(a, grid, st);
             if (pd.tk == 192) return launch_tn_dma<384, 192, 4, 4>(a, grid, st);
@@ -2469,7 +2498,7 @@ extern "C" int fmmt_linear_wgrad_partials(int dtype, int M, int N, int K,
     const int smax = tn_smax(M, N, K, dtype);
     int* hdr = reinterpret_cast<int*>(workspace);
     float* part_b = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + TN_HDR);
-    float* part_w = part_b + (size_t)smax * N;
+    float* part_w = part_b + (size_t)smax * tn_rows(M, N, K, dtype);
     return launch_tn_plan(dtype, M, N, K, dy, lddy, x, ldx, part_w, want_bias ? part_b : nullptr, rowscale, rows_per_scale, x_epi, hdr,
                           reinterpret_cast<hipStream_t>(stream));
 }
@@ -2484,10 +2513,11 @@ extern "C" int fmmt_linear_wgrad_finish(int dtype, int M, int N, int K, float* d
     const int smax = tn_smax(M, N, K, dtype);
     const int* hdr = reinterpret_cast<const int*>(workspace);
     const float* part_b = reinterpret_cast<const float*>(reinterpret_cast<const char*>(workspace) + TN_HDR);
-    const float* part_w = part_b + (size_t)smax * N;
+    const int rows = tn_rows(M, N, K, dtype);                // >= N: the grid covers the padded partials, the kernel reads the row count actually written from the header
+    const float* part_w = part_b + (size_t)smax * rows;
     const size_t nw = (size_t)N * K;
     if (nw % 4 || N % 4) return FMMT_EINVAL;
-    const int wblocks = (int)((nw / 4 + 63) / 64), bblocks = db ? (N / 4 + 63) / 64 : 0;
+    const int wblocks = (int)(((size_t)rows * K / 4 + 63) / 64), bblocks = db ? (rows / 4 + 63) / 64 : 0;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(wblocks + bblocks), dim3(64 * RP_GROUPS), 0, st, part_w, dw, nw, hdr, wblocks, part_b, db, (size_t)N, K);
     FMMT_CHECK_LAUNCH();
     return 0;

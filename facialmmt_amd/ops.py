@@ -479,6 +479,11 @@ def mlp_fused_raw(x2, w1l, b1, w2l, b2, res2, rowscale, rows_per_scale, h_pre, h
 
 
 _MLP_FUSED = True            # module constants, not environment switches: the tests and probes patch them (False = always the two-launch form)
+# the widths that take the fused kernels (they exist for 96 and 192; the others: LayerNorm + two GEMM launches).  Stage 1 (C = 192) left them in round 6: with the
+# derivative stored and the backward's product on the phase kernels the unfused form is the faster one there -- Swin forward + backward 40.71 / 40.66 -> 40.40 / 40.62 ms,
+# whole step 58.00 / 57.97 -> 57.82 / 57.57 ms, same call (the fused C = 192 kernels feed each 16-byte LDS weight read to two MFMAs, the GEMMs' 96 x 64 wave tiles to six;
+# at C = 96 the fused form moves 2.7 GB where two launches move 5.8 and wins 1.07 against 1.59 ms)
+_MLP_FUSED_WIDTHS = (96,)
 # fp32 (parity) models take the fused Mlp entry points too -- their element-type-generic instantiations, csrc/mlp_ref.hip -- so that the
 # fp32 goldens reach the fused kernels' algorithm at 1e-3 (False: LayerNorm + two GEMM launches, as in rounds 1-3; see set_fp32_route)
 _MLP_F32 = True
@@ -499,7 +504,7 @@ _MLP_FUSED_DG_WIDTHS = (96,)
 
 def _mlp_fusable(x2, w1, w2, b1, b2):
     C = x2.shape[1]
-    return (_MLP_FUSED and _mlp_dtype_ok(x2.dtype) and C in (96, 192) and w1.shape == (4 * C, C) and w2.shape == (C, 4 * C)
+    return (_MLP_FUSED and _mlp_dtype_ok(x2.dtype) and C in _MLP_FUSED_WIDTHS and w1.shape == (4 * C, C) and w2.shape == (C, 4 * C)
             and b1 is not None and b2 is not None and x2.shape[0] >= 4096)
 
 
@@ -645,7 +650,7 @@ class MlpLnFn(Function):
 
 def mlp_ln_fusable(x, w1, w2, b1, b2):
     C = x.shape[-1]
-    return (_MLP_FUSED and x.is_cuda and _mlp_dtype_ok(x.dtype) and C in (96, 192) and w1.shape == (4 * C, C) and w2.shape == (C, 4 * C)
+    return (_MLP_FUSED and x.is_cuda and _mlp_dtype_ok(x.dtype) and C in _MLP_FUSED_WIDTHS and w1.shape == (4 * C, C) and w2.shape == (C, 4 * C)
             and b1 is not None and b2 is not None and x.numel() // C >= 4096)
 
 

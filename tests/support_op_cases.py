@@ -158,7 +158,7 @@ def t_wgrad_large():
                       (20008, 1536, 384), (17000, 384, 1536), (31360, 2304, 768), (501760, 192, 384), (62720, 768, 384),
                       (31360, 768, 3072), (125440, 384, 768), (31360, 768, 1536), (20480, 1024, 256),
                       (15680, 2304, 768), (15680, 768, 3072), (12544, 3072, 768), (8256, 768, 768), (15680, 768, 768),      # 320-frame utterances (configs[4]): stage 3
-                      (125440, 768, 192), (62720, 1152, 192), (501760, 768, 192)]:      # round 6: the 384 x 192 tile of the DMA-staged kernel (K = 192: stage 1's fc1 weight gradient), three bias blocks per wave
+                      (125440, 768, 192), (62720, 1152, 192), (501760, 768, 192), (501760, 576, 192), (125440, 960, 192)]:      # round 6: the 384 x 192 tile of the DMA-staged kernel (K = 192: stage 1's fc1 weight gradient), three bias blocks per wave; N = 576 / 960: 192 short of a whole tile (padded partial rows, dropped by the finish pass)
         dy = rnd("dy", (M, N), 1, dtype=dt)
         x = rnd("x", (M, K), 2, dtype=dt)
         dw, db = ops.wgrad_raw(dy, x, True)

@@ -364,10 +364,12 @@ def test_fused_block_against_the_reference_generated_golden(dev, golden, shift):
 
 
 @pytest.mark.parametrize("C,M,use_rs", [(96, 8192 + 77, True), (192, 4096, False), (96, 3136 * 2, False), (96, 8192, True)])   # last: M % 256 == 0, the guard-free instantiation
-def test_mlp_half_with_layernorm_prologue(dev, C, M, use_rs):
+def test_mlp_half_with_layernorm_prologue(dev, C, M, use_rs, monkeypatch):
     """fmmt_mlp_ln_fwd (norm2 -> Mlp -> DropPath -> residual in one launch) against fmmt_layernorm_fwd followed by fmmt_mlp_fwd, and
-    both against fp64: forward, the saved LayerNorm output and statistics, every gradient; ragged last tile, dropped sample."""
+    both against fp64: forward, the saved LayerNorm output and statistics, every gradient; ragged last tile, dropped sample.
+    (Both widths the fused kernels exist for: the model itself runs them at C = 96 only since round 6, ops._MLP_FUSED_WIDTHS.)"""
     import support_wblock_cases as W
+    monkeypatch.setattr(ops, "_MLP_FUSED_WIDTHS", (96, 192))
     x = W.rnd("x", (M, C), 21, dtype=torch.bfloat16).requires_grad_(True)
     P = [(1.0 + 0.2 * W.rnd("g", (C,), 22)).requires_grad_(True), (0.1 * W.rnd("b", (C,), 23)).requires_grad_(True),
          W.rnd("w1", (4 * C, C), 24, C ** -0.5).requires_grad_(True), (0.1 * W.rnd("b1", (4 * C,), 25)).requires_grad_(True),
@@ -467,10 +469,11 @@ def test_generic_mlp_templates_in_bf16_reproduce_the_production_kernels(dev, C, 
 
 
 @pytest.mark.parametrize("C,M,use_rs", [(96, 8192 + 77, True), (192, 4096 + 130, False), (96, 3136 * 2, False)])
-def test_fp32_instantiation_of_the_fused_mlp_against_fp64(dev, C, M, use_rs):
+def test_fp32_instantiation_of_the_fused_mlp_against_fp64(dev, C, M, use_rs, monkeypatch):
     """The fp32 instantiations of the same templates (what fmmt_mlp_ln_fwd / fmmt_mlp_ln_bwd_input / fmmt_mlp_fwd / fmmt_mlp_bwd_input run for
     dtype FMMT_F32; erf GELU, nothing rounded): the op x + s * Mlp(LayerNorm(x)) forward and every gradient against fp64 at 1e-3 or better,
     and the op without the LayerNorm (ops.mlp) likewise."""
+    monkeypatch.setattr(ops, "_MLP_FUSED_WIDTHS", (96, 192))
     x, P, rs, rps = _mlp_operands(C, M, use_rs, torch.float32, 80)
     x.requires_grad_(True)
     leaves = [x] + [P[k].requires_grad_(True) for k in ("g", "b", "w1", "b1", "w2", "b2")]
