@@ -162,7 +162,7 @@ __global__ __launch_bounds__(512) void linear_nt_ph3_kernel(LinArgs p) {
 
     // ---- drip epilogue ----
     bf16x8 rb[4];
-    bf16x8 rg[4];                                              // EPI 3: the GELU rows beside the pre-activation rows in rb
+    bf16x8 rg[4];                                              // EPI 3: the GELU rows beside the pre-activation rows in rb; EPI 6: the rounding residuals of rb
     float rsv[4];                                              // EPI 5 / 6: DropPath scale of the four 8-row blocks' rows
     float* const rslab = reinterpret_cast<float*>(smem + 2 * BUF + 8 * (16 * 144) + 8 * 512) + wave * 256;   // two 128-float slots by tile parity: rowscale of this wave's 96 rows
     int em0 = 0, en0 = 0;
@@ -199,6 +199,21 @@ __global__ __launch_bounds__(512) void linear_nt_ph3_kernel(LinArgs p) {
             }
 #pragma unroll
             for (int h = 0; h < 2; ++h) rb[2 * t + h] = *reinterpret_cast<const bf16x8*>(wslab + (h * 8 + rr) * 144 + rc * 16);
+            if constexpr (EPI == 6) {
+                // the product with the stored derivative is formed on the read-back side, where the value has been rounded to bf16 once already: a second pass
+                // carries the rounding residual (value - bf16(value), itself to bf16: 2^-17 relative together), so that y = (hi + lo) * aux * scale rounds ONCE.
+                // (Without it the whole-Swin bf16 gradient statistics went from 0.089 to 0.10-0.12 relative L2 against the fp32 oracle: every Mlp backward of
+                // stages 1-3 rounded d(hidden) twice.)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    bf16x8 v;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (bf16)(tv[c][e] - (float)(bf16)tv[c][e]);
+                    *reinterpret_cast<bf16x8*>(wslab + li * 144 + (c * 32 + lg * 8) * 2) = v;
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) rg[2 * t + h] = *reinterpret_cast<const bf16x8*>(wslab + (h * 8 + rr) * 144 + rc * 16);
+            }
             if constexpr (EPI == 3) {                          // GELU of the fp32 value (as the persistent kernel's epilogue does), a second pass through the slab
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
@@ -268,7 +283,7 @@ __global__ __launch_bounds__(512) void linear_nt_ph3_kernel(LinArgs p) {
                         q3_gelu_grad_mul<4>(v, a);
                     } else if constexpr (EPI == 6) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = a[e] * (rsv[i] * v[e]);
+                        for (int e = 0; e < 4; ++e) v[e] = a[e] * (rsv[i] * (v[e] + (float)rg[i][4 * hf + e]));
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = a[e] + rsv[i] * v[e];

@@ -479,11 +479,12 @@ def mlp_fused_raw(x2, w1l, b1, w2l, b2, res2, rowscale, rows_per_scale, h_pre, h
 
 
 _MLP_FUSED = True            # module constants, not environment switches: the tests and probes patch them (False = always the two-launch form)
-# the widths that take the fused kernels (they exist for 96 and 192; the others: LayerNorm + two GEMM launches).  Stage 1 (C = 192) left them in round 6: with the
-# derivative stored and the backward's product on the phase kernels the unfused form is the faster one there -- Swin forward + backward 40.71 / 40.66 -> 40.40 / 40.62 ms,
-# whole step 58.00 / 57.97 -> 57.82 / 57.57 ms, same call (the fused C = 192 kernels feed each 16-byte LDS weight read to two MFMAs, the GEMMs' 96 x 64 wave tiles to six;
-# at C = 96 the fused form moves 2.7 GB where two launches move 5.8 and wins 1.07 against 1.59 ms)
-_MLP_FUSED_WIDTHS = (96,)
+# the widths that take the fused kernels (the others: LayerNorm + two GEMM launches).  Round 6 measured stage 1 (C = 192) both ways once the derivative was stored and the
+# backward's product ran on the phase kernels: Swin forward + backward 40.71 / 40.66 (fused) vs 40.40 / 40.62 ms, whole step 58.00 / 57.97 vs 57.82 / 57.57 and, another
+# box, 57.57 / 57.19 vs 57.42 / 57.39 -- a wash in time; but the unfused form rounds d(LN out) and gelu' to bf16 on the way and moved the whole-Swin bf16 gradient statistics
+# from < 0.10 to 0.12 relative L2 against the fp32 oracle (tests/test_gpu_swin.py): the fused kernels stay.  (The fused C = 192 kernels feed each 16-byte LDS weight read to
+# two MFMAs, the GEMMs' 96 x 64 wave tiles to six: that is why they are no faster; at C = 96 the fused form moves 2.7 GB where two launches move 5.8: 1.07 against 1.59 ms.)
+_MLP_FUSED_WIDTHS = (96, 192)
 # fp32 (parity) models take the fused Mlp entry points too -- their element-type-generic instantiations, csrc/mlp_ref.hip -- so that the
 # fp32 goldens reach the fused kernels' algorithm at 1e-3 (False: LayerNorm + two GEMM launches, as in rounds 1-3; see set_fp32_route)
 _MLP_F32 = True
