@@ -167,8 +167,7 @@ template <typename T, int IL = 4> __device__ __forceinline__ void gelu_inplace(f
     }
 }
 // v[e] <- gelu(v[e]), d[e] <- gelu'(v[e]) (before the update): exact for float, the shared-exponential form for bf16
-// GRP: elements evaluated together (0 = all n; 4 / 2 where the registers are short: the eight chains of a fragment keep ~6 temporaries each alive)
-template <typename T, int GRP = 0> __device__ __forceinline__ void gelu_both_inplace(float* v, float* d, int n) {
+template <typename T> __device__ __forceinline__ void gelu_both_inplace(float* v, float* d, int n) {
 #pragma unroll
     for (int e = 0; e < n; ++e) {
         const float x = v[e];
@@ -177,9 +176,6 @@ template <typename T, int GRP = 0> __device__ __forceinline__ void gelu_both_inp
             d[e] = gelu_grad_f(x);
         } else {
             gelu_both_exp_f(x, v[e], d[e]);
-        }
-        if constexpr (GRP > 0) {
-            if ((e + 1) % GRP == 0 && e + 1 < n) __builtin_amdgcn_sched_barrier(0);
         }
     }
 }

@@ -402,7 +402,8 @@ __global__ __launch_bounds__(512) void mlp_fused_fwd_kernel(MlpArgs p) {
                 const int tok = t0 + mt * 16 + li;
                 bf16x8 pre8;
                 if constexpr (DG) {
-                    // four values at a time, the derivative rounded at once: eight chains in lockstep keep ~50 temporaries alive (34 registers spilled at C = 192)
+                    // four values at a time, the derivative rounded at once (C = 192 sits at the register limit; the DG instantiation spills 34 registers either way and
+                    // its extra ~10 VALU instructions per element cost 0.72 -> 1.12 ms on a kernel whose VALU, LDS reads and MFMAs are co-limiting: not used, ops._MLP_FUSED_DG_WIDTHS)
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
                         float d[4];
