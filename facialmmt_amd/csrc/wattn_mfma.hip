@@ -378,7 +378,12 @@ void wattn_mfma_bwd_kernel(WaArgs p) {
             // (Round 6, measured and not kept: the row statistics through the MFMAs' C operand -- S' = K.Q^T - lse / scale, dP' = V.dO^T - delta -- instead of
             //  one v_sub per logit each, 2 of ~12 VALU slots: stage 0 / 1 backward 0.965 / 0.993 / 0.484 -> 0.951 / 0.937 / 0.470 ms, stage 2 0.256 -> 0.34,
             //  Swin forward + backward 41.2 -> 41.1 ms, the step 58.3 -> 58.3: nothing.  A two-instruction mask (AND against a sign-extended bit field instead
-            //  of test + compare + select) spilled 15-44 registers: the sixteen masks of a tile are formed early.  profiles/r06_wattn_fold.txt)
+            //  of test + compare + select) spilled 15-44 registers: the sixteen masks of a tile are formed early.  And P handed from pass 1 to pass 2 through a
+            //  64 x 64 bf16 tile of the pair's in LDS -- written as four keys per lane, read back transposed by ds_read_b64_tr_b16 as the four query rows of the lane's key
+            //  column -- instead of recomputed (per lane 32 logits, 8 MFMAs, 32 bias reads and the conversions of P^T's fragments less, one barrier more): correct, twin
+            //  and goldens green, stage 0 / 1 sizes 0.936 / 0.954 / 0.463 / 0.488 -> 0.889 / 0.881 / 0.447 / 0.461 ms, stage 2 / 3 unchanged (0.251 / 0.266 / 0.180 ->
+            //  0.257 / 0.267 / 0.190), Swin 40.1 -> 40.1 ms: a quarter of the VALU slots gone and 3 % of the time -- the kernels are bound by the latency of their
+            //  dependent LDS -> MFMA -> exponential chains at two waves per SIMD, not by issue slots.  profiles/r06_wattn_fold.txt)
             dl[a] = xor_sum(d);
             ls[a] = cur.ls[a] * WA_LOG2E;
             const int off = slot * TP + lg * 8;
