@@ -904,8 +904,9 @@ class GraphedTargetStep:
     Parity: tests/test_gpu_train_step.py walks this against the eager TargetStep (same losses, same parameters)."""
 
     # where the text branch's launches enter the capture order: "start" (in front of Swin's forward), "pe" (behind PatchEmbed), "s<i>"
-    # (behind Swin stage i).  Development switch FMMT_TEXT_FORK; measured in NOTES.md R5.3.
-    TEXT_FORK_AT = __import__("os").environ.get("FMMT_TEXT_FORK", "start")
+    # (behind Swin stage i).  A class constant the probes patch (PATCH="train_step.GraphedTargetStep.TEXT_FORK_AT='s0'" tools/probes/bench_patch.py),
+    # not an environment switch; measured in NOTES.md R5.3.
+    TEXT_FORK_AT = "start"
 
     def __init__(self, swin_model, multimodal_model, optimizer, scheduler, args, batch, autocast_dtype=None,
                  overlap_text=True, parallel_fusion=False, averager=None, warmup_iters=2, masters=None, discarded_swin_gradients="compute",
@@ -1035,7 +1036,7 @@ class GraphedTargetStep:
             # BRANCH_NOTE.  Inside ONE graph the text encoder and Swin are two branches, but the replay does not run them side by side: the
             # runtime enqueues a graph branch by branch, and a branch that continues on another queue waits for EVERYTHING the first branch
             # has enqueued so far, not for the node it depends on (profiles/r05_timeline.txt: the text encoder's forward runs alone for
-            # ~4 ms in front of Swin's forward -- behind it when the capture order is swapped, FMMT_TEXT_FORK --, its backward starts ~12 ms
+            # ~4 ms in front of Swin's forward -- behind it when the capture order is swapped, TEXT_FORK_AT --, its backward starts ~12 ms
             # into Swin's backward and ends ~5 ms after it).  Here every branch is a graph of its own, launched on one of two streams with
             # events between them -- dependencies exactly where the data flow has them:
             #     side:  T  text encoder forward ............................ TB text encoder backward, hand-over | B update

@@ -11,8 +11,10 @@ import facialmmt_amd.ops as ops                      # noqa: E402
 import facialmmt_amd.train_step as train_step        # noqa: E402
 for item in filter(None, os.environ.get("PATCH", "").split(";")):
     name, value = item.split("=", 1)
-    mod, attr = name.strip().split(".")
+    mod, *path, attr = name.strip().split(".")        # ops._X, or train_step.GraphedTargetStep.TEXT_FORK_AT
     target = {"ops": ops, "train_step": train_step}[mod]
+    for part in path:
+        target = getattr(target, part)
     assert hasattr(target, attr), name
     setattr(target, attr, eval(value))
     print(f"[bench_patch] {name} = {getattr(target, attr)!r}", file=sys.stderr)
