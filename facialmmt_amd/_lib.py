@@ -14,7 +14,9 @@ LIB_PATH = os.path.join(_HERE, "libfmmt_hip.so")
 F32, BF16 = 0, 1
 GENERIC = 0x100          # dtype flag of the fused Mlp entry points: the element-type-generic restatement (include/fmmt.h)
 EPI_NONE, EPI_GELU, EPI_GELU_BWD, EPI_GELU_DG, EPI_MUL_AUX = 0, 1, 2, 3, 4
-SAVE_DG = 0x200              # include/fmmt.h FMMT_SAVE_DG: dtype flag of the fused Mlp entry points (h_pre = gelu'(pre-activation))
+SAVE_DG = 0x200
+BATCH_MAJOR = 0x400          # include/fmmt.h FMMT_BATCH_MAJOR: fmmt_mha_fwd / _bwd on (batch, tokens, hidden) operands
+# include/fmmt.h FMMT_SAVE_DG: dtype flag of the fused Mlp entry points (h_pre = gelu'(pre-activation))
 RESIZE_PIL, RESIZE_CV2 = 0, 1
 
 _p, _i, _f, _sz, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_uint64

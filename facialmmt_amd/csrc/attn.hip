@@ -385,14 +385,14 @@ constexpr int MT = 32;   // rows of the "other side" staged in LDS per step
 
 // stage MT rows [r0, r0+MT) of a time-major tensor (row t -> base + (t*B + b)*ld + h*D) as fp32 into
 // LDS [MT][D+4]; 64 lanes: lane -> (row = lane/2, half = lane&1)
-template <typename T, int D>
-__device__ __forceinline__ void stage_rows(const T* base, int ld, int B, int b, int h, int r0, int L, float mul,
+template <typename T, int D, bool QROWS>
+__device__ __forceinline__ void stage_rows(const MhaArgs& p, const T* base, int ld, int b, int h, int r0, int L, float mul,
                                            float* S, int lane) {
     constexpr int P = D + 4;
     const int r = lane >> 1, half = lane & 1;
     const int t = min(r0 + r, L - 1);
     float tmp[D / 2];
-    load_row<T, D / 2>(base + ((size_t)t * B + b) * ld + h * D + half * (D / 2), tmp);
+    load_row<T, D / 2>(base + (QROWS ? p.rq(t, b) : p.rk(t, b)) * ld + h * D + half * (D / 2), tmp);
 #pragma unroll
     for (int c = 0; c < D / 8; ++c)
         *reinterpret_cast<f32x4*>(S + r * P + half * (D / 2) + c * 4) =
@@ -401,9 +401,10 @@ __device__ __forceinline__ void stage_rows(const T* base, int ld, int B, int b, 
 
 __device__ __forceinline__ float keep_scale(const MhaArgs& p, int bh, int i, int j) {
     if (p.drop_p <= 0.f) return 1.f;
-    const uint64_t idx = ((uint64_t)bh * p.Lq + i) * p.Lk + j;
-    const uint64_t seed = p.seed_dev ? *p.seed_dev : p.seed;
-    return hash_uniform(seed, idx) >= p.drop_p ? 1.0f / (1.0f - p.drop_p) : 0.f;
+    const AttnDrop d = attn_drop_setup(p.drop_p, p.seed_dev ? *p.seed_dev : p.seed, p.Lk);
+    uint32_t a, b;
+    attn_drop_words(d, (uint32_t)bh * (uint32_t)p.Lq + (uint32_t)i, (uint32_t)j >> 2, a, b);
+    return attn_drop_field(d, a, b, j & 3);
 }
 // additive logit bias of key j (the BERT-style "(1 - mask) * -10000" extended attention mask); 0 if absent
 __device__ __forceinline__ float key_bias(const MhaArgs& p, int b, int j) {
@@ -423,14 +424,14 @@ __global__ __launch_bounds__(64) void mha_fwd_kernel(MhaArgs p) {
     const int i = active ? i_raw : p.Lq - 1;
     const T* qg = reinterpret_cast<const T*>(p.q);
     float q[D], o[D];
-    load_row<T, D>(qg + ((size_t)i * p.B + b) * p.ldq + h * D, q);
+    load_row<T, D>(qg + p.rq(i, b) * p.ldq + h * D, q);
 #pragma unroll
     for (int d = 0; d < D; ++d) { q[d] *= p.scale; o[d] = 0.f; }
     float m = -INFINITY, l = 0.f;
     for (int j0 = 0; j0 < p.Lk; j0 += MT) {
         __syncthreads();
-        stage_rows<T, D>(reinterpret_cast<const T*>(p.k), p.ldkv, p.B, b, h, j0, p.Lk, 1.f, Ks, lane);
-        stage_rows<T, D>(reinterpret_cast<const T*>(p.v), p.ldkv, p.B, b, h, j0, p.Lk, 1.f, Vs, lane);
+        stage_rows<T, D, false>(p, reinterpret_cast<const T*>(p.k), p.ldkv, b, h, j0, p.Lk, 1.f, Ks, lane);
+        stage_rows<T, D, false>(p, reinterpret_cast<const T*>(p.v), p.ldkv, b, h, j0, p.Lk, 1.f, Vs, lane);
         __syncthreads();
 #pragma unroll 1
         for (int js = 0; js < MT; js += 8) {
@@ -461,7 +462,7 @@ __global__ __launch_bounds__(64) void mha_fwd_kernel(MhaArgs p) {
         const float inv = 1.0f / l;
 #pragma unroll
         for (int d = 0; d < D; ++d) o[d] *= inv;
-        store_row<T, D>(reinterpret_cast<T*>(p.out) + ((size_t)i * p.B + b) * p.ldo + h * D, o);
+        store_row<T, D>(reinterpret_cast<T*>(p.out) + p.rq(i, b) * p.ldo + h * D, o);
         p.lse[(size_t)bh * p.Lq + i] = m + __logf(l);
     }
 }
@@ -478,12 +479,12 @@ __global__ __launch_bounds__(64) void mha_bwd_dq_kernel(MhaArgs p) {
     const bool active = i_raw < p.Lq;
     const int i = active ? i_raw : p.Lq - 1;
     float q[D], dO[D], dq[D];
-    load_row<T, D>(reinterpret_cast<const T*>(p.q) + ((size_t)i * p.B + b) * p.ldq + h * D, q);
-    load_row<T, D>(reinterpret_cast<const T*>(p.dout) + ((size_t)i * p.B + b) * p.ldo + h * D, dO);
+    load_row<T, D>(reinterpret_cast<const T*>(p.q) + p.rq(i, b) * p.ldq + h * D, q);
+    load_row<T, D>(reinterpret_cast<const T*>(p.dout) + p.rq(i, b) * p.ldo + h * D, dO);
     float delta = 0.f;
     {
         float o[D];
-        load_row<T, D>(reinterpret_cast<const T*>(p.out) + ((size_t)i * p.B + b) * p.ldo + h * D, o);
+        load_row<T, D>(reinterpret_cast<const T*>(p.out) + p.rq(i, b) * p.ldo + h * D, o);
 #pragma unroll
         for (int d = 0; d < D; ++d) delta += o[d] * dO[d];
     }
@@ -492,8 +493,8 @@ __global__ __launch_bounds__(64) void mha_bwd_dq_kernel(MhaArgs p) {
     const float lse = p.lse[(size_t)bh * p.Lq + i];
     for (int j0 = 0; j0 < p.Lk; j0 += MT) {
         __syncthreads();
-        stage_rows<T, D>(reinterpret_cast<const T*>(p.k), p.ldkv, p.B, b, h, j0, p.Lk, 1.f, Ks, lane);
-        stage_rows<T, D>(reinterpret_cast<const T*>(p.v), p.ldkv, p.B, b, h, j0, p.Lk, 1.f, Vs, lane);
+        stage_rows<T, D, false>(p, reinterpret_cast<const T*>(p.k), p.ldkv, b, h, j0, p.Lk, 1.f, Ks, lane);
+        stage_rows<T, D, false>(p, reinterpret_cast<const T*>(p.v), p.ldkv, b, h, j0, p.Lk, 1.f, Vs, lane);
         __syncthreads();
 #pragma unroll 2
         for (int j = 0; j < MT; ++j) {
@@ -506,7 +507,7 @@ __global__ __launch_bounds__(64) void mha_bwd_dq_kernel(MhaArgs p) {
     if (active) {
 #pragma unroll
         for (int d = 0; d < D; ++d) dq[d] *= p.scale;
-        store_row<T, D>(reinterpret_cast<T*>(p.dq) + ((size_t)i * p.B + b) * p.lddq + h * D, dq);
+        store_row<T, D>(reinterpret_cast<T*>(p.dq) + p.rq(i, b) * p.lddq + h * D, dq);
     }
 }
 
@@ -523,25 +524,25 @@ __global__ __launch_bounds__(64) void mha_bwd_dkv_kernel(MhaArgs p) {
     const bool active = j_raw < p.Lk;
     const int j = active ? j_raw : p.Lk - 1;
     float kreg[D], acc[D];
-    load_row<T, D>(reinterpret_cast<const T*>(p.k) + ((size_t)j * p.B + b) * p.ldkv + h * D, kreg);
+    load_row<T, D>(reinterpret_cast<const T*>(p.k) + p.rk(j, b) * p.ldkv + h * D, kreg);
 #pragma unroll
     for (int d = 0; d < D; ++d) acc[d] = 0.f;
     const float kb = key_bias(p, b, j);
     float vreg[WHICH == 1 ? D : 1];
-    if constexpr (WHICH == 1) load_row<T, D>(reinterpret_cast<const T*>(p.v) + ((size_t)j * p.B + b) * p.ldkv + h * D, vreg);
+    if constexpr (WHICH == 1) load_row<T, D>(reinterpret_cast<const T*>(p.v) + p.rk(j, b) * p.ldkv + h * D, vreg);
     const T* og = reinterpret_cast<const T*>(p.out);
     const T* dog = reinterpret_cast<const T*>(p.dout);
     for (int i0 = 0; i0 < p.Lq; i0 += MT) {
         __syncthreads();
-        stage_rows<T, D>(reinterpret_cast<const T*>(p.q), p.ldq, p.B, b, h, i0, p.Lq, p.scale, Qs, lane);
-        stage_rows<T, D>(dog, p.ldo, p.B, b, h, i0, p.Lq, 1.f, Gs, lane);
+        stage_rows<T, D, true>(p, reinterpret_cast<const T*>(p.q), p.ldq, b, h, i0, p.Lq, p.scale, Qs, lane);
+        stage_rows<T, D, true>(p, dog, p.ldo, b, h, i0, p.Lq, 1.f, Gs, lane);
         if (lane < MT) {
             const int i = min(i0 + lane, p.Lq - 1);
             Ls[lane] = p.lse[(size_t)bh * p.Lq + i];
             if constexpr (WHICH == 1) {
                 float o[D], g[D];
-                load_row<T, D>(og + ((size_t)i * p.B + b) * p.ldo + h * D, o);
-                load_row<T, D>(dog + ((size_t)i * p.B + b) * p.ldo + h * D, g);
+                load_row<T, D>(og + p.rq(i, b) * p.ldo + h * D, o);
+                load_row<T, D>(dog + p.rq(i, b) * p.ldo + h * D, g);
                 float dl = 0.f;
 #pragma unroll
                 for (int d = 0; d < D; ++d) dl += o[d] * g[d];
@@ -564,7 +565,7 @@ __global__ __launch_bounds__(64) void mha_bwd_dkv_kernel(MhaArgs p) {
     }
     if (active) {
         T* dst = reinterpret_cast<T*>(WHICH == 0 ? p.dv : p.dk);
-        store_row<T, D>(dst + ((size_t)j * p.B + b) * p.lddkv + h * D, acc);
+        store_row<T, D>(dst + p.rk(j, b) * p.lddkv + h * D, acc);
     }
 }
 
@@ -585,12 +586,12 @@ template <typename T>
 __global__ __launch_bounds__(128) void mha_avg_weights_kernel(MhaArgs p, float* __restrict__ w) {
     extern __shared__ float qs[];                                   // the query row, all heads, pre-scaled
     const int i = blockIdx.x, b = blockIdx.y, hd = p.E / p.nH;
-    const T* qg = reinterpret_cast<const T*>(p.q) + ((size_t)i * p.B + b) * p.ldq;
+    const T* qg = reinterpret_cast<const T*>(p.q) + p.rq(i, b) * p.ldq;
     const T* kg = reinterpret_cast<const T*>(p.k);
     for (int c = threadIdx.x; c < p.E; c += 128) qs[c] = to_f32(qg[c]) * p.scale;
     __syncthreads();
     for (int j = threadIdx.x; j < p.Lk; j += 128) {
-        const T* kr = kg + ((size_t)j * p.B + b) * p.ldkv;
+        const T* kr = kg + p.rk(j, b) * p.ldkv;
         const float kb = key_bias(p, b, j);
         float acc = 0.f;
         for (int h = 0; h < p.nH; ++h) {
@@ -780,11 +781,13 @@ extern "C" int fmmt_mha_avg_weights(int dtype, int Lq, int Lk, int B, int E, int
 extern "C" int fmmt_mha_fwd(int dtype, int Lq, int Lk, int B, int E, int num_heads,
                             const void* q, int ldq, const void* k, const void* v, int ldkv, float scale, const float* key_bias,
                             float dropout_p, uint64_t seed, const uint64_t* seed_dev, void* out, int ldo, float* lse, void* stream) {
+    const int bm = (dtype & FMMT_BATCH_MAJOR) ? 1 : 0;
+    dtype &= ~FMMT_BATCH_MAJOR;
     if (int e = mha_check(dtype, Lq, Lk, B, E, num_heads)) return e;
     if (dropout_p < 0.f || dropout_p >= 1.f) return FMMT_EINVAL;
     MhaArgs a{};
     a.Lq = Lq; a.Lk = Lk; a.B = B; a.E = E; a.nH = num_heads; a.q = q; a.ldq = ldq; a.k = k; a.v = v; a.ldkv = ldkv;
-    a.scale = scale; a.key_bias = key_bias; a.drop_p = dropout_p; a.seed = seed; a.seed_dev = seed_dev; a.out = out; a.ldo = ldo; a.lse = lse;
+    a.scale = scale; a.key_bias = key_bias; a.drop_p = dropout_p; a.seed = seed; a.seed_dev = seed_dev; a.out = out; a.ldo = ldo; a.lse = lse; a.bm = bm;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == FMMT_BF16 && E / num_heads == 64 && ldq % 8 == 0 && ldkv % 8 == 0 && ldo % 8 == 0)
         return fmmt_mha_mfma_fwd_launch(a, st);                      // matrix-core path
@@ -796,12 +799,14 @@ extern "C" int fmmt_mha_bwd(int dtype, int Lq, int Lk, int B, int E, int num_hea
                             const void* q, int ldq, const void* k, const void* v, int ldkv, float scale, const float* key_bias,
                             float dropout_p, uint64_t seed, const uint64_t* seed_dev, const void* out, const void* dout, int ldo,
                             const float* lse, void* dq, int lddq, void* dk, void* dv, int lddkv, void* stream) {
+    const int bm = (dtype & FMMT_BATCH_MAJOR) ? 1 : 0;
+    dtype &= ~FMMT_BATCH_MAJOR;
     if (int e = mha_check(dtype, Lq, Lk, B, E, num_heads)) return e;
     if (dropout_p < 0.f || dropout_p >= 1.f) return FMMT_EINVAL;
     MhaArgs a{};
     a.Lq = Lq; a.Lk = Lk; a.B = B; a.E = E; a.nH = num_heads; a.q = q; a.ldq = ldq; a.k = k; a.v = v; a.ldkv = ldkv;
     a.scale = scale; a.key_bias = key_bias; a.drop_p = dropout_p; a.seed = seed; a.seed_dev = seed_dev; a.out = const_cast<void*>(out); a.ldo = ldo;
-    a.lse = const_cast<float*>(lse); a.dout = dout; a.dq = dq; a.lddq = lddq; a.dk = dk; a.dv = dv; a.lddkv = lddkv;
+    a.lse = const_cast<float*>(lse); a.dout = dout; a.dq = dq; a.lddq = lddq; a.dk = dk; a.dv = dv; a.lddkv = lddkv; a.bm = bm;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == FMMT_BF16 && E / num_heads == 64 && ldq % 8 == 0 && ldkv % 8 == 0 && ldo % 8 == 0 && lddq % 8 == 0 && lddkv % 8 == 0)
         return fmmt_mha_mfma_bwd_launch(a, st);                      // matrix-core path

@@ -239,6 +239,47 @@ __device__ __forceinline__ float hash_uniform(uint64_t seed, uint64_t idx) {
     return (float)(z >> 40) * (1.0f / 16777216.0f);
 }
 
+// ---------------------------------------------------------------------------------------------
+// keep-mask of the attention-probability dropout (fmmt_mha_fwd / _bwd; both formulations, replayed bit-identically in the backward).
+// splitmix64 per element was ~60 issue slots of 64-bit multiplies against ~10 for the softmax element itself (round 6: the 4 x 512-token text
+// shape ran 39 us without dropout, 75 with).  One pair of 32-bit avalanche mixes (two multiplies each; lowbias32 and the first rounds of
+// triple32, public-domain constants of the hash-prospector search) now serves the FOUR consecutive keys 4g .. 4g+3 of a query row, 16 bits per
+// decision: keep = field >= round(p * 2^16), kept values scaled by 2^16 / (2^16 - threshold) (the exact inverse of the realised keep rate).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mix32a(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint32_t mix32b(uint32_t x) {
+    x ^= x >> 17; x *= 0xed5ad4bbU; x ^= x >> 11; x *= 0xac4c1b51U; x ^= x >> 15;
+    return x;
+}
+struct AttnDrop {
+    uint32_t key, thresh, G;      // hashed seed; threshold of a 16-bit field; 4-key groups per query row
+    float inv;
+};
+__device__ __forceinline__ AttnDrop attn_drop_setup(float p, uint64_t seed, int Lk) {
+    AttnDrop d;
+    d.key = mix32a((uint32_t)seed ^ 0x85ebca6bU) + mix32b((uint32_t)(seed >> 32) ^ 0xc2b2ae35U);
+    const uint32_t t = (uint32_t)(p * 65536.0f + 0.5f);
+    d.thresh = t > 65535u ? 65535u : t;
+    d.inv = 65536.0f / (65536.0f - (float)d.thresh);
+    d.G = (uint32_t)(Lk + 3) >> 2;
+    return d;
+}
+// the two words of group `g` of query row `row` (row = (batch * heads + head) * Lq + query; 32-bit wrap-around is harmless)
+__device__ __forceinline__ void attn_drop_words(const AttnDrop& d, uint32_t row, uint32_t g, uint32_t& a, uint32_t& b) {
+    const uint32_t x = row * d.G + g + d.key;
+    a = mix32a(x);
+    b = mix32b(x);
+}
+// multiplier of key 4g + f from the group's words: fields 0, 1 = low / high half of a, fields 2, 3 of b
+__device__ __forceinline__ float attn_drop_field(const AttnDrop& d, uint32_t a, uint32_t b, int f) {
+    const uint32_t w = (f & 2) ? b : a;
+    const uint32_t v = (f & 1) ? (w >> 16) : (w & 0xFFFFu);
+    return v >= d.thresh ? d.inv : 0.f;
+}
+
 // per-sample (DropPath) multiplier lookup: rowscale == nullptr -> 1
 __device__ __forceinline__ float row_scale(const float* rowscale, int row, int rows_per_scale) {
     return rowscale ? rowscale[row / rows_per_scale] : 1.0f;

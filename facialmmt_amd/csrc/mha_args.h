@@ -13,6 +13,10 @@ struct MhaArgs {
     void* out; int ldo; float* lse;
     const void* dout;
     void* dq; int lddq; void* dk; void* dv; int lddkv;
+    int bm;                         // 0: time-major operands (row t of batch b at (t * B + b) * ld); 1: batch-major ((b * L + t) * ld; dtype | FMMT_BATCH_MAJOR)
+    // row index (in units of the row pitch) of query / key t of batch b
+    __host__ __device__ size_t rq(int t, int b) const { return bm ? (size_t)b * Lq + t : (size_t)t * B + b; }
+    __host__ __device__ size_t rk(int t, int b) const { return bm ? (size_t)b * Lk + t : (size_t)t * B + b; }
 };
 
 int fmmt_mha_mfma_fwd_launch(const MhaArgs& a, hipStream_t st);

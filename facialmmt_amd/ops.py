@@ -22,6 +22,13 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+def _c16(t: torch.Tensor) -> torch.Tensor:
+    """contiguous AND 16-byte aligned: a view that starts at an odd offset of its storage (a residual sliced out of a packed buffer) is copied rather than
+    handed to a kernel that would answer FMMT_EALIGN (round-5 ADVICE)"""
+    t = t.contiguous()
+    return t.clone() if t.data_ptr() % 16 else t
+
+
 def _need_cuda(t: torch.Tensor, what: str):
     if not t.is_cuda:
         raise _lib.FmmtError(f"{what}: the hot path runs on the GPU only (got a {t.device} tensor); "
@@ -371,7 +378,7 @@ class PlmSublayerTailFn(torch.autograd.Function):
     def forward(ctx, x, res, weight, bias, gamma, beta, eps, p, seed, salt):
         h = torch.nn.functional.linear(x, weight, bias)
         C = h.shape[-1]
-        h2, r2 = h.reshape(-1, C), res.reshape(-1, C).contiguous()
+        h2, r2 = h.reshape(-1, C), _c16(res.reshape(-1, C))
         M = h2.shape[0]
         xsum, y = torch.empty_like(h2), torch.empty_like(h2)
         seed_t = seed if isinstance(seed, torch.Tensor) else None
@@ -387,7 +394,7 @@ class PlmSublayerTailFn(torch.autograd.Function):
         x, weight, xsum, gamma, seed_t = ctx.saved_tensors
         eps, p, seed_i, salt = ctx.cfg
         M, C = xsum.shape
-        dy2 = dy.reshape(M, C).contiguous()
+        dy2 = _c16(dy.reshape(M, C))
         lib = _lib.load()
         dx, dh = torch.empty_like(xsum), torch.empty_like(xsum)
         dgamma, dbeta, dbias = torch.empty_like(gamma), torch.empty_like(gamma), torch.empty_like(gamma)
@@ -410,9 +417,9 @@ class DropAddLnFn(Function):
     def forward(ctx, h, res, gamma, beta, eps, p, seed, salt):
         _need_cuda(h, "dropadd_layer_norm")
         C = h.shape[-1]
-        h2, r2 = h.reshape(-1, C).contiguous(), res.reshape(-1, C).contiguous()
+        h2, r2 = _c16(h.reshape(-1, C)), _c16(res.reshape(-1, C))
         M = h2.shape[0]
-        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        g, b = _c16(gamma.detach()), _c16(beta.detach())
         assert h2.dtype == torch.bfloat16 and r2.dtype == torch.bfloat16 and g.dtype == b.dtype and g.dtype in (torch.float32, torch.bfloat16)
         xsum, y = torch.empty_like(h2), torch.empty_like(h2)
         seed_t = seed if isinstance(seed, torch.Tensor) else None
@@ -428,7 +435,7 @@ class DropAddLnFn(Function):
         xsum, g, seed_t = ctx.saved_tensors
         eps, p, seed_i, salt = ctx.cfg
         M, C = xsum.shape
-        dy2 = dy.reshape(M, C).contiguous()
+        dy2 = _c16(dy.reshape(M, C))
         lib = _lib.load()
         dx, dh = torch.empty_like(xsum), torch.empty_like(xsum)
         dgamma, dbeta = torch.empty_like(g), torch.empty_like(g)
@@ -1050,6 +1057,34 @@ def mha_bwd_raw(q, k, v, out, dout, lse, num_heads, scale, dropout_p, seed_i, se
     return dq, dk, dv
 
 
+def mha_packed_bm_fwd_raw(qkv, num_heads, scale, dropout_p, seed_i, seed_t, key_bias):
+    """fmmt_mha_fwd(dtype | FMMT_BATCH_MAJOR) of SELF-attention over a packed batch-major projection qkv (B, S, 3E) = [q | k | v]: the three operands are
+    column slices of it (row pitch 3E), nothing is transposed or copied.  Returns (out (B, S, E), lse)."""
+    B, S, E3 = qkv.shape
+    E = E3 // 3
+    es = qkv.element_size()
+    out = torch.empty((B, S, E), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty((B * num_heads * S,), dtype=torch.float32, device=qkv.device)
+    qp = qkv.data_ptr()
+    rc = _lib.load().fmmt_mha_fwd(dtype_code(qkv.dtype) | _lib.BATCH_MAJOR, S, S, B, E, num_heads, qp, E3, qp + E * es, qp + 2 * E * es, E3, scale, _p(key_bias),
+                                  dropout_p, seed_i, _p(seed_t), _p(out), E, _p(lse), _st())
+    check(rc, f"fmmt_mha_fwd(batch-major, S={S},B={B},E={E},heads={num_heads})")
+    return out, lse
+
+
+def mha_packed_bm_bwd_raw(qkv, out, dout, lse, num_heads, scale, dropout_p, seed_i, seed_t, key_bias):
+    """fmmt_mha_bwd(dtype | FMMT_BATCH_MAJOR): the gradient of the packed projection, (B, S, 3E) = [dq | dk | dv], written in place by the two kernels"""
+    B, S, E3 = qkv.shape
+    E = E3 // 3
+    es = qkv.element_size()
+    dqkv = torch.empty_like(qkv)
+    qp, dp = qkv.data_ptr(), dqkv.data_ptr()
+    rc = _lib.load().fmmt_mha_bwd(dtype_code(qkv.dtype) | _lib.BATCH_MAJOR, S, S, B, E, num_heads, qp, E3, qp + E * es, qp + 2 * E * es, E3, scale, _p(key_bias),
+                                  dropout_p, seed_i, _p(seed_t), _p(out), _p(dout), E, _p(lse), dp, E3, dp + E * es, dp + 2 * E * es, E3, _st())
+    check(rc, f"fmmt_mha_bwd(batch-major, S={S},B={B},E={E},heads={num_heads})")
+    return dqkv
+
+
 class MhaCoreFn(Function):
     """q: (Lq,B,E); kv: either a packed (Lk,B,2E) tensor [k | v] (v is None) or separate k, v (Lk,B,E)."""
 
@@ -1457,7 +1492,8 @@ class PatchEmbedU8LnFn(Function):
 
 def patch_embed_u8_ln_fusable(img_u8, weight, norm, dtype):
     return (_PATCH_U8_LN and _PATCH_LN and norm is not None and img_u8.is_cuda and dtype in (torch.bfloat16, torch.float32)
-            and tuple(weight.shape) == (96, 48) and tuple(norm.weight.shape) == (96,))
+            and tuple(weight.shape) == (96, 48) and tuple(norm.weight.shape) == (96,) and 0 < img_u8.shape[0] <= 65535      # the entry point's frame limit
+            and not any(t.data_ptr() % 16 for t in (weight, norm.weight, norm.bias)))
 
 
 def patch_embed_u8_ln(img_u8, mode, weight, bias, gamma, beta, eps, dtype):

@@ -36,6 +36,11 @@ extern "C" {
  * of the pre-activation -- the only thing the backward needs of it (Swin_Transformer.py:19-28) -- written by the forward beside gelu() (one shared
  * exponential), multiplied in by the backward (no polynomial there).  The fused counterpart of FMMT_EPI_GELU_DG / FMMT_EPI_MUL_AUX; round 6. */
 #define FMMT_SAVE_DG 0x200
+/* fmmt_mha_fwd / fmmt_mha_bwd, dtype | FMMT_BATCH_MAJOR: the operands are batch-major -- row t of batch b of q / out / dout / dq at
+ * (b * Lq + t) * ld, of k / v / dk / dv at (b * Lk + t) * ld -- instead of time-major ((t * B + b) * ld): the layout of the text encoder's
+ * (batch, tokens, hidden) activations (transformers' *SelfAttention, src/models.py:75-91), whose attention then needs no transposes.
+ * lse, key_bias and the dropout stream do not depend on the layout. */
+#define FMMT_BATCH_MAJOR 0x400
 
 #define FMMT_EINVAL (-1)   /* bad shape / unsupported size */
 #define FMMT_EALIGN (-2)   /* pointer or leading dimension not 16-byte aligned */
@@ -283,8 +288,8 @@ int fmmt_window_block_attn_bwd_ref(int dtype, int n_img, int H, int W, int C, in
  * (q *= scaling), :94-98 (head split), :109 (bmm), :121 (fp32 softmax), :124 (dropout), :126 (bmm),
  * :128 (head merge).  Time-major operands: q [Lq, B, E], k / v [Lk, B, ldkv] (k and v may be column
  * slices of one packed projection: pass the slice pointers and the shared row pitch ldkv).
- * head_dim = E / num_heads must be 64 or 32.  Dropout: keep-mask = hash(seed, element) >= p, kept
- * probabilities scaled by 1/(1-p); p == 0 disables.  If seed_dev != NULL the seed is read from that device
+ * head_dim = E / num_heads must be 64 or 32.  Dropout: keep-mask = 16-bit hash field(seed, query row, key) >= round(p * 2^16), kept
+ * probabilities scaled by the inverse of the realised keep rate (|it - 1/(1-p)| < 1e-5 / (1-p)^2); p == 0 disables.  If seed_dev != NULL the seed is read from that device
  * word at kernel run time (so a captured hipGraph draws a fresh mask on every replay) and `seed` is ignored.  The head-averaged weights the reference also
  * returns (:133-134) are discarded by every caller (CrossmodalTransformer.py:147,151) and are not produced.
  * key_bias (fp32 [B, Lk], may be NULL): added to the scaled logits of key j of batch b before the softmax.  The

@@ -487,6 +487,30 @@ def test_dropadd_layer_norm_with_fp32_parameters_against_torch_on_the_same_mask(
         assert (gh[~keep] == 0).all()
 
 
+def test_dropadd_layer_norm_takes_views_at_odd_storage_offsets():
+    """A residual / gradient that is a contiguous view 8 bytes into its storage (a slice of a packed buffer) is copied to an aligned buffer rather than
+    answered with FMMT_EALIGN (round-5 ADVICE): same bits as the aligned call, forward and backward."""
+    from facialmmt_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    M, C = 96, 768
+    h = torch.randn(M, C, device=dev).to(torch.bfloat16)
+    buf = (0.05 * torch.randn(M * C + 4, device=dev)).to(torch.bfloat16)
+    res_odd = buf[4:].view(M, C)
+    assert res_odd.is_contiguous() and res_odd.data_ptr() % 16 == 8
+    gm = (1 + 0.1 * torch.randn(C, device=dev)).requires_grad_(True)
+    bt = (0.1 * torch.randn(C, device=dev)).requires_grad_(True)
+    seed = torch.tensor([99], device=dev, dtype=torch.int64)
+    dbuf = torch.randn(M * C + 4, device=dev).to(torch.bfloat16)
+    outs = []
+    for res, dy in ((res_odd, dbuf[4:].view(M, C)), (res_odd.clone(), dbuf[4:].view(M, C).clone())):
+        hin, rin = h.clone().requires_grad_(True), res.detach().requires_grad_(True)
+        y = ops.dropadd_layer_norm(hin, rin, gm, bt, 1e-12, 0.1, seed, 7)
+        outs.append((y,) + torch.autograd.grad(y, [hin, rin, gm, bt], dy))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def test_meld_encoder_training_mode_fused_tails_match_the_separate_launches():
     """MELDTransEncoder in training mode, bf16: with hidden dropout forced to 0 inside _tail the fused launch and the three separate launches agree (same
     bf16 rounding op by op); with p = 0.1 both run, finite, and two passes under the same torch seed are identical (device-drawn seeds)."""
