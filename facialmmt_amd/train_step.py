@@ -354,6 +354,7 @@ class VendorLayerNorm(torch.nn.LayerNorm):
 
 # Module constants (the probes patch them), not environment switches: each is the off-switch of one fused launch family
 PLM_COLSUM, PLM_LN, FUSED_ADAMW, PIN_SHADOWS, FUSED_HANDOVER = True, True, True, True, True
+PLM_FUSE_ATTN = True                                        # a packed *SelfAttention runs its attention core on fmmt_mha_fwd / _bwd (False: the stock attention interface)
 PLM_FUSE_TAILS, PLM_FUSE_QKV = True, True                  # fuse_text_encoder: sublayer tails as one launch per direction / packed query-key-value GEMM
 
 
@@ -380,9 +381,10 @@ class _SeedBox:
 
     def __init__(self):
         self.t = None
+        self.words = 1            # word 0: the sublayer tails (each adds its salt); word 1 + i: attention module i (its kernels take no salt)
 
     def draw(self, device):
-        self.t = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64, device=device)
+        self.t = torch.randint(0, 2 ** 62, (self.words,), dtype=torch.int64, device=device)
 
 
 def _sublayer_tail_forward(self, hidden_states, input_tensor):
@@ -414,6 +416,9 @@ def _packed_qkv_forward(self, hidden_states, *args, **kwargs):
     if not ok or cross:
         return self._fmmt_stock_forward(hidden_states, *args, **kwargs)
     from . import ops
+    fused = _fused_attention(self, hidden_states, args, kwargs, w, b)
+    if fused is not None:
+        return fused
     yq, yk, yv = ops.PlmQkvFn.apply(hidden_states, q.weight, k.weight, v.weight, q.bias, k.bias, v.bias, w, b)
     saved = (self.query, self.key, self.value)
     try:                                                     # the stock forward calls self.query(x) ...: hand it the projections already made
@@ -421,6 +426,41 @@ def _packed_qkv_forward(self, hidden_states, *args, **kwargs):
         return self._fmmt_stock_forward(hidden_states, *args, **kwargs)
     finally:
         self.__dict__["_modules"] = dict(self._modules, query=saved[0], key=saved[1], value=saved[2])
+
+
+def _fused_attention(self, hidden_states, args, kwargs, w, b):
+    """the attention core of a packed *SelfAttention on the in-tree kernels (ops.PlmSelfAttnFn), or None where they do not apply (then: the stock attention
+    interface behind the packed projection).  Encoder self-attention only: bf16, head_dim 64, no cache, no head mask, no attention weights asked for; the
+    mask transformers hands down -- None, or the 4-d form of a (batch, keys) padding mask, boolean (sdpa) or additive (eager), whose rows are all alike for a
+    bidirectional encoder -- becomes the kernels' per-key logit bias from its first query row."""
+    if not PLM_FUSE_ATTN or hidden_states.dim() != 3 or hidden_states.dtype != torch.bfloat16:
+        return None
+    nH = int(getattr(self, "num_attention_heads", 0))
+    E = w.shape[1]
+    if nH <= 0 or E % nH or E // nH != 64 or getattr(self, "is_decoder", False) or getattr(self, "is_causal", False):
+        return None
+    if getattr(self, "position_embedding_type", "absolute") not in (None, "absolute"):
+        return None                                         # relative-position variants add a term to the scores
+    if kwargs.get("output_attentions") or kwargs.get("head_mask") is not None or any(a is not None for a in args[1:]):
+        return None
+    mask = args[0] if args else kwargs.get("attention_mask")
+    B, S, _ = hidden_states.shape
+    key_bias = None
+    if mask is not None:
+        if not torch.is_tensor(mask) or mask.dim() != 4 or mask.shape[0] != B or mask.shape[1] != 1 or mask.shape[-1] != S or mask.shape[2] not in (1, S):
+            return None
+        row = mask[:, 0, 0, :]
+        key_bias = (torch.where(row, 0.0, -30000.0) if row.dtype == torch.bool else row.float().clamp_min(-30000.0)).to(torch.float32).contiguous()
+    p = float(self.dropout.p) if self.training else 0.0
+    box = getattr(self, "_fmmt_seed", None)
+    if p > 0.0 and (box is None or box.t is None or box.t.numel() <= self._fmmt_attn_word):
+        return None
+    seed = box.t[self._fmmt_attn_word:self._fmmt_attn_word + 1] if p > 0.0 else 0
+    scale = float(getattr(self, "scaling", 64 ** -0.5))
+    from . import ops
+    q, k, v = self.query, self.key, self.value
+    out = ops.PlmSelfAttnFn.apply(hidden_states, q.weight, k.weight, v.weight, q.bias, k.bias, v.bias, w, b, nH, scale, p, seed, key_bias)
+    return out, None
 
 
 class _Fixed(torch.nn.Module):
@@ -437,8 +477,10 @@ def fuse_text_encoder(plm, tails: bool = True, qkv: bool = True):
     (MasterWeights): (a) every *SelfOutput / *Output runs dense + dropout + residual + LayerNorm as the vendor GEMM + one fused launch, backward one
     launch + a reduction + the two GEMMs (ops.PlmSublayerTailFn); (b) every *SelfAttention computes query / key / value with ONE GEMM over a packed
     (3E, E) weight of which the three nn.Linear parameters become row slices (same Parameter objects, same names, same state_dict; the optimizer's
-    views keep working).  Returns (tails changed, attentions packed).  Numerics: (a) rounds like the bf16 module op by op, with its own dropout
-    stream (counter-based, replayed in the backward instead of a stored mask); (b) is the same arithmetic as three GEMMs."""
+    views keep working) and, where the in-tree attention kernels apply (_fused_attention: bf16, head_dim 64, encoder self-attention), its attention core
+    with them on the packed projection (PLM_FUSE_ATTN).  Returns (tails changed, attentions packed).  Numerics: (a) rounds like the bf16 module op by op,
+    with its own dropout stream (counter-based, replayed in the backward instead of a stored mask); (b) is the same arithmetic as three GEMMs; the
+    attention core is a flash-style online softmax in fp32 with bf16 probabilities, like the library kernel it replaces, and its own dropout stream."""
     box = _SeedBox()
     n_tail = n_qkv = 0
     salt = 0
@@ -469,9 +511,12 @@ def fuse_text_encoder(plm, tails: bool = True, qkv: bool = True):
                     lin.bias.data = b[i * E:(i + 1) * E]
             m._fmmt_qkv = (w, b)
             m._fmmt_stock_forward = m.forward
+            m._fmmt_seed = box
+            m._fmmt_attn_word = box.words                   # its own word of the step's seed draw
+            box.words += 1
             m.forward = types.MethodType(_packed_qkv_forward, m)
             n_qkv += 1
-    if n_tail:
+    if n_tail or n_qkv:
         plm.register_forward_pre_hook(lambda mod, args, kwargs=None: box.draw(next(mod.parameters()).device) if mod.training else None)
     return n_tail, n_qkv
 

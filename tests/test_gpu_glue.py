@@ -401,6 +401,94 @@ def test_fused_text_encoder_sublayers_match_the_stock_module():
     assert not torch.equal(before, w) and att.key.weight.data_ptr() == w[256:].data_ptr()
 
 
+def test_fused_text_attention_core_with_dropout_against_torch_on_the_same_mask():
+    """ops.PlmSelfAttnFn (one GEMM over the packed weight + fmmt_mha_fwd / _bwd | FMMT_BATCH_MAJOR): the keep-mask is read back from the kernel (q = k = 0 makes
+    every probability 1 / S, one-hot values then leave keep / (S (1 - p)) in the output), its kept fraction is 1 - p, the same seed word replays it and another
+    does not; forward and every gradient against torch's softmax attention in fp32 on THAT mask, with a key-padding bias, at bf16 tolerance."""
+    from facialmmt_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    B, S, H, D, p = 3, 64, 4, 64, 0.1
+    E = H * D
+    seeds = torch.tensor([41, 42], device=dev, dtype=torch.int64)
+    probe = torch.zeros(B, S, 3 * E, device=dev, dtype=torch.bfloat16)
+    probe[..., 2 * E:] = torch.eye(S, D, device=dev, dtype=torch.bfloat16).repeat(1, H)[None]
+    o, _ = ops.mha_packed_bm_fwd_raw(probe, H, 0.125, p, 0, seeds[0:1], None)
+    keep = (o.view(B, S, H, D).permute(0, 2, 1, 3) != 0)                      # (B, H, query, key)
+    frac = keep.float().mean().item()
+    assert abs(frac - (1 - p)) < 0.01, frac
+    o2, _ = ops.mha_packed_bm_fwd_raw(probe, H, 0.125, p, 0, seeds[1:2], None)
+    assert not torch.equal(o, o2)
+    inv = o.float().max().item() * S                                          # the realised 1 / keep rate (2^16 / (2^16 - round(p 2^16)))
+    assert abs(inv - 1 / (1 - p)) < 1e-2
+    x = torch.randn(B, S, E, device=dev).to(torch.bfloat16)
+    w = (torch.randn(3 * E, E, device=dev) * E ** -0.5).to(torch.bfloat16)
+    b = (0.1 * torch.randn(3 * E, device=dev)).to(torch.bfloat16)
+    kb = torch.zeros(B, S, device=dev)
+    kb[1, 50:] = -30000.0
+    g = torch.randn(B, S, E, device=dev).to(torch.bfloat16)
+    xin = x.clone().requires_grad_(True)
+    ws = [w[i * E:(i + 1) * E].clone().requires_grad_(True) for i in range(3)]
+    bs = [b[i * E:(i + 1) * E].clone().requires_grad_(True) for i in range(3)]
+    y = ops.PlmSelfAttnFn.apply(xin, *ws, *bs, w, b, H, 0.125, p, seeds[0:1], kb)
+    y_again = ops.PlmSelfAttnFn.apply(x, *ws, *bs, w, b, H, 0.125, p, seeds[0:1], kb)
+    assert torch.equal(y, y_again)
+    grads = torch.autograd.grad(y, [xin] + ws + bs, g)
+    # torch, fp32, the same mask
+    xr = x.float().requires_grad_(True)
+    wr, br = w.float().requires_grad_(True), b.float().requires_grad_(True)
+    qkv = torch.nn.functional.linear(xr, wr, br).view(B, S, 3, H, D).permute(2, 0, 3, 1, 4)
+    sc = qkv[0] @ qkv[1].transpose(-1, -2) * 0.125 + kb[:, None, None, :]
+    pr = torch.softmax(sc, dim=-1) * keep.float() * inv
+    yr = (pr @ qkv[2]).transpose(1, 2).reshape(B, S, E)
+    gx, gw, gb = torch.autograd.grad(yr, [xr, wr, br], g.float())
+    assert (y.float() - yr).abs().max().item() <= 3e-2 * max(1.0, yr.abs().max().item())
+    refs = [gx] + [gw[i * E:(i + 1) * E] for i in range(3)] + [gb[i * E:(i + 1) * E] for i in range(3)]
+    for a, r_, name in zip(grads, refs, ("dx", "dWq", "dWk", "dWv", "dbq", "dbk", "dbv")):
+        if name == "dbk":                                                     # mathematically zero
+            continue
+        sc_ = r_.abs().max().item() + 1e-6
+        assert (a.float() - r_).abs().max().item() <= 4e-2 * sc_, (name, (a.float() - r_).abs().max().item(), sc_)
+
+
+def test_fused_text_encoder_trains_with_attention_dropout():
+    """a fused RoBERTa with attention and hidden dropout 0.1 in training mode: every attention module takes the in-tree core (its own seed word per module and
+    forward), losses are finite, the gradients reach every parameter, and eval mode (no dropout) agrees with the stock module."""
+    import copy
+    from transformers import RobertaConfig, RobertaModel
+    from facialmmt_amd import ops
+    from facialmmt_amd.train_step import fuse_text_encoder
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    cfg = RobertaConfig(vocab_size=1000, hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=512, max_position_embeddings=80,
+                        hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+    stock = RobertaModel(cfg, add_pooling_layer=False).to(dev).to(torch.bfloat16)
+    fused = copy.deepcopy(stock)
+    assert fuse_text_encoder(fused) == (4, 2)
+    calls = []
+    real = ops.PlmSelfAttnFn.apply
+    ops.PlmSelfAttnFn.apply = lambda *a: (calls.append(a[11:13]), real(*a))[1]
+    try:
+        ids = torch.randint(3, 1000, (2, 48), device=dev)
+        fused.train()
+        y1 = fused(input_ids=ids).last_hidden_state
+        y2 = fused(input_ids=ids).last_hidden_state
+        assert len(calls) == 4 and all(c[0] == 0.1 for c in calls)
+        assert calls[0][1].data_ptr() != calls[1][1].data_ptr()              # one seed word per attention module
+        assert torch.isfinite(y1.float()).all() and not torch.equal(y1, y2)   # a fresh draw per forward
+        y1.float().square().mean().backward()
+        assert all(p.grad is not None and torch.isfinite(p.grad.float()).all() for p in fused.parameters())
+        fused.eval(), stock.eval()
+        with torch.enable_grad():
+            ye = fused(input_ids=ids).last_hidden_state
+        assert len(calls) == 6 and calls[-1][0] == 0.0
+        with torch.no_grad():
+            ys = stock(input_ids=ids).last_hidden_state
+        assert (ye.float() - ys.float()).abs().max().item() <= 3e-2 * max(1.0, ys.float().abs().max().item())
+    finally:
+        ops.PlmSelfAttnFn.apply = real
+
+
 def test_fused_sublayer_tail_dropout_replays_its_mask_in_the_backward():
     """fmmt_plm_dropadd_ln_fwd / _bwd at p = 0.3: the kept fraction is 1 - p, a second forward with the same (seed, salt) is identical and a different
     salt is not; the backward's dense-output gradient is zero exactly where the forward dropped and dx * 1 / (1 - p) elsewhere; the bias gradient is its
