@@ -280,6 +280,25 @@ __device__ __forceinline__ float attn_drop_field(const AttnDrop& d, uint32_t a, 
     return v >= d.thresh ? d.inv : 0.f;
 }
 
+// The same generator for the elementwise dropout of the fused sublayer tails (plm_fused.hip): elements 4g .. 4g+3 of call site `salt` share a pair of words.
+struct ElemDrop {
+    uint32_t key, thresh;
+    float inv;
+};
+__device__ __forceinline__ ElemDrop elem_drop_setup(float p, uint64_t seed, uint64_t salt) {
+    ElemDrop d;
+    d.key = mix32a((uint32_t)seed ^ 0x85ebca6bU) + mix32b((uint32_t)(seed >> 32) ^ 0xc2b2ae35U) + mix32a((uint32_t)salt ^ 0x27d4eb2fU) + mix32b((uint32_t)(salt >> 32) ^ 0x165667b1U);
+    const uint32_t t = (uint32_t)(p * 65536.0f + 0.5f);
+    d.thresh = t > 65535u ? 65535u : t;
+    d.inv = 65536.0f / (65536.0f - (float)d.thresh);
+    return d;
+}
+// keep flags of elements 4g .. 4g+3 (bit f of the result: element 4g + f is kept)
+__device__ __forceinline__ uint32_t elem_keep4(const ElemDrop& d, uint32_t g) {
+    const uint32_t x = g + d.key, a = mix32a(x), b = mix32b(x);
+    return ((a & 0xFFFFu) >= d.thresh ? 1u : 0u) | ((a >> 16) >= d.thresh ? 2u : 0u) | ((b & 0xFFFFu) >= d.thresh ? 4u : 0u) | ((b >> 16) >= d.thresh ? 8u : 0u);
+}
+
 // per-sample (DropPath) multiplier lookup: rowscale == nullptr -> 1
 __device__ __forceinline__ float row_scale(const float* rowscale, int row, int rows_per_scale) {
     return rowscale ? rowscale[row / rows_per_scale] : 1.0f;

@@ -4,18 +4,22 @@
 // Stock PyTorch runs this as fused_dropout + add + layer_norm forward (3 launches) and, backward, LayerNorm' (2-3), masked_scale (1) and the dense
 // bias' column sum (1): 48 sublayers x ~8 dependent launches of 4-25 us in a chain that runs largely alone on the GPU (the text encoder's forward in
 // front of Swin's, the tail of its backward behind it).  Here: one forward launch, one backward launch + one reduction.
-//   * the dropout mask is not stored: keep(e) = hash_uniform(seed, salt + e) >= p, replayed bit for bit in the backward (the counter-based generator of
-//     the attention dropout, fmmt_common.h); `seed` is a device int64 word (graph-replay safe), `salt` separates the call sites;
+//   * the dropout mask is not stored: keep(e) = a 16-bit field of a pair of 32-bit mixes of (seed, salt, e / 4) >= round(p * 2^16), replayed bit for bit in the
+//     backward (the counter-based generator of the attention dropout, fmmt_common.h: splitmix64 per element cost more issue slots than the rest of the kernel);
+//     kept values are scaled by the exact inverse of the realised keep rate; `seed` is a device int64 word (graph-replay safe), `salt` separates the call sites;
 //   * rounding follows the bf16 module op by op: t = bf16(h * keep / (1 - p)), x = bf16(t + res), LayerNorm on x in fp32, y = bf16(...);
 //   * backward: dx = LayerNorm'(dy) rounded to bf16 IS the residual branch's gradient; dh = bf16(dx * keep / (1 - p)); partial sums of d gamma, d beta
 //     and of the dense bias' gradient colsum(dh) per block, finished in a fixed order by the reduction.
-// One wave per token row, rows grid-strided; C % 8 == 0, C <= 2048.
+// One wave per token row, rows grid-strided (forward: 4 waves per workgroup, up to 1024 workgroups; backward: 8 waves and at most 256 workgroups -- the count of
+// partial rows the reduction reads -- so that 2048 tokens are one row per wave: with 4 waves every wave walked two rows' dependent reduction chains alone on its
+// SIMD, 15.6 us for 17 MB); C % 8 == 0, C <= 2048.
 #include "fmmt_common.h"
 #include "../../include/fmmt.h"
 
 namespace {
 
 constexpr int PF_MAXV = 4;                                  // 8-element vectors per lane: C <= 2048
+constexpr int PF_BW = 8;                                    // waves (= rows in flight) per workgroup of the backward
 
 // Affine parameters (and their gradients) in bf16 (the text encoder's bf16 module) or fp32 (MELDTransEncoder's fp32 master LayerNorms,
 // modules/Transformer.py:109-137: same op sequence dense -> dropout -> + input -> LayerNorm)
@@ -39,8 +43,9 @@ __global__ __launch_bounds__(256) void plm_dropadd_ln_fwd_kernel(int M, int C, f
                                                                  bf16* __restrict__ xsum, bf16* __restrict__ y) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = C / 8;
-    const float invC = 1.0f / (float)C, scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
-    const unsigned long long seed = seed_ptr ? seed_ptr[0] : seed_i;
+    const float invC = 1.0f / (float)C;
+    const ElemDrop dr = elem_drop_setup(p, seed_ptr ? seed_ptr[0] : seed_i, salt);
+    const float scale = p > 0.f ? dr.inv : 1.0f;
     for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
         bf16x8 xv[PF_MAXV];
         float s = 0.f;
@@ -50,10 +55,12 @@ __global__ __launch_bounds__(256) void plm_dropadd_ln_fwd_kernel(int M, int C, f
             if (v < nv) {
                 const size_t o = (size_t)row * C + v * 8;
                 const bf16x8 hv = *reinterpret_cast<const bf16x8*>(h + o), rv = *reinterpret_cast<const bf16x8*>(res + o);
+                uint32_t keep = 0xFFu;
+                if (p > 0.f) keep = elem_keep4(dr, (uint32_t)(o >> 2)) | (elem_keep4(dr, (uint32_t)(o >> 2) + 1u) << 4);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float t = (float)hv[e];
-                    if (p > 0.f) t = hash_uniform(seed, salt + o + e) >= p ? (float)(bf16)(t * scale) : 0.f;
+                    if (p > 0.f) t = (keep >> e) & 1u ? (float)(bf16)(t * scale) : 0.f;
                     xv[i][e] = (bf16)(t + (float)rv[e]);
                     s += (float)xv[i][e];
                 }
@@ -87,11 +94,11 @@ __global__ __launch_bounds__(256) void plm_dropadd_ln_fwd_kernel(int M, int C, f
 
 // part: [block][3][C] fp32 (d gamma, d beta, d dense-bias)
 template <typename P>
-__global__ __launch_bounds__(256) void plm_dropadd_ln_bwd_kernel(int M, int C, float eps, const bf16* __restrict__ dy, const bf16* __restrict__ x,
+__global__ __launch_bounds__(512) void plm_dropadd_ln_bwd_kernel(int M, int C, float eps, const bf16* __restrict__ dy, const bf16* __restrict__ x,
                                                                  const P* __restrict__ gamma, float p, unsigned long long seed_i,
                                                                  const unsigned long long* __restrict__ seed_ptr, unsigned long long salt, bf16* __restrict__ dx, bf16* __restrict__ dh,
                                                                  float* __restrict__ part) {
-    __shared__ float red[4][3][64 * 8];
+    __shared__ float red[PF_BW][3][64 * 8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = C / 8;
     float dg[PF_MAXV][8], db[PF_MAXV][8], dc[PF_MAXV][8];
@@ -99,9 +106,10 @@ __global__ __launch_bounds__(256) void plm_dropadd_ln_bwd_kernel(int M, int C, f
     for (int i = 0; i < PF_MAXV; ++i)
 #pragma unroll
         for (int e = 0; e < 8; ++e) dg[i][e] = db[i][e] = dc[i][e] = 0.f;
-    const float invC = 1.0f / (float)C, scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
-    const unsigned long long seed = seed_ptr ? seed_ptr[0] : seed_i;
-    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    const float invC = 1.0f / (float)C;
+    const ElemDrop dr = elem_drop_setup(p, seed_ptr ? seed_ptr[0] : seed_i, salt);
+    const float scale = p > 0.f ? dr.inv : 1.0f;
+    for (int row = blockIdx.x * PF_BW + wave; row < M; row += gridDim.x * PF_BW) {
         bf16x8 xv[PF_MAXV], gv[PF_MAXV];
         float s = 0.f;
 #pragma unroll
@@ -150,12 +158,14 @@ __global__ __launch_bounds__(256) void plm_dropadd_ln_bwd_kernel(int M, int C, f
                 float gm[8];
                 pf_load8<P>(gamma + v * 8, gm);
                 bf16x8 ox, oh;
+                uint32_t keep = 0xFFu;
+                if (p > 0.f) keep = elem_keep4(dr, (uint32_t)(o >> 2)) | (elem_keep4(dr, (uint32_t)(o >> 2) + 1u) << 4);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float xh = ((float)xv[i][e] - mean) * rstd, g = (float)gv[i][e] * gm[e];
                     ox[e] = (bf16)(rstd * (g - s1 - xh * s2));
                     float t = (float)ox[e];
-                    if (p > 0.f) t = hash_uniform(seed, salt + o + e) >= p ? t * scale : 0.f;
+                    if (p > 0.f) t = (keep >> e) & 1u ? t * scale : 0.f;
                     oh[e] = (bf16)t;
                     dc[i][e] += (float)oh[e];
                 }
@@ -176,9 +186,14 @@ __global__ __launch_bounds__(256) void plm_dropadd_ln_bwd_kernel(int M, int C, f
             red[wave][2][lane * 8 + e] = dc[i][e];
         }
         __syncthreads();
-        for (int t = threadIdx.x; t < 3 * 512; t += 256) {
+        for (int t = threadIdx.x; t < 3 * 512; t += 64 * PF_BW) {
             const int which = t >> 9, col = t & 511, ch = i * 512 + col;
-            if (ch < C) pb[which * C + ch] = (red[0][which][col] + red[1][which][col]) + (red[2][which][col] + red[3][which][col]);
+            if (ch < C) {
+                float a = 0.f;
+#pragma unroll
+                for (int w = 0; w < PF_BW; ++w) a += red[w][which][col];      // fixed order
+                pb[which * C + ch] = a;
+            }
         }
     }
 }
@@ -191,8 +206,17 @@ __global__ __launch_bounds__(1024) void plm_dropadd_ln_reduce_kernel(const float
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int i = blockIdx.x * 32 + tx;                     // column of the [3][C] triple
     float a = 0.f;
-    if (i < 3 * C)
-        for (int b = ty; b < nblocks; b += 32) a += part[(size_t)b * 3 * C + i];
+    if (i < 3 * C) {
+        float v[8];                                         // nblocks <= 256: every load of the thread in flight at once (a rolled loop waited for each, ~2 us apiece)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int b = ty + 32 * u;
+            v[u] = b < nblocks ? part[(size_t)b * 3 * C + i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += v[u];
+        for (int b = ty + 256; b < nblocks; b += 32) a += part[(size_t)b * 3 * C + i];
+    }
     red[ty][tx] = a;
     __syncthreads();
     if (ty == 0 && i < 3 * C) {
@@ -205,7 +229,8 @@ __global__ __launch_bounds__(1024) void plm_dropadd_ln_reduce_kernel(const float
     }
 }
 
-int pf_blocks(int M) { return M / 4 < 1 ? 1 : (M / 4 > 256 ? 256 : M / 4); }
+int pf_blocks(int M) { return M / PF_BW < 1 ? 1 : (M / PF_BW > 256 ? 256 : M / PF_BW); }      // backward: workgroups = partial rows
+int pf_blocks_fwd(int M) { return M / 4 < 1 ? 1 : (M / 4 > 1024 ? 1024 : M / 4); }
 bool pf_misaligned(const void* a, const void* b, const void* c, const void* d) {
     return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) | reinterpret_cast<uintptr_t>(d)) & 15) != 0;
 }
@@ -220,10 +245,10 @@ extern "C" int fmmt_dropadd_ln_fwd(int param_dtype, int M, int C, float eps, con
     if (pf_misaligned(h, res, xsum, y) || pf_misaligned(gamma, beta, gamma, beta)) return FMMT_EALIGN;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (param_dtype == FMMT_BF16)
-        hipLaunchKernelGGL(plm_dropadd_ln_fwd_kernel<bf16>, dim3(pf_blocks(M)), dim3(256), 0, st, M, C, eps, (const bf16*)h, (const bf16*)res, (const bf16*)gamma,
+        hipLaunchKernelGGL(plm_dropadd_ln_fwd_kernel<bf16>, dim3(pf_blocks_fwd(M)), dim3(256), 0, st, M, C, eps, (const bf16*)h, (const bf16*)res, (const bf16*)gamma,
                            (const bf16*)beta, p, (unsigned long long)seed, (const unsigned long long*)seed_dev, (unsigned long long)salt, (bf16*)xsum, (bf16*)y);
     else
-        hipLaunchKernelGGL(plm_dropadd_ln_fwd_kernel<float>, dim3(pf_blocks(M)), dim3(256), 0, st, M, C, eps, (const bf16*)h, (const bf16*)res, (const float*)gamma,
+        hipLaunchKernelGGL(plm_dropadd_ln_fwd_kernel<float>, dim3(pf_blocks_fwd(M)), dim3(256), 0, st, M, C, eps, (const bf16*)h, (const bf16*)res, (const float*)gamma,
                            (const float*)beta, p, (unsigned long long)seed, (const unsigned long long*)seed_dev, (unsigned long long)salt, (bf16*)xsum, (bf16*)y);
     FMMT_CHECK_LAUNCH();
     return 0;
@@ -246,13 +271,13 @@ extern "C" int fmmt_dropadd_ln_bwd(int param_dtype, int M, int C, float eps, con
     const int blocks = pf_blocks(M);
     float* part = reinterpret_cast<float*>(workspace);
     if (param_dtype == FMMT_BF16) {
-        hipLaunchKernelGGL(plm_dropadd_ln_bwd_kernel<bf16>, dim3(blocks), dim3(256), 0, st, M, C, eps, (const bf16*)dy, (const bf16*)xsum, (const bf16*)gamma, p,
+        hipLaunchKernelGGL(plm_dropadd_ln_bwd_kernel<bf16>, dim3(blocks), dim3(64 * PF_BW), 0, st, M, C, eps, (const bf16*)dy, (const bf16*)xsum, (const bf16*)gamma, p,
                            (unsigned long long)seed, (const unsigned long long*)seed_dev, (unsigned long long)salt, (bf16*)dx, (bf16*)dh, part);
         FMMT_CHECK_LAUNCH();
         hipLaunchKernelGGL(plm_dropadd_ln_reduce_kernel<bf16>, dim3((3 * C + 31) / 32), dim3(1024), 0, st, (const float*)part, blocks, C, (bf16*)dgamma, (bf16*)dbeta,
                            (bf16*)dbias);
     } else {
-        hipLaunchKernelGGL(plm_dropadd_ln_bwd_kernel<float>, dim3(blocks), dim3(256), 0, st, M, C, eps, (const bf16*)dy, (const bf16*)xsum, (const float*)gamma, p,
+        hipLaunchKernelGGL(plm_dropadd_ln_bwd_kernel<float>, dim3(blocks), dim3(64 * PF_BW), 0, st, M, C, eps, (const bf16*)dy, (const bf16*)xsum, (const float*)gamma, p,
                            (unsigned long long)seed, (const unsigned long long*)seed_dev, (unsigned long long)salt, (bf16*)dx, (bf16*)dh, part);
         FMMT_CHECK_LAUNCH();
         hipLaunchKernelGGL(plm_dropadd_ln_reduce_kernel<float>, dim3((3 * C + 31) / 32), dim3(1024), 0, st, (const float*)part, blocks, C, (float*)dgamma,
