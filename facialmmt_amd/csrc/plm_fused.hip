@@ -229,6 +229,90 @@ __global__ __launch_bounds__(1024) void plm_dropadd_ln_reduce_kernel(const float
     }
 }
 
+// Backward of the text encoder's intermediate activation together with the bias gradient of the Linear in front of it (transformers' *Intermediate:
+// dense -> GELU, src/models.py:75-91):  d(pre) = d(act) * gelu'(pre),  d(bias) = colsum(d(pre)) -- stock PyTorch runs GeluBackward and a column sum (fmmt_colsum
+// here) as two passes over the (tokens x 4096) matrix.  A thread owns columns: its sums over the block's rows need no cross-thread step; per-block partial rows,
+// then a fixed-order reduction over the blocks.  H % 8 == 0, H <= 8192.
+constexpr int GB_MAXV = 4;                                  // 8-element vectors per thread: H <= 256 * 8 * 4
+constexpr int GB_BLOCKS = 256;
+__global__ __launch_bounds__(256) void plm_gelu_bwd_colsum_kernel(int M, int H, const bf16* __restrict__ dact, const bf16* __restrict__ pre, bf16* __restrict__ dpre,
+                                                                 float* __restrict__ part) {
+    const int nv = H / 8;
+    float acc[GB_MAXV][8];
+#pragma unroll
+    for (int j = 0; j < GB_MAXV; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
+    for (int row0 = blockIdx.x; row0 < M; row0 += 2 * gridDim.x) {      // two rows per step: all their loads in flight before the first is used
+        bf16x8 g[2][GB_MAXV], x[2][GB_MAXV];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int row = row0 + u * gridDim.x;
+#pragma unroll
+            for (int j = 0; j < GB_MAXV; ++j) {
+                const int v = threadIdx.x + 256 * j;
+                if (v < nv && row < M) {
+                    const size_t o = (size_t)row * H + v * 8;
+                    g[u][j] = *reinterpret_cast<const bf16x8*>(dact + o);
+                    x[u][j] = *reinterpret_cast<const bf16x8*>(pre + o);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int row = row0 + u * gridDim.x;
+#pragma unroll
+            for (int j = 0; j < GB_MAXV; ++j) {
+                const int v = threadIdx.x + 256 * j;
+                if (v < nv && row < M) {
+                    bf16x8 out;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        out[e] = (bf16)((float)g[u][j][e] * gelu_grad_exp_f((float)x[u][j][e]));
+                        acc[j][e] += (float)out[e];         // the sum of what is stored (what a column sum over d(pre) would see)
+                    }
+                    *reinterpret_cast<bf16x8*>(dpre + (size_t)row * H + v * 8) = out;
+                }
+            }
+        }
+    }
+    float* pb = part + (size_t)blockIdx.x * H;
+#pragma unroll
+    for (int j = 0; j < GB_MAXV; ++j) {
+        const int v = threadIdx.x + 256 * j;
+        if (v < nv) {
+            *reinterpret_cast<f32x4*>(pb + v * 8) = f32x4{acc[j][0], acc[j][1], acc[j][2], acc[j][3]};
+            *reinterpret_cast<f32x4*>(pb + v * 8 + 4) = f32x4{acc[j][4], acc[j][5], acc[j][6], acc[j][7]};
+        }
+    }
+}
+// 1024 threads = 32 columns x 32 row groups over the blocks' partial rows (<= GB_BLOCKS), fixed order
+__global__ __launch_bounds__(1024) void plm_colpart_reduce_kernel(const float* __restrict__ part, int nblocks, int H, bf16* __restrict__ out) {
+    __shared__ float red[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + tx;
+    float a = 0.f;
+    if (c < H) {
+        float v[GB_BLOCKS / 32];
+#pragma unroll
+        for (int u = 0; u < GB_BLOCKS / 32; ++u) {
+            const int b = ty + 32 * u;
+            v[u] = b < nblocks ? part[(size_t)b * H + c] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < GB_BLOCKS / 32; ++u) a += v[u];
+    }
+    red[ty][tx] = a;
+    __syncthreads();
+    if (ty == 0 && c < H) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 32; ++g) t += red[g][tx];
+        out[c] = (bf16)t;
+    }
+}
+int gb_blocks(int M) { return M < GB_BLOCKS ? M : GB_BLOCKS; }
+
 int pf_blocks(int M) { return M / PF_BW < 1 ? 1 : (M / PF_BW > 256 ? 256 : M / PF_BW); }      // backward: workgroups = partial rows
 int pf_blocks_fwd(int M) { return M / 4 < 1 ? 1 : (M / 4 > 1024 ? 1024 : M / 4); }
 bool pf_misaligned(const void* a, const void* b, const void* c, const void* d) {
@@ -297,4 +381,22 @@ extern "C" int fmmt_plm_dropadd_ln_bwd(int M, int C, float eps, const void* dy, 
                                        const uint64_t* seed_dev, uint64_t salt, void* dx, void* dh, void* dgamma, void* dbeta, void* dbias, void* workspace,
                                        size_t workspace_bytes, void* stream) {
     return fmmt_dropadd_ln_bwd(FMMT_BF16, M, C, eps, dy, xsum, gamma, p, seed, seed_dev, salt, dx, dh, dgamma, dbeta, dbias, workspace, workspace_bytes, stream);
+}
+
+extern "C" size_t fmmt_plm_gelu_bwd_colsum_workspace(int M, int H) {
+    if (M <= 0 || H <= 0) return 0;
+    return (size_t)gb_blocks(M) * (size_t)H * sizeof(float);
+}
+extern "C" int fmmt_plm_gelu_bwd_colsum(int M, int H, const void* dact, const void* pre, void* dpre, void* dbias, void* workspace, size_t workspace_bytes, void* stream) {
+    if (M <= 0 || H <= 0 || H % 8 || H > 256 * 8 * GB_MAXV) return FMMT_EINVAL;
+    if (!dact || !pre || !dpre || !dbias || !workspace) return FMMT_EINVAL;
+    if (workspace_bytes < fmmt_plm_gelu_bwd_colsum_workspace(M, H)) return FMMT_EWORKSPACE;
+    if (pf_misaligned(dact, pre, dpre, workspace)) return FMMT_EALIGN;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int blocks = gb_blocks(M);
+    hipLaunchKernelGGL(plm_gelu_bwd_colsum_kernel, dim3(blocks), dim3(256), 0, st, M, H, (const bf16*)dact, (const bf16*)pre, (bf16*)dpre, (float*)workspace);
+    FMMT_CHECK_LAUNCH();
+    hipLaunchKernelGGL(plm_colpart_reduce_kernel, dim3((H + 31) / 32), dim3(1024), 0, st, (const float*)workspace, blocks, H, (bf16*)dbias);
+    FMMT_CHECK_LAUNCH();
+    return 0;
 }

@@ -367,6 +367,76 @@ class VendorLinearFn(torch.autograd.Function):
         return dx, dw, db
 
 
+def plm_tail_fwd_raw(h2, r2, gamma, beta, eps, p, seed_i, seed_t, salt):
+    """fmmt_plm_dropadd_ln_fwd on (M, C) bf16 operands: returns (xsum, y)"""
+    M, C = h2.shape
+    xsum, y = torch.empty_like(h2), torch.empty_like(h2)
+    check(_lib.load().fmmt_plm_dropadd_ln_fwd(M, C, float(eps), _p(h2), _p(r2), _p(gamma), _p(beta), float(p), seed_i, _p(seed_t), int(salt), _p(xsum), _p(y), _st()),
+          f"fmmt_plm_dropadd_ln_fwd(M={M},C={C})")
+    return xsum, y
+
+
+def plm_tail_bwd_raw(dy2, xsum, gamma, eps, p, seed_i, seed_t, salt):
+    """fmmt_plm_dropadd_ln_bwd: returns (dx = the residual's gradient, dh = the dense output's, dgamma, dbeta, dbias)"""
+    M, C = xsum.shape
+    lib = _lib.load()
+    dx, dh = torch.empty_like(xsum), torch.empty_like(xsum)
+    dgamma, dbeta, dbias = torch.empty_like(gamma), torch.empty_like(gamma), torch.empty_like(gamma)
+    nbytes = lib.fmmt_plm_dropadd_ln_bwd_workspace(M, C)
+    ws = _ws(nbytes, xsum.device)
+    check(lib.fmmt_plm_dropadd_ln_bwd(M, C, eps, _p(dy2), _p(xsum), _p(gamma), p, seed_i, _p(seed_t), salt, _p(dx), _p(dh), _p(dgamma), _p(dbeta), _p(dbias), _p(ws), nbytes,
+                                      _st()), f"fmmt_plm_dropadd_ln_bwd(M={M},C={C})")
+    return dx, dh, dgamma, dbeta, dbias
+
+
+def plm_gelu_bwd_colsum_raw(dact2, pre2):
+    """fmmt_plm_gelu_bwd_colsum on (M, H) bf16: returns (dpre = dact * gelu'(pre), dbias = colsum(dpre))"""
+    M, H = pre2.shape
+    lib = _lib.load()
+    dpre = torch.empty_like(pre2)
+    dbias = torch.empty((H,), dtype=pre2.dtype, device=pre2.device)
+    nbytes = lib.fmmt_plm_gelu_bwd_colsum_workspace(M, H)
+    ws = _ws(nbytes, pre2.device)
+    check(lib.fmmt_plm_gelu_bwd_colsum(M, H, _p(dact2), _p(pre2), _p(dpre), _p(dbias), _p(ws), nbytes, _st()), f"fmmt_plm_gelu_bwd_colsum(M={M},H={H})")
+    return dpre, dbias
+
+
+class PlmFfnFn(torch.autograd.Function):
+    """y = LayerNorm(dropout(gelu(x W1^T + b1) W2^T + b2) + x): the feed-forward half of a BERT / RoBERTa layer (transformers' *Intermediate + *Output,
+    src/models.py:75-91) as ONE autograd node.  Forward: the launches of the two modules (vendor GEMMs, torch's exact GELU, fmmt_plm_dropadd_ln_fwd).  Backward:
+    the tail's launch + reduction, the two GEMMs behind it, d(pre) = d(act) gelu'(pre) together with b1's gradient in ONE pass (fmmt_plm_gelu_bwd_colsum; stock:
+    GeluBackward + a column sum), and the input gradient d(pre) W1 + (the residual's gradient) as ONE GEMM with an accumulate epilogue (torch.addmm) instead
+    of a GEMM and autograd's add.  Per layer and step 3 launches and two passes over the (tokens x 4096) matrix fewer."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, eps, p, seed, salt):
+        pre = torch.nn.functional.linear(x, w1, b1)
+        act = torch.nn.functional.gelu(pre)
+        h = torch.nn.functional.linear(act, w2, b2)
+        C = h.shape[-1]
+        x2 = _c16(x.reshape(-1, C))
+        seed_t = seed if isinstance(seed, torch.Tensor) else None
+        seed_i = 0 if seed_t is not None else int(seed)
+        xsum, y = plm_tail_fwd_raw(h.reshape(-1, C), x2, gamma.detach(), beta.detach(), eps, p, seed_i, seed_t, salt)
+        ctx.save_for_backward(x2, w1, w2, pre, act, xsum, gamma, seed_t)
+        ctx.cfg = (float(eps), float(p), seed_i, int(salt))
+        return y.reshape(h.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w1, w2, pre, act, xsum, gamma, seed_t = ctx.saved_tensors
+        eps, p, seed_i, salt = ctx.cfg
+        M, C = xsum.shape
+        dx_ln, dh, dgamma, dbeta, db2 = plm_tail_bwd_raw(_c16(dy.reshape(M, C)), xsum, gamma.detach(), eps, p, seed_i, seed_t, salt)
+        act2, pre2 = act.reshape(M, -1), pre.reshape(M, -1)
+        dact = dh.mm(w2)
+        dw2 = dh.t().mm(act2)
+        dpre, db1 = plm_gelu_bwd_colsum_raw(dact, pre2)
+        dx = torch.addmm(dx_ln, dpre, w1) if ctx.needs_input_grad[0] else None
+        dw1 = dpre.t().mm(x2)
+        return (dx.reshape(dy.shape) if dx is not None else None), dw1, db1, dw2, db2, dgamma, dbeta, None, None, None, None
+
+
 class PlmSublayerTailFn(torch.autograd.Function):
     """y = LayerNorm(dropout(x W^T + b) + res): a BERT / RoBERTa sublayer behind its attention / GELU (transformers' *SelfOutput / *Output,
     src/models.py:75-91) as the vendor library's GEMM + ONE launch (fmmt_plm_dropadd_ln_fwd); backward: one launch + its reduction

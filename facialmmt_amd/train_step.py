@@ -354,6 +354,7 @@ class VendorLayerNorm(torch.nn.LayerNorm):
 
 # Module constants (the probes patch them), not environment switches: each is the off-switch of one fused launch family
 PLM_COLSUM, PLM_LN, FUSED_ADAMW, PIN_SHADOWS, FUSED_HANDOVER = True, True, True, True, True
+PLM_FUSE_FFN = True                                         # intermediate + output of a layer as one autograd node (ops.PlmFfnFn); False: the two modules
 PLM_FUSE_ATTN = True                                        # a packed *SelfAttention runs its attention core on fmmt_mha_fwd / _bwd (False: the stock attention interface)
 PLM_FUSE_TAILS, PLM_FUSE_QKV = True, True                  # fuse_text_encoder: sublayer tails as one launch per direction / packed query-key-value GEMM
 
@@ -399,6 +400,30 @@ def _sublayer_tail_forward(self, hidden_states, input_tensor):
     from . import ops
     return ops.PlmSublayerTailFn.apply(hidden_states, input_tensor, d.weight, d.bias, ln.weight, ln.bias, ln.eps, p,
                                        box.t if p > 0.0 else 0, self._fmmt_salt)
+
+
+def _fused_ffn_chunk(self, attention_output):
+    """feed_forward_chunk of a re-classed transformers *Layer: intermediate + output as one autograd node (ops.PlmFfnFn), or the stock pair of modules"""
+    inter, out = self.intermediate, self.output
+    d1, d2, ln = inter.dense, out.dense, out.LayerNorm
+    p = float(out.dropout.p) if self.training else 0.0
+    box = out._fmmt_seed
+    x = attention_output
+    if (not PLM_FUSE_FFN or not x.is_cuda or x.dtype != torch.bfloat16 or not torch.is_grad_enabled() or d1.bias is None or d2.bias is None or ln.bias is None
+            or any(t.dtype != torch.bfloat16 for t in (d1.weight, d2.weight, ln.weight)) or d2.weight.shape[0] % 8 or d2.weight.shape[0] > 2048
+            or d1.weight.shape[0] % 8 or d1.weight.shape[0] > 8192 or d1.weight.shape[1] != d2.weight.shape[0] or (p > 0.0 and box.t is None)):
+        return self._fmmt_stock_ffn(attention_output)
+    from . import ops
+    return ops.PlmFfnFn.apply(x, d1.weight, d1.bias, d2.weight, d2.bias, ln.weight, ln.bias, ln.eps, p, box.t if p > 0.0 else 0, out._fmmt_salt)
+
+
+def _is_exact_gelu(fn):
+    """transformers' ACT2FN["gelu"] (GELUActivation over torch's erf gelu) or torch.nn.functional.gelu / nn.GELU() itself"""
+    if fn is torch.nn.functional.gelu:
+        return True
+    if isinstance(fn, torch.nn.GELU):
+        return fn.approximate == "none"
+    return type(fn).__name__ == "GELUActivation" and getattr(fn, "act", None) is torch.nn.functional.gelu
 
 
 def _packed_qkv_forward(self, hidden_states, *args, **kwargs):
@@ -478,7 +503,8 @@ def fuse_text_encoder(plm, tails: bool = True, qkv: bool = True):
     launch + a reduction + the two GEMMs (ops.PlmSublayerTailFn); (b) every *SelfAttention computes query / key / value with ONE GEMM over a packed
     (3E, E) weight of which the three nn.Linear parameters become row slices (same Parameter objects, same names, same state_dict; the optimizer's
     views keep working) and, where the in-tree attention kernels apply (_fused_attention: bf16, head_dim 64, encoder self-attention), its attention core
-    with them on the packed projection (PLM_FUSE_ATTN).  Returns (tails changed, attentions packed).  Numerics: (a) rounds like the bf16 module op by op,
+    with them on the packed projection (PLM_FUSE_ATTN); (c) where a layer's *Output took (a) and its *Intermediate is dense -> exact GELU, the two run as one
+    autograd node (ops.PlmFfnFn, PLM_FUSE_FFN; the count is left in plm._fmmt_fused_ffn).  Returns (tails changed, attentions packed).  Numerics: (a) rounds like the bf16 module op by op,
     with its own dropout stream (counter-based, replayed in the backward instead of a stored mask); (b) is the same arithmetic as three GEMMs; the
     attention core is a flash-style online softmax in fp32 with bf16 probabilities, like the library kernel it replaces, and its own dropout stream."""
     box = _SeedBox()
@@ -516,6 +542,17 @@ def fuse_text_encoder(plm, tails: bool = True, qkv: bool = True):
             box.words += 1
             m.forward = types.MethodType(_packed_qkv_forward, m)
             n_qkv += 1
+    # (c) the feed-forward half as one node: only where its output module took the fused tail (its seed box and salt are the node's)
+    n_ffn = 0
+    for name, m in plm.named_modules():
+        inter, out = getattr(m, "intermediate", None), getattr(m, "output", None)
+        if (tails and inter is not None and out is not None and hasattr(m, "feed_forward_chunk") and hasattr(out, "_fmmt_salt") and not hasattr(m, "_fmmt_stock_ffn")
+                and isinstance(getattr(inter, "dense", None), torch.nn.Linear) and _is_exact_gelu(getattr(inter, "intermediate_act_fn", None))
+                and type(inter).forward.__code__.co_names[:2] == ("dense", "intermediate_act_fn")):
+            m._fmmt_stock_ffn = m.feed_forward_chunk
+            m.feed_forward_chunk = types.MethodType(_fused_ffn_chunk, m)
+            n_ffn += 1
+    plm._fmmt_fused_ffn = n_ffn
     if n_tail or n_qkv:
         plm.register_forward_pre_hook(lambda mod, args, kwargs=None: box.draw(next(mod.parameters()).device) if mod.training else None)
     return n_tail, n_qkv

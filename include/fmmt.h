@@ -377,6 +377,13 @@ int fmmt_plm_dropadd_ln_bwd(int M, int C, float eps, const void* dy, const void*
                             const uint64_t* seed_dev, uint64_t salt, void* dx, void* dh, void* dgamma, void* dbeta, void* dbias, void* workspace,
                             size_t workspace_bytes, void* stream);
 
+/* Backward of the text encoder's intermediate activation with the bias gradient of the Linear in front of it (transformers' *Intermediate: dense -> exact GELU,
+ * src/models.py:75-91): dpre = dact * gelu'(pre) (bf16, the erf form to 7e-4 relative like every GELU' of this library) and dbias = colsum(dpre) over the
+ * values as stored, in one pass + a fixed-order reduction (stock: GeluBackward, then a column sum -- two passes over the tokens x 4096 matrix).
+ * dact, pre, dpre: bf16 [M][H]; dbias: bf16 [H]; H % 8 == 0, H <= 8192; workspace: fmmt_plm_gelu_bwd_colsum_workspace(M, H). */
+size_t fmmt_plm_gelu_bwd_colsum_workspace(int M, int H);
+int fmmt_plm_gelu_bwd_colsum(int M, int H, const void* dact, const void* pre, void* dpre, void* dbias, void* workspace, size_t workspace_bytes, void* stream);
+
 /* The same pair with the affine parameters' type as an argument (param_dtype FMMT_BF16 | FMMT_F32: gamma, beta, dgamma, dbeta, dbias in that type;
  * activations bf16): also serves MELDTransEncoder's sublayer tails, LayerNorm(dropout(dense(h)) + input) with fp32 master parameters
  * (modules/Transformer.py:109-137).  fmmt_plm_dropadd_ln_* = these with FMMT_BF16. */

@@ -375,7 +375,7 @@ def test_fused_text_encoder_sublayers_match_the_stock_module():
     dev = torch.device("cuda:0")
     stock = _small_roberta(dev, 0.0)
     fused = copy.deepcopy(stock)
-    assert fuse_text_encoder(fused) == (4, 2)
+    assert fuse_text_encoder(fused) == (4, 2) and fused._fmmt_fused_ffn == 2
     assert list(fused.state_dict()) == list(stock.state_dict())
     ids = torch.randint(3, 1000, (3, 64), device=dev)
     mask = torch.ones(3, 64, device=dev, dtype=torch.long)
@@ -399,6 +399,28 @@ def test_fused_text_encoder_sublayers_match_the_stock_module():
     before = w.clone()
     torch.optim.SGD(fused.parameters(), lr=0.1).step()
     assert not torch.equal(before, w) and att.key.weight.data_ptr() == w[256:].data_ptr()
+
+
+def test_gelu_backward_with_the_bias_gradient_in_one_pass():
+    """fmmt_plm_gelu_bwd_colsum (the text encoder's *Intermediate backward): dpre = dact * gelu'(pre) against torch's erf GELU backward in fp32 within one bf16
+    step (+ 2e-4 |dact| around the derivative's zero), dbias = the column sum of the STORED dpre (fixed order: two calls agree bit for bit); ragged row counts, the widest row the kernel takes."""
+    from facialmmt_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(4)
+    for M, H in ((2048, 4096), (77, 512), (301, 8192), (5, 8)):
+        pre = (3.0 * torch.randn(M, H, device=dev)).to(torch.bfloat16)
+        dact = torch.randn(M, H, device=dev).to(torch.bfloat16)
+        dpre, db = ops.plm_gelu_bwd_colsum_raw(dact, pre)
+        dpre2, db2 = ops.plm_gelu_bwd_colsum_raw(dact, pre)
+        assert torch.equal(dpre, dpre2) and torch.equal(db, db2)
+        x = pre.float().requires_grad_(True)
+        (g,) = torch.autograd.grad(torch.nn.functional.gelu(x), x, dact.float())
+        err = (dpre.float() - g).abs()
+        # one bf16 step of the result, plus the derivative's absolute error (1e-4: it crosses zero near x = -0.75, where no relative bound can hold) times |dact|
+        tol = 8.5e-3 * g.abs() + 2e-4 * dact.float().abs() + 1e-6
+        assert (err <= tol).all(), (M, H, (err / tol).max().item())
+        ref = dpre.float().sum(0)
+        assert (db.float() - ref).abs().max().item() <= 8e-3 * ref.abs().max().item() + 1e-3, (M, H)
 
 
 def test_fused_text_attention_core_with_dropout_against_torch_on_the_same_mask():
