@@ -68,6 +68,7 @@ SIGNATURES = {
     "fmmt_dropadd_ln_bwd_workspace": (_sz, [_i, _i]),
     "fmmt_dropadd_ln_bwd": (_i, [_i, _i, _i, _f, _p, _p, _p, _f, _u64, _p, _u64, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "fmmt_plm_dropadd_ln_fwd": (_i, [_i, _i, _f, _p, _p, _p, _p, _f, _u64, _p, _u64, _p, _p, _p]),
+    "fmmt_embedding_bwd": (_i, [_i, _i, _i, _p, C.c_int64, _p, _p, _p]),
     "fmmt_plm_gelu_bwd_colsum_workspace": (_sz, [_i, _i]),
     "fmmt_plm_gelu_bwd_colsum": (_i, [_i, _i, _p, _p, _p, _p, _p, _sz, _p]),
     "fmmt_plm_dropadd_ln_bwd_workspace": (_sz, [_i, _i]),

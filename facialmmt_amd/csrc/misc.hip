@@ -358,7 +358,15 @@ __global__ __launch_bounds__(256) void grad_handover_kernel(const HoDesc* __rest
 __global__ __launch_bounds__(1024) void sumsq_finish_kernel(const float* __restrict__ partial, int n, float* __restrict__ out) {
     __shared__ float red[1024];
     float a = 0.f;
-    for (int i = threadIdx.x; i < n; i += 1024) a += partial[i];
+    int i = threadIdx.x;
+    for (; i + 7 * 1024 < n; i += 8 * 1024) {               // eight loads in flight, added in the rolled loop's order (435 M gradients: 104 partials per thread)
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = partial[i + u * 1024];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += v[u];
+    }
+    for (; i < n; i += 1024) a += partial[i];
     red[threadIdx.x] = a;
     __syncthreads();
     for (int s = 512; s > 0; s >>= 1) {

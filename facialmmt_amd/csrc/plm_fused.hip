@@ -313,6 +313,104 @@ __global__ __launch_bounds__(1024) void plm_colpart_reduce_kernel(const float* _
 }
 int gb_blocks(int M) { return M < GB_BLOCKS ? M : GB_BLOCKS; }
 
+// Weight gradient of an nn.Embedding of the text encoder (transformers' *Embeddings: word / position / token-type tables, src/models.py:75-91) for a few
+// thousand tokens: dW[id] = sum over the tokens t with ids[t] == id of dy[t], tokens of padding_idx skipped.  torch's kernel for <= 3072 indices
+// (embedding_backward_feature_kernel) walks the indices in ballot-matched batches per feature block: 110-170 us per table at 2048 tokens x 1024, alone at
+// the very end of the text encoder's backward.  Here, deterministic (no atomics on the output, token order):
+//   * tables of more than EB_SMALL rows: one workgroup per token.  It marks the tokens that share its id in an LDS bitmap; the FIRST of them owns the row and
+//     adds the others' rows in token order (fp32, one rounding), four loads in flight.  dW is zeroed first (the rows no token names).
+//   * tables of at most EB_SMALL rows (token types: one or two ids for every token): per row a predicated column sum over all tokens (the layout of
+//     colsum_kernel), every row written.
+// C % 8 == 0, C <= 2048; dy bf16 [T][C]; ids int64 [T].
+constexpr int EB_SMALL = 8;
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(int T, int C, const long long* __restrict__ ids, long long padding_idx, const bf16* __restrict__ dy,
+                                                           bf16* __restrict__ dw) {
+    extern __shared__ unsigned eb_lds[];                    // [nwords] bitmap, then the ordered list of the duplicates (T ints)
+    const int nwords = (T + 31) >> 5;
+    unsigned* bits = eb_lds;
+    int* list = reinterpret_cast<int*>(eb_lds + nwords);
+    __shared__ int count;
+    const int t = blockIdx.x;
+    const long long my = ids[t];
+    if (my == padding_idx) return;                          // uniform
+    for (int w = threadIdx.x; w < nwords; w += 256) bits[w] = 0u;
+    __syncthreads();
+    int earlier = 0;
+    for (int j = threadIdx.x; j < T; j += 256)
+        if (ids[j] == my) {
+            if (j < t) earlier = 1;
+            atomicOr(&bits[j >> 5], 1u << (j & 31));
+        }
+    if (__syncthreads_or(earlier)) return;                  // an earlier token owns the row
+    if (threadIdx.x == 0) {                                 // ascending token order
+        int n = 0;
+        for (int w = t >> 5; w < nwords; ++w) {
+            unsigned word = bits[w];
+            while (word) {
+                const int b = __ffs(word) - 1;
+                word &= word - 1;
+                list[n++] = w * 32 + b;
+            }
+        }
+        count = n;
+    }
+    __syncthreads();
+    const int n = count, v = threadIdx.x;
+    if (v * 8 >= C) return;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    int k = 0;
+    for (; k + 3 < n; k += 4) {
+        bf16x8 r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) r[u] = *reinterpret_cast<const bf16x8*>(dy + (size_t)list[k + u] * C + v * 8);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += (float)r[u][e];
+    }
+    for (; k < n; ++k) {
+        const bf16x8 r = *reinterpret_cast<const bf16x8*>(dy + (size_t)list[k] * C + v * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += (float)r[e];
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16)acc[e];
+    *reinterpret_cast<bf16x8*>(dw + (size_t)my * C + v * 8) = o;
+}
+// grid (C / 32, rows): 4 column chunks (8 columns) x 64 token lanes; a lane strides over the tokens and adds the rows whose id is this row
+__global__ __launch_bounds__(256) void embedding_bwd_small_kernel(int T, int C, const long long* __restrict__ ids, long long padding_idx, const bf16* __restrict__ dy,
+                                                                 bf16* __restrict__ dw) {
+    __shared__ float red[64][33];
+    const int c = threadIdx.x & 3, r = threadIdx.x >> 2;
+    const int col = (blockIdx.x * 4 + c) * 8;
+    const long long row = blockIdx.y;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    if (col < C && row != padding_idx)
+        for (int m = r; m < T; m += 64)
+            if (ids[m] == row) {
+                const bf16x8 x = *reinterpret_cast<const bf16x8*>(dy + (size_t)m * C + col);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += (float)x[e];
+            }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[r][c * 8 + e] = acc[e];
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int oc = blockIdx.x * 32 + threadIdx.x;
+        if (oc < C) {
+            float t = 0.f;
+#pragma unroll 8
+            for (int i = 0; i < 64; ++i) t += red[i][threadIdx.x];
+            dw[(size_t)row * C + oc] = (bf16)t;
+        }
+    }
+}
+
 int pf_blocks(int M) { return M / PF_BW < 1 ? 1 : (M / PF_BW > 256 ? 256 : M / PF_BW); }      // backward: workgroups = partial rows
 int pf_blocks_fwd(int M) { return M / 4 < 1 ? 1 : (M / 4 > 1024 ? 1024 : M / 4); }
 bool pf_misaligned(const void* a, const void* b, const void* c, const void* d) {
@@ -397,6 +495,23 @@ extern "C" int fmmt_plm_gelu_bwd_colsum(int M, int H, const void* dact, const vo
     hipLaunchKernelGGL(plm_gelu_bwd_colsum_kernel, dim3(blocks), dim3(256), 0, st, M, H, (const bf16*)dact, (const bf16*)pre, (bf16*)dpre, (float*)workspace);
     FMMT_CHECK_LAUNCH();
     hipLaunchKernelGGL(plm_colpart_reduce_kernel, dim3((H + 31) / 32), dim3(1024), 0, st, (const float*)workspace, blocks, H, (bf16*)dbias);
+    FMMT_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int fmmt_embedding_bwd(int T, int C, int V, const int64_t* ids, int64_t padding_idx, const void* dy, void* dweight, void* stream) {
+    if (T <= 0 || C <= 0 || V <= 0 || C % 8 || C > 2048 || T > 32768 || !ids || !dy || !dweight) return FMMT_EINVAL;
+    if (pf_misaligned(dy, dweight, dy, dweight)) return FMMT_EALIGN;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (V <= EB_SMALL) {
+        hipLaunchKernelGGL(embedding_bwd_small_kernel, dim3((C + 31) / 32, V), dim3(256), 0, st, T, C, (const long long*)ids, (long long)padding_idx, (const bf16*)dy,
+                           (bf16*)dweight);
+        FMMT_CHECK_LAUNCH();
+        return 0;
+    }
+    if (hipError_t e = hipMemsetAsync(dweight, 0, (size_t)V * C * sizeof(bf16), st); e != hipSuccess) return (int)e;
+    const size_t lds = (size_t)((T + 31) / 32) * 4 + (size_t)T * 4;
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(T), dim3(256), lds, st, T, C, (const long long*)ids, (long long)padding_idx, (const bf16*)dy, (bf16*)dweight);
     FMMT_CHECK_LAUNCH();
     return 0;
 }

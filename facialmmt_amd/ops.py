@@ -401,6 +401,30 @@ def plm_gelu_bwd_colsum_raw(dact2, pre2):
     return dpre, dbias
 
 
+class PlmEmbeddingFn(torch.autograd.Function):
+    """torch.nn.functional.embedding with the weight gradient of fmmt_embedding_bwd: the text encoder's word / position / token-type tables (transformers'
+    *Embeddings, src/models.py:75-91).  torch's backward for <= 3072 indices is a 110-170 us launch per table (+ a fill) at the very end of the text encoder's
+    backward; this is the fill + 5-10 us, deterministic, sums in fp32 with one rounding.  bf16 weight (V, C), C % 8 == 0, C <= 2048; at most 32768 indices."""
+
+    @staticmethod
+    def forward(ctx, ids, weight, padding_idx):
+        ctx.save_for_backward(ids)
+        ctx.cfg = (tuple(weight.shape), -1 if padding_idx is None else int(padding_idx))
+        return torch.nn.functional.embedding(ids, weight, padding_idx)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (ids,) = ctx.saved_tensors
+        (V, C), pad = ctx.cfg
+        ids1 = ids.reshape(-1).contiguous()
+        if ids1.dtype != torch.int64:
+            ids1 = ids1.long()
+        dy2 = _c16(dy.reshape(-1, C))
+        dw = torch.empty((V, C), dtype=dy.dtype, device=dy.device)
+        check(_lib.load().fmmt_embedding_bwd(ids1.numel(), C, V, _p(ids1), pad, _p(dy2), _p(dw), _st()), f"fmmt_embedding_bwd(T={ids1.numel()},C={C},V={V})")
+        return None, dw, None
+
+
 class PlmFfnFn(torch.autograd.Function):
     """y = LayerNorm(dropout(gelu(x W1^T + b1) W2^T + b2) + x): the feed-forward half of a BERT / RoBERTa layer (transformers' *Intermediate + *Output,
     src/models.py:75-91) as ONE autograd node.  Forward: the launches of the two modules (vendor GEMMs, torch's exact GELU, fmmt_plm_dropadd_ln_fwd).  Backward:

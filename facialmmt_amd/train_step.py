@@ -354,6 +354,7 @@ class VendorLayerNorm(torch.nn.LayerNorm):
 
 # Module constants (the probes patch them), not environment switches: each is the off-switch of one fused launch family
 PLM_COLSUM, PLM_LN, FUSED_ADAMW, PIN_SHADOWS, FUSED_HANDOVER = True, True, True, True, True
+PLM_FUSE_EMBED = True                                       # nn.Embedding tables: the weight gradient by fmmt_embedding_bwd (False: torch's embedding backward)
 PLM_FUSE_FFN = True                                         # intermediate + output of a layer as one autograd node (ops.PlmFfnFn); False: the two modules
 PLM_FUSE_ATTN = True                                        # a packed *SelfAttention runs its attention core on fmmt_mha_fwd / _bwd (False: the stock attention interface)
 PLM_FUSE_TAILS, PLM_FUSE_QKV = True, True                  # fuse_text_encoder: sublayer tails as one launch per direction / packed query-key-value GEMM
@@ -415,6 +416,17 @@ def _fused_ffn_chunk(self, attention_output):
         return self._fmmt_stock_ffn(attention_output)
     from . import ops
     return ops.PlmFfnFn.apply(x, d1.weight, d1.bias, d2.weight, d2.bias, ln.weight, ln.bias, ln.eps, p, box.t if p > 0.0 else 0, out._fmmt_salt)
+
+
+def _fused_embedding_forward(self, input):
+    """forward of a re-classed nn.Embedding of the text encoder: the stock lookup, the weight gradient by fmmt_embedding_bwd (ops.PlmEmbeddingFn)"""
+    w = self.weight
+    if (not PLM_FUSE_EMBED or not input.is_cuda or w.dtype != torch.bfloat16 or not torch.is_grad_enabled() or not w.requires_grad or self.max_norm is not None
+            or self.scale_grad_by_freq or self.sparse or w.shape[1] % 8 or w.shape[1] > 2048 or input.numel() > 32768 or input.numel() == 0
+            or input.dtype not in (torch.int64, torch.int32)):
+        return self._fmmt_stock_forward(input)
+    from . import ops
+    return ops.PlmEmbeddingFn.apply(input, w, self.padding_idx)
 
 
 def _is_exact_gelu(fn):
@@ -504,7 +516,8 @@ def fuse_text_encoder(plm, tails: bool = True, qkv: bool = True):
     (3E, E) weight of which the three nn.Linear parameters become row slices (same Parameter objects, same names, same state_dict; the optimizer's
     views keep working) and, where the in-tree attention kernels apply (_fused_attention: bf16, head_dim 64, encoder self-attention), its attention core
     with them on the packed projection (PLM_FUSE_ATTN); (c) where a layer's *Output took (a) and its *Intermediate is dense -> exact GELU, the two run as one
-    autograd node (ops.PlmFfnFn, PLM_FUSE_FFN; the count is left in plm._fmmt_fused_ffn).  Returns (tails changed, attentions packed).  Numerics: (a) rounds like the bf16 module op by op,
+    autograd node (ops.PlmFfnFn, PLM_FUSE_FFN; the count is left in plm._fmmt_fused_ffn); (d) the nn.Embedding tables keep their forward and take
+    fmmt_embedding_bwd for the weight gradient (ops.PlmEmbeddingFn, PLM_FUSE_EMBED).  Returns (tails changed, attentions packed).  Numerics: (a) rounds like the bf16 module op by op,
     with its own dropout stream (counter-based, replayed in the backward instead of a stored mask); (b) is the same arithmetic as three GEMMs; the
     attention core is a flash-style online softmax in fp32 with bf16 probabilities, like the library kernel it replaces, and its own dropout stream."""
     box = _SeedBox()
@@ -553,6 +566,11 @@ def fuse_text_encoder(plm, tails: bool = True, qkv: bool = True):
             m.feed_forward_chunk = types.MethodType(_fused_ffn_chunk, m)
             n_ffn += 1
     plm._fmmt_fused_ffn = n_ffn
+    # (d) the embedding tables' weight gradients (the stock forward; the tables stay nn.Embedding modules)
+    for name, m in plm.named_modules():
+        if tails and type(m) is torch.nn.Embedding and not hasattr(m, "_fmmt_stock_forward"):
+            m._fmmt_stock_forward = m.forward
+            m.forward = types.MethodType(_fused_embedding_forward, m)
     if n_tail or n_qkv:
         plm.register_forward_pre_hook(lambda mod, args, kwargs=None: box.draw(next(mod.parameters()).device) if mod.training else None)
     return n_tail, n_qkv

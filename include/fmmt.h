@@ -384,6 +384,13 @@ int fmmt_plm_dropadd_ln_bwd(int M, int C, float eps, const void* dy, const void*
 size_t fmmt_plm_gelu_bwd_colsum_workspace(int M, int H);
 int fmmt_plm_gelu_bwd_colsum(int M, int H, const void* dact, const void* pre, void* dpre, void* dbias, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Weight gradient of an nn.Embedding with a few thousand indices (the text encoder's word / position / token-type tables, transformers' *Embeddings,
+ * src/models.py:75-91): dweight[id] = sum of dy[t] over the tokens t with ids[t] == id in token order (fp32 sums, one rounding), every other row zero,
+ * tokens of padding_idx (pass -1 for none) skipped -- torch.nn.functional.embedding's backward for a dense bf16 weight without max_norm /
+ * scale_grad_by_freq.  Deterministic: no atomics on the output.  ids: int64 [T] (values in [0, V)); dy: bf16 [T][C]; dweight: bf16 [V][C], written
+ * entirely; C % 8 == 0, C <= 2048, T <= 32768. */
+int fmmt_embedding_bwd(int T, int C, int V, const int64_t* ids, int64_t padding_idx, const void* dy, void* dweight, void* stream);
+
 /* The same pair with the affine parameters' type as an argument (param_dtype FMMT_BF16 | FMMT_F32: gamma, beta, dgamma, dbeta, dbias in that type;
  * activations bf16): also serves MELDTransEncoder's sublayer tails, LayerNorm(dropout(dense(h)) + input) with fp32 master parameters
  * (modules/Transformer.py:109-137).  fmmt_plm_dropadd_ln_* = these with FMMT_BF16. */

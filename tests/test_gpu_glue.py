@@ -401,6 +401,38 @@ def test_fused_text_encoder_sublayers_match_the_stock_module():
     assert not torch.equal(before, w) and att.key.weight.data_ptr() == w[256:].data_ptr()
 
 
+def test_embedding_weight_gradient_against_torch():
+    """fmmt_embedding_bwd (ops.PlmEmbeddingFn): the dense weight gradient of nn.Embedding for a few thousand indices against torch's own backward in fp32 -- a large
+    table with repeated ids (one of them ~100 times) and a padding index, a position-like table (every id B times), tables of one and two rows (the predicated
+    column-sum path); rows no token names are zero; two calls agree bit for bit."""
+    from facialmmt_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(6)
+    for V, C, T, pad in ((50265, 1024, 2048, 1), (514, 1024, 2048, 1), (1, 1024, 2048, None), (2, 768, 700, None), (30522, 768, 33, 0)):
+        if V > 8:
+            ids = torch.randint(0, V, (T,), device=dev)
+            ids[::20] = 2                                              # a separator every 20 tokens
+            ids[5:9] = pad if pad is not None else 3
+            if V == 514:
+                ids = (torch.arange(T, device=dev) % 512) + 2         # positions: every id T / 512 times
+        else:
+            ids = torch.randint(0, V, (T,), device=dev)
+        ids = ids.view(4, -1) if T % 4 == 0 else ids.view(1, -1)
+        w = torch.randn(V, C, device=dev).to(torch.bfloat16).requires_grad_(True)
+        dy = torch.randn(*ids.shape, C, device=dev).to(torch.bfloat16)
+        y = ops.PlmEmbeddingFn.apply(ids, w, pad)
+        assert torch.equal(y, torch.nn.functional.embedding(ids, w, pad))
+        (g,) = torch.autograd.grad(y, w, dy)
+        (g2,) = torch.autograd.grad(ops.PlmEmbeddingFn.apply(ids, w, pad), w, dy)
+        assert torch.equal(g, g2)
+        wr = w.detach().float().requires_grad_(True)
+        (gr,) = torch.autograd.grad(torch.nn.functional.embedding(ids, wr, pad), wr, dy.float())
+        assert (g.float() - gr).abs().max().item() <= 8e-3 * gr.abs().max().item() + 1e-6, (V, C, T)
+        assert torch.equal(g.float() == 0, gr == 0) or ((g.float() != 0) & (gr == 0)).sum().item() == 0
+        if pad is not None:
+            assert (g[pad] == 0).all()
+
+
 def test_gelu_backward_with_the_bias_gradient_in_one_pass():
     """fmmt_plm_gelu_bwd_colsum (the text encoder's *Intermediate backward): dpre = dact * gelu'(pre) against torch's erf GELU backward in fp32 within one bf16
     step (+ 2e-4 |dact| around the derivative's zero), dbias = the column sum of the STORED dpre (fixed order: two calls agree bit for bit); ragged row counts, the widest row the kernel takes."""
