@@ -104,18 +104,10 @@ __device__ __forceinline__ void keep4(const AttnDrop& d, uint32_t row, uint32_t 
 }
 
 // =============================================================================================
-// forward.  KB: the tile adds a per-key term to the logits (key_bias, and -inf for keys >= Lk of the last tile); DROP: dropout
-template <bool KB, bool DROP>
-__device__ __forceinline__ void fwd_tile(const MhaArgs& p, const AttnDrop& dr, const bf16* Kt, const bf16* Vt, const bf16x8* qf, f32x4* o, float& m, float& l,
-                                         float c2, uint32_t drow, int b, int j0, int li, int lg) {
-    float kb[16];
-    if constexpr (KB) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int key = j0 + (e >> 2) * 16 + lg * 4 + (e & 3);
-            kb[e] = key < p.Lk ? (p.key_bias ? p.key_bias[(size_t)b * p.Lk + key] * LOG2E : 0.f) : NEG_BIG;
-        }
-    }
+// forward.  Kb: the tile's per-key logit terms in the log2 domain (key_bias, 0 without one, -inf for keys >= Lk), staged with the tile
+template <bool DROP>
+__device__ __forceinline__ void fwd_tile(const AttnDrop& dr, const bf16* Kt, const bf16* Vt, const float* Kb, const bf16x8* qf, f32x4* o, float& m, float& l,
+                                         float c2, uint32_t drow, int j0, int li, int lg) {
     float s[16];
     float tmax = NEG_BIG;
 #pragma unroll
@@ -123,9 +115,10 @@ __device__ __forceinline__ void fwd_tile(const MhaArgs& p, const AttnDrop& dr, c
         const bf16* krow = Kt + (kt * 16 + li) * VP + lg * 8;
         f32x4 a = mfma(lds8(krow), qf[0], f32x4{0.f, 0.f, 0.f, 0.f});
         a = mfma(lds8(krow + 32), qf[1], a);
+        const f32x4 kb = *reinterpret_cast<const f32x4*>(Kb + kt * 16 + lg * 4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float v = KB ? __builtin_fmaf(a[r], c2, kb[kt * 4 + r]) : a[r] * c2;
+            const float v = __builtin_fmaf(a[r], c2, kb[r]);
             s[kt * 4 + r] = v;
             tmax = fmaxf(tmax, v);
         }
@@ -160,10 +153,16 @@ __device__ __forceinline__ void fwd_tile(const MhaArgs& p, const AttnDrop& dr, c
     }
 }
 
+// the per-key term of key `key` (log2 domain); the first 64 threads of a workgroup fetch one each with the tile
+__device__ __forceinline__ float key_term(const MhaArgs& p, int b, int key) {
+    return key < p.Lk ? (p.key_bias ? p.key_bias[(size_t)b * p.Lk + key] * LOG2E : 0.f) : NEG_BIG;
+}
+
 template <bool DROP>
 __global__ __launch_bounds__(256) void mha_mfma_fwd_kernel(MhaArgs p) {
     __shared__ __attribute__((aligned(16))) bf16 Kt[64 * VP];
     __shared__ __attribute__((aligned(16))) bf16 Vt[64 * VP];
+    __shared__ __attribute__((aligned(16))) float Kb[64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
     int bx, bh;
     block_of(bx, bh);
@@ -189,21 +188,21 @@ __global__ __launch_bounds__(256) void mha_mfma_fwd_kernel(MhaArgs p) {
     for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     RowRegs kr = fetch_row(kg, p.rk(min(sr, p.Lk - 1), b) * p.ldkv, sr < p.Lk);
     RowRegs vr = fetch_row(vg, p.rk(min(sr, p.Lk - 1), b) * p.ldkv, sr < p.Lk);
+    float kbr = wave == 0 ? key_term(p, b, lane) : 0.f;
     for (int j0 = 0; j0 < p.Lk; j0 += 64) {
         __syncthreads();
         put_row(Kt, sr, lg, kr);
         put_row(Vt, sr, lg, vr);
+        if (wave == 0) Kb[lane] = kbr;
         __syncthreads();
         if (j0 + 64 < p.Lk) {
             const int row = j0 + 64 + sr;
             const size_t off = p.rk(min(row, p.Lk - 1), b) * p.ldkv;
             kr = fetch_row(kg, off, row < p.Lk);
             vr = fetch_row(vg, off, row < p.Lk);
+            if (wave == 0) kbr = key_term(p, b, j0 + 64 + lane);
         }
-        if (active) {
-            if (p.key_bias || j0 + 64 > p.Lk) fwd_tile<true, DROP>(p, dr, Kt, Vt, qf, o, m, l, c2, drow, b, j0, li, lg);
-            else fwd_tile<false, DROP>(p, dr, Kt, Vt, qf, o, m, l, c2, drow, b, j0, li, lg);
-        }
+        if (active) fwd_tile<DROP>(dr, Kt, Vt, Kb, qf, o, m, l, c2, drow, j0, li, lg);
     }
     if (q0 + li < p.Lq) {
         store_row(reinterpret_cast<bf16*>(p.out) + p.rq(q, b) * p.ldo + h * D, o, 1.0f / l, lg);
@@ -213,9 +212,9 @@ __global__ __launch_bounds__(256) void mha_mfma_fwd_kernel(MhaArgs p) {
 
 // =============================================================================================
 // dQ: wave owns 16 queries, the workgroup streams key / value tiles
-template <bool KB, bool DROP>
-__device__ __forceinline__ void dq_tile(const MhaArgs& p, const AttnDrop& dr, const bf16* Kt, const bf16* Vt, const bf16x8* qf, const bf16x8* gf, f32x4* dq,
-                                        float ls2, float dl, float c2, uint32_t drow, int b, int j0, int li, int lg) {
+template <bool DROP>
+__device__ __forceinline__ void dq_tile(const AttnDrop& dr, const bf16* Kt, const bf16* Vt, const float* Kb, const bf16x8* qf, const bf16x8* gf, f32x4* dq,
+                                        float ls2, float dl, float c2, uint32_t drow, int j0, int li, int lg) {
 #pragma unroll
     for (int ks2 = 0; ks2 < 2; ++ks2) {                       // 32 keys at a time: key tiles 2*ks2, 2*ks2+1
         float ds[8];
@@ -228,16 +227,12 @@ __device__ __forceinline__ void dq_tile(const MhaArgs& p, const AttnDrop& dr, co
             a = mfma(lds8(krow + 32), qf[1], a);
             f32x4 dp = mfma(lds8(vrow), gf[0], f32x4{0.f, 0.f, 0.f, 0.f});
             dp = mfma(lds8(vrow + 32), gf[1], dp);
+            const f32x4 kb = *reinterpret_cast<const f32x4*>(Kb + kt * 16 + lg * 4);
             float k4[4];
             if constexpr (DROP) keep4(dr, drow, (uint32_t)(j0 + kt * 16 + lg * 4) >> 2, k4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float e = __builtin_fmaf(a[r], c2, -ls2);
-                if constexpr (KB) {
-                    const int key = j0 + kt * 16 + lg * 4 + r;
-                    e += key < p.Lk ? (p.key_bias ? p.key_bias[(size_t)b * p.Lk + key] * LOG2E : 0.f) : NEG_BIG;
-                }
-                const float pij = ex2(e);
+                const float pij = ex2(__builtin_fmaf(a[r], c2, kb[r] - ls2));
                 ds[u * 4 + r] = pij * ((DROP ? dp[r] * k4[r] : dp[r]) - dl);
             }
         }
@@ -251,6 +246,7 @@ template <bool DROP>
 __global__ __launch_bounds__(256) void mha_mfma_bwd_dq_kernel(MhaArgs p) {
     __shared__ __attribute__((aligned(16))) bf16 Kt[64 * VP];
     __shared__ __attribute__((aligned(16))) bf16 Vt[64 * VP];
+    __shared__ __attribute__((aligned(16))) float Kb[64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
     int bx, bh;
     block_of(bx, bh);
@@ -285,21 +281,21 @@ __global__ __launch_bounds__(256) void mha_mfma_bwd_dq_kernel(MhaArgs p) {
     for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     RowRegs kr = fetch_row(kg, p.rk(min(sr, p.Lk - 1), b) * p.ldkv, sr < p.Lk);
     RowRegs vr = fetch_row(vg, p.rk(min(sr, p.Lk - 1), b) * p.ldkv, sr < p.Lk);
+    float kbr = wave == 0 ? key_term(p, b, lane) : 0.f;
     for (int j0 = 0; j0 < p.Lk; j0 += 64) {
         __syncthreads();
         put_row(Kt, sr, lg, kr);
         put_row(Vt, sr, lg, vr);
+        if (wave == 0) Kb[lane] = kbr;
         __syncthreads();
         if (j0 + 64 < p.Lk) {
             const int row = j0 + 64 + sr;
             const size_t off = p.rk(min(row, p.Lk - 1), b) * p.ldkv;
             kr = fetch_row(kg, off, row < p.Lk);
             vr = fetch_row(vg, off, row < p.Lk);
+            if (wave == 0) kbr = key_term(p, b, j0 + 64 + lane);
         }
-        if (active) {
-            if (p.key_bias || j0 + 64 > p.Lk) dq_tile<true, DROP>(p, dr, Kt, Vt, qf, gf, dq, ls2, dl, c2, drow, b, j0, li, lg);
-            else dq_tile<false, DROP>(p, dr, Kt, Vt, qf, gf, dq, ls2, dl, c2, drow, b, j0, li, lg);
-        }
+        if (active) dq_tile<DROP>(dr, Kt, Vt, Kb, qf, gf, dq, ls2, dl, c2, drow, j0, li, lg);
     }
     if (q0 + li < p.Lq) store_row(reinterpret_cast<bf16*>(p.dq) + p.rq(q, b) * p.lddq + h * D, dq, p.scale, lg);
 }
