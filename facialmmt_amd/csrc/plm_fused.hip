@@ -234,55 +234,65 @@ __global__ __launch_bounds__(1024) void plm_dropadd_ln_reduce_kernel(const float
 // here) as two passes over the (tokens x 4096) matrix.  A thread owns columns: its sums over the block's rows need no cross-thread step; per-block partial rows,
 // then a fixed-order reduction over the blocks.  H % 8 == 0, H <= 8192.
 constexpr int GB_MAXV = 4;                                  // 8-element vectors per thread: H <= 256 * 8 * 4
-constexpr int GB_BLOCKS = 256;
-__global__ __launch_bounds__(256) void plm_gelu_bwd_colsum_kernel(int M, int H, const bf16* __restrict__ dact, const bf16* __restrict__ pre, bf16* __restrict__ dpre,
-                                                                 float* __restrict__ part) {
-    const int nv = H / 8;
+constexpr int GB_BLOCKS = 256;                              // partial rows the reduction reads
+constexpr int GB_PH = 4;                                    // row phases per workgroup: 1024 threads = four waves per SIMD, phase p takes the block's rows p, p + 4, ...
+                                                            // (one phase, 256 threads: 20 us for 50 MB at 2048 x 4096 -- one wave per SIMD walking eight rows)
+__global__ __launch_bounds__(256 * GB_PH) void plm_gelu_bwd_colsum_kernel(int M, int H, const bf16* __restrict__ dact, const bf16* __restrict__ pre, bf16* __restrict__ dpre,
+                                                                         float* __restrict__ part) {
+    __shared__ float red[GB_PH - 1][256][8];
+    const int nv = H / 8, tc = threadIdx.x & 255, ph = threadIdx.x >> 8;
     float acc[GB_MAXV][8];
 #pragma unroll
     for (int j = 0; j < GB_MAXV; ++j)
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
-    for (int row0 = blockIdx.x; row0 < M; row0 += 2 * gridDim.x) {      // two rows per step: all their loads in flight before the first is used
-        bf16x8 g[2][GB_MAXV], x[2][GB_MAXV];
+    for (int row = blockIdx.x + gridDim.x * ph; row < M; row += gridDim.x * GB_PH) {
+        bf16x8 g[GB_MAXV], x[GB_MAXV];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int row = row0 + u * gridDim.x;
-#pragma unroll
-            for (int j = 0; j < GB_MAXV; ++j) {
-                const int v = threadIdx.x + 256 * j;
-                if (v < nv && row < M) {
-                    const size_t o = (size_t)row * H + v * 8;
-                    g[u][j] = *reinterpret_cast<const bf16x8*>(dact + o);
-                    x[u][j] = *reinterpret_cast<const bf16x8*>(pre + o);
-                }
+        for (int j = 0; j < GB_MAXV; ++j) {                 // the row's loads first
+            const int v = tc + 256 * j;
+            if (v < nv) {
+                const size_t o = (size_t)row * H + v * 8;
+                g[j] = *reinterpret_cast<const bf16x8*>(dact + o);
+                x[j] = *reinterpret_cast<const bf16x8*>(pre + o);
             }
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int row = row0 + u * gridDim.x;
+        for (int j = 0; j < GB_MAXV; ++j) {
+            const int v = tc + 256 * j;
+            if (v < nv) {
+                bf16x8 out;
 #pragma unroll
-            for (int j = 0; j < GB_MAXV; ++j) {
-                const int v = threadIdx.x + 256 * j;
-                if (v < nv && row < M) {
-                    bf16x8 out;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        out[e] = (bf16)((float)g[u][j][e] * gelu_grad_exp_f((float)x[u][j][e]));
-                        acc[j][e] += (float)out[e];         // the sum of what is stored (what a column sum over d(pre) would see)
-                    }
-                    *reinterpret_cast<bf16x8*>(dpre + (size_t)row * H + v * 8) = out;
+                for (int e = 0; e < 8; ++e) {
+                    out[e] = (bf16)((float)g[j][e] * gelu_grad_exp_f((float)x[j][e]));
+                    acc[j][e] += (float)out[e];             // the sum of what is stored (what a column sum over d(pre) would see)
                 }
+                *reinterpret_cast<bf16x8*>(dpre + (size_t)row * H + v * 8) = out;
             }
         }
     }
+    // the phases' sums meet in LDS, one vector slot at a time, in phase order; phase 0 writes the block's partial row
     float* pb = part + (size_t)blockIdx.x * H;
 #pragma unroll
     for (int j = 0; j < GB_MAXV; ++j) {
-        const int v = threadIdx.x + 256 * j;
-        if (v < nv) {
-            *reinterpret_cast<f32x4*>(pb + v * 8) = f32x4{acc[j][0], acc[j][1], acc[j][2], acc[j][3]};
-            *reinterpret_cast<f32x4*>(pb + v * 8 + 4) = f32x4{acc[j][4], acc[j][5], acc[j][6], acc[j][7]};
+        if (256 * j >= nv) break;                           // uniform
+        __syncthreads();
+        if (ph > 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[ph - 1][tc][e] = acc[j][e];
+        }
+        __syncthreads();
+        const int v = tc + 256 * j;
+        if (ph == 0 && v < nv) {
+            float t[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                t[e] = acc[j][e];
+#pragma unroll
+                for (int q = 0; q < GB_PH - 1; ++q) t[e] += red[q][tc][e];
+            }
+            *reinterpret_cast<f32x4*>(pb + v * 8) = f32x4{t[0], t[1], t[2], t[3]};
+            *reinterpret_cast<f32x4*>(pb + v * 8 + 4) = f32x4{t[4], t[5], t[6], t[7]};
         }
     }
 }
@@ -311,7 +321,7 @@ __global__ __launch_bounds__(1024) void plm_colpart_reduce_kernel(const float* _
         out[c] = (bf16)t;
     }
 }
-int gb_blocks(int M) { return M < GB_BLOCKS ? M : GB_BLOCKS; }
+int gb_blocks(int M) { const int b = (M + GB_PH - 1) / GB_PH; return b < GB_BLOCKS ? b : GB_BLOCKS; }
 
 // Weight gradient of an nn.Embedding of the text encoder (transformers' *Embeddings: word / position / token-type tables, src/models.py:75-91) for a few
 // thousand tokens: dW[id] = sum over the tokens t with ids[t] == id of dy[t], tokens of padding_idx skipped.  torch's kernel for <= 3072 indices
@@ -492,7 +502,7 @@ extern "C" int fmmt_plm_gelu_bwd_colsum(int M, int H, const void* dact, const vo
     if (pf_misaligned(dact, pre, dpre, workspace)) return FMMT_EALIGN;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int blocks = gb_blocks(M);
-    hipLaunchKernelGGL(plm_gelu_bwd_colsum_kernel, dim3(blocks), dim3(256), 0, st, M, H, (const bf16*)dact, (const bf16*)pre, (bf16*)dpre, (float*)workspace);
+    hipLaunchKernelGGL(plm_gelu_bwd_colsum_kernel, dim3(blocks), dim3(256 * GB_PH), 0, st, M, H, (const bf16*)dact, (const bf16*)pre, (bf16*)dpre, (float*)workspace);
     FMMT_CHECK_LAUNCH();
     hipLaunchKernelGGL(plm_colpart_reduce_kernel, dim3((H + 31) / 32), dim3(1024), 0, st, (const float*)workspace, blocks, H, (bf16*)dbias);
     FMMT_CHECK_LAUNCH();

@@ -29,3 +29,15 @@ for M, C in ((2048, 1024), (2048, 768), (640, 768)):
         bw = lambda: _lib.check(lib.fmmt_plm_dropadd_ln_bwd(M, C, 1e-5, y.data_ptr(), xs.data_ptr(), g.data_ptr(), p, 0, seed.data_ptr(), 5 << 40, dx.data_ptr(), dh.data_ptr(), dg.data_ptr(), db.data_ptr(),
                                                             dbias.data_ptr(), ws.data_ptr(), nb, st), "b")
         print(f"M={M} C={C} p={p}: fwd {timeit(f):6.1f} us   bwd + reduce {timeit(bw):6.1f} us", flush=True)
+
+# the intermediate's backward: d(pre) = d(act) gelu'(pre) + colsum, against torch's two launches
+for M, H in ((2048, 4096), (2048, 3072)):
+    pre = (2.0 * torch.randn(M, H, device=dev)).to(torch.bfloat16); dact = torch.randn(M, H, device=dev).to(torch.bfloat16)
+    dpre = torch.empty_like(pre); db = torch.empty(H, device=dev, dtype=torch.bfloat16)
+    nb = lib.fmmt_plm_gelu_bwd_colsum_workspace(M, H); ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    f = lambda: _lib.check(lib.fmmt_plm_gelu_bwd_colsum(M, H, dact.data_ptr(), pre.data_ptr(), dpre.data_ptr(), db.data_ptr(), ws.data_ptr(), nb, st), "g")
+    x = pre.clone().requires_grad_(True); y = torch.nn.functional.gelu(x)
+    def ref():
+        (g,) = torch.autograd.grad(y, x, dact, retain_graph=True)
+        return g.sum(0)
+    print(f"M={M} H={H}: gelu' * dact + colsum {timeit(f):6.1f} us   (torch GeluBackward + sum(0): {timeit(ref):6.1f} us)", flush=True)
