@@ -32,6 +32,9 @@ def _require(cond: bool, msg: str):
         raise NotImplementedError("facialmmt_amd HIP path: " + msg)
 
 
+DROP_PATH_ONE_DRAW = True    # module constant (probes patch it): every stochastic-depth multiplier of a forward from one draw (SwinTransformer._draw_drop_paths)
+
+
 class DropPath(nn.Module):
     """Stochastic depth, per sample (timm semantics: keep mask / keep_prob).  On the HIP path the
     multiplier is handed to the GEMM epilogue as a per-sample vector; `sample_scale` draws it."""
@@ -39,10 +42,15 @@ class DropPath(nn.Module):
     def __init__(self, drop_prob: float = 0.0):
         super().__init__()
         self.drop_prob = float(drop_prob)
+        self._rows = None           # multipliers drawn ahead for this forward by the model (SwinTransformer._draw_drop_paths): a list, consumed in call order
 
     def sample_scale(self, n: int, device):
         if self.drop_prob == 0.0 or not self.training:
             return None
+        if self._rows:
+            row = self._rows.pop(0)
+            if row.shape[0] == n and row.device == torch.device(device):
+                return row
         keep = 1.0 - self.drop_prob
         return torch.empty(n, dtype=torch.float32, device=device).bernoulli_(keep).div_(keep)
 
@@ -380,6 +388,25 @@ class SwinTransformer(nn.Module):
                 downsample=PatchMerging if (i < self.num_layers - 1) else None, use_checkpoint=use_checkpoint))
         self.output_layer = nn.Sequential(norm_layer(self.num_features), Flatten(), nn.Linear(49 * 768, 512), nn.BatchNorm1d(512))
         self.apply(self._init_weights)
+        # keep probabilities of the DropPath draws of one forward, in call order (a block draws twice: attention branch, Mlp branch); not part of the state_dict
+        keep = [1.0 - blk.drop_path.drop_prob for layer in self.layers for blk in layer.blocks
+                if isinstance(blk.drop_path, DropPath) and blk.drop_path.drop_prob > 0.0 for _ in range(2)]
+        self.register_buffer("_dp_keep", torch.tensor(keep, dtype=torch.float32).view(-1, 1), persistent=False)
+        self.register_buffer("_dp_inv", (1.0 / torch.tensor(keep, dtype=torch.float64)).float().view(-1, 1), persistent=False)
+
+    def _draw_drop_paths(self, n, device):
+        """Every stochastic-depth multiplier of this forward in ONE draw: rand, compare, select over a (draws, n) matrix whose rows the DropPath modules then
+        hand out in call order -- instead of bernoulli_ + div_ per draw (44 launches of ~5 us in front of the blocks of Swin-tiny's forward, which runs alone on
+        the GPU).  Same distribution: row r is 1 / keep_r with probability keep_r, else 0."""
+        dps = [blk.drop_path for layer in self.layers for blk in layer.blocks if isinstance(blk.drop_path, DropPath) and blk.drop_path.drop_prob > 0.0]
+        for dp in dps:
+            dp._rows = None
+        if not DROP_PATH_ONE_DRAW or not self.training or not dps or self._dp_keep.numel() != 2 * len(dps) or self._dp_keep.device != torch.device(device):
+            return
+        keep = self._dp_keep
+        pool = torch.where(torch.rand(keep.shape[0], n, dtype=torch.float32, device=device) < keep, self._dp_inv, 0.0)          # three launches
+        for i, dp in enumerate(dps):
+            dp._rows = [pool[2 * i], pool[2 * i + 1]]
 
     def _init_weights(self, m):
         if isinstance(m, nn.Linear):
@@ -418,6 +445,7 @@ class SwinTransformer(nn.Module):
             x = self.patch_embed.forward_u8(x, self.input_resize, self.input_dtype)
         else:
             x = self.patch_embed(x)
+        self._draw_drop_paths(x.shape[0], x.device)
         for layer in self.layers:
             x = layer(x)
         return self._head(x)

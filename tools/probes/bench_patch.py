@@ -9,10 +9,11 @@ if os.environ.get("PROBE_LIB"):
     _lib.LIB_PATH = os.environ["PROBE_LIB"]
 import facialmmt_amd.ops as ops                      # noqa: E402
 import facialmmt_amd.train_step as train_step        # noqa: E402
+import facialmmt_amd.modules.SwinTransformer.Swin_Transformer as swin_mod        # noqa: E402
 for item in filter(None, os.environ.get("PATCH", "").split(";")):
     name, value = item.split("=", 1)
     mod, *path, attr = name.strip().split(".")        # ops._X, or train_step.GraphedTargetStep.TEXT_FORK_AT
-    target = {"ops": ops, "train_step": train_step}[mod]
+    target = {"ops": ops, "train_step": train_step, "swin": swin_mod}[mod]
     for part in path:
         target = getattr(target, part)
     assert hasattr(target, attr), name
