@@ -228,18 +228,6 @@ __device__ __forceinline__ float swap_sum(float v) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// counter-based RNG for attention-probability dropout (replayed bit-identically in backward):
-// splitmix64 of (seed, element index) -> 24-bit uniform
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float hash_uniform(uint64_t seed, uint64_t idx) {
-    uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull + 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    return (float)(z >> 40) * (1.0f / 16777216.0f);
-}
-
-// ---------------------------------------------------------------------------------------------
 // keep-mask of the attention-probability dropout (fmmt_mha_fwd / _bwd; both formulations, replayed bit-identically in the backward).
 // splitmix64 per element was ~60 issue slots of 64-bit multiplies against ~10 for the softmax element itself (round 6: the 4 x 512-token text
 // shape ran 39 us without dropout, 75 with).  One pair of 32-bit avalanche mixes (two multiplies each; lowbias32 and the first rounds of

@@ -384,7 +384,7 @@ class _SeedBox:
     def __init__(self):
         self.t = None
         self.words = 1            # word 0: the sublayer tails (each adds its salt); word 1 + i: attention module i (its kernels take no salt)
-        self.key_bias = None      # (the 4-d mask the layers were handed, its per-key logit bias): _fused_attention
+        self.key_bias = None      # (the 4-d mask the layers were handed, its version counter, its per-key logit bias): _fused_attention
 
     def draw(self, device):
         self.t = torch.randint(0, 2 ** 62, (self.words,), dtype=torch.int64, device=device)
@@ -489,12 +489,12 @@ def _fused_attention(self, hidden_states, args, kwargs, w, b):
             return None
         # once per forward of the encoder, not once per layer: every layer is handed the same mask tensor (the box keeps it, so its identity cannot recur)
         cached = getattr(self._fmmt_seed, "key_bias", None)
-        if cached is not None and cached[0] is mask:
-            key_bias = cached[1]
+        if cached is not None and cached[0] is mask and cached[1] == mask._version:
+            key_bias = cached[2]
         else:
             row = mask[:, 0, 0, :]
             key_bias = (torch.where(row, 0.0, -30000.0) if row.dtype == torch.bool else row.float().clamp_min(-30000.0)).to(torch.float32).contiguous()
-            self._fmmt_seed.key_bias = (mask, key_bias)
+            self._fmmt_seed.key_bias = (mask, mask._version, key_bias)
     p = float(self.dropout.p) if self.training else 0.0
     box = getattr(self, "_fmmt_seed", None)
     if p > 0.0 and (box is None or box.t is None or box.t.numel() <= self._fmmt_attn_word):

@@ -368,7 +368,8 @@ int fmmt_layernorm_bwd_bf16(int M, int C, float eps, const void* dy, const void*
  * layer_norm (forward) and LayerNorm' + masked_scale + the dense bias' column sum (backward).  bf16 activations and bf16 affine parameters.
  *   forward : t = bf16(h * keep / (1 - p)); xsum = bf16(t + res) (saved for the backward); y = LayerNorm(xsum) * gamma + beta
  *   backward: dx = LayerNorm'(dy) (= the residual branch's gradient); dh = bf16(dx * keep / (1 - p)); dgamma, dbeta; dbias = colsum(dh) (may be NULL)
- * keep(e) = hash(seed, salt + e) >= p with the counter-based generator of fmmt_mha_fwd: no mask is stored, the backward replays it from the same
+ * keep(e) = a 16-bit hash field of (seed, salt, e) >= round(p * 2^16) -- the counter-based generator of fmmt_mha_fwd, four elements per hash pair; "1 - p" above is
+ * the realised keep rate 1 - round(p * 2^16) / 2^16 --: no mask is stored, the backward replays it from the same
  * (seed | *seed_dev, salt).  h, res, xsum, y, dy, dx, dh: bf16 [M][C]; gamma, beta, dgamma, dbeta, dbias: bf16 [C]; C % 8 == 0, C <= 2048, 0 <= p < 1. */
 int fmmt_plm_dropadd_ln_fwd(int M, int C, float eps, const void* h, const void* res, const void* gamma, const void* beta, float p,
                             uint64_t seed, const uint64_t* seed_dev, uint64_t salt, void* xsum, void* y, void* stream);
