@@ -429,7 +429,7 @@ class PlmFfnFn(torch.autograd.Function):
     """y = LayerNorm(dropout(gelu(x W1^T + b1) W2^T + b2) + x): the feed-forward half of a BERT / RoBERTa layer (transformers' *Intermediate + *Output,
     src/models.py:75-91) as ONE autograd node.  Forward: the launches of the two modules (vendor GEMMs, torch's exact GELU, fmmt_plm_dropadd_ln_fwd).  Backward:
     the tail's launch + reduction, the two GEMMs behind it, d(pre) = d(act) gelu'(pre) together with b1's gradient in ONE pass (fmmt_plm_gelu_bwd_colsum; stock:
-    GeluBackward + a column sum), and the input gradient d(pre) W1 + (the residual's gradient) as ONE GEMM with an accumulate epilogue (torch.addmm) instead
+    GeluBackward + a column sum), and the input gradient d(pre) W1 + (the residual's gradient) as ONE GEMM with an accumulate epilogue (addmm_ into the tail's own dx buffer) instead
     of a GEMM and autograd's add.  Per layer and step 3 launches and two passes over the (tokens x 4096) matrix fewer."""
 
     @staticmethod
@@ -456,7 +456,7 @@ class PlmFfnFn(torch.autograd.Function):
         dact = dh.mm(w2)
         dw2 = dh.t().mm(act2)
         dpre, db1 = plm_gelu_bwd_colsum_raw(dact, pre2)
-        dx = torch.addmm(dx_ln, dpre, w1) if ctx.needs_input_grad[0] else None
+        dx = dx_ln.addmm_(dpre, w1) if ctx.needs_input_grad[0] else None      # in place: torch.addmm would first copy dx_ln into its result (a 4 MB memcpy node per layer)
         dw1 = dpre.t().mm(x2)
         return (dx.reshape(dy.shape) if dx is not None else None), dw1, db1, dw2, db2, dgamma, dbeta, None, None, None, None
 

@@ -456,6 +456,35 @@ def t_mha():
             report(f"mha bwd dq {tag}", q.grad, q64.grad, tol * 2)
             report(f"mha bwd dk {tag}", k.grad, k64.grad, tol * 2)
             report(f"mha bwd dv {tag}", v.grad, v64.grad, tol * 2)
+        # FMMT_BATCH_MAJOR (round 6): the same launch on (batch, tokens, hidden) operands is the time-major one on transposed data, bit for bit -- both kernel
+        # families (MFMA: bf16 head_dim 64; VALU: fp32, head_dim 32), cross lengths with ragged tails, packed column slices, key bias, replayed dropout
+        from facialmmt_amd import _lib
+        lib = _lib.load()
+        st = torch.cuda.current_stream().cuda_stream
+        for (Lq, Lk, B, E, nh, p) in [(77, 130, 3, 768, 12, 0.0), (130, 77, 2, 768, 12, 0.2), (64, 64, 4, 256, 8, 0.1), (200, 200, 2, 1024, 16, 0.1)]:
+            es = 4 if dt == torch.float32 else 2
+            code = _lib.dtype_code(dt)
+            qb = rnd("qb", (B, Lq, E), 1, dtype=dt)
+            kvb = rnd("kvb", (B, Lk, 2 * E), 2, dtype=dt)
+            kb = rnd("kbb", (B, Lk), 3) * 0.5
+            kb[:, Lk - 3:] = -10000.0
+            dob = rnd("dob", (B, Lq, E), 4, dtype=dt)
+            seed = torch.tensor([77], device=dev, dtype=torch.int64)
+            res = []
+            for bm in (1, 0):
+                q_, kv_, do_ = (t if bm else t.transpose(0, 1).contiguous() for t in (qb, kvb, dob))
+                out, dq, dkv = torch.empty_like(q_), torch.empty_like(q_), torch.empty_like(kv_)
+                lse = torch.empty(B * nh * Lq, device=dev, dtype=torch.float32)
+                flag = code | (_lib.BATCH_MAJOR if bm else 0)
+                _lib.check(lib.fmmt_mha_fwd(flag, Lq, Lk, B, E, nh, q_.data_ptr(), E, kv_.data_ptr(), kv_.data_ptr() + E * es, 2 * E, (E // nh) ** -0.5, kb.data_ptr(), p, 0,
+                                            seed.data_ptr(), out.data_ptr(), E, lse.data_ptr(), st), "mha fwd")
+                _lib.check(lib.fmmt_mha_bwd(flag, Lq, Lk, B, E, nh, q_.data_ptr(), E, kv_.data_ptr(), kv_.data_ptr() + E * es, 2 * E, (E // nh) ** -0.5, kb.data_ptr(), p, 0,
+                                            seed.data_ptr(), out.data_ptr(), do_.data_ptr(), E, lse.data_ptr(), dq.data_ptr(), E, dkv.data_ptr(), dkv.data_ptr() + E * es, 2 * E,
+                                            st), "mha bwd")
+                res.append(tuple(t if bm else t.transpose(0, 1) for t in (out, dq, dkv)) + (lse,))
+            ok = all(torch.equal(a, b) for a, b in zip(*res)) and bool(torch.isfinite(res[0][0].float()).all())
+            RES.append((f"mha batch-major {dt} {Lq}x{Lk} B{B} E{E} p{p}", ok))
+            print(f"{'OK  ' if ok else 'FAIL'} mha batch-major == time-major {dt} {Lq}x{Lk} B{B} E{E} heads{nh} p={p}", flush=True)
         # separate k, v tensors + dropout statistics
         q = rnd("q", (64, 2, 768), 1, dtype=dt)
         k = rnd("k", (96, 2, 768), 2, dtype=dt)
